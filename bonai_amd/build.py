@@ -1,0 +1,61 @@
+"""Build libloft_hip.so (gfx950) in-tree with hipcc.  `python -m bonai_amd.build [--force]`.
+
+Each .hip translation unit is compiled to an object (so per-file flags are possible: the
+bit-exact integer/box kernels are built with -ffp-contract=off) and linked into ONE shared
+library, bonai_amd/csrc/libloft_hip.so, which travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB = os.path.join(CSRC, 'libloft_hip.so')
+ARCH = 'gfx950'
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wno-unused-result']
+# per-file extra flags
+FLAGS = {
+    'roi_align.hip': ['-ffp-contract=off'],
+    'nms.hip': ['-ffp-contract=off'],
+    'boxes.hip': ['-ffp-contract=off'],
+}
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _newest_header():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs.append(os.path.join(os.path.dirname(CSRC), '..', 'include', 'loft_hip.h'))
+    return max(os.path.getmtime(h) for h in hs if os.path.exists(h))
+
+
+def _compile(src, force):
+    obj = os.path.join(CSRC, src[:-4] + '.o')
+    spath = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(spath)
+            and os.path.getmtime(obj) >= _newest_header()):
+        return obj, False
+    cmd = [HIPCC] + COMMON + FLAGS.get(src, []) + ['-c', spath, '-o', obj]
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [r[0] for r in res]
+    if force or any(r[1] for r in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        subprocess.check_call(cmd)
+        if verbose:
+            print('linked', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,166 @@
+"""torch-tensor front-ends of the C-ABI kernels (include/loft_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream and autograd bookkeeping.
+Every function launches hand-written gfx950 kernels through ctypes; nothing falls back to
+eager PyTorch or the CPU (bonai_amd.lib raises instead).
+
+Layout contract: 4-D activations are NCHW-*shaped* tensors with channels_last strides, i.e. NHWC
+in memory (SURVEY.md section 8b "Tensor conventions"), so reference checkpoints and call sites
+keep their shapes while the kernels see channel-contiguous pixels.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+c_int, c_int64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+def _nhwc(t):
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise L.LoftHipError('expected a 4-D channels_last (NHWC-in-memory) tensor, got strides '
+                             f'{tuple(t.stride())} for shape {tuple(t.shape)}')
+    return t
+
+
+def empty_nhwc(n, c, h, w, dtype, device):
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+def zeros_nhwc(n, c, h, w, dtype, device):
+    return torch.zeros((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------ RoIAlign
+
+def _level_args(feats, strides):
+    H = L.arr(c_int, [f.shape[2] for f in feats])
+    W = L.arr(c_int, [f.shape[3] for f in feats])
+    S = L.arr(c_float, [1.0 / s for s in strides])
+    return H, W, S
+
+
+def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
+    lib = L.load()
+    L.dev_check(rois, *feats)
+    feats = [_nhwc(f) for f in feats]
+    rois = rois.float().contiguous()
+    K, C = rois.shape[0], feats[0].shape[1]
+    out = empty_nhwc(n_rot * K, C, P, P, feats[0].dtype, rois.device)
+    if K == 0:
+        return out
+    H, W, S = _level_args(feats, strides)
+    fp = L.arr(c_void_p, [f.data_ptr() for f in feats])
+    L.check(lib.loft_roi_align_fwd(fp, H, W, S, len(feats), int(finest_scale), C, L.dtype_code(feats[0]), L.ptr(rois),
+                                   K, int(P), int(n_rot), L.ptr(out), L.stream()), 'loft_roi_align_fwd')
+    return out
+
+
+def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_rot=1, grad_feats=None):
+    """Accumulates into fp32 NHWC buffers (created zeroed when not supplied) and returns them."""
+    lib = L.load()
+    L.dev_check(grad_out, rois)
+    grad_out = _nhwc(grad_out)
+    rois = rois.float().contiguous()
+    K, C = rois.shape[0], grad_out.shape[1]
+    if grad_feats is None:
+        grad_feats = [zeros_nhwc(s[0], s[1], s[2], s[3], torch.float32, rois.device) for s in feat_shapes]
+    if K == 0:
+        return grad_feats
+    H = L.arr(c_int, [s[2] for s in feat_shapes])
+    W = L.arr(c_int, [s[3] for s in feat_shapes])
+    S = L.arr(c_float, [1.0 / s for s in strides])
+    gp = L.arr(c_void_p, [g.data_ptr() for g in grad_feats])
+    L.check(lib.loft_roi_align_bwd(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
+                                   L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), L.stream()),
+            'loft_roi_align_bwd')
+    return grad_feats
+
+
+class _RoIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, P, strides, finest_scale, n_rot, *feats):
+        ctx.save_for_backward(rois)
+        ctx.meta = (P, tuple(strides), finest_scale, n_rot, [tuple(f.shape) for f in feats], feats[0].dtype)
+        return roi_align_fwd(list(feats), rois, P, strides, finest_scale, n_rot)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        P, strides, fs, n_rot, shapes, dt = ctx.meta
+        g = g.contiguous(memory_format=torch.channels_last)
+        grads = roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot)
+        return (None, None, None, None, None) + tuple(x.to(dt) for x in grads)
+
+
+def roi_align(feats, rois, P, strides, finest_scale=56, n_rot=1):
+    """Differentiable multi-level RoIAlign (SingleRoIExtractor.forward in one launch)."""
+    return _RoIAlign.apply(rois, P, tuple(strides), finest_scale, n_rot, *feats)
+
+
+def map_roi_levels(rois, num_levels=4, finest_scale=56):
+    lib = L.load()
+    L.dev_check(rois)
+    rois = rois.float().contiguous()
+    out = torch.empty(rois.shape[0], dtype=torch.int32, device=rois.device)
+    L.check(lib.loft_map_roi_levels(L.ptr(rois), rois.shape[0], num_levels, finest_scale, L.ptr(out), L.stream()),
+            'loft_map_roi_levels')
+    return out
+
+
+# ------------------------------------------------------------------ NMS / sort
+
+def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segment=None):
+    """boxes_sorted [T,4] fp32 sorted (score desc, index asc) inside each segment;
+    seg_offsets int64 [S+1] (device).  -> keep mask uint8 [T]."""
+    lib = L.load()
+    L.dev_check(boxes_sorted, seg_offsets, seg_shift)
+    boxes_sorted = boxes_sorted.float().contiguous()
+    T = boxes_sorted.shape[0]
+    S = seg_offsets.numel() - 1
+    keep = torch.zeros(T, dtype=torch.uint8, device=boxes_sorted.device)
+    if T == 0 or S <= 0:
+        return keep
+    if max_segment is None:
+        max_segment = int((seg_offsets[1:] - seg_offsets[:-1]).max().item())
+    ws = torch.empty(lib.loft_nms_workspace_bytes(T, max_segment), dtype=torch.uint8, device=boxes_sorted.device)
+    L.check(lib.loft_nms_segmented(L.ptr(boxes_sorted), L.ptr(seg_offsets), L.ptr(seg_shift), S, c_int64(T),
+                                   c_int64(max_segment), c_float(iou_thr), L.ptr(ws), L.ptr(keep), L.stream()),
+            'loft_nms_segmented')
+    return keep
+
+
+def segmented_sort_desc(keys, seg_offsets, values=None):
+    """Stable descending sort inside each segment -> (sorted_keys, sorted_values int32)."""
+    lib = L.load()
+    L.dev_check(keys, seg_offsets)
+    keys = keys.float().contiguous()
+    n = keys.numel()
+    S = seg_offsets.numel() - 1
+    if values is None:
+        values = torch.arange(n, dtype=torch.int32, device=keys.device)
+    values = values.to(torch.int32).contiguous()
+    ko, vo = torch.empty_like(keys), torch.empty_like(values)
+    if n == 0:
+        return ko, vo
+    nbytes = c_int64(0)
+    L.check(lib.loft_segmented_sort_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), c_int64(n), S,
+                                         L.ptr(seg_offsets), c_void_p(0), ctypes.byref(nbytes), L.stream()),
+            'loft_segmented_sort_desc(query)')
+    ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=keys.device)
+    L.check(lib.loft_segmented_sort_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), c_int64(n), S,
+                                         L.ptr(seg_offsets), L.ptr(ws), ctypes.byref(nbytes), L.stream()),
+            'loft_segmented_sort_desc')
+    return ko, vo
+
+
+def nms(boxes, scores, iou_thr):
+    """mmcv.ops.nms contract: -> (dets [M,5], keep [M] int64 in score-descending order)."""
+    n = boxes.shape[0]
+    off = torch.tensor([0, n], dtype=torch.int64, device=boxes.device)
+    _, order = segmented_sort_desc(scores, off)
+    order = order.long()
+    keep_mask = nms_segmented(boxes[order], off, iou_thr, max_segment=n)
+    keep = order[keep_mask.bool()]
+    return torch.cat([boxes[keep], scores[keep, None]], dim=1), keep

@@ -1,0 +1,127 @@
+"""GPU parity: HIP RoIAlign / NMS / sort vs the plain-C oracle (oracle/loft_oracle.c)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cops, ops_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_rois(rng, n, B, size, wmin=4, wmax=400):
+    w = np.exp(rng.uniform(np.log(wmin), np.log(wmax), n))
+    h = np.exp(rng.uniform(np.log(wmin), np.log(wmax), n))
+    x1 = rng.uniform(-20, size - 8, n)
+    y1 = rng.uniform(-20, size - 8, n)
+    b = rng.randint(0, B, n)
+    return torch.tensor(np.stack([b, x1, y1, x1 + w, y1 + h], 1), dtype=torch.float32)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('P,n_rot', [(7, 1), (14, 1), (7, 4)])
+def test_roi_align_fwd_bwd(dtype, P, n_rot):
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(0)
+    B, C, size = 2, 64, 256
+    strides = [4, 8, 16, 32]
+    torch.manual_seed(0)
+    feats = [torch.randn(B, C, size // s, size // s) for s in strides]
+    if dtype == torch.bfloat16:
+        feats = [f.bfloat16().float() for f in feats]  # oracle sees the same rounded inputs
+    rois = _rand_rois(rng, 300, B, size)
+    # edge cases: zero-size box, box fully outside, box covering the image
+    rois[0, 1:] = torch.tensor([10., 10., 10., 10.])
+    rois[1, 1:] = torch.tensor([-500., -500., -400., -400.])
+    rois[2, 1:] = torch.tensor([0., 0., float(size), float(size)])
+    ref = ops_ref.roi_extract(feats, rois, P, strides)
+    dfeats = [f.to('cuda', dtype).contiguous(memory_format=torch.channels_last) for f in feats]
+    out = K.roi_align_fwd(dfeats, rois.cuda(), P, strides, n_rot=n_rot)
+    assert out.shape == (n_rot * rois.shape[0], C, P, P)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    for r in range(n_rot):
+        got = out[r * rois.shape[0]:(r + 1) * rois.shape[0]].float().cpu()
+        want = torch.rot90(ref, r, (2, 3))
+        err = (got - want).abs().max().item()
+        assert err <= tol * max(1.0, want.abs().max().item()), (r, err)
+    # level map
+    lv = K.map_roi_levels(rois.cuda()).cpu().long()
+    assert torch.equal(lv, ops_ref.map_roi_levels(rois))
+    # backward
+    g = torch.randn(n_rot * rois.shape[0], C, P, P)
+    if dtype == torch.bfloat16:
+        g = g.bfloat16().float()
+    gsum = sum(torch.rot90(g[r * rois.shape[0]:(r + 1) * rois.shape[0]], -r, (2, 3)) for r in range(n_rot))
+    lv = ops_ref.map_roi_levels(rois)
+    want_grads = []
+    for i, s in enumerate(strides):
+        m = lv == i
+        want_grads.append(cops.roi_align_bwd(gsum[m], rois[m], feats[i].shape, 1.0 / s) if m.any()
+                          else torch.zeros_like(feats[i]))
+    got_grads = K.roi_align_bwd(g.to('cuda', dtype).contiguous(memory_format=torch.channels_last), rois.cuda(),
+                                [tuple(f.shape) for f in feats], P, strides, n_rot=n_rot)
+    for gg, ww in zip(got_grads, want_grads):
+        err = (gg.cpu() - ww).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ww.abs().max().item()), err
+
+
+def test_roi_align_empty():
+    from bonai_amd import kernels as K
+    f = [torch.randn(1, 8, 16, 16, device='cuda').contiguous(memory_format=torch.channels_last)]
+    out = K.roi_align_fwd(f, torch.zeros(0, 5, device='cuda'), 7, [4])
+    assert out.shape == (0, 8, 7, 7)
+
+
+def _rand_boxes(rng, n, size=1024.):
+    cx, cy = rng.uniform(0, size, n), rng.uniform(0, size, n)
+    w, h = rng.uniform(8, 200, n), rng.uniform(8, 200, n)
+    b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).clip(0, size)
+    return torch.tensor(b, dtype=torch.float32)
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 64, 65, 1000, 12768])
+def test_nms_bit_exact(n):
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(n)
+    boxes = _rand_boxes(rng, n)
+    # quantised scores force many exact ties -> exercises the (score desc, index asc) order
+    scores = torch.tensor(np.round(rng.uniform(0, 1, n), 2), dtype=torch.float32)
+    if n > 10:
+        boxes[5] = boxes[3]          # identical boxes
+        scores[5] = scores[3]
+    dets_ref, keep_ref = cops.nms(boxes, scores, 0.7)
+    dets, keep = K.nms(boxes.cuda(), scores.cuda(), 0.7)
+    assert torch.equal(keep.cpu(), keep_ref)
+    assert torch.equal(dets.cpu(), dets_ref)
+
+
+def test_nms_segmented_matches_batched():
+    """Segment-wise NMS + global re-sort == mmcv batched_nms on the shifted boxes."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(7)
+    sizes = [3000, 3000, 1500, 700, 0, 64]
+    boxes = torch.cat([_rand_boxes(rng, s) for s in sizes])
+    scores = torch.tensor(np.round(rng.uniform(0, 1, boxes.shape[0]), 3), dtype=torch.float32)
+    ids = torch.cat([torch.full((s,), i, dtype=torch.long) for i, s in enumerate(sizes)])
+    dets_ref, keep_ref = cops.batched_nms(boxes, scores, ids, dict(type='nms', iou_threshold=0.7))
+    off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64).cuda()
+    ks, order = K.segmented_sort_desc(scores.cuda(), off)
+    order = order.long()
+    shift = (torch.arange(len(sizes), dtype=torch.float32) * (boxes.max() + 1)).cuda()
+    keep_mask = K.nms_segmented(boxes.cuda()[order], off, 0.7, seg_shift=shift)
+    kept = order[keep_mask.bool()]
+    # global order: score desc, original index asc
+    kept_cpu = kept.cpu()
+    kk = sorted(kept_cpu.tolist(), key=lambda i: (-scores[i].item(), i))
+    assert kk == keep_ref.tolist()
+
+
+def test_sort_stability():
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(3)
+    n = 200000
+    keys = torch.tensor(np.round(rng.randn(n), 1), dtype=torch.float32)
+    off = torch.tensor([0, 70000, 70000, n], dtype=torch.int64)
+    ks, vs = K.segmented_sort_desc(keys.cuda(), off.cuda())
+    for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
+        want = cops.argsort_desc(keys[a:b]) + a
+        assert torch.equal(vs[a:b].cpu().long(), want)

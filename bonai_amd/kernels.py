@@ -29,7 +29,7 @@ def empty_nhwc(n, c, h, w, dtype, device):
 
 
 def zeros_nhwc(n, c, h, w, dtype, device):
-    return torch.zeros((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
+    return torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last).zero_()
 
 
 # ------------------------------------------------------------------ RoIAlign

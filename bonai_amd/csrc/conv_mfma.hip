@@ -1,0 +1,415 @@
+// conv_mfma.hip -- im2col-free NHWC "tap" convolution on gfx950 MFMA (bf16 in, fp32 accumulate).
+//
+// One kernel serves every dense contraction on the LOFT path
+// (reference: nn.Conv2d/cuDNN call sites in mmdet/models/backbones/resnet.py:266-298,
+//  necks/fpn.py:170-199, dense_heads/rpn_head.py:38-44, roi_heads/mask_heads/fcn_mask_head.py:118-126,
+//  roi_heads/attribute_heads/offset_head_expand_feature.py:134-161, bbox_heads/convfc_bbox_head.py:135-173):
+//
+//   out[b, oy*os+oo_y, ox*os+oo_x, n] = act( bias[n] + res[...] +
+//        sum_t sum_c src[b, oy*ss+dy[t], ox*ss+dx[t], c] * wgt[wt[t]][n][c] )
+//
+//   * forward conv RxS/stride s/pad p : taps (r-p, s-p), ss = s, os = 1
+//   * data-gradient (dgrad), stride 1 : taps (p-r, p-s), weights packed transposed [t][Cin][Cout]
+//   * dgrad of a stride-2 conv        : 4 output-parity classes, each its own tap subset (os = 2)
+//   * ConvTranspose2d(k=2,s=2)        : 4 parity classes of one tap each (os = 2)
+//   * nn.Linear                        : one tap, H = W = 1
+//   * FOA's 4 rotation branches        : blockIdx.z = branch ("group") with per-group strides
+//
+// GEMM view: M = B*OH*OW output pixels, N = Cout, K = T*Cin.  The K loop walks (tap, 64-channel
+// chunk); a chunk of one tap is a contiguous 128-byte run of the shifted source pixel, so the A
+// tile is gathered straight from the NHWC activation with `global_load_lds` (16 B per lane, LDS
+// destination lane-linear) -- no im2col buffer, out-of-image taps read a zero page.
+//
+// CDNA4 mapping: 256 threads = 4 wave64; block tile BMxBNx64, double-buffered in LDS (64 KiB ->
+// 2 blocks/CU); v_mfma_f32_32x32x16_bf16 with the WEIGHT tile as the A operand and the activation
+// tile as the B operand so each lane ends up holding 4 consecutive output channels of one pixel
+// (contiguous NHWC stores).  LDS rows are 128 B; 16-byte chunk q of row r is stored at slot
+// q ^ ((r>>1)&7), applied on the per-lane *global source* address (the LDS image of a glds is
+// lane-linear) and again on the ds_read_b128 address: conflict-free for the 16-lane groups that
+// ds_read_b128 is serviced in.  Roofline: MFMA (dense bf16 2.5 PFLOP/s).
+#include "loft_common.h"
+#include "../../include/loft_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+#define CONV_MAX_TAPS 16
+#define BK 64
+
+struct ConvArgs {
+    const bf16_t* src;
+    const bf16_t* wgt;
+    const float* bias;
+    const bf16_t* residual;
+    void* out;
+    const bf16_t* zero_page;
+    int B, IH, IW, Cin, Cout;
+    int OH, OW, OHf, OWf;
+    int os, oo_y, oo_x, ss;
+    int T;
+    int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    int relu, out_f32, accumulate;
+    long src_gs, wgt_gs, out_gs, bias_gs;
+    int M;
+};
+
+__device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_tap_kernel(const ConvArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // glds instructions per thread per K step
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int g = blockIdx.z;
+    const bf16_t* src = a.src + (long)g * a.src_gs;
+    const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
+
+    // ---- per-thread gather bookkeeping for the rows this thread stages
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    int a_base[A_LOADS], a_y[A_LOADS], a_x[A_LOADS], a_c[A_LOADS];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = i * 32 + wave * 8 + lrow;
+        const int m = m0 + row;
+        a_c[i] = swz(row, lchunk) * 8;
+        if (m < a.M) {
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            a_base[i] = b * a.IH * a.IW;
+            a_y[i] = oy * a.ss;
+            a_x[i] = ox * a.ss;
+        } else {
+            a_base[i] = 0; a_y[i] = -100000; a_x[i] = -100000;
+        }
+    }
+    long b_off[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int row = i * 32 + wave * 8 + lrow;
+        int n = n0 + row;
+        b_off[i] = (n < a.Cout) ? ((long)n * a.Cin + swz(row, lchunk) * 8) : -1;
+    }
+
+    const int kchunks = a.Cin / BK;
+    const int nk = a.T * kchunks;
+
+    auto stage = [&](int kk, int buf) {
+        const int t = kk / kchunks, c0 = (kk - t * kchunks) * BK;
+        const int dy = a.dy[t], dx = a.dx[t];
+        char* abuf = lds + buf * (A_BYTES + B_BYTES);
+        char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+            const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
+            const bf16_t* p = ok ? src + ((long)(a_base[i] + iy * a.IW + ix) * a.Cin + c0 + a_c[i]) : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(abuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+        const bf16_t* wt = wgt + (long)a.wt[t] * a.Cout * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const bf16_t* p = (b_off[i] >= 0) ? wt + b_off[i] : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(bbuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int frow = lane & 31, fq = lane >> 5;
+
+    stage(0, 0);
+    for (int kk = 0; kk < nk; ++kk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
+        const char* abuf = lds + (kk & 1) * (A_BYTES + B_BYTES);
+        const char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks * 2 + fq;
+            bf16x8 wf[NT], xf[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int row = wn * WN + i * 32 + frow;
+                wf[i] = *reinterpret_cast<const bf16x8*>(bbuf + row * 128 + swz(row, q) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int row = wm * WM + j * 32 + frow;
+                xf[j] = *reinterpret_cast<const bf16x8*>(abuf + row * 128 + swz(row, q) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+    const long out_g = (long)g * a.out_gs;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * WM + j * 32 + frow;
+        if (m >= a.M) continue;
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * WN + i * 32 + 8 * gq + 4 * fq;
+                if (n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = out_g + opix * a.Cout + n;
+                if (a.residual) {
+                    float rv[4];
+                    ld4(a.residual + o, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out) + o;
+                    if (a.accumulate) {
+                        float ov[4];
+                        ld4(op, ov);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                    }
+                    st4(op, v);
+                } else {
+                    st4(reinterpret_cast<bf16_t*>(a.out) + o, v);
+                }
+            }
+        }
+    }
+}
+
+LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual, void* out,
+                                   const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                                   int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                                   const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
+                                   int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                                   void* stream) {
+    if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
+    ConvArgs a;
+    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual;
+    a.out = out; a.zero_page = (const bf16_t*)zero_page;
+    a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf;
+    a.os = os; a.oo_y = oo_y; a.oo_x = oo_x; a.ss = ss; a.T = T;
+    for (int t = 0; t < T; ++t) { a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t]; }
+    a.relu = relu; a.out_f32 = out_f32; a.accumulate = accumulate;
+    a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
+    const long M = (long)B * OH * OW;
+    if (M <= 0) return 0;
+    if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    a.M = (int)M;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout % 128 == 0) {
+        dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
+        hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 64), groups);
+        hipLaunchKernelGGL((conv_tap_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, a);
+    }
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================
+// Weight gradient:  dW[wt[t]][n][c] += sum_m  G[b, oy*gos+goy[t], ox*gos+gox[t], n] * X[b, oy*ss+dy[t], ox*ss+dx[t], c]
+//
+// GEMM view: M' = Cout (n), N' = Cin (c), K' = B*OH*OW pixels -- the reduction runs over pixels, and both
+// operands are pixel-major (channels contiguous), i.e. K-strided.  The 64-pixel x 128-channel tiles are
+// staged pixel-major with global_load_lds and consumed through ds_read_b64_tr_b16 (gfx950 LDS transpose
+// read): a 16-lane group turns a [4 pixel][16 channel] block into "4 consecutive k for my channel",
+// which is exactly an MFMA operand quad -- no register shuffles, no transposed copy of the activations.
+// Split-K over pixel ranges (grid.z) with fp32 atomic accumulation into dW (caller zeroes it).
+// Rows are 256 B = one full bank row, so 16-byte chunk q of pixel row r is stored at q ^ ((r&3)<<2).
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradArgs {
+    const bf16_t* g;
+    const bf16_t* x;
+    float* dw;
+    const bf16_t* zero_page;
+    int B, GH, GW, Cout, XH, XW, Cin, OH, OW;
+    int gos, ss, T;
+    int goy[CONV_MAX_TAPS], gox[CONV_MAX_TAPS], dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    long g_gs, x_gs, dw_gs;
+    int M, pix_per_split, ctiles;
+};
+
+__device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
+    // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][128] bf16 tile:
+    // lane l -> channel col0 + (l&31), pixels kbase + 8*(l>>5) + 0..7
+    const int il = lane & 15, gl = lane >> 4;
+    const int col = col0 + 16 * (gl & 1) + (il & 3) * 4;
+    const int r0 = kbase + 8 * (gl >> 1) + (il >> 2);
+    const int r1 = r0 + 4;
+    const char* p0 = tile + r0 * 256 + wswz(r0, col >> 3) * 16 + (col & 7) * 2;
+    const char* p1 = tile + r1 * 256 + wswz(r1, col >> 3) * 16 + (col & 7) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int TILE_BYTES = 64 * 128 * 2;  // 16 KiB
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [buf][G|X]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x / a.ctiles, ct = blockIdx.x - nt * a.ctiles;
+    const int t = blockIdx.y % a.T, grp = blockIdx.y / a.T;
+    const int n0 = nt * 128, c0 = ct * 128;
+    const int mbeg = blockIdx.z * a.pix_per_split;
+    const int mend = min(a.M, mbeg + a.pix_per_split);
+    if (mbeg >= mend) return;
+    const bf16_t* G = a.g + (long)grp * a.g_gs;
+    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const int ohw = a.OH * a.OW;
+    const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
+
+    const int lrow = lane >> 4, lchunk = lane & 15;
+    auto stage = [&](int m_base, int buf) {
+        char* gbuf = lds + buf * 2 * TILE_BYTES;
+        char* xbuf = gbuf + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + wave * 4 + lrow;
+            const int m = m_base + row;
+            const int q = wswz(row, lchunk) * 8;
+            const bf16_t* pg = a.zero_page;
+            const bf16_t* px = a.zero_page;
+            if (m < mend) {
+                const int b = m / ohw, rem = m - b * ohw;
+                const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
+                const int iy = oy * a.ss + dy, ix = ox * a.ss + dx;
+                if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                    pg = G + ((long)(b * a.GH + gy) * a.GW + gx) * a.Cout + n0 + q;
+                    px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + q;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(gbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)px, (lds_ptr_t)(xbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wn = wave >> 1, wc = wave & 1;
+    const int nsteps = (mend - mbeg + 63) / 64;
+    stage(mbeg, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) stage(mbeg + (s + 1) * 64, (s + 1) & 1);
+        const char* gbuf = lds + (s & 1) * 2 * TILE_BYTES;
+        const char* xbuf = gbuf + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 gf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gf[i] = tr_frag(gbuf, ks * 16, wn * 64 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xf[j] = tr_frag(xbuf, ks * 16, wc * 64 + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[i][j][r]);
+            }
+        }
+}
+
+LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                                     int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                     const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                     const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                                     int splits, void* stream) {
+    if (T < 1 || T > CONV_MAX_TAPS || (Cin % 128) || (Cout % 128) || groups < 1) return (int)hipErrorInvalidValue;
+    WgradArgs a;
+    a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
+    a.B = B; a.GH = GH; a.GW = GW; a.Cout = Cout; a.XH = XH; a.XW = XW; a.Cin = Cin; a.OH = OH; a.OW = OW;
+    a.gos = gos; a.ss = ss; a.T = T;
+    for (int t = 0; t < T; ++t) {
+        a.goy[t] = goy_host[t]; a.gox[t] = gox_host[t]; a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t];
+    }
+    a.g_gs = g_gs; a.x_gs = x_gs; a.dw_gs = dw_gs;
+    const long M = (long)B * OH * OW;
+    if (M <= 0) return 0;
+    if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    a.M = (int)M;
+    a.ctiles = Cin / 128;
+    const int tiles = (Cout / 128) * a.ctiles;
+    if (splits <= 0) {  // aim for ~1024 workgroups, at least 4 K-steps each
+        long want = 1024 / ((long)tiles * T * groups);
+        long maxs = (M + 255) / 256;
+        splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+    }
+    int pps = (int)((M + splits - 1) / splits);
+    pps = ((pps + 63) / 64) * 64;
+    a.pix_per_split = pps;
+    splits = (int)((M + pps - 1) / pps);
+    dim3 grid(tiles, T * groups, splits);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

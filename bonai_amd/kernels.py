@@ -164,3 +164,150 @@ def nms(boxes, scores, iou_thr):
     keep_mask = nms_segmented(boxes[order], off, iou_thr, max_segment=n)
     keep = order[keep_mask.bool()]
     return torch.cat([boxes[keep], scores[keep, None]], dim=1), keep
+
+
+# ------------------------------------------------------------------ dense contractions (MFMA)
+
+_ZERO_PAGES = {}
+
+
+def zero_page(device):
+    key = str(device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros(512, dtype=torch.uint8, device=device)
+    return _ZERO_PAGES[key]
+
+
+def pack_w_fwd(w):
+    """[Cout,Cin,R,S] (reference / checkpoint layout) -> bf16 [R*S, Cout, Cin]."""
+    co, ci, r, s = w.shape
+    return w.permute(2, 3, 0, 1).reshape(r * s, co, ci).to(torch.bfloat16).contiguous()
+
+
+def pack_w_dgrad(w):
+    """[Cout,Cin,R,S] -> bf16 [R*S, Cin, Cout] (transposed for the data-gradient pass)."""
+    co, ci, r, s = w.shape
+    return w.permute(2, 3, 1, 0).reshape(r * s, ci, co).to(torch.bfloat16).contiguous()
+
+
+def unpack_dw(dwp, shape):
+    """fp32 [R*S, Cout, Cin] -> [Cout,Cin,R,S]."""
+    co, ci, r, s = shape
+    return dwp.view(r, s, co, ci).permute(2, 3, 0, 1).contiguous()
+
+
+def _bf16(t):
+    if t.dtype != torch.bfloat16:
+        raise L.LoftHipError(f'expected bfloat16, got {t.dtype}')
+    return t
+
+
+def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
+             residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0):
+    """Raw launch of loft_conv_tap_bf16.  taps: list of (dy, dx, weight_tap_index)."""
+    lib = L.load()
+    L.dev_check(src, wgt, out, bias, residual)
+    _bf16(src), _bf16(wgt)
+    if residual is not None:
+        _bf16(residual)
+    T = len(taps)
+    dy = L.arr(c_int, [t[0] for t in taps])
+    dx = L.arr(c_int, [t[1] for t in taps])
+    wt = L.arr(c_int, [t[2] for t in taps])
+    out_f32 = out.dtype == torch.float32
+    if not out_f32:
+        _bf16(out)
+    L.check(lib.loft_conv_tap_bf16(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(out),
+                                   L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
+                                   oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
+                                   c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
+            'loft_conv_tap_bf16')
+    return out
+
+
+def conv_out_size(i, k, stride, pad):
+    return (i + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=torch.bfloat16, groups=1):
+    """x [G*B,Cin,IH,IW] channels_last bf16, wp [G][R*S,Cout,Cin] bf16 -> [G*B,Cout,OH,OW] channels_last."""
+    x = _nhwc(x)
+    GB, Cin, IH, IW = x.shape
+    B = GB // groups
+    Cout = wp.shape[-2]
+    OH, OW = conv_out_size(IH, R, stride, pad), conv_out_size(IW, S, stride, pad)
+    out = empty_nhwc(GB, Cout, OH, OW, out_dtype, x.device)
+    taps = [(r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
+    conv_tap(x, wp, out, B, IH, IW, Cin, Cout, OH, OW, OH, OW, taps, ss=stride, bias=bias, residual=residual,
+             relu=relu, groups=groups, src_gs=B * IH * IW * Cin, wgt_gs=R * S * Cout * Cin,
+             out_gs=B * OH * OW * Cout, bias_gs=Cout)
+    return out
+
+
+def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=torch.bfloat16, groups=1,
+                 out=None, accumulate=False):
+    """g [G*B,Cout,OH,OW] channels_last bf16, wpt [G][R*S,Cin,Cout] -> grad of the conv input [G*B,Cin,IH,IW]."""
+    g = _nhwc(g)
+    GB, Cout, OH, OW = g.shape
+    B = GB // groups
+    Cin = wpt.shape[-2]
+    IH, IW = in_hw
+    if out is None:
+        out = empty_nhwc(GB, Cin, IH, IW, out_dtype, g.device)
+    gs = dict(groups=groups, src_gs=B * OH * OW * Cout, wgt_gs=R * S * Cin * Cout, out_gs=B * IH * IW * Cin)
+    if stride == 1:
+        taps = [(pad - r, pad - s, r * S + s) for r in range(R) for s in range(S)]
+        conv_tap(g, wpt, out, B, OH, OW, Cout, Cin, IH, IW, IH, IW, taps, residual=residual, accumulate=accumulate,
+                 **gs)
+        return out
+    # strided: one launch per output-parity class, each with the taps that reach it
+    covered = 0
+    launches = []
+    for py in range(stride):
+        for px in range(stride):
+            taps = [((py + pad - r) // stride, (px + pad - s) // stride, r * S + s)
+                    for r in range(R) for s in range(S)
+                    if (py + pad - r) % stride == 0 and (px + pad - s) % stride == 0]
+            nh, nw = (IH - py + stride - 1) // stride, (IW - px + stride - 1) // stride
+            if taps and nh > 0 and nw > 0:
+                launches.append((py, px, taps, nh, nw))
+                covered += 1
+    if covered < stride * stride and not accumulate:
+        if residual is not None:
+            out.copy_(residual)
+        else:
+            out.zero_()
+        residual_for_launch = residual
+    else:
+        residual_for_launch = residual
+    for py, px, taps, nh, nw in launches:
+        conv_tap(g, wpt, out, B, OH, OW, Cout, Cin, nh, nw, IH, IW, taps, ss=1, os=stride, oo=(py, px),
+                 residual=residual_for_launch, accumulate=accumulate, **gs)
+    return out
+
+
+def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,
+               splits=0, dw=None):
+    """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index)."""
+    lib = L.load()
+    L.dev_check(g, x)
+    _bf16(g), _bf16(x)
+    if dw is None:
+        dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
+    A = lambda i: L.arr(c_int, [t[i] for t in taps])
+    L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
+                                     XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
+                                     c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.stream()),
+            'loft_conv_wgrad_bf16')
+    return dw
+
+
+def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0):
+    """-> fp32 [G, R*S, Cout, Cin] (packed layout; see unpack_dw)."""
+    g, x = _nhwc(g), _nhwc(x)
+    GB, Cout, OH, OW = g.shape
+    _, Cin, IH, IW = x.shape
+    B = GB // groups
+    taps = [(0, 0, r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
+    return conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
+                      g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits)

@@ -66,6 +66,39 @@ int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_
                              int64_t num_items, int num_segments, const int64_t* seg_offsets, void* workspace,
                              int64_t* workspace_bytes, void* stream);
 
+/* ---- dense contractions on MFMA -----------------------------------------------------------
+ * loft_conv_tap_bf16: im2col-free NHWC convolution / linear layer, bf16 operands, fp32 accumulate.
+ * Replaces the nn.Conv2d (cuDNN) / nn.Linear / nn.ConvTranspose2d calls of
+ * mmdet/models/backbones/resnet.py:266-298, necks/fpn.py:170-199, dense_heads/rpn_head.py:38-44,
+ * roi_heads/bbox_heads/convfc_bbox_head.py:135-173, roi_heads/mask_heads/fcn_mask_head.py:118-126,
+ * roi_heads/attribute_heads/offset_head_expand_feature.py:134-161 -- forward AND data-gradient
+ * (the caller supplies the tap table and the matching weight packing).
+ *
+ *   out[g][b, oy*os+oo_y, ox*os+oo_x, n] = act( bias[g][n] + residual[same index] +
+ *        sum_{t<T} sum_{c<Cin} src[g][b, oy*ss+dy[t], ox*ss+dx[t], c] * wgt[g][wt[t]][n][c] )
+ *
+ * src [B,IH,IW,Cin] bf16; wgt [taps][Cout][Cin] bf16; bias fp32 [Cout] or NULL; residual bf16 with
+ * the layout of out, or NULL; out [B,OHf,OWf,Cout] bf16, or fp32 when out_f32 (accumulate=1 adds to
+ * the existing fp32 contents).  The launch iterates oy<OH, ox<OW; source pixels outside
+ * [0,IH)x[0,IW) contribute zero.  zero_page: >=256 bytes of device zeros.  Cin % 64 == 0,
+ * Cout % 4 == 0, T <= 16.  groups/g: independent problems at the given element strides
+ * (FOA rotation branches).  dy/dx/wt are HOST arrays. */
+int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual, void* out,
+                       const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
+                       int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
+                       const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
+                       int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream);
+/* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
+ *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
+ * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32
+ * [taps][Cout][Cin] accumulated with atomics (caller zeroes).  Cin % 128 == 0, Cout % 128 == 0.
+ * splits <= 0 lets the library choose the split-K factor. */
+int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW,
+                         int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                         const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                         const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""GPU parity: the MFMA tap-convolution family vs torch-CPU fp32 on the same bf16-rounded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _r(t):  # bf16 rounding, kept in fp32 for the reference
+    return t.bfloat16().float()
+
+
+def _cl(t, dtype=torch.bfloat16):
+    return t.to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+
+
+CASES = [
+    # B, Cin, Cout, H, W, R, stride, pad
+    (2, 64, 64, 20, 24, 1, 1, 0),
+    (2, 64, 128, 20, 24, 3, 1, 1),
+    (1, 128, 256, 17, 19, 3, 1, 1),     # ragged M
+    (2, 256, 128, 16, 16, 3, 2, 1),
+    (2, 256, 512, 16, 16, 1, 2, 0),
+    (3, 256, 256, 7, 7, 3, 1, 1),       # RoI-sized maps
+    (1, 128, 16, 12, 12, 1, 1, 0),      # narrow N (RPN cls/reg style, padded to 16)
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,R,stride,pad', CASES)
+def test_conv_fwd(B, Cin, Cout, H, W, R, stride, pad):
+    from bonai_amd import kernels as K
+    torch.manual_seed(1)
+    x = _r(torch.randn(B, Cin, H, W))
+    w = _r(torch.randn(Cout, Cin, R, R) / (Cin * R * R) ** 0.5)
+    b = torch.randn(Cout)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    res = _r(torch.randn_like(ref))
+    out = K.conv2d_fwd(_cl(x), K.pack_w_fwd(w.cuda()), b.cuda(), R, R, stride, pad, out_dtype=torch.float32)
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    out2 = K.conv2d_fwd(_cl(x), K.pack_w_fwd(w.cuda()), b.cuda(), R, R, stride, pad, relu=True, residual=_cl(res))
+    ref2 = F.relu(ref + res)
+    assert (out2.float().cpu() - ref2).abs().max().item() < 1e-2 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,R,stride,pad', [c for c in CASES if c[2] % 64 == 0])
+def test_conv_dgrad(B, Cin, Cout, H, W, R, stride, pad):
+    from bonai_amd import kernels as K
+    torch.manual_seed(2)
+    x = torch.randn(B, Cin, H, W, requires_grad=True)
+    w = _r(torch.randn(Cout, Cin, R, R) / (Cin * R * R) ** 0.5)
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    g = _r(torch.randn_like(y))
+    (ref,) = torch.autograd.grad(y, x, g)
+    out = K.conv2d_dgrad(_cl(g), K.pack_w_dgrad(w.cuda()), (H, W), R, R, stride, pad, out_dtype=torch.float32)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,R,stride,pad', [c for c in CASES if c[1] % 128 == 0 and c[2] % 128 == 0])
+def test_conv_wgrad(B, Cin, Cout, H, W, R, stride, pad):
+    from bonai_amd import kernels as K
+    torch.manual_seed(3)
+    x = _r(torch.randn(B, Cin, H, W))
+    w = torch.randn(Cout, Cin, R, R, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=stride, padding=pad)
+    g = _r(torch.randn_like(y))
+    (ref,) = torch.autograd.grad(y, w, g)
+    for splits in (0, 1, 3):
+        dwp = K.conv2d_wgrad(_cl(g), _cl(x), R, R, stride, pad, splits=splits)
+        got = K.unpack_dw(dwp[0], w.shape).cpu()
+        assert (got - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item()), splits
+
+
+def test_conv_grouped_matches_loop():
+    """FOA-style: 4 independent branches in one launch (blockIdx.z)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(4)
+    G, B, C = 4, 5, 256
+    x = _r(torch.randn(G * B, C, 7, 7))
+    w = _r(torch.randn(G, C, C, 3, 3) / (C * 9) ** 0.5)
+    b = torch.randn(G, C)
+    wp = torch.stack([K.pack_w_fwd(w[i].cuda()) for i in range(G)])
+    out = K.conv2d_fwd(_cl(x), wp, b.cuda().contiguous(), 3, 3, 1, 1, relu=True, out_dtype=torch.float32, groups=G)
+    for i in range(G):
+        ref = F.relu(F.conv2d(x[i * B:(i + 1) * B], w[i], b[i], padding=1))
+        assert (out[i * B:(i + 1) * B].cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_linear_as_conv():
+    from bonai_amd import kernels as K
+    torch.manual_seed(5)
+    N, Kd, O = 300, 12544, 1024
+    x = _r(torch.randn(N, Kd))
+    w = _r(torch.randn(O, Kd) / Kd ** 0.5)
+    b = torch.randn(O)
+    ref = F.relu(F.linear(x, w, b))
+    out = K.conv2d_fwd(_cl(x.view(N, Kd, 1, 1)), K.pack_w_fwd(w.view(O, Kd, 1, 1).cuda()), b.cuda(), 1, 1, relu=True,
+                       out_dtype=torch.float32)
+    assert (out.view(N, O).cpu() - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())

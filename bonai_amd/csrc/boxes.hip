@@ -1,0 +1,344 @@
+// boxes.hip -- box / target arithmetic of the LOFT path on gfx950 (fp32 + integer, HBM/latency bound).
+// Compiled with -ffp-contract=off: IoUs and thresholds round exactly like the CPU restatement
+// (oracle/ops_ref.py), so assignment indices are bit-exact.
+//
+//   iou_assign       MaxIoUAssigner.assign incl. the per-gt low-quality loop, without materialising
+//                    the KxN IoU matrix (mmdet/core/bbox/assigners/max_iou_assigner.py:60-212,
+//                    iou_calculators/iou2d_calculator.py:39-130)
+//   rpn_scores/rpn_decode  sigmoid + gather + delta2bbox of the sorted top-k candidates
+//                    (mmdet/models/dense_heads/rpn_head.py:116-150, delta_xywh_bbox_coder.py:119-197)
+//   delta2bbox / bbox2delta   DeltaXYWHBBoxCoder (delta_xywh_bbox_coder.py:78-197)
+//   foa_targets      4-rotation offset targets (offset_head_expand_feature.py:271-344,
+//                    delta_xy_offset_coder.py:46-65) -- replaces the per-RoI python loop
+//   foa_fuse_decode  offset_fusion('max') + DeltaXYOffsetCoder.decode (offset_head_expand_feature.py:346-448)
+//   mask_target      BitmapMasks.crop_and_resize via RoIAlign(28, aligned) >= 0.5 on device
+//                    (mmdet/core/mask/mask_target.py:33-62, structures.py:261-291) -- replaces the
+//                    GPU->CPU->GPU round trip
+#include "loft_common.h"
+#include "../../include/loft_hip.h"
+
+__device__ __forceinline__ float iou_pair(const float4 g, const float4 b) {
+    // bboxes1 = gt (g), bboxes2 = box (b); iou2d_calculator.py:110-128
+    const float ltx = fmaxf(g.x, b.x), lty = fmaxf(g.y, b.y);
+    const float rbx = fminf(g.z, b.z), rby = fminf(g.w, b.w);
+    const float w = fmaxf(rbx - ltx, 0.f), h = fmaxf(rby - lty, 0.f);
+    const float overlap = w * h;
+    const float a1 = (g.z - g.x) * (g.w - g.y);
+    const float a2 = (b.z - b.x) * (b.w - b.y);
+    const float uni = fmaxf(a1 + a2 - overlap, 1e-6f);
+    return overlap / uni;
+}
+
+// pass 1: per box max/argmax over gts; per gt max over boxes (atomicMax on the non-negative float bits)
+__global__ __launch_bounds__(256) void iou_pass1_kernel(const float* __restrict__ boxes, const int* __restrict__ nbox, int Nmax,
+                                                        const float* __restrict__ gts, const int* __restrict__ ngt, int Kmax,
+                                                        float* __restrict__ max_ov, int32_t* __restrict__ argmax,
+                                                        unsigned* __restrict__ gt_max_bits) {
+    extern __shared__ float4 sg[];
+    const int b = blockIdx.y;
+    const int K = ngt[b], N = nbox[b];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) sg[i] = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + i];
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
+    float best = -1.f;
+    int bi = 0;
+    for (int i = 0; i < K; ++i) {
+        const float v = iou_pair(sg[i], bx);
+        if (v > best) { best = v; bi = i; }
+        atomicMax(gt_max_bits + (long)b * Kmax + i, __float_as_uint(v));
+    }
+    max_ov[(long)b * Nmax + n] = K > 0 ? best : 0.f;
+    argmax[(long)b * Nmax + n] = bi;
+}
+
+__global__ __launch_bounds__(256) void iou_pass2_kernel(const float* __restrict__ boxes, const int* __restrict__ nbox, int Nmax,
+                                                        const float* __restrict__ gts, const int* __restrict__ ngt, int Kmax,
+                                                        const float* __restrict__ max_ov, const int32_t* __restrict__ argmax,
+                                                        const unsigned* __restrict__ gt_max_bits, float pos_thr, float neg_thr,
+                                                        float min_pos, int low_quality, int64_t* __restrict__ gt_inds) {
+    extern __shared__ float4 sg[];
+    float* sgm = reinterpret_cast<float*>(sg + Kmax);
+    const int b = blockIdx.y;
+    const int K = ngt[b], N = nbox[b];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        sg[i] = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + i];
+        sgm[i] = __uint_as_float(gt_max_bits[(long)b * Kmax + i]);
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Nmax) return;
+    if (n >= N) { gt_inds[(long)b * Nmax + n] = -1; return; }
+    if (K == 0) { gt_inds[(long)b * Nmax + n] = 0; return; }
+    const float mo = max_ov[(long)b * Nmax + n];
+    long a = -1;
+    if (mo >= 0.f && mo < neg_thr) a = 0;
+    if (mo >= pos_thr) a = argmax[(long)b * Nmax + n] + 1;
+    if (low_quality) {
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
+        for (int i = 0; i < K; ++i) {
+            const float gm = sgm[i];
+            if (gm >= min_pos && iou_pair(sg[i], bx) == gm) a = i + 1;
+        }
+    }
+    gt_inds[(long)b * Nmax + n] = a;
+}
+
+LOFT_EXPORT int loft_iou_assign(const float* boxes, const int* nbox, int Nmax, const float* gts, const int* ngt, int Kmax,
+                                int B, float pos_thr, float neg_thr, float min_pos, int low_quality, float* max_ov,
+                                int32_t* argmax_ws, uint32_t* gt_max_ws, int64_t* gt_inds, void* stream) {
+    if (B <= 0 || Nmax <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gt_max_ws, 0, sizeof(uint32_t) * (size_t)B * (Kmax > 0 ? Kmax : 1), s);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(loft_cdiv(Nmax, 256), B);
+    const size_t sh = (size_t)(Kmax > 0 ? Kmax : 1) * (sizeof(float4) + sizeof(float));
+    hipLaunchKernelGGL(iou_pass1_kernel, grid, dim3(256), sh, s, boxes, nbox, Nmax, gts, ngt, Kmax, max_ov, argmax_ws,
+                       gt_max_ws);
+    LOFT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(iou_pass2_kernel, grid, dim3(256), sh, s, boxes, nbox, Nmax, gts, ngt, Kmax, max_ov, argmax_ws,
+                       gt_max_ws, pos_thr, neg_thr, min_pos, low_quality, gt_inds);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- DeltaXYWHBBoxCoder ---------------------------------------------------------------------
+__device__ __forceinline__ float4 decode_box(const float4 r, float d0, float d1, float d2, float d3, const float* means,
+                                             const float* stds, float max_ratio, float max_h, float max_w) {
+    const float dx = d0 * stds[0] + means[0], dy = d1 * stds[1] + means[1];
+    float dw = d2 * stds[2] + means[2], dh = d3 * stds[3] + means[3];
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float px = (r.x + r.z) * 0.5f, py = (r.y + r.w) * 0.5f;
+    const float pw = r.z - r.x, ph = r.w - r.y;
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    float4 o;
+    o.x = gx - gw * 0.5f; o.y = gy - gh * 0.5f; o.z = gx + gw * 0.5f; o.w = gy + gh * 0.5f;
+    if (max_w > 0.f) {
+        o.x = fminf(fmaxf(o.x, 0.f), max_w); o.z = fminf(fmaxf(o.z, 0.f), max_w);
+        o.y = fminf(fmaxf(o.y, 0.f), max_h); o.w = fminf(fmaxf(o.w, 0.f), max_h);
+    }
+    return o;
+}
+
+struct Coder4 { float means[4], stds[4]; };
+
+__global__ void delta2bbox_kernel(const float* __restrict__ rois, const float* __restrict__ deltas, long n, Coder4 c,
+                                  float max_ratio, float max_h, float max_w, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = reinterpret_cast<const float4*>(rois)[i];
+    const float4 d = reinterpret_cast<const float4*>(deltas)[i];
+    reinterpret_cast<float4*>(out)[i] = decode_box(r, d.x, d.y, d.z, d.w, c.means, c.stds, max_ratio, max_h, max_w);
+}
+LOFT_EXPORT int loft_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means_host,
+                                const float* stds_host, float wh_ratio_clip, float max_h, float max_w, float* out,
+                                void* stream) {
+    if (n <= 0) return 0;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    const float max_ratio = fabsf(logf(wh_ratio_clip));
+    hipLaunchKernelGGL(delta2bbox_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, deltas, (long)n, c,
+                       max_ratio, max_h, max_w, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bbox2delta_kernel(const float* __restrict__ props, const float* __restrict__ gt, long n, Coder4 c,
+                                  float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = reinterpret_cast<const float4*>(props)[i];
+    const float4 g = reinterpret_cast<const float4*>(gt)[i];
+    const float px = (p.x + p.z) * 0.5f, py = (p.y + p.w) * 0.5f, pw = p.z - p.x, ph = p.w - p.y;
+    const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+    float4 o;
+    o.x = ((gx - px) / pw - c.means[0]) / c.stds[0];
+    o.y = ((gy - py) / ph - c.means[1]) / c.stds[1];
+    o.z = (logf(gw / pw) - c.means[2]) / c.stds[2];
+    o.w = (logf(gh / ph) - c.means[3]) / c.stds[3];
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+LOFT_EXPORT int loft_bbox2delta(const float* proposals, const float* gt, int64_t n, const float* means_host,
+                                const float* stds_host, float* out, void* stream) {
+    if (n <= 0) return 0;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    hipLaunchKernelGGL(bbox2delta_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, proposals, gt, (long)n, c,
+                       out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- RPN proposal candidates -----------------------------------------------------------------
+// head output of one level: fp32 [B,H,W,Cp]; channel a (<A) = objectness logit of anchor a,
+// channel A + 4a + j = delta j of anchor a.  keys[b][lvl_off + pos*A + a] = sigmoid(logit).
+__global__ void rpn_scores_kernel(const float* __restrict__ head, int B, int HW, int Cp, int A, long img_stride, long lvl_off,
+                                  float* __restrict__ keys) {
+    const long n = (long)B * HW * A;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = (int)(i % A);
+    const long p = i / A;
+    const int pos = (int)(p % HW);
+    const int b = (int)(p / HW);
+    const float x = head[((long)b * HW + pos) * Cp + a];
+    keys[(long)b * img_stride + lvl_off + (long)pos * A + a] = 1.f / (1.f + expf(-x));
+}
+LOFT_EXPORT int loft_rpn_scores(const float* head, int B, int H, int W, int Cp, int A, int64_t img_stride, int64_t lvl_off,
+                                float* keys, void* stream) {
+    const long n = (long)B * H * W * A;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(rpn_scores_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, head, B, H * W, Cp, A,
+                       (long)img_stride, (long)lvl_off, keys);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// For level `lvl` of every image: rank r < topk of the sorted candidate list -> anchor + deltas -> box.
+// sorted_idx holds, per (image, level) segment, the within-image candidate index (lvl_off + pos*A + a).
+// out_boxes [B][cand_stride][4] at slot cand_off + r.
+__global__ void rpn_decode_kernel(const float* __restrict__ head, const int32_t* __restrict__ sorted_idx, int B, int H, int W,
+                                  int Cp, int A, long img_stride, long lvl_off, int topk, const float* __restrict__ base_anchors,
+                                  int stride, Coder4 c, float max_ratio, float max_h, float max_w, long cand_stride, long cand_off,
+                                  float* __restrict__ out_boxes) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * topk) return;
+    const int r = (int)(i % topk), b = (int)(i / topk);
+    const int idx = sorted_idx[(long)b * img_stride + lvl_off + r] - (int)lvl_off - (int)((long)b * img_stride);
+    const int a = idx % A, pos = idx / A;
+    const int y = pos / W, x = pos - y * W;
+    const float sx = (float)(x * stride), sy = (float)(y * stride);
+    float4 anc;
+    anc.x = base_anchors[a * 4 + 0] + sx; anc.y = base_anchors[a * 4 + 1] + sy;
+    anc.z = base_anchors[a * 4 + 2] + sx; anc.w = base_anchors[a * 4 + 3] + sy;
+    const float* d = head + ((long)b * H * W + pos) * Cp + A + a * 4;
+    reinterpret_cast<float4*>(out_boxes)[(long)b * cand_stride + cand_off + r] =
+        decode_box(anc, d[0], d[1], d[2], d[3], c.means, c.stds, max_ratio, max_h, max_w);
+}
+LOFT_EXPORT int loft_rpn_decode(const float* head, const int32_t* sorted_idx, int B, int H, int W, int Cp, int A,
+                                int64_t img_stride, int64_t lvl_off, int topk, const float* base_anchors, int stride,
+                                const float* means_host, const float* stds_host, float wh_ratio_clip, float max_h, float max_w,
+                                int64_t cand_stride, int64_t cand_off, float* out_boxes, void* stream) {
+    const long n = (long)B * topk;
+    if (n <= 0) return 0;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, head, sorted_idx, B, H, W,
+                       Cp, A, (long)img_stride, (long)lvl_off, topk, base_anchors, stride, c, fabsf(logf(wh_ratio_clip)), max_h,
+                       max_w, (long)cand_stride, (long)cand_off, out_boxes);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- FOA targets ---------------------------------------------------------------------------------
+// out[k*N + i] = target of RoI i in rotation branch k (k = 0..3 <-> 0/90/180/270 deg).
+// The reference rotates the gt offset by -k*90 deg through a python-float polar round trip; in fp32
+// that equals the exact permutation (x,y),(y,-x),(-x,-y),(-y,x), then encodes
+// (gx/pw, gy/ph)/std, with x' normalised by ph and y' by pw for the 90/270 branches (appendix A.5).
+__global__ void foa_targets_kernel(const float* __restrict__ pos_boxes, const float* __restrict__ gt_off, long n, float std_x,
+                                   float std_y, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = reinterpret_cast<const float4*>(pos_boxes)[i];
+    const float ox = gt_off[2 * i], oy = gt_off[2 * i + 1];
+    const float pw = p.z - p.x, ph = p.w - p.y;
+    const float rx[4] = {ox, oy, -ox, -oy};
+    const float ry[4] = {oy, -ox, -oy, ox};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float tx, ty;
+        if (k & 1) {  // encode(pos, (y',x')) then swap back: x' / ph / std_y... see offset_head_expand_feature.py:295-298
+            const float e0 = (ry[k] / pw) / std_x;  // encoded "x" slot holds y'
+            const float e1 = (rx[k] / ph) / std_y;  // encoded "y" slot holds x'
+            tx = e1; ty = e0;
+        } else {
+            tx = (rx[k] / pw) / std_x;
+            ty = (ry[k] / ph) / std_y;
+        }
+        out[((long)k * n + i) * 2 + 0] = tx;
+        out[((long)k * n + i) * 2 + 1] = ty;
+    }
+}
+LOFT_EXPORT int loft_foa_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_t n, float std_x, float std_y,
+                                 float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(foa_targets_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pos_boxes, pos_gt_offsets,
+                       (long)n, std_x, std_y, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// pred [4N,2] branch-major -> fused+decoded offsets [N,2]
+__global__ void foa_fuse_decode_kernel(const float* __restrict__ pred, const float* __restrict__ boxes, long n, float std_x,
+                                       float std_y, float max_h, float max_w, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b0x = pred[(0 * n + i) * 2], b0y = pred[(0 * n + i) * 2 + 1];
+    const float b1x = pred[(1 * n + i) * 2], b1y = pred[(1 * n + i) * 2 + 1];
+    const float b2x = pred[(2 * n + i) * 2], b2y = pred[(2 * n + i) * 2 + 1];
+    const float b3x = pred[(3 * n + i) * 2], b3y = pred[(3 * n + i) * 2 + 1];
+    const float vx = fmaxf(fmaxf(fabsf(b0x), fabsf(b1y)), fmaxf(fabsf(b2x), fabsf(b3y)));
+    const float vy = fmaxf(fmaxf(fabsf(b0y), fabsf(b1x)), fmaxf(fabsf(b2y), fabsf(b3x)));
+    const float fx = vx * (b0x > 0.f ? 1.f : -1.f), fy = vy * (b0y > 0.f ? 1.f : -1.f);
+    const float4 r = reinterpret_cast<const float4*>(boxes)[i];
+    float gx = (r.z - r.x) * (fx * std_x), gy = (r.w - r.y) * (fy * std_y);
+    gx = fminf(fmaxf(gx, -max_w), max_w);
+    gy = fminf(fmaxf(gy, -max_h), max_h);
+    out[2 * i] = gx; out[2 * i + 1] = gy;
+}
+LOFT_EXPORT int loft_foa_fuse_decode(const float* pred, const float* boxes, int64_t n, float std_x, float std_y, float max_h,
+                                     float max_w, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(foa_fuse_decode_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, boxes, (long)n,
+                       std_x, std_y, max_h, max_w, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- mask targets -------------------------------------------------------------------------------
+// masks u8 [Ktot,H,W]; for RoI i: mask index gt_idx[i], box (already clipped to the image) boxes[i];
+// out[i][S][S] = (RoIAlign_avg_aligned(mask, box, S, scale 1, adaptive grid) >= 0.5) as fp32 0/1.
+__global__ __launch_bounds__(256) void mask_target_kernel(const uint8_t* __restrict__ masks, int H, int W,
+                                                          const float* __restrict__ boxes, const int64_t* __restrict__ gt_idx, int S,
+                                                          float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const float4 r = reinterpret_cast<const float4*>(boxes)[i];
+    const uint8_t* m = masks + (long)gt_idx[i] * H * W;
+    const float start_w = r.x - 0.5f, start_h = r.y - 0.5f;
+    const float rw = (r.z - 0.5f) - start_w, rh = (r.w - 0.5f) - start_h;
+    const float bin_h = rh / (float)S, bin_w = rw / (float)S;
+    const int grid_h = (int)ceilf(rh / (float)S), grid_w = (int)ceilf(rw / (float)S);
+    const int cnt = grid_h * grid_w;
+    const float count = (float)(cnt > 1 ? cnt : 1);
+    for (int t = threadIdx.x; t < S * S; t += blockDim.x) {
+        const int py = t / S, px = t - py * S;
+        float acc = 0.f;
+        for (int iy = 0; iy < grid_h; ++iy) {
+            float y = start_h + py * bin_h + ((float)iy + .5f) * bin_h / (float)grid_h;
+            for (int ix = 0; ix < grid_w; ++ix) {
+                float x = start_w + px * bin_w + ((float)ix + .5f) * bin_w / (float)grid_w;
+                if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+                float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+                int y_low = (int)yy, x_low = (int)xx, y_high, x_high;
+                if (y_low >= H - 1) { y_high = y_low = H - 1; yy = (float)y_low; } else y_high = y_low + 1;
+                if (x_low >= W - 1) { x_high = x_low = W - 1; xx = (float)x_low; } else x_high = x_low + 1;
+                const float ly = yy - (float)y_low, lx = xx - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+                const float v = hy * hx * (float)m[y_low * W + x_low] + hy * lx * (float)m[y_low * W + x_high] +
+                                ly * hx * (float)m[y_high * W + x_low] + ly * lx * (float)m[y_high * W + x_high];
+                acc += v;
+            }
+        }
+        out[(long)i * S * S + t] = (acc / count) >= 0.5f ? 1.f : 0.f;
+    }
+}
+LOFT_EXPORT int loft_mask_target(const uint8_t* masks, int H, int W, const float* boxes, const int64_t* gt_idx, int64_t n,
+                                 int S, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mask_target_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, masks, H, W, boxes, gt_idx, S,
+                       out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

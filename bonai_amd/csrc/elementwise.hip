@@ -1,0 +1,376 @@
+// elementwise.hip -- HBM-bound glue kernels of the LOFT path (gfx950), all NHWC, 16-byte vector accesses.
+//
+//   relu_bwd        : g * (y > 0)                    (autograd of F.relu / ConvModule activation)
+//   colsum          : per-channel sum over pixels     (bias gradients; frozen-BN beta gradients)
+//   upsample_add    : lat[l] += nearest_x2(lat[l+1])  (mmdet/models/necks/fpn.py:176-181) and its adjoint
+//   subsample2      : P6 = max_pool2d(P5, 1, stride=2) (fpn.py:189-191) and its adjoint
+//   maxpool3x3s2    : ResNet stem pooling              (mmdet/models/backbones/resnet.py:631)
+//   stem7x7         : conv 7x7/2 (3->64) + frozen BN + ReLU, fp32 NCHW image -> bf16 NHWC (resnet.py:628-630)
+//   cast / add      : fp32 accumulators -> bf16, bf16 a+b
+//   sgd_momentum    : fused gradient-clip scale + weight-decay + momentum SGD on a flat fp32 arena
+//                     (mmcv OptimizerHook(grad_clip) + torch.optim.SGD, schedule_2x_bonai.py:2-3)
+// Roofline for all of these: HBM bandwidth.
+#include "loft_common.h"
+#include "../../include/loft_hip.h"
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+
+static inline dim3 ew_grid(long nvec) {
+    long b = (nvec + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+// ---- relu backward -------------------------------------------------------------------------
+__global__ void relu_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ out,
+                                long nvec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float gv[8], yv[8];
+        ld8(g + i * 8, gv); ld8(y + i * 8, yv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gv[q] = yv[q] > 0.f ? gv[q] : 0.f;
+        st8(out + i * 8, gv);
+    }
+}
+LOFT_EXPORT int loft_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(relu_bwd_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+                       (const bf16_t*)y, (bf16_t*)out, n / 8);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- column sum: out[c] += sum_m x[m][c]   (x bf16 [M][C], out fp32, atomics; caller zeroes) ----
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, long M, int C, float* __restrict__ out,
+                                                     int rows_per_block) {
+    const int cg = C >> 3;                       // 8-channel groups
+    const int lanes_c = cg < 256 ? cg : 256;     // threads across channels
+    const int rpar = 256 / lanes_c;              // rows handled in parallel
+    const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int c8 = tc; c8 < cg; c8 += lanes_c) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tr < rpar)
+            for (long r = r0 + tr; r < r1; r += rpar) {
+                float v[8];
+                ld8(x + r * C + c8 * 8, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += v[q];
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) unsafeAtomicAdd(out + c8 * 8 + q, acc[q]);
+    }
+}
+LOFT_EXPORT int loft_colsum_bf16(const void* x, int64_t M, int C, float* out, void* stream) {
+    if (M <= 0) return 0;
+    if (C % 8) return (int)hipErrorInvalidValue;
+    int rows = 512;
+    long blocks = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)M,
+                       C, out, rows);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- FPN top-down: fine[b,y,x,:] += coarse[b,y/2,x/2,:] ; adjoint: coarse += sum of the 2x2 block ----
+__global__ void upsample_add_kernel(bf16_t* __restrict__ fine, const bf16_t* __restrict__ coarse, int B, int H, int W,
+                                    int C) {
+    const long nvec = (long)B * H * W * (C >> 3);
+    const int cg = C >> 3;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        long p = i / cg;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        const long ci = (((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C + c8 * 8;
+        float a[8], c[8];
+        ld8(fine + i * 8, a); ld8(coarse + ci, c);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += c[q];
+        st8(fine + i * 8, a);
+    }
+}
+LOFT_EXPORT int loft_upsample2x_add_bf16(void* fine, const void* coarse, int B, int H, int W, int C, void* stream) {
+    if ((C % 8) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(upsample_add_kernel, ew_grid((long)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)fine, (const bf16_t*)coarse, B, H, W, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void downsum_add_kernel(bf16_t* __restrict__ coarse, const bf16_t* __restrict__ fine, int B, int Hc, int Wc,
+                                   int C) {
+    const int cg = C >> 3;
+    const long nvec = (long)B * Hc * Wc * cg;
+    const int W = Wc * 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        long p = i / cg;
+        const int x = (int)(p % Wc); p /= Wc;
+        const int y = (int)(p % Hc);
+        const int b = (int)(p / Hc);
+        const long f0 = (((long)b * Hc * 2 + y * 2) * W + x * 2) * C + c8 * 8;
+        float a[8], t[8];
+        ld8(coarse + i * 8, a);
+        ld8(fine + f0, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += t[q];
+        ld8(fine + f0 + C, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += t[q];
+        ld8(fine + f0 + (long)W * C, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += t[q];
+        ld8(fine + f0 + (long)W * C + C, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += t[q];
+        st8(coarse + i * 8, a);
+    }
+}
+LOFT_EXPORT int loft_downsum2x_add_bf16(void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(downsum_add_kernel, ew_grid((long)B * Hc * Wc * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)coarse, (const bf16_t*)fine, B, Hc, Wc, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stride-2 subsample (P6) and its adjoint (scatter-add into the even positions) ----
+__global__ void subsample2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int Ho, int Wo, int Hi,
+                                  int Wi, int C, int adjoint) {
+    const int cg = C >> 3;
+    const long nvec = (long)B * Ho * Wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        long p = i / cg;
+        const int x = (int)(p % Wo); p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const long big = (((long)b * Hi + y * 2) * Wi + x * 2) * C + c8 * 8;
+        float v[8];
+        if (!adjoint) {
+            ld8(src + big, v);
+            st8(dst + i * 8, v);
+        } else {  // dst (big) += src (small)
+            float a[8];
+            ld8(src + i * 8, v); ld8(dst + big, a);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += v[q];
+            st8(dst + big, a);
+        }
+    }
+}
+LOFT_EXPORT int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, int adjoint,
+                                     void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(subsample2_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, B, Ho, Wo, Hi, Wi, C, adjoint);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- max pool 3x3 stride 2 pad 1 (forward only: it sits in the frozen stem) ----
+__global__ void maxpool3x3s2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int Hi, int Wi, int Ho,
+                                    int Wo, int C) {
+    const int cg = C >> 3;
+    const long nvec = (long)B * Ho * Wo * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        long p = i / cg;
+        const int x = (int)(p % Wo); p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -3.0e38f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = y * 2 + dy;
+            if (iy < 0 || iy >= Hi) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = x * 2 + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                float v[8];
+                ld8(src + (((long)b * Hi + iy) * Wi + ix) * C + c8 * 8, v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], v[q]);
+            }
+        }
+        st8(dst + i * 8, m);
+    }
+}
+LOFT_EXPORT int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, Ho, Wo, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stem: conv 7x7 stride 2 pad 3, 3 -> 64, + folded frozen BN (scale/shift) + ReLU ----
+// img fp32 NCHW [B,3,H,W] (what the reference's data pipeline hands over); w fp32 [64][3][7][7];
+// out bf16 NHWC [B,H/2,W/2,64].  Block = 16x16 output pixels; the 37x37x3 input patch and the
+// 64x147 weights live in LDS; each thread produces one pixel x 64 channels in 4 passes of 16.
+__global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      bf16_t* __restrict__ out, int B, int H, int W, int Ho, int Wo) {
+    __shared__ float patch[3][37][38];
+    __shared__ float wl[147][64];  // [k][oc]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int oc = i / 147, k = i - oc * 147;
+        wl[k][oc] = w[i];
+    }
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = tid; i < 3 * 37 * 37; i += 256) {
+        const int c = i / (37 * 37), r = i - c * 37 * 37;
+        const int py = r / 37, px = r - py * 37;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((long)b * 3 + c) * H + iy) * W + ix];
+        patch[c][py][px] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= Ho || ox >= Wo) return;
+    bf16_t* op = out + (((long)b * Ho + oy) * Wo + ox) * 64;
+    for (int pass = 0; pass < 4; ++pass) {
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int s = 0; s < 7; ++s) {
+                    const float v = patch[c][ty * 2 + r][tx * 2 + s];
+                    const float* wk = &wl[(c * 7 + r) * 7 + s][pass * 16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = fmaf(v, wk[q], acc[q]);
+                }
+        float o[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int oc = pass * 16 + q;
+            o[q] = fmaxf(acc[q] * scale[oc] + shift[oc], 0.f);
+        }
+        st8(op + pass * 16, o);
+        st8(op + pass * 16 + 8, o + 8);
+    }
+}
+LOFT_EXPORT int loft_stem7x7_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out,
+                                     int B, int H, int W, void* stream) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    dim3 grid(loft_cdiv(Wo, 16), loft_cdiv(Ho, 16), B);
+    hipLaunchKernelGGL(stem7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, w, scale, shift, (bf16_t*)out, B, H, W,
+                       Ho, Wo);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- casts / adds ----
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long nvec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float v[8];
+        float4 a = *reinterpret_cast<const float4*>(src + i * 8);
+        float4 b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        st8(dst + i * 8, v);
+    }
+}
+LOFT_EXPORT int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 8);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+                                long nvec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        ld8(a + i * 8, x); ld8(b + i * 8, y);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] += y[q];
+        st8(out + i * 8, x);
+    }
+}
+LOFT_EXPORT int loft_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_bf16_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)out, n / 8);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- optimizer: sum of squares (for clip_grad_norm_) and fused SGD step on a flat fp32 arena ----
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        acc += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+LOFT_EXPORT int loft_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sumsq_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// p, g, m: flat fp32 [n].  gnorm_sq: device scalar (sum of squares of ALL grads, after all-reduce
+// averaging).  clip = max_norm / (norm + 1e-6) if norm > max_norm else 1 (torch clip_grad_norm_).
+// torch.optim.SGD: d = g*clip + wd*p ; m = mu*m + d ; p -= lr*m   (first step m = d is the caller's
+// business: start from m = 0 and it is identical).
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n,
+                           const float* __restrict__ gnorm_sq, float max_norm, float lr, float mu, float wd,
+                           float gscale) {
+    float clip = 1.f;
+    if (max_norm > 0.f) {
+        const float norm = sqrtf(*gnorm_sq) * gscale;
+        if (norm > max_norm) clip = max_norm / (norm + 1e-6f);
+    }
+    const float s = clip * gscale;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float d = g[i] * s + wd * pv;
+        const float mv = mu * m[i] + d;
+        m[i] = mv;
+        p[i] = pv - lr * mv;
+    }
+}
+LOFT_EXPORT int loft_sgd_momentum_f32(float* p, const float* g, float* m, int64_t n, const float* gnorm_sq, float max_norm,
+                                      float lr, float momentum, float weight_decay, float grad_scale, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sgd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, (long)n, gnorm_sq, max_norm, lr,
+                       momentum, weight_decay, grad_scale);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

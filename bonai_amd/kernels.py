@@ -311,3 +311,218 @@ def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0):
     taps = [(0, 0, r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
     return conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
                       g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits)
+
+
+# ------------------------------------------------------------------ HBM-bound glue
+
+def relu_bwd(g, y):
+    lib = L.load()
+    L.dev_check(g, y)
+    out = torch.empty_like(g)
+    L.check(lib.loft_relu_bwd_bf16(L.ptr(_bf16(g)), L.ptr(_bf16(y)), L.ptr(out), c_int64(g.numel()), L.stream()),
+            'loft_relu_bwd_bf16')
+    return out
+
+
+def colsum(x2d_like, C):
+    """x: any bf16 tensor whose memory is [M][C] -> fp32 [C]."""
+    lib = L.load()
+    L.dev_check(x2d_like)
+    out = torch.zeros(C, dtype=torch.float32, device=x2d_like.device)
+    L.check(lib.loft_colsum_bf16(L.ptr(_bf16(x2d_like)), c_int64(x2d_like.numel() // C), C, L.ptr(out), L.stream()),
+            'loft_colsum_bf16')
+    return out
+
+
+def upsample2x_add_(fine, coarse):
+    lib = L.load()
+    fine, coarse = _nhwc(fine), _nhwc(coarse)
+    B, C, H, W = fine.shape
+    L.check(lib.loft_upsample2x_add_bf16(L.ptr(_bf16(fine)), L.ptr(_bf16(coarse)), B, H, W, C, L.stream()),
+            'loft_upsample2x_add_bf16')
+    return fine
+
+
+def downsum2x_add_(coarse, fine):
+    lib = L.load()
+    fine, coarse = _nhwc(fine), _nhwc(coarse)
+    B, C, Hc, Wc = coarse.shape
+    L.check(lib.loft_downsum2x_add_bf16(L.ptr(_bf16(coarse)), L.ptr(_bf16(fine)), B, Hc, Wc, C, L.stream()),
+            'loft_downsum2x_add_bf16')
+    return coarse
+
+
+def subsample2(x):
+    lib = L.load()
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = empty_nhwc(B, C, Ho, Wo, x.dtype, x.device)
+    L.check(lib.loft_subsample2_bf16(L.ptr(_bf16(x)), L.ptr(out), B, Ho, Wo, H, W, C, 0, L.stream()),
+            'loft_subsample2_bf16')
+    return out
+
+
+def subsample2_adjoint_add_(big, small):
+    lib = L.load()
+    big, small = _nhwc(big), _nhwc(small)
+    B, C, H, W = big.shape
+    L.check(lib.loft_subsample2_bf16(L.ptr(_bf16(small)), L.ptr(_bf16(big)), B, small.shape[2], small.shape[3], H, W, C,
+                                     1, L.stream()), 'loft_subsample2_bf16(adjoint)')
+    return big
+
+
+def maxpool3x3s2(x):
+    lib = L.load()
+    x = _nhwc(x)
+    B, C, H, W = x.shape
+    out = empty_nhwc(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.dtype, x.device)
+    L.check(lib.loft_maxpool3x3s2_bf16(L.ptr(_bf16(x)), L.ptr(out), B, H, W, C, L.stream()), 'loft_maxpool3x3s2_bf16')
+    return out
+
+
+def stem7x7_bn_relu(img, w, scale, shift):
+    """img fp32 NCHW [B,3,H,W] -> bf16 channels_last [B,64,H/2,W/2]."""
+    lib = L.load()
+    L.dev_check(img, w, scale, shift)
+    img = img.float().contiguous()
+    w, scale, shift = w.float().contiguous(), scale.float().contiguous(), shift.float().contiguous()
+    B, _, H, W = img.shape
+    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, torch.bfloat16, img.device)
+    L.check(lib.loft_stem7x7_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale),
+                                     L.ptr(shift), L.ptr(out), B, H, W, L.stream()),
+            'loft_stem7x7_bn_relu')
+    return out
+
+
+def cast_bf16(x_f32):
+    lib = L.load()
+    L.dev_check(x_f32)
+    out = torch.empty_like(x_f32, dtype=torch.bfloat16)
+    L.check(lib.loft_cast_f32_to_bf16(L.ptr(x_f32), L.ptr(out), c_int64(x_f32.numel()), L.stream()),
+            'loft_cast_f32_to_bf16')
+    return out
+
+
+def add_bf16(a, b):
+    lib = L.load()
+    L.dev_check(a, b)
+    out = torch.empty_like(a)
+    L.check(lib.loft_add_bf16(L.ptr(_bf16(a)), L.ptr(_bf16(b)), L.ptr(out), c_int64(a.numel()), L.stream()),
+            'loft_add_bf16')
+    return out
+
+
+def sumsq_(g_flat, out):
+    lib = L.load()
+    L.check(lib.loft_sumsq_f32(L.ptr(g_flat), c_int64(g_flat.numel()), L.ptr(out), L.stream()), 'loft_sumsq_f32')
+    return out
+
+
+def sgd_momentum_(p, g, m, gnorm_sq, max_norm, lr, momentum, weight_decay, grad_scale=1.0):
+    lib = L.load()
+    L.dev_check(p, g, m, gnorm_sq)
+    L.check(lib.loft_sgd_momentum_f32(L.ptr(p), L.ptr(g), L.ptr(m), c_int64(p.numel()), L.ptr(gnorm_sq),
+                                      c_float(max_norm), c_float(lr), c_float(momentum), c_float(weight_decay),
+                                      c_float(grad_scale), L.stream()), 'loft_sgd_momentum_f32')
+
+
+# ------------------------------------------------------------------ boxes / targets
+
+def iou_assign(boxes, nbox, gts, ngt, pos_thr, neg_thr, min_pos, low_quality=True):
+    """boxes [B,N,4], nbox int32 [B], gts [B,K,4], ngt int32 [B] -> (gt_inds int64 [B,N], max_ov [B,N])."""
+    lib = L.load()
+    L.dev_check(boxes, nbox, gts, ngt)
+    boxes, gts = boxes.float().contiguous(), gts.float().contiguous()
+    B, N = boxes.shape[:2]
+    K = gts.shape[1]
+    dev = boxes.device
+    max_ov = torch.empty(B, N, dtype=torch.float32, device=dev)
+    argmax = torch.empty(B, N, dtype=torch.int32, device=dev)
+    gtmax = torch.empty(B, max(K, 1), dtype=torch.int32, device=dev)
+    gt_inds = torch.empty(B, N, dtype=torch.int64, device=dev)
+    nbox_i, ngt_i = nbox.int().contiguous(), ngt.int().contiguous()  # keep alive across the launch
+    L.check(lib.loft_iou_assign(L.ptr(boxes), L.ptr(nbox_i), N, L.ptr(gts), L.ptr(ngt_i), K, B,
+                                c_float(pos_thr), c_float(neg_thr), c_float(min_pos), int(low_quality), L.ptr(max_ov),
+                                L.ptr(argmax), L.ptr(gtmax), L.ptr(gt_inds), L.stream()), 'loft_iou_assign')
+    return gt_inds, max_ov
+
+
+def delta2bbox(rois, deltas, means, stds, max_shape=None, wh_ratio_clip=16 / 1000):
+    lib = L.load()
+    L.dev_check(rois, deltas)
+    rois, deltas = rois.float().contiguous(), deltas.float().contiguous()
+    out = torch.empty_like(rois)
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if max_shape is not None else (0.0, 0.0)
+    L.check(lib.loft_delta2bbox(L.ptr(rois), L.ptr(deltas), c_int64(rois.shape[0]), L.arr(c_float, list(means)),
+                                L.arr(c_float, list(stds)), c_float(wh_ratio_clip), c_float(mh), c_float(mw), L.ptr(out),
+                                L.stream()), 'loft_delta2bbox')
+    return out
+
+
+def bbox2delta(proposals, gt, means, stds):
+    lib = L.load()
+    L.dev_check(proposals, gt)
+    proposals, gt = proposals.float().contiguous(), gt.float().contiguous()
+    out = torch.empty_like(proposals)
+    L.check(lib.loft_bbox2delta(L.ptr(proposals), L.ptr(gt), c_int64(proposals.shape[0]), L.arr(c_float, list(means)),
+                                L.arr(c_float, list(stds)), L.ptr(out), L.stream()), 'loft_bbox2delta')
+    return out
+
+
+def rpn_scores(head, A, img_stride, lvl_off, keys):
+    lib = L.load()
+    head = _nhwc(head)
+    B, Cp, H, W = head.shape
+    L.check(lib.loft_rpn_scores(L.ptr(head), B, H, W, Cp, A, c_int64(img_stride), c_int64(lvl_off), L.ptr(keys),
+                                L.stream()), 'loft_rpn_scores')
+
+
+def rpn_decode(head, sorted_idx, A, img_stride, lvl_off, topk, base_anchors, stride, means, stds, max_shape, cand_stride,
+               cand_off, out_boxes, wh_ratio_clip=16 / 1000):
+    lib = L.load()
+    head = _nhwc(head)
+    B, Cp, H, W = head.shape
+    L.check(lib.loft_rpn_decode(L.ptr(head), L.ptr(sorted_idx), B, H, W, Cp, A, c_int64(img_stride), c_int64(lvl_off),
+                                int(topk), L.ptr(base_anchors), int(stride), L.arr(c_float, list(means)),
+                                L.arr(c_float, list(stds)), c_float(wh_ratio_clip), c_float(max_shape[0]),
+                                c_float(max_shape[1]), c_int64(cand_stride), c_int64(cand_off), L.ptr(out_boxes),
+                                L.stream()), 'loft_rpn_decode')
+
+
+def foa_targets(pos_boxes, pos_gt_offsets, stds=(0.5, 0.5)):
+    lib = L.load()
+    L.dev_check(pos_boxes, pos_gt_offsets)
+    pos_boxes, pos_gt_offsets = pos_boxes.float().contiguous(), pos_gt_offsets.float().contiguous()
+    n = pos_boxes.shape[0]
+    out = torch.empty(4 * n, 2, dtype=torch.float32, device=pos_boxes.device)
+    L.check(lib.loft_foa_targets(L.ptr(pos_boxes), L.ptr(pos_gt_offsets), c_int64(n), c_float(stds[0]), c_float(stds[1]),
+                                 L.ptr(out), L.stream()), 'loft_foa_targets')
+    return out
+
+
+def foa_fuse_decode(pred, boxes, stds=(0.5, 0.5), max_shape=(1024, 1024)):
+    lib = L.load()
+    L.dev_check(pred, boxes)
+    pred, boxes = pred.float().contiguous(), boxes[:, :4].float().contiguous()
+    n = boxes.shape[0]
+    out = torch.empty(n, 2, dtype=torch.float32, device=pred.device)
+    L.check(lib.loft_foa_fuse_decode(L.ptr(pred), L.ptr(boxes), c_int64(n), c_float(stds[0]), c_float(stds[1]),
+                                     c_float(max_shape[0]), c_float(max_shape[1]), L.ptr(out), L.stream()),
+            'loft_foa_fuse_decode')
+    return out
+
+
+def mask_target(masks_u8, boxes, gt_idx, S=28):
+    """masks uint8 [K,H,W] (device), boxes [n,4] already clipped to the image, gt_idx int64 [n]."""
+    lib = L.load()
+    L.dev_check(masks_u8, boxes, gt_idx)
+    masks_u8 = masks_u8.contiguous()
+    boxes = boxes.float().contiguous()
+    n = boxes.shape[0]
+    gt_idx = gt_idx.long().contiguous()
+    out = torch.empty(n, S, S, dtype=torch.float32, device=boxes.device)
+    L.check(lib.loft_mask_target(L.ptr(masks_u8), masks_u8.shape[1], masks_u8.shape[2], L.ptr(boxes),
+                                 L.ptr(gt_idx), c_int64(n), S, L.ptr(out), L.stream()),
+            'loft_mask_target')
+    return out

@@ -99,6 +99,72 @@ int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* ze
                          const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
                          void* stream);
 
+/* ---- HBM-bound glue (bf16 NHWC unless noted; n = element counts, multiples of 8) ------------
+ * relu_bwd: out = g * (y > 0)  -- autograd of the ReLUs fused into the conv epilogues
+ *           (mmdet/models/backbones/resnet.py:266-298 `self.relu`, mmcv ConvModule activations).
+ * colsum:   out[c] += sum_m x[m][c] (fp32 atomics; bias / frozen-BN beta gradients).
+ * upsample2x_add / downsum2x_add: FPN top-down `laterals[i-1] += F.interpolate(laterals[i],
+ *           mode='nearest')` (mmdet/models/necks/fpn.py:176-181) and its adjoint.
+ * subsample2: P6 = F.max_pool2d(P5, 1, stride=2) (fpn.py:189-191); adjoint=1 scatter-adds back.
+ * maxpool3x3s2: nn.MaxPool2d(3, 2, 1) of the stem (resnet.py:631), forward only (frozen stage).
+ * stem7x7_bn_relu: conv1 7x7/2 + frozen bn1 + relu (resnet.py:628-630): img fp32 NCHW [B,3,H,W],
+ *           w fp32 [64,3,7,7], scale/shift fp32 [64] (folded BN) -> bf16 NHWC [B,H/2,W/2,64]. */
+int loft_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, void* stream);
+int loft_colsum_bf16(const void* x, int64_t M, int C, float* out, void* stream);
+int loft_upsample2x_add_bf16(void* fine, const void* coarse, int B, int H, int W, int C, void* stream);
+int loft_downsum2x_add_bf16(void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream);
+int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, int adjoint,
+                         void* stream);
+int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream);
+int loft_stem7x7_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out, int B,
+                         int H, int W, void* stream);
+int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int loft_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* Optimizer step of the reference run (mmcv OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)) +
+ * torch.optim.SGD(lr, momentum=0.9, weight_decay=1e-4); configs/_base_/schedules/schedule_2x_bonai.py:2-3)
+ * on one flat fp32 parameter arena: sumsq accumulates sum(g^2) into *out (caller zeroes);
+ * sgd applies g*grad_scale, the clip factor from sqrt(*gnorm_sq)*grad_scale, weight decay, momentum. */
+int loft_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+int loft_sgd_momentum_f32(float* p, const float* g, float* m, int64_t n, const float* gnorm_sq, float max_norm, float lr,
+                          float momentum, float weight_decay, float grad_scale, void* stream);
+
+/* ---- box / target arithmetic (fp32 + integer) -------------------------------------------------
+ * iou_assign: MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:60-212 with
+ *   gt_max_assign_all=True, no ignore regions) for B images at once: boxes [B,Nmax,4] (nbox[b] valid),
+ *   gts [B,Kmax,4] (ngt[b] valid) -> gt_inds int64 [B,Nmax] (0 neg, -1 ignore/padding, i+1 pos),
+ *   max_ov fp32 [B,Nmax].  argmax_ws int32 [B,Nmax], gt_max_ws uint32 [B,Kmax] are workspaces. */
+int loft_iou_assign(const float* boxes, const int* nbox, int Nmax, const float* gts, const int* ngt, int Kmax, int B,
+                    float pos_thr, float neg_thr, float min_pos, int low_quality, float* max_ov, int32_t* argmax_ws,
+                    uint32_t* gt_max_ws, int64_t* gt_inds, void* stream);
+/* DeltaXYWHBBoxCoder.decode / .encode (mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:78-197), [n,4] each;
+ * max_w <= 0 disables the clamp. */
+int loft_delta2bbox(const float* rois, const float* deltas, int64_t n, const float* means_host, const float* stds_host,
+                    float wh_ratio_clip, float max_h, float max_w, float* out, void* stream);
+int loft_bbox2delta(const float* proposals, const float* gt, int64_t n, const float* means_host, const float* stds_host,
+                    float* out, void* stream);
+/* RPN candidate generation for one pyramid level of all B images (rpn_head.py:116-150):
+ * head fp32 [B,H,W,Cp]: channel a<A objectness logit, channel A+4a+j delta j.  rpn_scores writes
+ * sigmoid scores into keys[b*img_stride + lvl_off + pos*A + a]; after loft_segmented_sort_desc over
+ * the (image, level) segments, rpn_decode turns ranks r<topk into boxes (anchor = base_anchors[a] +
+ * (x*stride, y*stride), decoded and clamped) at out_boxes[b*cand_stride + cand_off + r]. */
+int loft_rpn_scores(const float* head, int B, int H, int W, int Cp, int A, int64_t img_stride, int64_t lvl_off,
+                    float* keys, void* stream);
+int loft_rpn_decode(const float* head, const int32_t* sorted_idx, int B, int H, int W, int Cp, int A, int64_t img_stride,
+                    int64_t lvl_off, int topk, const float* base_anchors, int stride, const float* means_host,
+                    const float* stds_host, float wh_ratio_clip, float max_h, float max_w, int64_t cand_stride,
+                    int64_t cand_off, float* out_boxes, void* stream);
+/* FOA: 4-rotation offset targets (offset_head_expand_feature.py:271-344 + delta_xy_offset_coder.py:46-65)
+ * -> out [4n,2] branch-major; and inference fusion + decode (:346-448) pred [4n,2] -> out [n,2]. */
+int loft_foa_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_t n, float std_x, float std_y, float* out,
+                     void* stream);
+int loft_foa_fuse_decode(const float* pred, const float* boxes, int64_t n, float std_x, float std_y, float max_h,
+                         float max_w, float* out, void* stream);
+/* Mask targets on device (mmdet/core/mask/mask_target.py:33-62 -> structures.py:261-291):
+ * masks u8 [K,H,W]; RoI i crops mask gt_idx[i] with box boxes[i] (clipped to the image) to SxS,
+ * RoIAlign(avg, aligned, adaptive grid) >= 0.5 -> out fp32 {0,1} [n,S,S]. */
+int loft_mask_target(const uint8_t* masks, int H, int W, const float* boxes, const int64_t* gt_idx, int64_t n, int S,
+                     float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,7 @@ def _load(path):
     path = os.path.abspath(path)
     ns = runpy.run_path(path)
     cfg = {k: v for k, v in ns.items()
-           if not k.startswith('__') and not callable(v) and type(v).__name__ != 'module'}
+           if (k == BASE_KEY or not k.startswith('_')) and not callable(v) and type(v).__name__ != 'module'}
     bases = cfg.pop(BASE_KEY, [])
     if isinstance(bases, str):
         bases = [bases]

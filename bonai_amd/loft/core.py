@@ -1,0 +1,156 @@
+"""Host-side mirrors of the reference's core box machinery, executing on the HIP kernels:
+AnchorGenerator (mmdet/core/anchor/anchor_generator.py:9-329), DeltaXYWHBBoxCoder
+(core/bbox/coder/delta_xywh_bbox_coder.py:9-197), DeltaXYOffsetCoder (delta_xy_offset_coder.py:19-88),
+MaxIoUAssigner (core/bbox/assigners/max_iou_assigner.py:9-212), RandomSampler
+(core/bbox/samplers/random_sampler.py:8-75 + base_sampler.py:34-101), BboxOverlaps2D.
+
+Everything here is *batched over the images of the step* and stays on the device; the reference's
+per-image python loops and its per-gt low-quality loop are gone (SURVEY.md section 7 "hard parts" (d)).
+"""
+import numpy as np
+import torch
+
+from .. import kernels as K
+from .builder import ANCHOR_GENERATORS, BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, IOU_CALCULATORS
+
+
+@ANCHOR_GENERATORS.register_module()
+class AnchorGenerator:
+    def __init__(self, strides, ratios, scales=None, base_sizes=None, scale_major=True, octave_base_scale=None,
+                 scales_per_octave=None, centers=None, center_offset=0.):
+        if scales is None or octave_base_scale is not None or centers is not None or center_offset != 0. or not scale_major:
+            raise NotImplementedError('only the (scales, ratios, strides) form used by configs/loft_foa')
+        self.strides = [int(s) for s in strides]
+        self.base_sizes = list(self.strides) if base_sizes is None else list(base_sizes)
+        self.scales = torch.tensor(scales, dtype=torch.float32)
+        self.ratios = torch.tensor(ratios, dtype=torch.float32)
+        self.base_anchors = [self._base(b) for b in self.base_sizes]
+        self._cache = {}
+
+    def _base(self, base_size):
+        # anchor_generator.py:142-181, same fp32 op order so anchors are bit-identical
+        h_ratios = torch.sqrt(self.ratios)
+        w_ratios = 1 / h_ratios
+        ws = (base_size * w_ratios[:, None] * self.scales[None, :]).view(-1)
+        hs = (base_size * h_ratios[:, None] * self.scales[None, :]).view(-1)
+        return torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], dim=-1)
+
+    @property
+    def num_levels(self):
+        return len(self.strides)
+
+    @property
+    def num_base_anchors(self):
+        return [b.size(0) for b in self.base_anchors]
+
+    def grid_anchors(self, featmap_sizes, device='cuda'):
+        key = (tuple(tuple(int(v) for v in s) for s in featmap_sizes), str(device))
+        if key not in self._cache:
+            out = []
+            for (h, w), s, ba in zip(featmap_sizes, self.strides, self.base_anchors):
+                sx = torch.arange(0, int(w), dtype=torch.float32) * s
+                sy = torch.arange(0, int(h), dtype=torch.float32) * s
+                xx = sx.repeat(int(h))
+                yy = sy.view(-1, 1).repeat(1, int(w)).view(-1)
+                shifts = torch.stack([xx, yy, xx, yy], dim=-1)
+                out.append((ba[None] + shifts[:, None]).view(-1, 4).to(device))
+            self._cache[key] = out
+        return self._cache[key]
+
+
+class _Coder:
+    def __init__(self, target_means, target_stds):
+        self.means = tuple(float(v) for v in target_means)
+        self.stds = tuple(float(v) for v in target_stds)
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYWHBBoxCoder(_Coder):
+    def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.)):
+        super().__init__(target_means, target_stds)
+
+    def encode(self, bboxes, gt_bboxes):
+        assert bboxes.size(0) == gt_bboxes.size(0)
+        return K.bbox2delta(bboxes, gt_bboxes, self.means, self.stds)
+
+    def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
+        assert pred_bboxes.size(0) == bboxes.size(0) and pred_bboxes.size(1) == 4
+        return K.delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip)
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYOffsetCoder(_Coder):
+    def __init__(self, target_means=(0., 0.), target_stds=(0.5, 0.5)):
+        super().__init__(target_means, target_stds)
+        if self.means != (0., 0.):
+            raise NotImplementedError('non-zero offset means')
+
+
+@IOU_CALCULATORS.register_module()
+class BboxOverlaps2D:
+    pass
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner:
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        if not gt_max_assign_all or ignore_iof_thr > 0 or isinstance(neg_iou_thr, tuple):
+            raise NotImplementedError('assigner variant not used by configs/loft_foa')
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = float(pos_iou_thr), float(neg_iou_thr), float(min_pos_iou)
+        self.match_low_quality = match_low_quality
+
+    def assign_batched(self, boxes, nbox, gts, ngt):
+        """boxes [B,N,4], nbox [B], gts [B,K,4], ngt [B] (device) -> (gt_inds int64 [B,N], max_overlaps [B,N])."""
+        return K.iou_assign(boxes, nbox, gts, ngt, self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou,
+                            self.match_low_quality)
+
+
+@BBOX_SAMPLERS.register_module()
+class RandomSampler:
+    """choice_mode 'random' = uniform without replacement (random_sampler.py:31-55);
+    'first' = lowest indices, the deterministic rule parity runs inject on both sides."""
+    choice_mode = 'random'
+
+    def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+        if neg_pos_ub >= 0:
+            raise NotImplementedError('neg_pos_ub')
+        self.num, self.pos_fraction, self.add_gt_as_proposals = int(num), float(pos_fraction), add_gt_as_proposals
+
+    def sample_batched(self, gt_inds):
+        """gt_inds int64 [B,N].  -> dict(pos_idx [B,P], pos_valid [B,P], neg_idx [B,Q], neg_valid [B,Q]) with the
+        chosen indices in ascending order inside each image (base_sampler.py:86,96 `.unique()`)."""
+        B, N = gt_inds.shape
+        dev = gt_inds.device
+        P = min(int(self.num * self.pos_fraction), N)
+        Q = min(self.num, N)
+        if self.choice_mode == 'first':
+            key = torch.arange(N, dtype=torch.float32, device=dev).expand(B, N)
+        else:
+            key = torch.rand(B, N, device=dev)
+        inf = torch.full((), float('inf'), device=dev)
+        pv, pidx = torch.topk(torch.where(gt_inds > 0, key, inf), P, dim=1, largest=False)
+        pvalid = pv < inf
+        npos = pvalid.sum(1)
+        nv, nidx = torch.topk(torch.where(gt_inds == 0, key, inf), Q, dim=1, largest=False)
+        quota = (self.num - npos)[:, None]
+        nvalid = (nv < inf) & (torch.arange(Q, device=dev)[None] < quota)
+        big = torch.full((), N, device=dev, dtype=pidx.dtype)
+        pidx, order = torch.sort(torch.where(pvalid, pidx, big), dim=1)
+        pvalid = torch.gather(pvalid, 1, order)
+        nidx, order = torch.sort(torch.where(nvalid, nidx, big), dim=1)
+        nvalid = torch.gather(nvalid, 1, order)
+        return dict(pos_idx=pidx.clamp(max=N - 1), pos_valid=pvalid, neg_idx=nidx.clamp(max=N - 1), neg_valid=nvalid)
+
+
+def pad_gts(gt_bboxes, device):
+    """list[[K_i,4]] -> (gts [B,Kmax,4] fp32, ngt int32 [B])."""
+    B = len(gt_bboxes)
+    kmax = max(1, max(int(g.shape[0]) for g in gt_bboxes))
+    gts = torch.zeros(B, kmax, 4, dtype=torch.float32, device=device)
+    for i, g in enumerate(gt_bboxes):
+        if g.shape[0]:
+            gts[i, :g.shape[0]] = g.to(device=device, dtype=torch.float32)
+    ngt = torch.tensor([int(g.shape[0]) for g in gt_bboxes], dtype=torch.int32, device=device)
+    return gts, ngt

@@ -1,0 +1,139 @@
+"""LOFT detector: the reference's two-stage orchestration on the MI355X-native pieces.
+
+Mirrors mmdet/models/detectors/loft.py:11-32, two_stage.py:17-199 and base.py:123-243: same constructor
+(backbone, neck, rpn_head, roi_head, train_cfg, test_cfg, pretrained), same ``forward(img, img_metas,
+return_loss=True, **kw)`` dispatch, ``train_step`` return dict and ``log_vars`` key set.  The eight
+per-key blocking all-reduces + ``.item()`` of base.py:201-206 become ONE 8-float all-reduce and one
+device->host copy.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .builder import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module()
+class LOFT(nn.Module):
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        if rpn_head is not None:
+            rpn_cfg = dict(rpn_head)
+            rpn_cfg.update(train_cfg=train_cfg.rpn if train_cfg is not None else None, test_cfg=test_cfg.rpn)
+            self.rpn_head = build_head(rpn_cfg)
+        if roi_head is not None:
+            roi_cfg = dict(roi_head)
+            roi_cfg.update(train_cfg=train_cfg.rcnn if train_cfg is not None else None, test_cfg=test_cfg.rcnn)
+            self.roi_head = build_head(roi_cfg)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.with_vis_feat = True
+        self.init_weights(pretrained)
+
+    with_neck = property(lambda self: self.neck is not None)
+    with_rpn = property(lambda self: hasattr(self, 'rpn_head'))
+    with_roi_head = property(lambda self: hasattr(self, 'roi_head'))
+
+    def init_weights(self, pretrained=None):
+        """two_stage.py:60-78.  ``torchvision://`` checkpoints cannot be fetched here (no network): a path loads by key."""
+        if isinstance(pretrained, str) and '://' in pretrained:
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_rpn:
+            self.rpn_head.init_weights()
+        if self.with_roi_head:
+            self.roi_head.init_weights(pretrained)
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
+                      gt_offsets=None, **kwargs):
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            rpn_losses, proposal_list = self.rpn_head.forward_train(x, img_metas, gt_bboxes, gt_labels=None,
+                                                                    gt_bboxes_ignore=gt_bboxes_ignore,
+                                                                    proposal_cfg=proposal_cfg)
+            losses.update(rpn_losses)
+        else:
+            proposal_list = proposals
+        losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore,
+                                                  gt_masks, gt_offsets=gt_offsets, **kwargs))
+        return losses
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        if len(imgs) != 1:
+            raise NotImplementedError('test-time augmentation (configs/loft_foa: flip=False, one scale)')
+        assert imgs[0].size(0) == 1, 'samples_per_gpu must be 1 at test time (base.py:142-143)'
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        x = self.extract_feat(img)
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+
+    @staticmethod
+    def _parse_losses(losses):
+        """base.py:175-208, with the per-key all_reduce + .item() folded into one collective / one copy."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        vec = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(vec)
+            vec = vec / dist.get_world_size()
+        return loss, log_vars, vec
+
+    def train_step(self, data, optimizer=None):
+        losses = self(**data)
+        loss, log_vars, vec = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=_LazyLogVars(list(log_vars.keys()), vec), num_samples=len(data['img_metas']))
+
+
+class _LazyLogVars(OrderedDict):
+    """log_vars whose float values are fetched from the device only when read (no per-step host sync)."""
+
+    def __init__(self, keys, vec):
+        super().__init__((k, None) for k in keys)
+        self._vec, self._done = vec, False
+
+    def _materialise(self):
+        if not self._done:
+            vals = self._vec.tolist()
+            for k, v in zip(list(super().keys()), vals):
+                super().__setitem__(k, v)
+            self._done = True
+
+    def __getitem__(self, k):
+        self._materialise()
+        return super().__getitem__(k)
+
+    def items(self):
+        self._materialise()
+        return super().items()
+
+    def values(self):
+        self._materialise()
+        return super().values()

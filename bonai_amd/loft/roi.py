@@ -1,0 +1,434 @@
+"""RoI side of LOFT on the HIP kernels: SingleRoIExtractor, Shared2FCBBoxHead, FCNMaskHead,
+OffsetHead / OffsetHeadExpandFeature (FOA) and LoftRoIHead.
+
+Mirrors (constructor arguments, parameter names, loss keys, output ordering):
+  roi_extractors/single_level_roi_extractor.py:9-80     -> one fused multi-level RoIAlign launch
+  bbox_heads/convfc_bbox_head.py:176-189, bbox_head.py  -> MFMA GEMMs, fc_cls+fc_reg as one contraction
+  mask_heads/fcn_mask_head.py:19-149                    -> tap-conv chain + parity-class deconv
+  attribute_heads/offset_head_expand_feature.py:25-461  -> the 4 rotation branches as ONE grouped launch per
+        layer; the rotations themselves are written by the RoIAlign kernel (rot90 index permutation)
+  attribute_heads/offset_head.py:23-265                 -> plain LOFT head (no FOA)
+  loft_roi_head.py:22-227 (+ standard_roi_head.py, test_mixins.py:211-241)
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .. import nn as F2
+from .backbone import ConvW
+from .builder import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head, build_loss,
+                      build_roi_extractor, build_sampler)
+from .core import pad_gts
+from .losses import accuracy
+
+
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56):
+        super().__init__()
+        cfg = dict(roi_layer)
+        if cfg.pop('type') != 'RoIAlign' or cfg.get('sampling_ratio', 0) != 0 or cfg.get('pool_mode', 'avg') != 'avg' \
+                or not cfg.get('aligned', True):
+            raise NotImplementedError('only RoIAlign(sampling_ratio=0, avg, aligned) is built natively')
+        self.output_size = int(cfg['output_size'])
+        self.out_channels, self.featmap_strides, self.finest_scale = out_channels, list(featmap_strides), finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def init_weights(self):
+        pass
+
+    def forward(self, feats, rois, roi_scale_factor=None, n_rot=1):
+        if roi_scale_factor is not None:
+            raise NotImplementedError('roi_scale_factor')
+        return F2.roi_align(list(feats), rois, self.output_size, self.featmap_strides, self.finest_scale, n_rot)
+
+
+class _FC(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+def _fc_after_flatten(x, fc, relu=True):
+    """``x.flatten(1)`` of an NCHW tensor followed by nn.Linear, on NHWC memory: permute the weight columns
+    from (c,y,x) to (y,x,c) order instead of the activations."""
+    N, C, H, W = x.shape
+    w = fc.weight.view(-1, C, H, W).permute(0, 2, 3, 1).reshape(fc.weight.shape[0], -1)
+    return F2.linear(x.permute(0, 2, 3, 1).reshape(N, -1), w, fc.bias, relu=relu)
+
+
+@HEADS.register_module()
+class Shared2FCBBoxHead(nn.Module):
+    def __init__(self, fc_out_channels=1024, with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7,
+                 in_channels=256, num_classes=80, bbox_coder=None, reg_class_agnostic=False, reg_decoded_bbox=False,
+                 loss_cls=None, loss_bbox=None, **kwargs):
+        super().__init__()
+        if with_avg_pool or not (with_cls and with_reg) or reg_decoded_bbox:
+            raise NotImplementedError('bbox head variant not used by configs/loft_foa')
+        self.roi_feat_size, self.in_channels, self.num_classes = roi_feat_size, in_channels, num_classes
+        self.reg_class_agnostic = reg_class_agnostic
+        self.fc_out_channels = fc_out_channels
+        self.bbox_coder = build_bbox_coder(bbox_coder or dict(type='DeltaXYWHBBoxCoder', target_stds=[.1, .1, .2, .2]))
+        self.loss_cls = build_loss(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+        self.loss_bbox = build_loss(loss_bbox or dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
+        area = roi_feat_size * roi_feat_size
+        self.shared_fcs = nn.ModuleList([_FC(in_channels * area, fc_out_channels), _FC(fc_out_channels, fc_out_channels)])
+        self.fc_cls = _FC(fc_out_channels, num_classes + 1)
+        self.fc_reg = _FC(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+
+    def init_weights(self):
+        """bbox_head.py:66-73 + convfc_bbox_head.py:126-133."""
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01)
+        nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001)
+        nn.init.constant_(self.fc_reg.bias, 0)
+        for fc in self.shared_fcs:
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.constant_(fc.bias, 0)
+
+    def forward(self, x):
+        """x bf16 [N,256,7,7] -> (cls_score fp32 [N,num_classes+1], bbox_pred fp32 [N,4*num_classes])."""
+        N = x.shape[0]
+        ncls = self.num_classes + 1
+        nreg = self.fc_reg.weight.shape[0]
+        if N == 0:
+            return x.new_zeros(0, ncls, dtype=torch.float32), x.new_zeros(0, nreg, dtype=torch.float32)
+        h = _fc_after_flatten(x, self.shared_fcs[0])
+        h = F2.linear(h, self.shared_fcs[1].weight, self.shared_fcs[1].bias, relu=True)
+        w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0)
+        b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)
+        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), w, b).reshape(N, -1)
+        return o[:, :ncls], o[:, ncls:ncls + nreg]
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights):
+        """bbox_head.py:140-185."""
+        losses = dict()
+        avg = (label_weights > 0).sum().float().clamp(min=1.)
+        losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg)
+        losses['acc'] = accuracy(cls_score, labels)
+        pos = (labels >= 0) & (labels < self.num_classes)
+        n = bbox_pred.shape[0]
+        pred = bbox_pred.view(n, -1, 4)
+        idx = labels.clamp(max=pred.shape[1] - 1)
+        pred = pred[torch.arange(n, device=pred.device), idx]
+        w = bbox_weights * pos[:, None].float()
+        losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, w, avg_factor=float(max(n, 1)))
+        return losses
+
+
+@HEADS.register_module()
+class FCNMaskHead(nn.Module):
+    def __init__(self, num_convs=4, roi_feat_size=14, in_channels=256, conv_kernel_size=3, conv_out_channels=256,
+                 num_classes=80, class_agnostic=False, upsample_cfg=dict(type='deconv', scale_factor=2), conv_cfg=None,
+                 norm_cfg=None, loss_mask=None):
+        super().__init__()
+        if upsample_cfg.get('type') != 'deconv' or upsample_cfg.get('scale_factor', 2) != 2 or conv_kernel_size != 3 \
+                or conv_cfg is not None or norm_cfg is not None:
+            raise NotImplementedError('mask head variant not used by configs/loft_foa')
+        self.num_convs, self.num_classes, self.class_agnostic = num_convs, num_classes, class_agnostic
+        self.loss_mask = build_loss(loss_mask or dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))
+
+        class _CM(nn.Module):
+            def __init__(self, cin, cout):
+                super().__init__()
+                self.conv = ConvW(cin, cout, 3, bias=True)
+        self.convs = nn.ModuleList([_CM(in_channels if i == 0 else conv_out_channels, conv_out_channels)
+                                    for i in range(num_convs)])
+        self.upsample = nn.Module()
+        self.upsample.weight = nn.Parameter(torch.empty(conv_out_channels, conv_out_channels, 2, 2))
+        self.upsample.bias = nn.Parameter(torch.zeros(conv_out_channels))
+        self.conv_logits = ConvW(conv_out_channels, 1 if class_agnostic else num_classes, 1, bias=True)
+
+    def init_weights(self):
+        """ConvModule default init for convs (kaiming, relu); fcn_mask_head.py:107-116 for the rest."""
+        for m in self.convs:
+            nn.init.kaiming_normal_(m.conv.weight, a=0, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(m.conv.bias, 0)
+        for m in (self.upsample, self.conv_logits):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        """x bf16 [N,256,14,14] -> mask logits fp32 [N,num_classes,28,28]."""
+        nout = self.conv_logits.weight.shape[0]
+        if x.shape[0] == 0:
+            return x.new_zeros(0, nout, 2 * x.shape[2], 2 * x.shape[3], dtype=torch.float32)
+        for m in self.convs:
+            x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True)
+        x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias)
+        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias)
+        return o[:, :nout]
+
+    def loss(self, mask_pred, mask_targets, labels):
+        if mask_pred.size(0) == 0:
+            return dict(loss_mask=mask_pred.sum() * 0)
+        if self.class_agnostic:
+            labels = torch.zeros_like(labels)
+        return dict(loss_mask=self.loss_mask(mask_pred, mask_targets, labels))
+
+
+class _OffsetBase(nn.Module):
+    def _common(self, roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
+                loss_offset, offset_coordinate, reg_decoded_offset):
+        if reg_num != 2 or offset_coordinate != 'rectangle' or reg_decoded_offset or num_fcs < 1:
+            raise NotImplementedError('offset head variant not used by configs/loft_foa')
+        self.roi_feat_size, self.in_channels, self.conv_out_channels = roi_feat_size, in_channels, conv_out_channels
+        self.fc_out_channels, self.reg_num = fc_out_channels, reg_num
+        self.offset_coder = build_bbox_coder(offset_coder)
+        self.loss_offset = build_loss(loss_offset)
+        area = roi_feat_size * roi_feat_size
+        self.fcs = nn.ModuleList([_FC(conv_out_channels * area if i == 0 else fc_out_channels, fc_out_channels)
+                                  for i in range(num_fcs)])
+        self.fc_offset = _FC(fc_out_channels, reg_num)
+
+    def _init_fcs(self):
+        for fc in self.fcs:
+            nn.init.kaiming_uniform_(fc.weight, a=1, mode='fan_in', nonlinearity='leaky_relu')
+            nn.init.constant_(fc.bias, 0)
+        nn.init.normal_(self.fc_offset.weight, 0, 0.01)
+        nn.init.constant_(self.fc_offset.bias, 0)
+
+    def _fc_tail(self, x):
+        N = x.shape[0]
+        h = _fc_after_flatten(x, self.fcs[0])
+        for fc in list(self.fcs)[1:]:
+            h = F2.linear(h, fc.weight, fc.bias, relu=True)
+        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), self.fc_offset.weight,
+                           self.fc_offset.bias)
+        return o.reshape(N, -1)[:, :self.reg_num]
+
+    def loss(self, offset_pred, offset_targets):
+        if offset_pred.size(0) == 0:
+            return dict(loss_offset=offset_pred.sum() * 0)
+        return dict(loss_offset=self.loss_offset(offset_pred, offset_targets))
+
+
+@HEADS.register_module()
+class OffsetHeadExpandFeature(_OffsetBase):
+    """FOA: 4 rotated copies of the RoI feature, per-branch 10x(conv3x3+ReLU), shared FCs."""
+
+    def __init__(self, roi_feat_size=7, in_channels=256, num_convs=4, num_fcs=2, reg_num=2, conv_out_channels=256,
+                 fc_out_channels=1024, expand_feature_num=4, share_expand_fc=False, rotations=[0, 90, 180, 270],
+                 offset_coordinate='rectangle', offset_coder=dict(type='DeltaXYOffsetCoder', target_means=[0.0, 0.0],
+                                                                    target_stds=[0.5, 0.5]),
+                 reg_decoded_offset=False, conv_cfg=None, norm_cfg=None, loss_offset=dict(type='MSELoss', loss_weight=1.0)):
+        super().__init__()
+        if expand_feature_num != 4 or list(rotations) != [0, 90, 180, 270] or not share_expand_fc \
+                or in_channels != conv_out_channels:
+            raise NotImplementedError('FOA is built natively for 4 rotations (0/90/180/270) with shared FCs')
+        self.expand_feature_num, self.rotations, self.share_expand_fc = expand_feature_num, list(rotations), True
+        self.num_convs = num_convs
+        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
+                     loss_offset, offset_coordinate, reg_decoded_offset)
+        self.expand_convs = nn.ModuleList([nn.ModuleList([ConvW(conv_out_channels, conv_out_channels, 3, bias=True)
+                                                          for _ in range(num_convs)]) for _ in range(4)])
+
+    def init_weights(self):
+        """offset_head_expand_feature.py:109-132."""
+        for convs in self.expand_convs:
+            for c in convs:
+                nn.init.kaiming_normal_(c.weight, a=0, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(c.bias, 0)
+        self._init_fcs()
+
+    def forward_rotated(self, x4):
+        """x4 bf16 [4N,256,7,7], branch-major (the RoIAlign kernel already wrote the 4 rotations)
+        -> fp32 [4N,2] branch-major (= torch.cat(offsets, 0) of offset_head_expand_feature.py:160)."""
+        if x4.shape[0] == 0:
+            return x4.new_zeros(0, 2 * self.expand_feature_num, dtype=torch.float32)  # appendix A.1 quirk
+        for i in range(self.num_convs):
+            w = torch.stack([self.expand_convs[k][i].weight for k in range(4)])
+            b = torch.stack([self.expand_convs[k][i].bias for k in range(4)])
+            x4 = F2.conv2d(x4, w, b, pad=1, relu=True, groups=4)
+        return self._fc_tail(x4)
+
+    def forward(self, x):
+        """Reference signature: un-rotated RoI features [N,256,7,7] in, [4N,2] out."""
+        x4 = torch.cat([torch.rot90(x, k, (2, 3)) for k in range(4)], 0).contiguous(memory_format=torch.channels_last)
+        return self.forward_rotated(x4)
+
+    def get_targets(self, pos_bboxes, pos_gt_offsets):
+        return K.foa_targets(pos_bboxes, pos_gt_offsets, self.offset_coder.stds)
+
+    def get_offsets(self, offset_pred, det_bboxes, scale_factor=None, rescale=False, img_shape=(1024, 1024)):
+        return K.foa_fuse_decode(offset_pred, det_bboxes, self.offset_coder.stds, img_shape).cpu().numpy().astype(np.float32)
+
+
+@HEADS.register_module()
+class OffsetHead(_OffsetBase):
+    """Basic LOFT offset head without FOA (attribute_heads/offset_head.py:23-265)."""
+
+    def __init__(self, roi_feat_size=7, in_channels=256, num_convs=4, num_fcs=2, reg_num=2, conv_out_channels=256,
+                 fc_out_channels=1024, offset_coordinate='rectangle', offset_coder=dict(
+                     type='DeltaXYOffsetCoder', target_means=[0.0, 0.0], target_stds=[0.5, 0.5]),
+                 reg_decoded_offset=False, conv_cfg=None, norm_cfg=None, loss_offset=dict(type='MSELoss', loss_weight=1.0)):
+        super().__init__()
+        self.num_convs = num_convs
+        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
+                     loss_offset, offset_coordinate, reg_decoded_offset)
+        self.convs = nn.ModuleList([ConvW(in_channels if i == 0 else conv_out_channels, conv_out_channels, 3, bias=True)
+                                    for i in range(num_convs)])
+
+    def init_weights(self):
+        for c in self.convs:
+            nn.init.kaiming_normal_(c.weight, a=0, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(c.bias, 0)
+        self._init_fcs()
+
+    def forward(self, x):
+        if x.shape[0] == 0:
+            return x.new_zeros(0, 2, dtype=torch.float32)
+        for c in self.convs:
+            x = F2.conv2d(x, c.weight, c.bias, pad=1, relu=True)
+        return self._fc_tail(x)
+
+
+def _masks_to_device(gt_masks, device):
+    """list of BitmapMasks-like (``.masks`` ndarray [K,H,W]) / ndarrays / uint8 tensors -> (uint8 [sumK,H,W], offsets)."""
+    ts = []
+    for m in gt_masks:
+        a = getattr(m, 'masks', m)
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        ts.append(t.to(device=device, dtype=torch.uint8))
+    offs = [0]
+    for t in ts:
+        offs.append(offs[-1] + int(t.shape[0]))
+    return torch.cat(ts, 0), offs
+
+
+@HEADS.register_module()
+class LoftRoIHead(nn.Module):
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 offset_roi_extractor=None, offset_head=None, shared_head=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        assert offset_head is not None and bbox_head is not None
+        if shared_head is not None:
+            raise NotImplementedError('shared_head')
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        self.bbox_head = build_head(bbox_head)
+        self.with_mask = mask_head is not None
+        if self.with_mask:
+            self.share_roi_extractor = mask_roi_extractor is None
+            self.mask_roi_extractor = self.bbox_roi_extractor if mask_roi_extractor is None else build_roi_extractor(
+                mask_roi_extractor)
+            self.mask_head = build_head(mask_head)
+        self.offset_roi_extractor = build_roi_extractor(offset_roi_extractor)
+        self.offset_head = build_head(offset_head)
+        self.with_vis_feat = False
+        if train_cfg is not None:
+            self.bbox_assigner = build_assigner(train_cfg.assigner)
+            self.bbox_sampler = build_sampler(train_cfg.sampler)
+        self.last_stats = {}
+
+    with_bbox = True
+    with_offset = True
+
+    def init_weights(self, pretrained=None):
+        self.bbox_head.init_weights()
+        if self.with_mask:
+            self.mask_head.init_weights()
+        self.offset_head.init_weights()
+
+    # ---------------------------------------------------------------- training
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      gt_offsets=None):
+        """proposal_list: (proposals [B,P,5], counts [B]) from RPNHead, or the reference's list of (n_i,5) tensors."""
+        dev = x[0].device
+        B = len(img_metas)
+        if isinstance(proposal_list, (list,)):
+            P = max(1, max(int(p.shape[0]) for p in proposal_list))
+            props = torch.zeros(B, P, 5, device=dev)
+            for i, p in enumerate(proposal_list):
+                props[i, :p.shape[0], :p.shape[1]] = p
+            nprop = torch.tensor([int(p.shape[0]) for p in proposal_list], device=dev)
+        else:
+            props, nprop = proposal_list
+        with torch.no_grad():
+            gts, ngt = pad_gts(gt_bboxes, dev)
+            Kmax = gts.shape[1]
+            gi_p, _ = self.bbox_assigner.assign_batched(props[..., :4].contiguous(), nprop.int(), gts, ngt)
+            if self.bbox_sampler.add_gt_as_proposals:
+                ar = torch.arange(Kmax, device=dev)[None]
+                gi_g = torch.where(ar < ngt[:, None], ar + 1, torch.full_like(ar, -1)).expand(B, -1)
+                gt_inds = torch.cat([gi_g, gi_p], 1)
+                cand = torch.cat([gts, props[..., :4]], 1)
+            else:
+                gt_inds, cand = gi_p, props[..., :4]
+            smp = self.bbox_sampler.sample_batched(gt_inds)
+            pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
+            # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53); one host sync for the counts
+            idx = torch.cat([pidx, nidx], 1)
+            val = torch.cat([pval, nval], 1)
+            is_pos = torch.cat([pval, torch.zeros_like(nval)], 1)
+            bidx = torch.arange(B, device=dev)[:, None].expand_as(idx)
+            sel = val.reshape(-1).nonzero(as_tuple=False).flatten()
+            b_s, i_s, pos_s = bidx.reshape(-1)[sel], idx.reshape(-1)[sel], is_pos.reshape(-1)[sel]
+            boxes_s = cand[b_s, i_s]
+            rois = torch.cat([b_s[:, None].float(), boxes_s], 1)
+            assigned = (gt_inds[b_s, i_s] - 1).clamp(min=0)
+            pos_sel = pos_s.nonzero(as_tuple=False).flatten()
+            pos_rois, pos_b, pos_gt_i = rois[pos_sel], b_s[pos_sel], assigned[pos_sel]
+            pos_gt_boxes = gts[pos_b, pos_gt_i]
+            lab_pad = torch.zeros(B, Kmax, dtype=torch.long, device=dev)
+            for i, l in enumerate(gt_labels):
+                lab_pad[i, :l.shape[0]] = l.to(dev)
+            M = rois.shape[0]
+            labels = torch.full((M,), self.bbox_head.num_classes, dtype=torch.long, device=dev)
+            labels[pos_sel] = lab_pad[pos_b, pos_gt_i]
+            bbox_targets = torch.zeros(M, 4, device=dev)
+            bbox_weights = torch.zeros(M, 4, device=dev)
+            if pos_sel.numel():
+                bbox_targets[pos_sel] = self.bbox_head.bbox_coder.encode(pos_rois[:, 1:].contiguous(), pos_gt_boxes)
+                bbox_weights[pos_sel] = 1.0
+            label_weights = torch.ones(M, device=dev)
+        self.last_stats = dict(num_rois=int(M), num_pos=int(pos_sel.numel()))
+
+        losses = dict()
+        feats = x[:self.bbox_roi_extractor.num_inputs]
+        bbox_feats = self.bbox_roi_extractor(feats, rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights))
+
+        if self.with_mask:
+            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+            mask_pred = self.mask_head(mask_feats)
+            with torch.no_grad():
+                masks, moffs = _masks_to_device(gt_masks, dev)
+                H, W = masks.shape[1], masks.shape[2]
+                pb = pos_rois[:, 1:].clone()
+                pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
+                pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
+                gidx = pos_gt_i + torch.tensor(moffs[:-1], device=dev)[pos_b]
+                mask_targets = K.mask_target(masks, pb, gidx, int(self.train_cfg.mask_size))
+            losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel]))
+
+        with torch.no_grad():
+            off_pad = torch.zeros(B, Kmax, 2, device=dev)
+            for i, o in enumerate(gt_offsets):
+                off_pad[i, :o.shape[0]] = o.to(dev)
+            pos_gt_off = off_pad[pos_b, pos_gt_i]
+        offset_pred = self._offset_forward(x, pos_rois)
+        if hasattr(self.offset_head, 'get_targets') and isinstance(self.offset_head, OffsetHeadExpandFeature):
+            offset_targets = self.offset_head.get_targets(pos_rois[:, 1:].contiguous(), pos_gt_off)
+        else:
+            from .core import DeltaXYOffsetCoder  # noqa
+            s = self.offset_head.offset_coder.stds
+            wh = pos_rois[:, 3:5] - pos_rois[:, 1:3]
+            offset_targets = pos_gt_off / wh / pos_gt_off.new_tensor(s)
+        if offset_pred.shape[0] == 0:
+            losses.update(loss_offset=offset_pred.sum() * 0)
+        else:
+            losses.update(self.offset_head.loss(offset_pred, offset_targets))
+        return losses
+
+    def _offset_forward(self, x, rois):
+        feats = x[:self.offset_roi_extractor.num_inputs]
+        if isinstance(self.offset_head, OffsetHeadExpandFeature):
+            return self.offset_head.forward_rotated(self.offset_roi_extractor(feats, rois, n_rot=4))
+        return self.offset_head(self.offset_roi_extractor(feats, rois))

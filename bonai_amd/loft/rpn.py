@@ -1,0 +1,203 @@
+"""RPNHead on the HIP kernels, batched over the images of the step.
+
+Mirrors mmdet/models/dense_heads/rpn_head.py:12-168 (+ AnchorHead anchor_head.py:35-652,
+BaseDenseHead.forward_train base_dense_head.py:22-59, RPNTestMixin rpn_test_mixin.py:25-38):
+same constructor arguments, parameter names (rpn_conv / rpn_cls / rpn_reg), loss keys and
+proposal semantics.  What changed underneath:
+
+  * rpn_cls and rpn_reg run as ONE 1x1 contraction (15 outputs, fp32) per level;
+  * target assignment is one IoU-assign launch for all images (no KxN matrix, no per-gt loop);
+  * the per image x per level sort / top-k / decode / NMS python loops (rpn_head.py:116-168) are
+    segment-batched: one sort, five decode launches, one NMS mask launch and one NMS scan launch for
+    the whole batch, with no host synchronisation;
+  * the losses are evaluated on the <=512 sampled anchors per image only (identical value: all other
+    anchors carry weight 0 in anchor_head.py:180-245).
+"""
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .. import nn as F2
+from .backbone import ConvW
+from .builder import HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler
+from .core import pad_gts
+
+
+@HEADS.register_module()
+class RPNHead(nn.Module):
+    def __init__(self, in_channels, feat_channels=256, anchor_generator=None, bbox_coder=None, reg_decoded_bbox=False,
+                 background_label=0, loss_cls=None, loss_bbox=None, train_cfg=None, test_cfg=None, num_classes=1):
+        super().__init__()
+        self.in_channels, self.feat_channels = in_channels, feat_channels
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self.bbox_coder = build_bbox_coder(bbox_coder or dict(type='DeltaXYWHBBoxCoder'))
+        self.loss_cls = build_loss(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
+        self.loss_bbox = build_loss(loss_bbox or dict(type='L1Loss', loss_weight=1.0))
+        self.use_sigmoid_cls = getattr(self.loss_cls, 'use_sigmoid', True)
+        if not self.use_sigmoid_cls or reg_decoded_bbox:
+            raise NotImplementedError('RPN with softmax cls / decoded-box regression')
+        self.cls_out_channels = 1
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.sampling = True
+        if train_cfg is not None:
+            self.assigner = build_assigner(train_cfg.assigner)
+            self.sampler = build_sampler(train_cfg.get('sampler', dict(type='RandomSampler', num=256, pos_fraction=.5)))
+        self.rpn_conv = ConvW(in_channels, feat_channels, 3, bias=True)
+        self.rpn_cls = ConvW(feat_channels, self.num_anchors * self.cls_out_channels, 1, bias=True)
+        self.rpn_reg = ConvW(feat_channels, self.num_anchors * 4, 1, bias=True)
+        self._static = {}
+
+    def init_weights(self):
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    # ---------------------------------------------------------------- forward
+    def forward_fused(self, feats):
+        """-> per level fp32 [B,16,H,W] NHWC: channels [0,A) objectness, [A,5A) deltas (anchor-major)."""
+        A = self.num_anchors
+        w = torch.cat([self.rpn_cls.weight.view(A, -1), self.rpn_reg.weight.view(4 * A, -1)], 0)
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
+        outs = []
+        for x in feats:
+            h = F2.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, pad=1, relu=True)
+            outs.append(F2.narrow_head(h, w, b))
+        return outs
+
+    def forward(self, feats):
+        """Reference signature: (cls_scores, bbox_preds), NCHW-shaped views of the fused outputs."""
+        A = self.num_anchors
+        fused = self.forward_fused(feats)
+        return [f[:, :A] for f in fused], [f[:, A:5 * A] for f in fused]
+
+    # ---------------------------------------------------------------- static geometry
+    def _geometry(self, fused, device):
+        sizes = tuple((int(f.shape[2]), int(f.shape[3])) for f in fused)
+        key = (sizes, int(fused[0].shape[0]), str(device))
+        if key not in self._static:
+            A, B = self.num_anchors, int(fused[0].shape[0])
+            n_l = [h * w * A for h, w in sizes]
+            lvl_off = [0]
+            for n in n_l:
+                lvl_off.append(lvl_off[-1] + n)
+            anchors = torch.cat(self.anchor_generator.grid_anchors(sizes, device), 0)
+            seg = torch.tensor([b * lvl_off[-1] + o for b in range(B) for o in lvl_off[:-1]] + [B * lvl_off[-1]],
+                               dtype=torch.int64, device=device)
+            self._static[key] = dict(sizes=sizes, n_l=n_l, lvl_off=lvl_off, N=lvl_off[-1], anchors=anchors,
+                                     anchors_b=anchors[None].expand(B, -1, -1).contiguous(), seg=seg,
+                                     base=[b.to(device).contiguous() for b in self.anchor_generator.base_anchors])
+        return self._static[key]
+
+    def _flatten(self, fused):
+        """[B, N] logits and [B, N, 4] deltas in the reference's (position, anchor) order."""
+        A = self.num_anchors
+        B = fused[0].shape[0]
+        cls = torch.cat([f.permute(0, 2, 3, 1)[..., :A].reshape(B, -1) for f in fused], 1)
+        reg = torch.cat([f.permute(0, 2, 3, 1)[..., A:5 * A].reshape(B, -1, 4) for f in fused], 1)
+        return cls, reg
+
+    # ---------------------------------------------------------------- loss
+    def loss_fused(self, fused, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+        dev = fused[0].device
+        geo = self._geometry(fused, dev)
+        if self.train_cfg.get('allowed_border', -1) >= 0:
+            raise NotImplementedError('allowed_border >= 0 (configs/loft_foa use -1: every anchor is valid)')
+        B, N = fused[0].shape[0], geo['N']
+        gts, ngt = pad_gts(gt_bboxes, dev)
+        nbox = torch.full((B,), N, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            gt_inds, _ = self.assigner.assign_batched(geo['anchors_b'], nbox, gts, ngt)
+            smp = self.sampler.sample_batched(gt_inds)
+            pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
+            num_pos = pval.sum(1).clamp(min=1).sum()
+            num_neg = nval.sum(1).clamp(min=1).sum()
+            avg = (num_pos + num_neg).float()
+            pos_anchor = geo['anchors'][pidx.reshape(-1)]
+            pos_gt_i = (torch.gather(gt_inds, 1, pidx) - 1).clamp(min=0)
+            pos_gt = torch.gather(gts, 1, pos_gt_i[..., None].expand(-1, -1, 4)).reshape(-1, 4)
+            tgt = self.bbox_coder.encode(pos_anchor, pos_gt).view(B, -1, 4)
+            tgt = torch.where(pval[..., None], tgt, torch.zeros_like(tgt))
+        cls, reg = self._flatten(fused)
+        sel = torch.cat([pidx, nidx], 1)
+        logit = torch.gather(cls, 1, sel)
+        label = torch.cat([pval.long(), torch.zeros_like(nval, dtype=torch.long)], 1)
+        w = torch.cat([pval, nval], 1).float()
+        loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
+        pred = torch.gather(reg, 1, pidx[..., None].expand(-1, -1, 4))
+        loss_bbox = self.loss_bbox(pred, tgt, pval[..., None].float().expand_as(pred), avg_factor=avg)
+        return dict(loss_rpn_cls=loss_cls, loss_rpn_bbox=loss_bbox)
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+        fused = [torch.cat([c, r, c.new_zeros(c.shape[0], 1, *c.shape[2:])], 1).contiguous(memory_format=torch.channels_last)
+                 for c, r in zip(cls_scores, bbox_preds)]
+        return self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore)
+
+    # ---------------------------------------------------------------- proposals
+    @torch.no_grad()
+    def get_bboxes_fused(self, fused, img_metas, cfg=None):
+        """-> (proposals fp32 [B, max_num, 5] sorted by score, padded with zeros; counts int64 [B])."""
+        cfg = self.test_cfg if cfg is None else cfg
+        if cfg.get('min_bbox_size', 0) > 0 or cfg.get('nms_across_levels', False):
+            raise NotImplementedError('min_bbox_size > 0 / nms_across_levels (configs/loft_foa use 0 / False)')
+        dev = fused[0].device
+        geo = self._geometry(fused, dev)
+        A, B, N = self.num_anchors, fused[0].shape[0], geo['N']
+        img_shape = img_metas[0]['img_shape']
+        for m in img_metas:
+            if tuple(m['img_shape'][:2]) != tuple(img_shape[:2]):
+                raise NotImplementedError('per-image img_shape inside one batch')
+        keys = torch.empty(B * N, dtype=torch.float32, device=dev)
+        for f, off in zip(fused, geo['lvl_off']):
+            K.rpn_scores(f, A, N, off, keys)
+        skeys, sidx = K.segmented_sort_desc(keys, geo['seg'])
+        topk = [min(cfg.nms_pre, n) if cfg.nms_pre > 0 else n for n in geo['n_l']]
+        coff = [0]
+        for t in topk:
+            coff.append(coff[-1] + t)
+        C = coff[-1]
+        cand = torch.empty(B, C, 4, dtype=torch.float32, device=dev)
+        for l, f in enumerate(fused):
+            K.rpn_decode(f, sidx, A, N, geo['lvl_off'][l], topk[l], geo['base'][l], self.anchor_generator.strides[l],
+                         self.bbox_coder.means, self.bbox_coder.stds, img_shape, C, coff[l], cand)
+        sk = skeys.view(B, N)
+        cscore = torch.cat([sk[:, geo['lvl_off'][l]:geo['lvl_off'][l] + topk[l]] for l in range(len(fused))], 1)
+        # batched_nms: boxes + level * (max_coordinate + 1), one segment per (image, level)
+        nlv = len(fused)
+        max_coord = cand.view(B, -1).amax(dim=1)
+        shift = (torch.arange(nlv, device=dev, dtype=torch.float32)[None] * (max_coord[:, None] + 1)).reshape(-1)
+        key = ('nms_seg', B, tuple(topk))
+        if key not in self._static:
+            self._static[key] = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64,
+                                             device=dev)
+            self._static[('img_seg', B, C)] = torch.arange(B + 1, dtype=torch.int64, device=dev) * C
+        keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk))
+        masked = torch.where(keep.view(B, C).bool(), cscore, torch.full_like(cscore, -1.0))
+        fs, fi = K.segmented_sort_desc(masked.reshape(-1), self._static[('img_seg', B, C)])
+        post = min(cfg.nms_post, cfg.max_num) if cfg.get('max_num', 0) > 0 else cfg.nms_post
+        post = min(post, C)
+        fs = fs.view(B, C)[:, :post]
+        fi = fi.view(B, C)[:, :post].long()
+        boxes = cand.view(-1, 4)[fi.reshape(-1)].view(B, post, 4)
+        valid = fs >= 0
+        props = torch.cat([boxes, fs[..., None]], -1) * valid[..., None]
+        return props, valid.sum(1)
+
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False):
+        """Reference return type: list of (n_i, 5) tensors."""
+        fused = [torch.cat([c, r, c.new_zeros(c.shape[0], 1, *c.shape[2:])], 1).contiguous(memory_format=torch.channels_last)
+                 for c, r in zip(cls_scores, bbox_preds)]
+        props, counts = self.get_bboxes_fused(fused, img_metas, cfg)
+        return [props[i, :int(n)] for i, n in enumerate(counts.tolist())]
+
+    # ---------------------------------------------------------------- train / test entry points
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
+        fused = self.forward_fused(x)
+        losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes_fused([f.detach() for f in fused], img_metas, proposal_cfg)
+
+    def simple_test_rpn(self, x, img_metas):
+        fused = self.forward_fused(x)
+        return self.get_bboxes_fused(fused, img_metas)

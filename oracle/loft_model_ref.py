@@ -1,0 +1,227 @@
+"""End-to-end CPU restatement (torch-CPU fp32) of the reference's LOFT R50-FPN training forward.
+TEST INFRASTRUCTURE: the parity checker for the HIP path and bench.py's cpu_baseline ("port").
+
+Functional style over a plain ``state_dict`` with the reference's key names; per-image python loops
+exactly where the reference has them.  Follows (paths relative to /root/reference/mmdet):
+  models/detectors/two_stage.py:105-167 (forward_train), base.py:175-208 (_parse_losses)
+  models/backbones/resnet.py:266-298,623-638; models/necks/fpn.py:170-199
+  models/dense_heads/rpn_head.py:38-44,79-168; anchor_head.py:180-497
+  models/roi_heads/loft_roi_head.py:44-194; standard_roi_head.py:148-161
+  models/roi_heads/bbox_heads/convfc_bbox_head.py:135-173, bbox_head.py:84-185
+  models/roi_heads/mask_heads/fcn_mask_head.py:118-149; core/mask/mask_target.py:33-62
+  models/roi_heads/attribute_heads/offset_head_expand_feature.py:134-205,271-344
+Pinned against the reference itself by tests/golden/e2e_256.npz (oracle/ref_harness/make_goldens.py).
+The mmcv-1.0.5 ops (RoIAlign, nms) are the plain-C restatement in both (parity unpinned there).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from . import cops
+from . import ops_ref as R
+
+STRIDES = (4, 8, 16, 32, 64)
+STAGE_BLOCKS = (3, 4, 6, 3)
+
+
+def _bn(x, sd, p, eps=1e-5):
+    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'], False, 0., eps)
+
+
+def backbone(sd, img, prefix='backbone.'):
+    x = F.relu(_bn(F.conv2d(img, sd[prefix + 'conv1.weight'], None, 2, 3), sd, prefix + 'bn1'))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, nb in enumerate(STAGE_BLOCKS):
+        for bi in range(nb):
+            p = f'{prefix}layer{li + 1}.{bi}.'
+            stride = 2 if (bi == 0 and li > 0) else 1
+            out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
+            out = F.relu(_bn(F.conv2d(out, sd[p + 'conv2.weight'], None, stride, 1), sd, p + 'bn2'))
+            out = _bn(F.conv2d(out, sd[p + 'conv3.weight']), sd, p + 'bn3')
+            idt = x
+            if (p + 'downsample.0.weight') in sd:
+                idt = _bn(F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride), sd, p + 'downsample.1')
+            x = F.relu(out + idt)
+        outs.append(x)
+    return outs
+
+
+def fpn(sd, feats, prefix='neck.'):
+    lats = [F.conv2d(f, sd[f'{prefix}lateral_convs.{i}.conv.weight'], sd[f'{prefix}lateral_convs.{i}.conv.bias'])
+            for i, f in enumerate(feats)]
+    for i in range(len(lats) - 1, 0, -1):
+        lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
+    outs = [F.conv2d(l, sd[f'{prefix}fpn_convs.{i}.conv.weight'], sd[f'{prefix}fpn_convs.{i}.conv.bias'], padding=1)
+            for i, l in enumerate(lats)]
+    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+    return outs
+
+
+def rpn_forward(sd, feats, prefix='rpn_head.'):
+    cls, reg = [], []
+    for x in feats:
+        h = F.relu(F.conv2d(x, sd[prefix + 'rpn_conv.weight'], sd[prefix + 'rpn_conv.bias'], padding=1))
+        cls.append(F.conv2d(h, sd[prefix + 'rpn_cls.weight'], sd[prefix + 'rpn_cls.bias']))
+        reg.append(F.conv2d(h, sd[prefix + 'rpn_reg.weight'], sd[prefix + 'rpn_reg.bias']))
+    return cls, reg
+
+
+def rpn_loss(cls, reg, gt_bboxes, choose=R.choose_first):
+    B = cls[0].shape[0]
+    sizes = [tuple(c.shape[2:]) for c in cls]
+    anchors = torch.cat(R.grid_anchors(sizes, STRIDES), 0)
+    flat_cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c in cls], 1)
+    flat_reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in reg], 1)
+    labels, lw, bt, bw, npos, nneg = [], [], [], [], 0, 0
+    for i in range(B):
+        gi, _ = R.max_iou_assign(anchors, gt_bboxes[i], 0.7, 0.3, 0.3, True)
+        pos, neg = R.sample(gi, 512, 0.5, choose)
+        lab = torch.zeros(anchors.shape[0], dtype=torch.long)
+        w = torch.zeros(anchors.shape[0])
+        t = torch.zeros(anchors.shape[0], 4)
+        tw = torch.zeros(anchors.shape[0], 4)
+        if pos.numel():
+            t[pos] = R.bbox2delta(anchors[pos], gt_bboxes[i][gi[pos] - 1])
+            tw[pos] = 1.0
+            lab[pos] = 1
+            w[pos] = 1.0
+        if neg.numel():
+            w[neg] = 1.0
+        labels.append(lab); lw.append(w); bt.append(t); bw.append(tw)
+        npos += max(pos.numel(), 1); nneg += max(neg.numel(), 1)
+    avg = float(npos + nneg)
+    labels, lw, bt, bw = torch.stack(labels), torch.stack(lw), torch.stack(bt), torch.stack(bw)
+    loss_cls = R.bce_sigmoid_loss(flat_cls.reshape(-1, 1), labels.reshape(-1), lw.reshape(-1), avg)
+    loss_bbox = R.l1_loss(flat_reg.reshape(-1, 4), bt.reshape(-1, 4), bw.reshape(-1, 4), avg)
+    return loss_cls, loss_bbox
+
+
+def rpn_proposals(cls, reg, img_shape, nms_pre=3000, nms_post=3000, nms_thr=0.7):
+    """rpn_head.py:79-168, per image."""
+    B = cls[0].shape[0]
+    sizes = [tuple(c.shape[2:]) for c in cls]
+    mlvl_anchors = R.grid_anchors(sizes, STRIDES)
+    out = []
+    for i in range(B):
+        scores, deltas, ancs, ids = [], [], [], []
+        for l in range(len(cls)):
+            s = cls[l][i].detach().permute(1, 2, 0).reshape(-1).sigmoid()
+            d = reg[l][i].detach().permute(1, 2, 0).reshape(-1, 4)
+            a = mlvl_anchors[l]
+            if nms_pre > 0 and s.shape[0] > nms_pre:
+                order = cops.argsort_desc(s)[:nms_pre]
+                s, d, a = s[order], d[order], a[order]
+            scores.append(s); deltas.append(d); ancs.append(a)
+            ids.append(torch.full((s.shape[0],), l, dtype=torch.long))
+        scores, deltas, ancs, ids = torch.cat(scores), torch.cat(deltas), torch.cat(ancs), torch.cat(ids)
+        props = R.delta2bbox(ancs, deltas, max_shape=img_shape)
+        dets, _ = cops.batched_nms(props, scores, ids, dict(type='nms', iou_threshold=nms_thr))
+        out.append(dets[:nms_post])
+    return out
+
+
+def _fc(sd, p, x):
+    return F.linear(x, sd[p + '.weight'], sd[p + '.bias'])
+
+
+def bbox_head(sd, x, prefix='roi_head.bbox_head.'):
+    h = x.flatten(1)
+    h = F.relu(_fc(sd, prefix + 'shared_fcs.0', h))
+    h = F.relu(_fc(sd, prefix + 'shared_fcs.1', h))
+    return _fc(sd, prefix + 'fc_cls', h), _fc(sd, prefix + 'fc_reg', h)
+
+
+def mask_head(sd, x, prefix='roi_head.mask_head.'):
+    for i in range(4):
+        x = F.relu(F.conv2d(x, sd[f'{prefix}convs.{i}.conv.weight'], sd[f'{prefix}convs.{i}.conv.bias'], padding=1))
+    x = F.relu(F.conv_transpose2d(x, sd[prefix + 'upsample.weight'], sd[prefix + 'upsample.bias'], stride=2))
+    return F.conv2d(x, sd[prefix + 'conv_logits.weight'], sd[prefix + 'conv_logits.bias'])
+
+
+def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.'):
+    outs = []
+    for k in range(4):
+        h = R.foa_rotate_feature(x, k)
+        for i in range(num_convs):
+            h = F.relu(F.conv2d(h, sd[f'{prefix}expand_convs.{k}.{i}.weight'], sd[f'{prefix}expand_convs.{k}.{i}.bias'],
+                                padding=1))
+        h = h.reshape(h.shape[0], -1)
+        h = F.relu(_fc(sd, prefix + 'fcs.0', h))
+        h = F.relu(_fc(sd, prefix + 'fcs.1', h))
+        outs.append(_fc(sd, prefix + 'fc_offset', h))
+    return torch.cat(outs, 0)
+
+
+def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.choose_first,
+                      num_classes=1):
+    B = len(proposals)
+    res = []
+    for i in range(B):
+        props = proposals[i][:, :4]
+        gi, _ = R.max_iou_assign(props, gt_bboxes[i], 0.5, 0.5, 0.5, True)
+        K = gt_bboxes[i].shape[0]
+        boxes = torch.cat([gt_bboxes[i], props], 0)
+        gi = torch.cat([torch.arange(1, K + 1, dtype=torch.long), gi])
+        pos, neg = R.sample(gi, 1024, 0.25, choose)
+        res.append(dict(pos_bboxes=boxes[pos], neg_bboxes=boxes[neg], pos_gt_inds=gi[pos] - 1,
+                        pos_gt_bboxes=gt_bboxes[i][gi[pos] - 1], pos_gt_labels=gt_labels[i][gi[pos] - 1]))
+    rois = R.bbox2roi([torch.cat([r['pos_bboxes'], r['neg_bboxes']]) for r in res])
+    p4 = feats[:4]
+    cls_score, bbox_pred = bbox_head(sd, R.roi_extract(p4, rois, 7))
+    labels, lw, bt, bw = [], [], [], []
+    for r in res:
+        npos, nneg = r['pos_bboxes'].shape[0], r['neg_bboxes'].shape[0]
+        lab = torch.full((npos + nneg,), num_classes, dtype=torch.long)
+        lab[:npos] = r['pos_gt_labels']
+        t = torch.zeros(npos + nneg, 4); w = torch.zeros(npos + nneg, 4)
+        if npos:
+            t[:npos] = R.bbox2delta(r['pos_bboxes'], r['pos_gt_bboxes'], stds=(.1, .1, .2, .2))
+            w[:npos] = 1
+        labels.append(lab); lw.append(torch.ones(npos + nneg)); bt.append(t); bw.append(w)
+    labels, lw, bt, bw = torch.cat(labels), torch.cat(lw), torch.cat(bt), torch.cat(bw)
+    losses = OrderedDict()
+    losses['loss_cls'] = R.ce_loss(cls_score, labels, lw, max(float((lw > 0).sum()), 1.))
+    losses['acc'] = R.accuracy(cls_score, labels)
+    posm = labels < num_classes
+    pred = bbox_pred.view(bbox_pred.shape[0], -1, 4)[posm, labels[posm]]
+    losses['loss_bbox'] = R.l1_loss(pred, bt[posm], bw[posm], float(bt.shape[0])) if posm.any() else bbox_pred.sum() * 0
+    pos_rois = R.bbox2roi([r['pos_bboxes'] for r in res])
+    mask_pred = mask_head(sd, R.roi_extract(p4, pos_rois, 14))
+    mts = []
+    for i, r in enumerate(res):
+        if r['pos_bboxes'].shape[0] == 0:
+            mts.append(torch.zeros(0, 28, 28)); continue
+        H, W = gt_masks[i].shape[1:]
+        pb = r['pos_bboxes'].clone()
+        pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W); pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
+        rr = torch.cat([torch.arange(pb.shape[0], dtype=torch.float32)[:, None], pb], 1)
+        sel = gt_masks[i][r['pos_gt_inds']].float()[:, None]
+        mts.append((cops.roi_align_fwd(sel, rr, 28, 1.0, 0, True).squeeze(1) >= 0.5).float())
+    mask_targets = torch.cat(mts)
+    pos_labels = torch.cat([r['pos_gt_labels'] for r in res])
+    losses['loss_mask'] = R.mask_bce_loss(mask_pred, mask_targets, pos_labels) if mask_pred.shape[0] else mask_pred.sum() * 0
+    offset_pred = foa_head(sd, R.roi_extract(p4, pos_rois, 7))
+    offset_targets = R.foa_offset_targets([r['pos_bboxes'] for r in res], [r['pos_gt_inds'] for r in res], gt_offsets)
+    losses['loss_offset'] = 16.0 * R.smooth_l1_loss(offset_pred, offset_targets) if offset_pred.shape[0] else offset_pred.sum() * 0
+    extras = dict(rois=rois, pos_rois=pos_rois, cls_score=cls_score, bbox_pred=bbox_pred, mask_pred=mask_pred,
+                  mask_targets=mask_targets, offset_pred=offset_pred, offset_targets=offset_targets, labels=labels)
+    return losses, extras
+
+
+def forward_train(sd, img, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.choose_first, return_extras=False):
+    """-> OrderedDict of the 7 losses + acc (+ 'loss'), keys as base.py:_parse_losses logs them."""
+    H, W = img.shape[2:]
+    feats = fpn(sd, backbone(sd, img))
+    cls, reg = rpn_forward(sd, feats)
+    l_cls, l_box = rpn_loss(cls, reg, gt_bboxes, choose)
+    props = rpn_proposals(cls, reg, (H, W, 3))
+    losses = OrderedDict(loss_rpn_cls=l_cls, loss_rpn_bbox=l_box)
+    roi_losses, extras = roi_forward_train(sd, feats, props, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose)
+    losses.update(roi_losses)
+    losses['loss'] = sum(v.sum() for k, v in losses.items() if 'loss' in k)
+    if return_extras:
+        extras.update(feats=feats, rpn_cls=cls, rpn_reg=reg, proposals=props)
+        return losses, extras
+    return losses

@@ -2,6 +2,8 @@
 import ctypes
 import os
 
+import torch  # noqa: F401  (load torch's HIP runtime before libloft_hip.so)
+
 from bonai_amd import lib as L
 
 

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- training img/s of LOFT R50-FPN (FOA) at 1024x1024 on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = one full optimisation step of the hot path on one batch of synthetic 1024x1024 tiles per GPU:
+backbone + FPN + RPN (losses, proposals, NMS) + RoI heads (bbox, mask, FOA offset) forward, all losses,
+backward, gradient all-reduce (RCCL over xGMI, bucketed, overlapped), clip, SGD.  Inputs are resident in HBM
+before the timed region.  Weak scaling: the per-GPU batch is fixed (8), the global batch grows with N.
+Rank 0 prints ONE JSON line (see the prompt contract) with `roofline` (dominant kernel, measured live with
+HIP events) and `cpu_baseline` (the CPU oracle -- the restated reference -- timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--num-gt', type=int, default=80)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def f_train_gflop(n_roi, n_pos):
+    """Algorithmic training FLOPs per image, SURVEY.md section 8(d)."""
+    return 32.8 + 3.0 * (360.3 + 0.0278 * n_roi + 3.451 * n_pos)
+
+
+def cpu_baseline(size, num_gt):
+    """The CPU oracle (restated reference path, oracle/loft_model_ref.py) forward+loss+backward on a bounded
+    sample of the same workload: BASELINE configs[0] (2 x 1024x1024 tiles), on min(host cores, 32) threads
+    (more threads than that only adds oversubscription overhead on the many small per-RoI ops)."""
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import make_batch
+    from oracle import loft_model_ref as M
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    torch.manual_seed(0)
+    ref = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    frozen = ('backbone.conv1', 'backbone.bn1', 'backbone.layer1')
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k and not k.startswith(frozen):
+            v.requires_grad_(True)
+    nimg = 2
+    data = make_batch(nimg, size, num_gt)
+    t0 = time.perf_counter()
+    losses = M.forward_train(sd, data['img'], data['gt_bboxes'], data['gt_labels'], data['gt_masks'], data['gt_offsets'])
+    losses['loss'].backward()
+    dt = time.perf_counter() - t0
+    return dict(value=round(nimg / dt, 5), unit='img/s', cores=cores, kind='port',
+                sample=f'{nimg} images {size}x{size}, {num_gt} gt each (BASELINE configs[0]), one forward+losses+backward of '
+                       f'the CPU oracle (fp32, {cores} threads of {os.cpu_count()} host cores), {dt:.1f} s')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs MI355X GPUs: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # 'nccl' is RCCL on ROCm
+    from bonai_amd import kernels as K
+    from bonai_amd.config import Config
+    from bonai_amd.engine import Trainer, step_lr
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import make_batch
+    K.L.load()
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    torch.manual_seed(0)                                   # same random-init weights on every rank
+    model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+    trainer = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
+                      max_norm=cfg.optimizer_config.grad_clip.max_norm)
+    data = make_batch(args.batch, args.size, args.num_gt, rank=rank, device='cuda')
+    n_pos, n_roi = [], []
+
+    def one_step(it):
+        trainer.train_step(data, lr=step_lr(cfg.optimizer.lr, it, 0))
+        n_pos.append(model.roi_head.last_stats['num_pos'])
+        n_roi.append(model.roi_head.last_stats['num_rois'])
+
+    for it in range(args.warmup):
+        one_step(it)
+    n_pos.clear(); n_roi.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        one_step(args.warmup + it)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        st = torch.tensor([float(sum(n_pos)), float(sum(n_roi))], device='cuda')
+        dist.all_reduce(st)
+        tot_pos, tot_roi = [float(v) / world for v in st.tolist()]
+    else:
+        tot_pos, tot_roi = float(sum(n_pos)), float(sum(n_roi))
+    imgs = args.batch * world * args.steps
+    value = imgs / elapsed
+    mean_pos = tot_pos / (args.steps * args.batch)
+    mean_roi = tot_roi / (args.steps * args.batch)
+
+    roofline = None
+    if not args.no_roofline:
+        # live per-launch HIP-event timing of the MFMA kernels over two extra steps (same stream as the launches)
+        K.PROFILE = []
+        for it in range(2):
+            one_step(args.warmup + args.steps + it)
+        torch.cuda.synchronize()
+        fam = {}
+        for name, fl, a, b in K.PROFILE:
+            d = fam.setdefault(name, [0.0, 0.0, 0])
+            d[0] += fl; d[1] += a.elapsed_time(b) * 1e-3; d[2] += 1
+        K.PROFILE = None
+        dom = max(fam, key=lambda k: fam[k][1])
+        ach = fam[dom][0] / fam[dom][1] / 1e12
+        roofline = dict(bound='mfma', kernel='conv_tap_kernel' if dom == 'conv_tap' else 'conv_wgrad_kernel',
+                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=None,
+                        launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
+                        families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
+                                          launches_per_step=v[2] // 2) for k, v in fam.items()})
+    if rank == 0:
+        f_img = f_train_gflop(mean_roi, mean_pos)
+        res = dict(metric='training img/s at 1024x1024 LOFT R50-FPN', value=round(value, 3), unit='img/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                   config=dict(workload=f'LOFT R50-FPN + FOA, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
+                                        f'(BASELINE configs[1]), {args.num_gt} gt/img, full train step '
+                                        '(fwd+losses+bwd+allreduce+clip+SGD), random-init weights',
+                               global_batch=args.batch * world, per_gpu_batch=args.batch, parallelism=f'dp{world}',
+                               mean_num_pos_per_img=round(mean_pos, 1), mean_num_rois_per_img=round(mean_roi, 1),
+                               algorithmic_gflop_per_img=round(f_img, 1),
+                               conv_roofline_frac=round(f_img * 1e9 * value / (world * 2.5e15), 4)),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.size, args.num_gt)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -170,6 +170,27 @@ def nms(boxes, scores, iou_thr):
 
 _ZERO_PAGES = {}
 
+# bench.py's live roofline probe: when set to a list, every MFMA launch appends
+# (family, algorithmic_flops, start_event, end_event) recorded on the launch stream.
+PROFILE = None
+ALGO_SCALE = 1.0   # callers that zero-pad a contraction (narrow heads) scale the counted FLOPs back to the real ones
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev, family, flops):
+    if ev is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    PROFILE.append((family, float(flops) * ALGO_SCALE, ev, end))
+
 
 def zero_page(device):
     key = str(device)
@@ -217,11 +238,13 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
     out_f32 = out.dtype == torch.float32
     if not out_f32:
         _bf16(out)
+    _ev = _prof_begin()
     L.check(lib.loft_conv_tap_bf16(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(out),
                                    L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
                                    oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
                                    c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
             'loft_conv_tap_bf16')
+    _prof_end(_ev, 'conv_tap', 2.0 * groups * B * OH * OW * Cout * Cin * T)
     return out
 
 
@@ -295,10 +318,12 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     if dw is None:
         dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
     A = lambda i: L.arr(c_int, [t[i] for t in taps])
+    _ev = _prof_begin()
     L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                      XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
                                      c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.stream()),
             'loft_conv_wgrad_bf16')
+    _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps))
     return dw
 
 

@@ -89,7 +89,9 @@ class _NarrowHeadFn(torch.autograd.Function):
         bpad = torch.zeros(c4, dtype=torch.float32, device=w.device)
         if b is not None:
             bpad[:Cout] = b
+        K.ALGO_SCALE = Cout / c4
         y = K.conv2d_fwd(x, K.pack_w_fwd(wpad)[None], bpad, 1, 1, out_dtype=torch.float32)
+        K.ALGO_SCALE = 1.0
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -103,6 +105,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         gp = torch.zeros(N, P, H, W, dtype=torch.bfloat16, device=g.device).contiguous(memory_format=torch.channels_last)
         gp[:, :Cout] = g[:, :Cout]
         gx = gw = gb = None
+        K.ALGO_SCALE = Cout / P
         if ctx.needs_input_grad[0]:
             wt = torch.zeros(1, Cin, P, dtype=torch.bfloat16, device=w.device)
             wt[0, :, :Cout] = w.view(Cout, Cin).t()
@@ -110,6 +113,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dwp = K.conv2d_wgrad(gp, x, 1, 1)
             gw = dwp[0, 0, :Cout].reshape(w.shape)
+        K.ALGO_SCALE = 1.0
         if ctx.has_b and ctx.needs_input_grad[2]:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
         return gx, gw, gb

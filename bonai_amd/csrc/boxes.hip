@@ -29,28 +29,42 @@ __device__ __forceinline__ float iou_pair(const float4 g, const float4 b) {
     return overlap / uni;
 }
 
-// pass 1: per box max/argmax over gts; per gt max over boxes (atomicMax on the non-negative float bits)
+// pass 1: per box max/argmax over gts; per gt max over boxes.  The per-gt maximum is reduced inside the
+// wavefront (DPP/shuffle max), then across the block's 4 waves in LDS, and only then published with one
+// atomicMax per (block, gt) on the non-negative float's bit pattern -- not one per (box, gt).
 __global__ __launch_bounds__(256) void iou_pass1_kernel(const float* __restrict__ boxes, const int* __restrict__ nbox, int Nmax,
                                                         const float* __restrict__ gts, const int* __restrict__ ngt, int Kmax,
                                                         float* __restrict__ max_ov, int32_t* __restrict__ argmax,
                                                         unsigned* __restrict__ gt_max_bits) {
     extern __shared__ float4 sg[];
+    unsigned* sgm = reinterpret_cast<unsigned*>(sg + Kmax);
     const int b = blockIdx.y;
     const int K = ngt[b], N = nbox[b];
-    for (int i = threadIdx.x; i < K; i += blockDim.x) sg[i] = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + i];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        sg[i] = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + i];
+        sgm[i] = 0u;
+    }
     __syncthreads();
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const float4 bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
+    const bool live = n < N;
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
     float best = -1.f;
     int bi = 0;
     for (int i = 0; i < K; ++i) {
-        const float v = iou_pair(sg[i], bx);
-        if (v > best) { best = v; bi = i; }
-        atomicMax(gt_max_bits + (long)b * Kmax + i, __float_as_uint(v));
+        float v = live ? iou_pair(sg[i], bx) : 0.f;
+        if (live && v > best) { best = v; bi = i; }
+        float m = v;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(sgm + i, __float_as_uint(m));
     }
-    max_ov[(long)b * Nmax + n] = K > 0 ? best : 0.f;
-    argmax[(long)b * Nmax + n] = bi;
+    if (live) {
+        max_ov[(long)b * Nmax + n] = K > 0 ? best : 0.f;
+        argmax[(long)b * Nmax + n] = bi;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+        if (sgm[i] != 0u) atomicMax(gt_max_bits + (long)b * Kmax + i, sgm[i]);
 }
 
 __global__ __launch_bounds__(256) void iou_pass2_kernel(const float* __restrict__ boxes, const int* __restrict__ nbox, int Nmax,

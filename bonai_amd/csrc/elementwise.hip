@@ -56,16 +56,21 @@ LOFT_EXPORT int loft_relu_bwd_bf16(const void* g, const void* y, void* out, int6
     return 0;
 }
 
-// ---- column sum: out[c] += sum_m x[m][c]   (x bf16 [M][C], out fp32, atomics; caller zeroes) ----
+// ---- column sum: out[c] += sum_m x[m][c]   (x bf16 [M][C], out fp32; caller zeroes) ----
+// Each block reduces a slab of rows: thread t owns the 8-channel group (t % ncg) of rows t/ncg, t/ncg + rpar, ...
+// (16-byte loads, a wave covers whole 128..512-byte rows), partial sums are combined through LDS and only
+// the first row-group issues the C global atomics.  The slab height is chosen so that ~2k blocks exist
+// whatever M is (layer4's M=8192 would otherwise leave 240 CUs idle).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, long M, int C, float* __restrict__ out,
                                                      int rows_per_block) {
-    const int cg = C >> 3;                       // 8-channel groups
-    const int lanes_c = cg < 256 ? cg : 256;     // threads across channels
-    const int rpar = 256 / lanes_c;              // rows handled in parallel
-    const int tc = threadIdx.x % lanes_c, tr = threadIdx.x / lanes_c;
+    __shared__ float part[256 * 8];
+    const int cg = C >> 3;
+    const int ncg = cg < 256 ? cg : 256;   // channel groups handled per pass
+    const int rpar = 256 / ncg;
+    const int tc = threadIdx.x % ncg, tr = threadIdx.x / ncg;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    for (int c8 = tc; c8 < cg; c8 += lanes_c) {
+    for (int c8 = tc; c8 < cg; c8 += ncg) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (tr < rpar)
             for (long r = r0 + tr; r < r1; r += rpar) {
@@ -74,17 +79,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc[q] += v[q];
             }
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) unsafeAtomicAdd(out + c8 * 8 + q, acc[q]);
+        for (int q = 0; q < 8; ++q) part[threadIdx.x * 8 + q] = acc[q];
+        __syncthreads();
+        if (tr == 0) {
+            for (int j = 1; j < rpar; ++j)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += part[(j * ncg + tc) * 8 + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) unsafeAtomicAdd(out + c8 * 8 + q, acc[q]);
+        }
     }
 }
 LOFT_EXPORT int loft_colsum_bf16(const void* x, int64_t M, int C, float* out, void* stream) {
     if (M <= 0) return 0;
     if (C % 8) return (int)hipErrorInvalidValue;
-    int rows = 512;
+    long rows = (M + 2047) / 2048;
+    if (rows < 16) rows = 16;
     long blocks = (M + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)M,
-                       C, out, rows);
+                       C, out, (int)rows);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -64,8 +64,10 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     grad_out = _nhwc(grad_out)
     rois = rois.float().contiguous()
     K, C = rois.shape[0], grad_out.shape[1]
+    accumulate = grad_feats is not None
     if grad_feats is None:
-        grad_feats = [zeros_nhwc(s[0], s[1], s[2], s[3], torch.float32, rois.device) for s in feat_shapes]
+        mk = zeros_nhwc if K == 0 else empty_nhwc
+        grad_feats = [mk(s[0], s[1], s[2], s[3], torch.float32, rois.device) for s in feat_shapes]
     if K == 0:
         return grad_feats
     H = L.arr(c_int, [s[2] for s in feat_shapes])
@@ -73,7 +75,8 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     S = L.arr(c_float, [1.0 / s for s in strides])
     gp = L.arr(c_void_p, [g.data_ptr() for g in grad_feats])
     L.check(lib.loft_roi_align_bwd(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
-                                   L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), L.stream()),
+                                   L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
+                                   int(accumulate), L.stream()),
             'loft_roi_align_bwd')
     return grad_feats
 

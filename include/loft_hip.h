@@ -37,14 +37,15 @@ extern "C" {
  * rois: [K,5] fp32 (batch_idx, x1, y1, x2, y2).  The level of each RoI is computed in-kernel
  * (map_roi_levels, :32-51).  out: [n_rot, K, P, P, C] in `dtype`; n_rot = 1, or 4 to emit the
  * four FOA rotations (offset_head_expand_feature.py:163-196) in the same pass.
- * bwd: grad_out has the layout of out; grad_feats[l] are fp32 NHWC accumulators (atomic adds;
- * the caller zeroes them).  H/W/scales are HOST arrays of num_levels entries. */
+ * bwd: grad_out has the layout of out; grad_feats[l] are fp32 NHWC maps [B,H[l],W[l],C], every pixel
+ * of which is written (accumulate=0) or added to (accumulate=1) exactly once -- no atomics reach HBM.
+ * H/W/scales are HOST arrays of num_levels entries. */
 int loft_roi_align_fwd(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                        int n_rot, void* out, void* stream);
 int loft_roi_align_bwd(float* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
-                       int n_rot, const void* grad_out, void* stream);
+                       int n_rot, const void* grad_out, int B, int accumulate, void* stream);
 /* map_roi_levels alone (single_level_roi_extractor.py:32-51) -> int32 [K]. */
 int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out, void* stream);
 

@@ -269,6 +269,8 @@ struct WgradArgs {
     int goy[CONV_MAX_TAPS], gox[CONV_MAX_TAPS], dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
     long g_gs, x_gs, dw_gs;
     int M, pix_per_split, ctiles;
+    float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
+    int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
 };
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
@@ -342,6 +344,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wn = wave >> 1, wc = wave & 1;
+    // bias gradient rides along on the blocks of the first channel tile: one extra MFMA per n-tile against an
+    // all-ones operand gives sum_k G[k][n] in every column of the result.
+    const bool do_db = a.db != nullptr && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
+    f32x16 accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
     const int nsteps = (mend - mbeg + 63) / 64;
     stage(mbeg, 0);
     for (int s = 0; s < nsteps; ++s) {
@@ -362,7 +375,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+            if (do_db) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], ones, accb[i], 0, 0, 0);
+            }
         }
+    }
+
+    if (do_db && (lane & 31) == 0) {
+        float* db = a.db + (long)grp * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                unsafeAtomicAdd(db + n, accb[i][r]);
+            }
     }
 
     float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
@@ -383,7 +411,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
                                      int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                                      const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                                      const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
-                                     int splits, void* stream) {
+                                     int splits, float* db, int db_tap, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 128) || (Cout % 128) || groups < 1) return (int)hipErrorInvalidValue;
     WgradArgs a;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
@@ -393,6 +421,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
         a.goy[t] = goy_host[t]; a.gox[t] = gox_host[t]; a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t];
     }
     a.g_gs = g_gs; a.x_gs = x_gs; a.dw_gs = dw_gs;
+    a.db = db; a.db_tap = db ? db_tap : -1;
     const long M = (long)B * OH * OW;
     if (M <= 0) return 0;
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
@@ -410,6 +439,99 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     splits = (int)((M + pps - 1) / pps);
     dim3 grid(tiles, T * groups, splits);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================
+// Stem: conv 7x7 / stride 2 / pad 3, 3 -> 64 channels, + folded frozen BN + ReLU on MFMA
+// (mmdet/models/backbones/resnet.py:628-630).  K = 3*7*7 = 147 is far too shallow per tap for the tap
+// kernel, so the A tile is an *LDS-only* im2col: each workgroup gathers its 8x16 output pixels' patches
+// straight from the fp32 NCHW image into the swizzled bf16 LDS layout (k = c*49 + r*7 + s, zero padded
+// to 192 = 3 chunks of 64) -- nothing im2col-shaped ever touches HBM.  wgt: bf16 [64][192] with the BN
+// scale folded in, bias = BN shift.  out: bf16 NHWC [B, H/2, W/2, 64].
+// =====================================================================================
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ img, const bf16_t* __restrict__ wgt,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int H, int W,
+                                                        int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) char lds[128 * 128 + 64 * 128];  // A chunk [128][64] + B chunk [64][64]
+    char* abuf = lds;
+    char* bbuf = lds + 128 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, oy0 = blockIdx.y * 8, ox0 = blockIdx.x * 16;
+    const int m = tid & 127, kh = tid >> 7;
+    const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+    const float* ib = img + (long)b * 3 * H * W;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int frow = lane & 31, fq = lane >> 5;
+#pragma unroll
+    for (int chunk = 0; chunk < 3; ++chunk) {
+        if (chunk) __syncthreads();
+        // ---- gather A: this thread fills k = chunk*64 + kh*32 + [0,32) of row m
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = chunk * 64 + kh * 32 + q8 * 8 + e;
+                float x = 0.f;
+                if (k < 147) {
+                    const int c = k / 49, rs = k - c * 49, r = rs / 7, s2 = rs - r * 7;
+                    const int iy = 2 * oy + r - 3, ix = 2 * ox + s2 - 3;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W && oy < Ho && ox < Wo) x = ib[((long)c * H + iy) * W + ix];
+                }
+                v[e] = (short)f32_to_bf16(x);
+            }
+            const int q = kh * 4 + q8;
+            *reinterpret_cast<bf16x8*>(abuf + m * 128 + swz(m, q) * 16) = v;
+        }
+        // ---- B chunk: 64 rows x 8 sixteen-byte pieces = 512 pieces, 2 per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = tid + i * 256, row = piece >> 3, q = piece & 7;
+            *reinterpret_cast<uint4*>(bbuf + row * 128 + swz(row, q) * 16) =
+                *reinterpret_cast<const uint4*>(wgt + row * 192 + chunk * 64 + q * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks * 2 + fq;
+            const int arow = wave * 32 + frow;
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(abuf + arow * 128 + swz(arow, q) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int brow = i * 32 + frow;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(bbuf + brow * 128 + swz(brow, q) * 16);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    const int mo = wave * 32 + frow;
+    const int py = oy0 + (mo >> 4), px = ox0 + (mo & 15);
+    if (py >= Ho || px >= Wo) return;
+    bf16_t* op = out + (((long)b * Ho + py) * Wo + px) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = i * 32 + 8 * gq + 4 * fq;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            float v[4] = {fmaxf(acc[i][gq * 4 + 0] + bv.x, 0.f), fmaxf(acc[i][gq * 4 + 1] + bv.y, 0.f),
+                          fmaxf(acc[i][gq * 4 + 2] + bv.z, 0.f), fmaxf(acc[i][gq * 4 + 3] + bv.w, 0.f)};
+            st4(op + n, v);
+        }
+}
+
+LOFT_EXPORT int loft_stem7x7_mfma(const float* img, const void* wgt_packed, const float* bias, void* out, int B, int H, int W,
+                                  void* stream) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    dim3 grid(loft_cdiv(Wo, 16), loft_cdiv(Ho, 8), B);
+    hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, (const bf16_t*)wgt_packed, bias,
+                       (bf16_t*)out, H, W, Ho, Wo);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

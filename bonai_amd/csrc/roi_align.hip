@@ -137,13 +137,29 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiLevels L, const f
 // Versus the scatter formulation (one global fp32 atomic per sample-corner-channel, ~3.7e9 per step at
 // batch 8) this moves all accumulation traffic into LDS; HBM sees each gradient pixel once.
 #define RB_TILE 8
-#define RB_LIST 128
+#define RB_LIST 256
+
+// prepass: one record per RoI = (batch, level, clamped pixel footprint) so the tile owners scan 16-byte
+// records instead of redoing sqrt/log2 per (tile, RoI) pair.
+__global__ void roi_prep_kernel(RoiLevels L, const float* __restrict__ rois, int K, int P, int4* __restrict__ rec) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float* roi = rois + 5 * (size_t)k;
+    const RoiGeom g = roi_geom(roi, L, P);
+    const int H = L.H[g.level], W = L.W[g.level];
+    const float end_w = g.start_w + g.bin_w * (float)P, end_h = g.start_h + g.bin_h * (float)P;
+    const float lo_x = fminf(g.start_w, end_w) - 1.f, hi_x = fmaxf(g.start_w, end_w) + 1.f;
+    const float lo_y = fminf(g.start_h, end_h) - 1.f, hi_y = fmaxf(g.start_h, end_h) + 1.f;
+    const int x0 = (int)floorf(fminf(fmaxf(lo_x, 0.f), (float)(W - 1))), x1 = (int)ceilf(fminf(fmaxf(hi_x, 0.f), (float)(W - 1)));
+    const int y0 = (int)floorf(fminf(fmaxf(lo_y, 0.f), (float)(H - 1))), y1 = (int)ceilf(fminf(fmaxf(hi_y, 0.f), (float)(H - 1)));
+    rec[k] = make_int4(g.batch, g.level, x0 | (x1 << 16), y0 | (y1 << 16));
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, int level, const float* __restrict__ rois,
                                                                  int K, int C, int P, int n_rot,
                                                                  const T* __restrict__ gout, float* __restrict__ grad,
-                                                                 int accumulate) {
+                                                                 int accumulate, const int4* __restrict__ rec, int sorted) {
     extern __shared__ __attribute__((aligned(16))) float acc[];  // [64][C]
     __shared__ int list[RB_LIST];
     __shared__ int nlist;
@@ -152,24 +168,25 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = C >> 2;
     for (int i = tid; i < RB_TILE * RB_TILE * C; i += 256) acc[i] = 0.f;
-    for (int base = 0; base < K; base += RB_LIST) {  // RoIs in chunks that always fit the list
+    // RoIs are image-major (bbox2roi order): binary-search this image's range once, then scan only it
+    __shared__ int range[2];
+    if (tid < 2) {
+        int lo = 0, hi = K;
+        const int key = b + tid;   // first record with batch >= b (tid 0) / >= b+1 (tid 1)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
+        range[tid] = lo;
+    }
+    __syncthreads();
+    const int kbeg = sorted ? range[0] : 0, kend = sorted ? range[1] : K;
+    for (int base = kbeg; base < kend; base += RB_LIST) {  // chunks that always fit the list
         if (tid == 0) nlist = 0;
         __syncthreads();
         const int k = base + tid;
-        if (tid < RB_LIST && k < K) {
-            const float* roi = rois + 5 * (size_t)k;
-            if ((int)roi[0] == b) {
-                const RoiGeom g = roi_geom(roi, L, P);
-                if (g.level == level) {
-                    // pixels a sample of this RoI can touch: floor(start)-ish .. ceil(end)+1, after clamping to the map
-                    const float end_w = g.start_w + g.bin_w * (float)P, end_h = g.start_h + g.bin_h * (float)P;
-                    const float lo_x = fminf(g.start_w, end_w) - 1.f, hi_x = fmaxf(g.start_w, end_w) + 1.f;
-                    const float lo_y = fminf(g.start_h, end_h) - 1.f, hi_y = fmaxf(g.start_h, end_h) + 1.f;
-                    const float cx0 = fminf(fmaxf(lo_x, 0.f), (float)(W - 1)), cx1 = fminf(fmaxf(hi_x, 0.f), (float)(W - 1));
-                    const float cy0 = fminf(fmaxf(lo_y, 0.f), (float)(H - 1)), cy1 = fminf(fmaxf(hi_y, 0.f), (float)(H - 1));
-                    if (cx1 >= (float)tx0 && cx0 < (float)(tx0 + RB_TILE) && cy1 >= (float)ty0 && cy0 < (float)(ty0 + RB_TILE))
-                        list[atomicAdd(&nlist, 1)] = k;
-                }
+        if (k < kend) {
+            const int4 r = rec[k];
+            if (r.x == b && r.y == level) {
+                const int x0 = r.z & 0xffff, x1 = r.z >> 16, y0 = r.w & 0xffff, y1 = r.w >> 16;
+                if (x1 >= tx0 && x0 < tx0 + RB_TILE && y1 >= ty0 && y0 < ty0 + RB_TILE) list[atomicAdd(&nlist, 1)] = k;
             }
         }
         __syncthreads();
@@ -281,11 +298,17 @@ LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const
 
 LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const int* W, const float* scales,
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
-                                   int P, int n_rot, const void* grad_out, int B, int accumulate, void* stream) {
+                                   int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
+                                   void* workspace, void* stream) {
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || C > 512)
         return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(nullptr, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
+    int4* rec = (int4*)workspace;
+    if (K > 0) {
+        hipLaunchKernelGGL(roi_prep_kernel, dim3(loft_cdiv(K, 256)), dim3(256), 0, s, L, rois, K, P, rec);
+        LOFT_LAUNCH_CHECK();
+    }
     const size_t sh = (size_t)RB_TILE * RB_TILE * C * sizeof(float);
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
@@ -297,10 +320,10 @@ LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const
         }
         if (dtype == LOFT_BF16)
             hipLaunchKernelGGL(roi_align_bwd_tile_kernel<bf16_t>, grid, dim3(256), sh, s, L, l, rois, K, C, P, n_rot,
-                               (const bf16_t*)grad_out, grad_feats[l], accumulate);
+                               (const bf16_t*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
         else if (dtype == LOFT_F32)
             hipLaunchKernelGGL(roi_align_bwd_tile_kernel<float>, grid, dim3(256), sh, s, L, l, rois, K, C, P, n_rot,
-                               (const float*)grad_out, grad_feats[l], accumulate);
+                               (const float*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
         else
             return (int)hipErrorInvalidValue;
         LOFT_LAUNCH_CHECK();

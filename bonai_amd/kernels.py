@@ -57,7 +57,8 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
     return out
 
 
-def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_rot=1, grad_feats=None):
+def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_rot=1, grad_feats=None,
+                  rois_sorted=False):
     """Accumulates into fp32 NHWC buffers (created zeroed when not supplied) and returns them."""
     lib = L.load()
     L.dev_check(grad_out, rois)
@@ -74,9 +75,10 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     W = L.arr(c_int, [s[3] for s in feat_shapes])
     S = L.arr(c_float, [1.0 / s for s in strides])
     gp = L.arr(c_void_p, [g.data_ptr() for g in grad_feats])
+    ws = torch.empty(16 * K, dtype=torch.uint8, device=rois.device)
     L.check(lib.loft_roi_align_bwd(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
                                    L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
-                                   int(accumulate), L.stream()),
+                                   int(accumulate), int(rois_sorted), L.ptr(ws), L.stream()),
             'loft_roi_align_bwd')
     return grad_feats
 
@@ -313,8 +315,9 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
 
 
 def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,
-               splits=0, dw=None):
-    """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index)."""
+               splits=0, dw=None, db=None, db_tap=-1):
+    """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index).
+    db: optional zeroed fp32 [groups, Cout] -> bias gradient accumulated in the same pass."""
     lib = L.load()
     L.dev_check(g, x)
     _bf16(g), _bf16(x)
@@ -324,21 +327,29 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     _ev = _prof_begin()
     L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                      XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
-                                     c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.stream()),
+                                     c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
+                                     int(db_tap), L.stream()),
             'loft_conv_wgrad_bf16')
     _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps))
     return dw
 
 
-def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0):
-    """-> fp32 [G, R*S, Cout, Cin] (packed layout; see unpack_dw)."""
+def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0, with_bias=False):
+    """-> fp32 [G, R*S, Cout, Cin] (packed layout; see unpack_dw); with_bias: also -> fp32 [G, Cout] bias gradient."""
     g, x = _nhwc(g), _nhwc(x)
     GB, Cout, OH, OW = g.shape
     _, Cin, IH, IW = x.shape
     B = GB // groups
     taps = [(0, 0, r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
-    return conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
-                      g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits)
+    db, db_tap = None, -1
+    if with_bias:
+        centre = [i for i, t in enumerate(taps) if t[2] == 0 and t[3] == 0]
+        if not centre:
+            raise L.LoftHipError('fused bias gradient needs a tap with zero offset')
+        db, db_tap = torch.zeros(groups, Cout, dtype=torch.float32, device=g.device), centre[0]
+    dw = conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
+                    g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits, db=db, db_tap=db_tap)
+    return (dw, db) if with_bias else dw
 
 
 # ------------------------------------------------------------------ HBM-bound glue
@@ -420,6 +431,21 @@ def stem7x7_bn_relu(img, w, scale, shift):
     L.check(lib.loft_stem7x7_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale),
                                      L.ptr(shift), L.ptr(out), B, H, W, L.stream()),
             'loft_stem7x7_bn_relu')
+    return out
+
+
+def stem7x7_mfma(img, w, scale, shift):
+    """MFMA stem: img fp32 NCHW [B,3,H,W], w fp32 [64,3,7,7], folded BN scale/shift -> bf16 channels_last [B,64,H/2,W/2]."""
+    lib = L.load()
+    L.dev_check(img, w, scale, shift)
+    img = img.float().contiguous()
+    wp = torch.zeros(64, 192, dtype=torch.bfloat16, device=img.device)
+    wp[:, :147] = (w.float() * scale.float()[:, None, None, None]).reshape(64, 147).to(torch.bfloat16)
+    bias = shift.float().contiguous()
+    B, _, H, W = img.shape
+    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, torch.bfloat16, img.device)
+    L.check(lib.loft_stem7x7_mfma(L.ptr(img), L.ptr(wp), L.ptr(bias), L.ptr(out), B, H, W, L.stream()),
+            'loft_stem7x7_mfma')
     return out
 
 

@@ -48,11 +48,17 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = torch.stack([K.pack_w_dgrad(wg[i]) for i in range(G)]) if G > 1 else K.pack_w_dgrad(wg[0])[None]
             gx = K.conv2d_dgrad(g, wpt, in_hw, R, S, stride, pad, groups=G)
+        want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dwp = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G)          # [G, R*S, Cout, Cin] fp32
+            if want_b:   # bias gradient rides along in the wgrad kernel (ones-operand MFMA)
+                dwp, gb = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, with_bias=True)
+                gb = gb if grouped else gb[0]
+                want_b = False
+            else:
+                dwp = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G)      # [G, R*S, Cout, Cin] fp32
             gw = dwp.view(G, R, S, Cout, Cin).permute(0, 3, 4, 1, 2)
             gw = gw if grouped else gw[0]
-        if has_b and ctx.needs_input_grad[2]:
+        if want_b:
             if G == 1:
                 gb = K.colsum(g, Cout)
             else:
@@ -155,9 +161,11 @@ class _DeconvFn(torch.autograd.Function):
             K.conv_tap(g, wt, gx, N, 2 * H, 2 * W, Cout, Cin, H, W, H, W, taps, ss=2)
         if ctx.needs_input_grad[1]:
             taps = [(py, px, 0, 0, py * 2 + px) for py in range(2) for px in range(2)]
-            dwp = K.conv_wgrad(g, x, N, 2 * H, 2 * W, Cout, H, W, Cin, H, W, taps, 4, gos=2, ss=1)
+            db = torch.zeros(1, Cout, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+            dwp = K.conv_wgrad(g, x, N, 2 * H, 2 * W, Cout, H, W, Cin, H, W, taps, 4, gos=2, ss=1, db=db, db_tap=-2)
             gw = dwp[0].view(2, 2, Cout, Cin).permute(3, 2, 0, 1)
-        if ctx.needs_input_grad[2]:
+            gb = db[0] if db is not None else None
+        elif ctx.needs_input_grad[2]:
             gb = K.colsum(g, Cout)
         return gx, gw, gb
 
@@ -177,7 +185,7 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
         P, strides, fs, n_rot, shapes, dt = ctx.meta
-        grads = K.roi_align_bwd(to_nhwc(g), rois, shapes, P, strides, fs, n_rot)
+        grads = K.roi_align_bwd(to_nhwc(g), rois, shapes, P, strides, fs, n_rot, rois_sorted=True)  # bbox2roi order
         return (None, None, None, None, None) + tuple(K.cast_bf16(x) if dt == torch.bfloat16 else x for x in grads)
 
 

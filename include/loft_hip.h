@@ -39,13 +39,15 @@ extern "C" {
  * four FOA rotations (offset_head_expand_feature.py:163-196) in the same pass.
  * bwd: grad_out has the layout of out; grad_feats[l] are fp32 NHWC maps [B,H[l],W[l],C], every pixel
  * of which is written (accumulate=0) or added to (accumulate=1) exactly once -- no atomics reach HBM.
- * H/W/scales are HOST arrays of num_levels entries. */
+ * rois_sorted=1 promises the RoIs are ordered by batch index (bbox2roi order) so each tile scans only its
+ * image's RoIs; workspace: 16*K bytes.  H/W/scales are HOST arrays of num_levels entries. */
 int loft_roi_align_fwd(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                        int n_rot, void* out, void* stream);
 int loft_roi_align_bwd(float* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
-                       int n_rot, const void* grad_out, int B, int accumulate, void* stream);
+                       int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,
+                       void* stream);
 /* map_roi_levels alone (single_level_roi_extractor.py:32-51) -> int32 [K]. */
 int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out, void* stream);
 
@@ -93,12 +95,15 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32
  * [taps][Cout][Cin] accumulated with atomics (caller zeroes).  Cin % 128 == 0, Cout % 128 == 0.
- * splits <= 0 lets the library choose the split-K factor. */
+ * splits <= 0 lets the library choose the split-K factor.  db (may be NULL): fp32 [groups][Cout] bias
+ * gradient sum_pixels G, accumulated in the same pass from tap db_tap (a tap whose X gather never
+ * leaves the image, e.g. the centre tap; -2 = from every tap, for the transposed-conv case where the
+ * taps partition the G pixels); caller zeroes. */
 int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW,
                          int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                          const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
-                         void* stream);
+                         float* db, int db_tap, void* stream);
 
 /* ---- HBM-bound glue (bf16 NHWC unless noted; n = element counts, multiples of 8) ------------
  * relu_bwd: out = g * (y > 0)  -- autograd of the ReLUs fused into the conv epilogues
@@ -119,6 +124,10 @@ int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int 
 int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream);
 int loft_stem7x7_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out, int B,
                          int H, int W, void* stream);
+/* MFMA form of the stem (same reference lines): wgt_packed bf16 [64][192], row n = the 147 weights of output
+ * channel n in (c, r, s) order times the folded BN scale, zero padded; bias fp32 [64] = folded BN shift. */
+int loft_stem7x7_mfma(const float* img, const void* wgt_packed, const float* bias, void* out, int B, int H, int W,
+                      void* stream);
 int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int loft_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 /* Optimizer step of the reference run (mmcv OptimizerHook(grad_clip=dict(max_norm=35, norm_type=2)) +

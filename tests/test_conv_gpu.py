@@ -69,6 +69,10 @@ def test_conv_wgrad(B, Cin, Cout, H, W, R, stride, pad):
         dwp = K.conv2d_wgrad(_cl(g), _cl(x), R, R, stride, pad, splits=splits)
         got = K.unpack_dw(dwp[0], w.shape).cpu()
         assert (got - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item()), splits
+    dwp, db = K.conv2d_wgrad(_cl(g), _cl(x), R, R, stride, pad, with_bias=True)   # fused bias gradient
+    want_b = g.sum(dim=(0, 2, 3))
+    assert (db[0].cpu() - want_b).abs().max().item() < 1e-3 * max(1.0, want_b.abs().max().item())
+    assert (K.unpack_dw(dwp[0], w.shape).cpu() - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
 
 
 def test_conv_grouped_matches_loop():

@@ -53,6 +53,13 @@ def test_stem():
     out = K.stem7x7_bn_relu(img.cuda(), w.cuda(), scale.cuda(), shift.cuda()).float().cpu()
     assert out.shape == ref.shape
     assert (out - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+    # MFMA stem: bf16 operands (image and folded weights rounded), fp32 accumulate
+    imr = img.bfloat16().float()
+    wr = (w * scale[:, None, None, None]).bfloat16().float()
+    ref2 = F.relu(F.conv2d(imr, wr, None, 2, 3) + shift[None, :, None, None])
+    out2 = K.stem7x7_mfma(img.cuda(), w.cuda(), scale.cuda(), shift.cuda()).float().cpu()
+    assert out2.shape == ref2.shape
+    assert (out2 - ref2).abs().max().item() < 1e-2 * max(1.0, ref2.abs().max().item())
 
 
 def test_sgd_and_norm():

@@ -346,12 +346,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int wn = wave >> 1, wc = wave & 1;
     // bias gradient rides along on the blocks of the first channel tile: one extra MFMA per n-tile against an
     // all-ones operand gives sum_k G[k][n] in every column of the result.
-    const bool do_db = a.db != nullptr && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
-    f32x16 accb[2];
+    // (each of the 4 waves takes ONE of the block's four 32-row n-tiles: n-tile index = wn*2 + wc)
+    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);
+    f32x16 accb;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
@@ -375,22 +374,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
-            if (do_db) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], ones, accb[i], 0, 0, 0);
-            }
+            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[wc], ones, accb, 0, 0, 0);
         }
     }
 
     if (do_db && (lane & 31) == 0) {
         float* db = a.db + (long)grp * a.Cout;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                unsafeAtomicAdd(db + n, accb[i][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            unsafeAtomicAdd(db + n, accb[r]);
+        }
     }
 
     float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;

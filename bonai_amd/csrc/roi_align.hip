@@ -128,19 +128,20 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiLevels L, const f
     }
 }
 
-// ---- backward: tile-owner gather, no global atomics -------------------------------------------
-// One workgroup OWNS an 8x8-pixel tile of one image's gradient map at one pyramid level and keeps it
-// in LDS as fp32 [64 px][C] (64 KiB at C=256).  It scans the RoI list, compacts the RoIs of its
-// (image, level) whose footprint touches the tile, and for each of them replays the bins / bilinear
-// samples whose corners land inside the tile with LDS float atomics (ds_add_f32).  The tile is then
-// written (or added, when several extractors feed the same map) to HBM exactly once, coalesced.
-// Versus the scatter formulation (one global fp32 atomic per sample-corner-channel, ~3.7e9 per step at
-// batch 8) this moves all accumulation traffic into LDS; HBM sees each gradient pixel once.
+// ---- backward: tile-owner gather -- no atomics at all, neither in HBM nor in LDS ----------------------
+// One workgroup OWNS an 8x8-pixel tile of one image's gradient map at one pyramid level.  Wave w owns tile rows
+// 2w, 2w+1 and lane l owns channels 4l..4l+3, so the whole tile lives in 64 accumulator VGPRs per lane.  For every
+// RoI of this (image, level) whose footprint touches the tile (16-byte records from a prepass, RoIs of one image
+// found by binary search) the bilinear scatter is turned into a SEPARABLE gather:
+//     grad[y,x,:] += sum_{py,px} gout[py,px,:] / count * WY[py][y] * WX[px][x]
+// with WY[py][y] = sum over the bin's sample rows of the (clamped) hat weight of row y -- exactly the weights
+// mmcv's roi_align backward applies sample by sample, regrouped.  The two 1-D tables (<= 14x8 each) are rebuilt in
+// LDS per (RoI, tile); each needed gout row is read once per wave as one coalesced 512-byte access.
+// The tile is written (or added to) in HBM exactly once.
 #define RB_TILE 8
 #define RB_LIST 256
+#define RB_MAXP 14
 
-// prepass: one record per RoI = (batch, level, clamped pixel footprint) so the tile owners scan 16-byte
-// records instead of redoing sqrt/log2 per (tile, RoI) pair.
 __global__ void roi_prep_kernel(RoiLevels L, const float* __restrict__ rois, int K, int P, int4* __restrict__ rec) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -152,7 +153,24 @@ __global__ void roi_prep_kernel(RoiLevels L, const float* __restrict__ rois, int
     const float lo_y = fminf(g.start_h, end_h) - 1.f, hi_y = fmaxf(g.start_h, end_h) + 1.f;
     const int x0 = (int)floorf(fminf(fmaxf(lo_x, 0.f), (float)(W - 1))), x1 = (int)ceilf(fminf(fmaxf(hi_x, 0.f), (float)(W - 1)));
     const int y0 = (int)floorf(fminf(fmaxf(lo_y, 0.f), (float)(H - 1))), y1 = (int)ceilf(fminf(fmaxf(hi_y, 0.f), (float)(H - 1)));
-    rec[k] = make_int4(g.batch, g.level, x0 | (x1 << 16), y0 | (y1 << 16));
+    const int empty = (g.grid_h <= 0 || g.grid_w <= 0) ? 1 : 0;   // zero-size RoI: no samples, no gradient
+    rec[k] = make_int4(g.batch, g.level | (empty << 8), x0 | (x1 << 16), y0 | (y1 << 16));
+}
+
+// 1-D weight of tile row/col `pix` from the samples of bin `p`: same clamping rules as bil_setup
+__device__ __forceinline__ float axis_weight(float start, float bin, int grid, int p, int pix, int size) {
+    float w = 0.f;
+    for (int i = 0; i < grid; ++i) {
+        float v = start + p * bin + ((float)i + .5f) * bin / (float)grid;
+        if (v < -1.0f || v > (float)size) continue;
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
+        const float l = v - (float)lo, h = 1.f - l;
+        if (lo == pix) w += h;
+        if (hi == pix) w += l;
+    }
+    return w;
 }
 
 template <typename T>
@@ -160,103 +178,116 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, in
                                                                  int K, int C, int P, int n_rot,
                                                                  const T* __restrict__ gout, float* __restrict__ grad,
                                                                  int accumulate, const int4* __restrict__ rec, int sorted) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];  // [64][C]
     __shared__ int list[RB_LIST];
-    __shared__ int nlist;
+    __shared__ int wcnt[4];
+    __shared__ int range[2];
+    __shared__ float WY[RB_MAXP][RB_TILE], WX[RB_MAXP][RB_TILE];
+    __shared__ int rowany[RB_MAXP][4], colany[RB_MAXP];
     const int H = L.H[level], W = L.W[level];
     const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = C >> 2;
-    for (int i = tid; i < RB_TILE * RB_TILE * C; i += 256) acc[i] = 0.f;
-    // RoIs are image-major (bbox2roi order): binary-search this image's range once, then scan only it
-    __shared__ int range[2];
     if (tid < 2) {
         int lo = 0, hi = K;
-        const int key = b + tid;   // first record with batch >= b (tid 0) / >= b+1 (tid 1)
+        const int key = b + tid;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
         range[tid] = lo;
     }
     __syncthreads();
     const int kbeg = sorted ? range[0] : 0, kend = sorted ? range[1] : K;
-    for (int base = kbeg; base < kend; base += RB_LIST) {  // chunks that always fit the list
-        if (tid == 0) nlist = 0;
-        __syncthreads();
-        const int k = base + tid;
-        if (k < kend) {
-            const int4 r = rec[k];
-            if (r.x == b && r.y == level) {
-                const int x0 = r.z & 0xffff, x1 = r.z >> 16, y0 = r.w & 0xffff, y1 = r.w >> 16;
-                if (x1 >= tx0 && x0 < tx0 + RB_TILE && y1 >= ty0 && y0 < ty0 + RB_TILE) list[atomicAdd(&nlist, 1)] = k;
+    for (int cb = 0; cb < cg; cb += 64) {      // 256 channels per pass (one pass for the FPN's C = 256)
+        const int c0 = (cb + lane) << 2;
+        const bool cact = (cb + lane) < cg;
+        float acc[16][4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
+        for (int base = kbeg; base < kend; base += RB_LIST) {
+            // ---- deterministic compaction of the RoIs that touch this tile
+            const int k = base + tid;
+            bool hit = false;
+            if (k < kend) {
+                const int4 r = rec[k];
+                if (r.x == b && r.y == level) {   // (the empty flag lives in bits 8+ of r.y -> empty RoIs never match)
+                    const int x0 = r.z & 0xffff, x1 = r.z >> 16, y0 = r.w & 0xffff, y1 = r.w >> 16;
+                    hit = x1 >= tx0 && x0 < tx0 + RB_TILE && y1 >= ty0 && y0 < ty0 + RB_TILE;
+                }
             }
-        }
-        __syncthreads();
-        const int n = nlist;
-        for (int li = 0; li < n; ++li) {
-            const int kk = list[li];
-            const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
-            for (int bin = wave; bin < P * P; bin += 4) {
-                const int py = bin / P, px = bin - py * P;
-                // cheap reject: the bin's sample span (+1 px for the high corner) vs the tile, in clamped coordinates
-                const float by0 = g.start_h + py * g.bin_h, by1 = by0 + g.bin_h;
-                const float bx0 = g.start_w + px * g.bin_w, bx1 = bx0 + g.bin_w;
-                const float qy0 = fminf(fmaxf(fminf(by0, by1) - 1.f, 0.f), (float)(H - 1));
-                const float qy1 = fminf(fmaxf(fmaxf(by0, by1) + 1.f, 0.f), (float)(H - 1));
-                const float qx0 = fminf(fmaxf(fminf(bx0, bx1) - 1.f, 0.f), (float)(W - 1));
-                const float qx1 = fminf(fmaxf(fmaxf(bx0, bx1) + 1.f, 0.f), (float)(W - 1));
-                if (qy1 < (float)ty0 || qy0 >= (float)(ty0 + RB_TILE) || qx1 < (float)tx0 || qx0 >= (float)(tx0 + RB_TILE))
-                    continue;
-                for (int c4 = lane; c4 < cg; c4 += 64) {
-                    const int c0 = c4 << 2;
-                    float gv[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int r = 0; r < n_rot; ++r) {
-                        float t[4];
-                        ld4(gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + c0, t);
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = 0;
+            for (int w2 = 0; w2 < wave; ++w2) off += wcnt[w2];
+            const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            if (hit) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+            __syncthreads();
+            for (int li = 0; li < n; ++li) {
+                const int kk = list[li];
+                const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
+                if (tid < P * RB_TILE) {
+                    const int p = tid / RB_TILE, pix = tid % RB_TILE;
+                    WY[p][pix] = axis_weight(g.start_h, g.bin_h, g.grid_h, p, ty0 + pix, H);
+                } else if (tid >= 128 && tid < 128 + P * RB_TILE) {
+                    const int t = tid - 128, p = t / RB_TILE, pix = t % RB_TILE;
+                    WX[p][pix] = axis_weight(g.start_w, g.bin_w, g.grid_w, p, tx0 + pix, W);
+                }
+                __syncthreads();
+                if (tid < P) {
+                    int any = 0;
+                    for (int x = 0; x < RB_TILE; ++x) any |= (WX[tid][x] != 0.f);
+                    colany[tid] = any;
+                } else if (tid >= 64 && tid < 64 + P * 4) {
+                    const int t = tid - 64, p = t >> 2, w2 = t & 3;
+                    rowany[p][w2] = (WY[p][2 * w2] != 0.f) | (WY[p][2 * w2 + 1] != 0.f);
+                }
+                __syncthreads();
+                const float inv = 1.f / g.count;
+                for (int py = 0; py < P; ++py) {
+                    if (!rowany[py][wave]) continue;
+                    const float wy0 = WY[py][2 * wave] * inv, wy1 = WY[py][2 * wave + 1] * inv;
+                    for (int px = 0; px < P; ++px) {
+                        if (!colany[px]) continue;
+                        float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (cact)
+                            for (int r = 0; r < n_rot; ++r) {
+                                float t[4];
+                                ld4(gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + c0, t);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) gv[q] += t[q];
-                    }
+                                for (int q = 0; q < 4; ++q) gv[q] += t[q];
+                            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) gv[q] /= g.count;
-                    for (int iy = 0; iy < g.grid_h; ++iy) {
-                        const float y = g.start_h + py * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-                        for (int ix = 0; ix < g.grid_w; ++ix) {
-                            const float x = g.start_w + px * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-                            const Bil bl = bil_setup(y, x, H, W);
-                            if (!bl.valid) continue;
-                            const int ys[2] = {bl.y_low - ty0, bl.y_high - ty0};
-                            const int xs[2] = {bl.x_low - tx0, bl.x_high - tx0};
-                            const float ws[4] = {bl.w1, bl.w2, bl.w3, bl.w4};
+                        for (int x = 0; x < RB_TILE; ++x) {
+                            const float wx = WX[px][x];
+                            const float a0 = wy0 * wx, a1 = wy1 * wx;
 #pragma unroll
-                            for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                                for (int cx = 0; cx < 2; ++cx) {
-                                    if ((unsigned)ys[cy] < RB_TILE && (unsigned)xs[cx] < RB_TILE) {
-                                        float* a = acc + (size_t)(ys[cy] * RB_TILE + xs[cx]) * C + c0;
-                                        const float wgt = ws[cy * 2 + cx];
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) atomicAdd(a + q, gv[q] * wgt);
-                                    }
-                                }
+                            for (int q = 0; q < 4; ++q) {
+                                acc[x][q] += a0 * gv[q];
+                                acc[8 + x][q] += a1 * gv[q];
+                            }
                         }
                     }
                 }
+                __syncthreads();   // tables are rewritten by the next RoI
             }
         }
-        __syncthreads();
-    }
-    // flush the tile, one coalesced pass
-    for (int i = tid; i < RB_TILE * RB_TILE * cg; i += 256) {
-        const int pix = i / cg, c0 = (i - pix * cg) << 2;
-        const int y = ty0 + pix / RB_TILE, x = tx0 + pix % RB_TILE;
-        if (y >= H || x >= W) continue;
-        float* gp = grad + (((size_t)b * H + y) * W + x) * C + c0;
-        float v[4] = {acc[pix * C + c0], acc[pix * C + c0 + 1], acc[pix * C + c0 + 2], acc[pix * C + c0 + 3]};
-        if (accumulate) {
-            float o[4];
-            ld4(gp, o);
+        // ---- flush: wave w writes its two rows, every pixel one coalesced 1 KiB (fp32) access
+        if (cact) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += o[q];
+            for (int i = 0; i < 16; ++i) {
+                const int y = ty0 + 2 * wave + (i >> 3), x = tx0 + (i & 7);
+                if (y >= H || x >= W) continue;
+                float* gp = grad + (((size_t)b * H + y) * W + x) * C + c0;
+                float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                if (accumulate) {
+                    float o[4];
+                    ld4(gp, o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += o[q];
+                }
+                st4(gp, v);
+            }
         }
-        st4(gp, v);
     }
 }
 
@@ -300,7 +331,7 @@ LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
                                    int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
                                    void* workspace, void* stream) {
-    if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || C > 512)
+    if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || P > RB_MAXP)
         return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(nullptr, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
@@ -309,20 +340,13 @@ LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const
         hipLaunchKernelGGL(roi_prep_kernel, dim3(loft_cdiv(K, 256)), dim3(256), 0, s, L, rois, K, P, rec);
         LOFT_LAUNCH_CHECK();
     }
-    const size_t sh = (size_t)RB_TILE * RB_TILE * C * sizeof(float);
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
-        if (sh > 60000) {  // 64 KiB tile + the static list exceeds the default 64 KiB dynamic-LDS cap
-            hipError_t e = dtype == LOFT_BF16
-                ? hipFuncSetAttribute((const void*)roi_align_bwd_tile_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)
-                : hipFuncSetAttribute((const void*)roi_align_bwd_tile_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-            if (e != hipSuccess) return (int)e;
-        }
         if (dtype == LOFT_BF16)
-            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<bf16_t>, grid, dim3(256), sh, s, L, l, rois, K, C, P, n_rot,
+            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<bf16_t>, grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
         else if (dtype == LOFT_F32)
-            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<float>, grid, dim3(256), sh, s, L, l, rois, K, C, P, n_rot,
+            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<float>, grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const float*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
         else
             return (int)hipErrorInvalidValue;

@@ -269,11 +269,23 @@ struct WgradArgs {
     int goy[CONV_MAX_TAPS], gox[CONV_MAX_TAPS], dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
     long g_gs, x_gs, dw_gs;
     int M, pix_per_split, ctiles;
+    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW and OW via multiply-high (host-computed)
     float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
     int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
 };
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
+
+// n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned sh) {
+    return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> sh);
+}
+static inline void fastdiv_setup(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *sh = l;
+}
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
     // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][128] bf16 tile:
@@ -321,8 +333,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const bf16_t* pg = a.zero_page;
             const bf16_t* px = a.zero_page;
             if (m < mend) {
-                const int b = m / ohw, rem = m - b * ohw;
-                const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
                 const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
                 const int iy = oy * a.ss + dy, ix = ox * a.ss + dx;
                 if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
@@ -374,7 +386,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
-            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[wc], ones, accb, 0, 0, 0);
+            if (do_db) {   // static register select (a runtime-indexed fragment array would be demoted to scratch)
+                const bf16x8 gsel = wc ? gf[1] : gf[0];
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gsel, ones, accb, 0, 0, 0);
+            }
         }
     }
 
@@ -420,6 +435,8 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     if (M <= 0) return 0;
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
+    fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
+    fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
     a.ctiles = Cin / 128;
     const int tiles = (Cout / 128) * a.ctiles;
     if (splits <= 0) {  // aim for ~1024 workgroups, at least 4 K-steps each

@@ -69,7 +69,8 @@ class BucketedAllReduce:
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self.param_bucket[id(p)] = bi
-        self.stream = torch.cuda.Stream() if self.enabled else None
+        self.on_gpu = arena.data.is_cuda
+        self.stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.works = []
         if self.enabled:
             for p in arena.order:
@@ -88,6 +89,10 @@ class BucketedAllReduce:
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        self._remaining[bi] = -1
+        if not self.on_gpu:   # gloo / CPU (tests): same bucket order, no stream juggling
+            self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.stream.wait_event(ev)
@@ -103,7 +108,8 @@ class BucketedAllReduce:
                 self._launch(bi)
         for w in self.works:
             w.wait()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
 
 def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16, 22), gamma=0.1):

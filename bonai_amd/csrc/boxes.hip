@@ -356,3 +356,49 @@ LOFT_EXPORT int loft_mask_target(const uint8_t* masks, int H, int W, const float
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- mask paste (inference) ---------------------------------------------------------------------
+// FCNMaskHead.get_seg_masks -> _do_paste_mask (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:151-308):
+// sigmoid of the SxS logits, bilinear grid_sample(align_corners=False, zero padding) of each instance into its box
+// on the full image, threshold.  One thread per output pixel, only the pixels that can see the box are sampled.
+__global__ void mask_paste_kernel(const float* __restrict__ logits, const float* __restrict__ boxes, int N, int S, int img_h,
+                                  int img_w, float thr, uint8_t* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, n = blockIdx.z;
+    if (x >= img_w) return;
+    const float4 b = reinterpret_cast<const float4*>(boxes)[n];
+    // reference CPU path (skip_empty=True, one instance per chunk): only the tight integer region around the box
+    if ((float)x < fmaxf(floorf(b.x) - 1.f, 0.f) || (float)x >= fminf(ceilf(b.z) + 1.f, (float)img_w) ||
+        (float)y < fmaxf(floorf(b.y) - 1.f, 0.f) || (float)y >= fminf(ceilf(b.w) + 1.f, (float)img_h)) {
+        out[((long)n * img_h + y) * img_w + x] = 0;
+        return;
+    }
+    float gx = ((float)x + 0.5f - b.x) / (b.z - b.x) * 2.f - 1.f;
+    float gy = ((float)y + 0.5f - b.y) / (b.w - b.y) * 2.f - 1.f;
+    if (isinf(gx)) gx = 0.f;
+    if (isinf(gy)) gy = 0.f;
+    // grid_sample, align_corners=False: source coordinate = ((g + 1) * S - 1) / 2
+    const float sx = ((gx + 1.f) * (float)S - 1.f) * 0.5f, sy = ((gy + 1.f) * (float)S - 1.f) * 0.5f;
+    float v = 0.f;
+    if (sx > -1.f && sx < (float)S && sy > -1.f && sy < (float)S) {
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float lx = sx - fx, ly = sy - fy;
+        const float* m = logits + (long)n * S * S;
+        auto at = [&](int yy, int xx) -> float {
+            if (yy < 0 || yy >= S || xx < 0 || xx >= S) return 0.f;
+            return 1.f / (1.f + expf(-m[yy * S + xx]));
+        };
+        v = at(y0, x0) * (1.f - ly) * (1.f - lx) + at(y0, x0 + 1) * (1.f - ly) * lx + at(y0 + 1, x0) * ly * (1.f - lx) +
+            at(y0 + 1, x0 + 1) * ly * lx;
+    }
+    out[((long)n * img_h + y) * img_w + x] = v >= thr ? 1 : 0;
+}
+LOFT_EXPORT int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr,
+                                uint8_t* out, void* stream) {
+    if (N <= 0) return 0;
+    dim3 grid(loft_cdiv(img_w, 256), img_h, N);
+    hipLaunchKernelGGL(mask_paste_kernel, grid, dim3(256), 0, (hipStream_t)stream, logits, boxes, N, S, img_h, img_w, thr, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

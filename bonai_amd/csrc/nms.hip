@@ -158,3 +158,161 @@ LOFT_EXPORT int loft_segmented_sort_desc(const float* keys_in, float* keys_out, 
     if (!workspace) *workspace_bytes = (int64_t)bytes;
     return (int)e;
 }
+
+// ---------------------------------------------------------------- linear / naive / gaussian soft-NMS
+// mmcv-1.0.5 ships soft_nms as a CPU-only op (the reference therefore round-trips every test image through the
+// host: mmdet/core/post_processing/bbox_nms.py:63 with test_cfg.rcnn.nms.type='soft_nms').  This is the same
+// in-place max-selection algorithm as oracle/loft_oracle.c::orc_soft_nms, one workgroup per call:
+//   per output slot i:  (1) argmax over the live range [i, nb) with FIRST-position tie break (block reduction),
+//                       (2) swap into slot i, (3) decay every live score against box i in parallel,
+//                       (4) drop the boxes that fell below min_score with the SAME final arrangement the
+//                           sequential "overwrite with the last element and re-examine" loop produces: holes left
+//                           of the new end are filled, in ascending order, by the surviving tail elements taken in
+//                           descending order (two block-wide scans instead of a serial loop).
+// State lives in a caller-provided global workspace (L2 resident for the <= few thousand boxes of this path).
+#define SNMS_THREADS 1024
+
+struct SnmsState { float* x1; float* y1; float* x2; float* y2; float* sc; float* ar; int64_t* idx; };
+
+__device__ __forceinline__ void snms_swap(const SnmsState& s, int a, int b) {
+    float t;
+    t = s.x1[a]; s.x1[a] = s.x1[b]; s.x1[b] = t;  t = s.y1[a]; s.y1[a] = s.y1[b]; s.y1[b] = t;
+    t = s.x2[a]; s.x2[a] = s.x2[b]; s.x2[b] = t;  t = s.y2[a]; s.y2[a] = s.y2[b]; s.y2[b] = t;
+    t = s.sc[a]; s.sc[a] = s.sc[b]; s.sc[b] = t;  t = s.ar[a]; s.ar[a] = s.ar[b]; s.ar[b] = t;
+    int64_t u = s.idx[a]; s.idx[a] = s.idx[b]; s.idx[b] = u;
+}
+
+// exclusive block scan of one int per thread (1024 threads = 16 waves); returns the exclusive prefix, *total = sum
+__device__ __forceinline__ int block_exscan(int v, int* total, int* wsum /*[16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < SNMS_THREADS / 64; ++w) {
+        const int t = wsum[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SNMS_THREADS) void soft_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                               int n, float iou_thr, float sigma, float min_score, int method,
+                                                               SnmsState s, float* __restrict__ dets, int64_t* __restrict__ inds,
+                                                               int* __restrict__ n_out) {
+    __shared__ float red_v[SNMS_THREADS / 64];
+    __shared__ int red_p[SNMS_THREADS / 64];
+    __shared__ int wsum[SNMS_THREADS / 64];
+    __shared__ int s_maxpos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < n; p += SNMS_THREADS) {
+        const float4 b = reinterpret_cast<const float4*>(boxes)[p];
+        s.x1[p] = b.x; s.y1[p] = b.y; s.x2[p] = b.z; s.y2[p] = b.w;
+        s.sc[p] = scores[p]; s.ar[p] = (b.z - b.x) * (b.w - b.y); s.idx[p] = p;
+    }
+    __syncthreads();
+    int nb = n;
+    const int per = (n + SNMS_THREADS - 1) / SNMS_THREADS;   // contiguous slab of positions per thread (keeps scans ordered)
+    for (int i = 0; i < nb; ++i) {
+        // (1) first-position argmax over [i, nb)
+        float bv = -3.0e38f;
+        int bp = 0x7fffffff;
+        for (int p = i + tid; p < nb; p += SNMS_THREADS) {
+            const float v = s.sc[p];
+            if (v > bv) { bv = v; bp = p; }      // ascending p per thread -> first maximum kept
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int op = __shfl_xor(bp, o, 64);
+            if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_p[wave] = bp; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0]; int p = red_p[0];
+            for (int w = 1; w < SNMS_THREADS / 64; ++w)
+                if (red_v[w] > v || (red_v[w] == v && red_p[w] < p)) { v = red_v[w]; p = red_p[w]; }
+            s_maxpos = p;
+            // (2) swap the winner into slot i and emit it
+            snms_swap(s, i, p);
+            dets[5 * i] = s.x1[i]; dets[5 * i + 1] = s.y1[i]; dets[5 * i + 2] = s.x2[i]; dets[5 * i + 3] = s.y2[i];
+            dets[5 * i + 4] = s.sc[i];
+            inds[i] = s.idx[i];
+        }
+        __syncthreads();
+        const float ix1 = s.x1[i], iy1 = s.y1[i], ix2 = s.x2[i], iy2 = s.y2[i], iar = s.ar[i];
+        // (3) decay; (4) survivor bookkeeping on contiguous slabs [lo, hi) of the live tail (i, nb)
+        const int lo = i + 1 + tid * per, hi = min(nb, lo + per);
+        int surv = 0;
+        for (int p = lo; p < hi; ++p) {
+            const float xx1 = fmaxf(ix1, s.x1[p]), yy1 = fmaxf(iy1, s.y1[p]);
+            const float xx2 = fminf(ix2, s.x2[p]), yy2 = fminf(iy2, s.y2[p]);
+            const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+            const float inter = w * h;
+            const float ovr = inter / (iar + s.ar[p] - inter);
+            float weight = 1.f;
+            if (method == 0) { if (ovr >= iou_thr) weight = 0.f; }
+            else if (method == 1) { if (ovr >= iou_thr) weight = 1.f - ovr; }
+            else { weight = expf(-(ovr * ovr) / sigma); }
+            const float v = s.sc[p] * weight;
+            s.sc[p] = v;
+            surv += (v >= min_score) ? 1 : 0;    // the sequential loop drops sc < min_score
+        }
+        int total_surv;
+        const int surv_before = block_exscan(surv, &total_surv, wsum);
+        const int nb_new = i + 1 + total_surv;
+        if (nb_new < nb) {
+            // holes: dead positions < nb_new, ranked ascending; fillers: survivors at positions >= nb_new, ranked descending
+            int holes = 0, fill = 0;
+            for (int p = lo; p < hi; ++p) {
+                const bool alive = s.sc[p] >= min_score;
+                holes += (!alive && p < nb_new) ? 1 : 0;
+                fill += (alive && p >= nb_new) ? 1 : 0;
+            }
+            int tot_h, tot_f;
+            const int hole_rank0 = block_exscan(holes, &tot_h, wsum);
+            const int fill_before = block_exscan(fill, &tot_f, wsum);   // ascending rank; descending rank = tot_f-1-asc
+            // publish filler positions by descending rank into the (now free) dets tail as scratch: use inds tail
+            int r = fill_before;
+            for (int p = lo; p < hi; ++p)
+                if (s.sc[p] >= min_score && p >= nb_new) { inds[n - 1 - (tot_f - 1 - r)] = p; ++r; }  // slot n-1-d holds rank d
+            __syncthreads();
+            int hr = hole_rank0;
+            for (int p = lo; p < hi; ++p)
+                if (!(s.sc[p] >= min_score) && p < nb_new) {
+                    const int src = (int)inds[n - 1 - hr];
+                    s.x1[p] = s.x1[src]; s.y1[p] = s.y1[src]; s.x2[p] = s.x2[src]; s.y2[p] = s.y2[src];
+                    s.sc[p] = s.sc[src]; s.ar[p] = s.ar[src]; s.idx[p] = s.idx[src];
+                    ++hr;
+                }
+            (void)surv_before;
+            nb = nb_new;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = nb;
+}
+
+LOFT_EXPORT int64_t loft_soft_nms_workspace_bytes(int64_t n) { return n * (6 * 4 + 8) + 64; }
+
+LOFT_EXPORT int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_thr, float sigma, float min_score,
+                              int method, void* workspace, float* dets, int64_t* inds, int* n_out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return (int)hipMemsetAsync(n_out, 0, sizeof(int), st);
+    char* w = (char*)workspace;
+    SnmsState s;
+    s.idx = (int64_t*)w; w += 8 * n;
+    s.x1 = (float*)w; w += 4 * n; s.y1 = (float*)w; w += 4 * n; s.x2 = (float*)w; w += 4 * n; s.y2 = (float*)w; w += 4 * n;
+    s.sc = (float*)w; w += 4 * n; s.ar = (float*)w;
+    hipLaunchKernelGGL(soft_nms_kernel, dim3(1), dim3(SNMS_THREADS), 0, st, boxes, scores, (int)n, iou_thr, sigma, min_score,
+                       method, s, dets, inds, n_out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

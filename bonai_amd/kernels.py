@@ -580,3 +580,55 @@ def mask_target(masks_u8, boxes, gt_idx, S=28):
                                  L.ptr(gt_idx), c_int64(n), S, L.ptr(out), L.stream()),
             'loft_mask_target')
     return out
+
+
+# ------------------------------------------------------------------ inference post-processing
+
+def soft_nms(boxes, scores, iou_threshold=0.3, sigma=0.5, min_score=1e-3, method='linear'):
+    """mmcv.ops.soft_nms contract on the device: -> (dets [M,5], inds int64 [M]) in selection order."""
+    lib = L.load()
+    L.dev_check(boxes, scores)
+    boxes, scores = boxes.float().contiguous(), scores.float().contiguous()
+    n = boxes.shape[0]
+    dets = torch.zeros(n, 5, dtype=torch.float32, device=boxes.device)
+    inds = torch.zeros(n, dtype=torch.int64, device=boxes.device)
+    if n == 0:
+        return dets, inds
+    ws = torch.empty(lib.loft_soft_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    m = {'naive': 0, 'linear': 1, 'gaussian': 2}[method]
+    L.check(lib.loft_soft_nms(L.ptr(boxes), L.ptr(scores), c_int64(n), c_float(iou_threshold), c_float(sigma),
+                              c_float(min_score), m, L.ptr(ws), L.ptr(dets), L.ptr(inds), L.ptr(cnt), L.stream()),
+            'loft_soft_nms')
+    k = int(cnt.item())
+    return dets[:k], inds[:k]
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.batched_nms: shift by idx*(max_coord+1), dispatch on nms_cfg['type']."""
+    cfg = dict(nms_cfg)
+    class_agnostic = cfg.pop('class_agnostic', class_agnostic)
+    if class_agnostic or boxes.numel() == 0:
+        shifted = boxes
+    else:
+        shifted = boxes + (idxs.to(boxes) * (boxes.max() + 1))[:, None]
+    typ = cfg.pop('type', 'nms')
+    if typ == 'nms':
+        dets, keep = nms(shifted, scores, cfg['iou_threshold'])
+    elif typ == 'soft_nms':
+        dets, keep = soft_nms(shifted, scores, **cfg)
+    else:
+        raise L.LoftHipError(f'unknown nms type {typ}')
+    return torch.cat([boxes[keep], dets[:, -1:]], dim=-1), keep
+
+
+def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
+    """logits fp32 [N,S,S], boxes [N,4] -> uint8 [N,img_h,img_w]."""
+    lib = L.load()
+    L.dev_check(logits, boxes)
+    logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
+    N, S = logits.shape[0], logits.shape[-1]
+    out = torch.empty(N, img_h, img_w, dtype=torch.uint8, device=logits.device)
+    L.check(lib.loft_mask_paste(L.ptr(logits), L.ptr(boxes), N, S, int(img_h), int(img_w), c_float(thr), L.ptr(out),
+                                L.stream()), 'loft_mask_paste')
+    return out

@@ -32,6 +32,8 @@ def load():
         lib = ctypes.CDLL(_LIB_PATH)
         lib.loft_nms_workspace_bytes.restype = c_int64
         lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64]
+        lib.loft_soft_nms_workspace_bytes.restype = c_int64
+        lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
         _lib = lib
     return _lib
 

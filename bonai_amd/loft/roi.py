@@ -427,6 +427,83 @@ class LoftRoIHead(nn.Module):
             losses.update(self.offset_head.loss(offset_pred, offset_targets))
         return losses
 
+    # ---------------------------------------------------------------- inference
+    def multiclass_nms(self, multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1):
+        """mmdet/core/post_processing/bbox_nms.py:5-69 on the device (soft-NMS included)."""
+        num_classes = multi_scores.size(1) - 1
+        if multi_bboxes.shape[1] > 4:
+            bboxes = multi_bboxes.view(multi_scores.size(0), -1, 4)
+        else:
+            bboxes = multi_bboxes[:, None].expand(multi_scores.size(0), num_classes, 4)
+        scores = multi_scores[:, :-1]
+        valid = scores > score_thr
+        bboxes = bboxes[valid]
+        scores = scores[valid]
+        labels = valid.nonzero(as_tuple=False)[:, 1]
+        if bboxes.numel() == 0:
+            return multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0,), dtype=torch.long)
+        dets, keep = K.batched_nms(bboxes.contiguous(), scores.contiguous(), labels, nms_cfg)
+        if max_num > 0:
+            dets, keep = dets[:max_num], keep[:max_num]
+        return dets, labels[keep]
+
+    @torch.no_grad()
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
+        """loft_roi_head.py:196-227 (+ test_mixins.py:53-72,152-177,213-241): one image ->
+        (bbox_results, segm_results, offset_results) with the reference's types."""
+        dev = x[0].device
+        if isinstance(proposal_list, (list,)):
+            props = proposal_list[0]
+        else:
+            p, cnt = proposal_list
+            props = p[0, :int(cnt[0])]
+        meta = img_metas[0]
+        img_shape, scale_factor, ori_shape = meta['img_shape'], meta['scale_factor'], meta['ori_shape']
+        rois = torch.cat([props.new_zeros(props.shape[0], 1), props[:, :4]], 1)
+        cfg = self.test_cfg
+        cls_score, bbox_pred = self.bbox_head(self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois))
+        scores = torch.softmax(cls_score, dim=1)
+        ncls = self.bbox_head.num_classes
+        bp = bbox_pred.reshape(-1, 4)
+        rr = rois[:, 1:].repeat_interleave(bbox_pred.shape[1] // 4, dim=0)
+        bboxes = self.bbox_head.bbox_coder.decode(rr, bp, max_shape=img_shape).view(rois.shape[0], -1)
+        sf = torch.as_tensor(np.asarray(scale_factor, dtype=np.float32), device=dev)
+        if rescale:
+            bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf).view(bboxes.size(0), -1)
+        det_bboxes, det_labels = self.multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms, cfg.max_per_img)
+        db = det_bboxes.cpu().numpy()
+        dl = det_labels.cpu().numpy()
+        bbox_results = [db[dl == i, :] for i in range(ncls)] if db.shape[0] else \
+            [np.zeros((0, 5), dtype=np.float32) for _ in range(ncls)]
+        if det_bboxes.shape[0] == 0:
+            segm = [[] for _ in range(ncls)] if self.with_mask else None
+            return bbox_results, segm, [[] for _ in range(2)]
+        _bboxes = det_bboxes[:, :4] * sf if rescale else det_bboxes[:, :4]
+        det_rois = torch.cat([_bboxes.new_zeros(_bboxes.shape[0], 1), _bboxes], 1).contiguous()
+        segm_results = None
+        if self.with_mask:
+            mask_pred = self.mask_head(self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], det_rois))
+            sel = mask_pred[torch.arange(mask_pred.shape[0], device=dev), 0 if self.mask_head.class_agnostic else det_labels]
+            if rescale:
+                img_h, img_w = ori_shape[:2]
+                pb = _bboxes / sf
+            else:
+                img_h = int(np.round(ori_shape[0] * float(np.asarray(scale_factor).reshape(-1)[1 if np.size(scale_factor) > 1 else 0])))
+                img_w = int(np.round(ori_shape[1] * float(np.asarray(scale_factor).reshape(-1)[0])))
+                pb = _bboxes
+            im = K.mask_paste(sel, pb.contiguous(), img_h, img_w, cfg.mask_thr_binary).bool().cpu().numpy()
+            segm_results = [[] for _ in range(ncls)]
+            for i in range(im.shape[0]):
+                segm_results[int(dl[i])].append(im[i])
+        offset_pred = self._offset_forward(x, det_rois)
+        if isinstance(self.offset_head, OffsetHeadExpandFeature):
+            offset_results = self.offset_head.get_offsets(offset_pred, _bboxes.contiguous(), scale_factor, rescale)
+        else:
+            s = self.offset_head.offset_coder.stds
+            wh = _bboxes[:, 2:4] - _bboxes[:, 0:2]
+            offset_results = (offset_pred * offset_pred.new_tensor(s) * wh).clamp(-1024, 1024).cpu().numpy().astype(np.float32)
+        return bbox_results, segm_results, offset_results
+
     def _offset_forward(self, x, rois):
         feats = x[:self.offset_roi_extractor.num_inputs]
         if isinstance(self.offset_head, OffsetHeadExpandFeature):

@@ -175,6 +175,19 @@ int loft_foa_fuse_decode(const float* pred, const float* boxes, int64_t n, float
 int loft_mask_target(const uint8_t* masks, int H, int W, const float* boxes, const int64_t* gt_idx, int64_t n, int S,
                      float* out, void* stream);
 
+/* ---- inference post-processing --------------------------------------------------------------------
+ * loft_soft_nms: mmcv.ops.soft_nms (CPU-only in mmcv 1.0.5), reached from multiclass_nms
+ * (mmdet/core/post_processing/bbox_nms.py:63, test_cfg.rcnn.nms = dict(type='soft_nms', iou_threshold=0.5)).
+ * boxes [n,4], scores [n] -> dets [n,5] and inds int64 [n] in selection order, *n_out kept.  method 0 naive,
+ * 1 linear, 2 gaussian.  Same in-place max-selection order (ties: first position) as the reference op.
+ * loft_mask_paste: FCNMaskHead.get_seg_masks / _do_paste_mask (fcn_mask_head.py:151-308): logits fp32 [N,S,S]
+ * (class already selected), boxes [N,4] in output-image pixels -> out uint8 {0,1} [N,img_h,img_w]. */
+int64_t loft_soft_nms_workspace_bytes(int64_t n);
+int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_thr, float sigma, float min_score, int method,
+                  void* workspace, float* dets, int64_t* inds, int* n_out, void* stream);
+int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

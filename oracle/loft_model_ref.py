@@ -225,3 +225,31 @@ def forward_train(sd, img, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.
         extras.update(feats=feats, rpn_cls=cls, rpn_reg=reg, proposals=props)
         return losses, extras
     return losses
+
+
+def simple_test(sd, img, rescale=False, scale_factor=(1., 1., 1., 1.), score_thr=0.05, max_per_img=2000):
+    """two_stage.py:187-199 -> loft_roi_head.py:196-227 for ONE image (test_cfg of bonai_loft_foa_r50_fpn_basic.py:127-140).
+    -> (det_bboxes [n,5], det_labels [n], masks bool [n,H,W], offsets [n,2])."""
+    H, W = img.shape[2:]
+    feats = fpn(sd, backbone(sd, img))
+    cls, reg = rpn_forward(sd, feats)
+    props = rpn_proposals(cls, reg, (H, W, 3))[0]
+    rois = R.bbox2roi([props])
+    p4 = feats[:4]
+    cls_score, bbox_pred = bbox_head(sd, R.roi_extract(p4, rois, 7))
+    scores = torch.softmax(cls_score, dim=1)
+    bboxes = R.delta2bbox(rois[:, 1:], bbox_pred, stds=(.1, .1, .2, .2), max_shape=(H, W, 3))
+    sf = torch.tensor(scale_factor, dtype=torch.float32)
+    if rescale:
+        bboxes = bboxes / sf
+    det, lab = R.multiclass_nms(bboxes, scores, score_thr, dict(type='soft_nms', iou_threshold=0.5), max_per_img)
+    if det.shape[0] == 0:
+        return det, lab, torch.zeros(0, H, W, dtype=torch.bool), torch.zeros(0, 2)
+    _b = det[:, :4] * sf if rescale else det[:, :4]
+    drois = R.bbox2roi([_b])
+    mp = mask_head(sd, R.roi_extract(p4, drois, 14)).sigmoid()
+    mp = mp[torch.arange(mp.shape[0]), lab][:, None]
+    masks = R.paste_masks(mp, _b / sf if rescale else _b, H, W, 0.5)
+    op = foa_head(sd, R.roi_extract(p4, drois, 7))
+    offsets = R.delta2offset(_b, R.foa_fuse(op), max_shape=[1024, 1024])
+    return det, lab, masks, offsets

@@ -173,7 +173,32 @@ def e2e(size=256, batch=2, num_gt=10):
     print(f'e2e_{size}.npz', {k: float(v) for k, v in log_vars.items()})
 
 
+def e2e_test(size=256):
+    """Reference LOFT in eval mode: forward_test -> simple_test 3-tuple on a seeded tile."""
+    from bonai_amd.config import Config
+    from bonai_amd.synth import make_batch
+    from mmdet.models import build_detector
+    from oracle.synth_weights import synth_state_dict
+    cfg = Config.fromfile('/root/reference/configs/loft_foa/loft_foa_r50_fpn_2x_bonai.py')
+    cfg.model.pretrained = None
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict(synth_state_dict(m.state_dict()))
+    m.eval()
+    data = make_batch(1, size, 4)
+    with torch.no_grad():
+        bbox_results, segm_results, offset_results = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False,
+                                                       rescale=True)
+    det = bbox_results[0]
+    masks = np.stack(segm_results[0]) if len(segm_results[0]) else np.zeros((0, size, size), bool)
+    out = dict(det=det.astype(np.float32), offsets=np.asarray(offset_results, np.float32),
+               mask_area=masks.reshape(masks.shape[0], -1).sum(1).astype(np.int64),
+               mask_rowsum=masks.sum(2).astype(np.int32)[:64], meta=np.array([size]))
+    np.savez_compressed(os.path.join(GOLD, f'e2e_test_{size}.npz'), **out)
+    print(f'e2e_test_{size}.npz dets', det.shape, 'top', det[:2], 'offsets', out['offsets'][:2], 'areas', out['mask_area'][:5])
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
     core_ops()
     e2e()
+    e2e_test()

@@ -27,6 +27,9 @@
 // q ^ ((r>>1)&7), applied on the per-lane *global source* address (the LDS image of a glds is
 // lane-linear) and again on the ds_read_b128 address: conflict-free for the 16-lane groups that
 // ds_read_b128 is serviced in.  Roofline: MFMA (dense bf16 2.5 PFLOP/s).
+// Measured alternative (round 1): a 3-stage counted-vmcnt pipeline at 96 KiB LDS (1 block/CU) was SLOWER than this
+// 2-stage / 2-blocks-per-CU form (fpn P2 3x3: 538 vs 649 TFLOP/s) -- the second resident block hides more than the
+// deeper prefetch does; the next step is a 256-row, 8-wave tile with fragment double-buffering, not more stages.
 #include "loft_common.h"
 #include "../../include/loft_hip.h"
 

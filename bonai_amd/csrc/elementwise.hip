@@ -389,3 +389,83 @@ LOFT_EXPORT int loft_sgd_momentum_f32(float* p, const float* g, float* m, int64_
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- weight fold + pack (one launch per conv per step) and its chain rule -------------------------------
+// Forward: from the fp32 master weight in the reference layout [Cout][Cin][R][S] (+ optional frozen-statistics BN
+// gamma/beta/mean/var, tools/fuse_conv_bn.py:10-23) produce in ONE pass the bf16 operand packings the MFMA kernels
+// consume: fwd [R*S][Cout][Cin], dgrad [R*S][Cin][Cout] (either may be NULL), and the fp32 epilogue bias
+// (BN shift, or the conv bias).  Backward: from the packed fp32 weight gradient of the folded weight and the bias
+// gradient produce dW in the reference layout, dgamma, dbeta.
+__global__ void fold_pack_kernel(const float* __restrict__ w, const float* __restrict__ cbias, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+                                 float eps, int Cout, int Cin, int RS, bf16_t* __restrict__ wp, bf16_t* __restrict__ wpt,
+                                 float* __restrict__ bias_out) {
+    const long total = (long)Cout * Cin * RS;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the fwd packing [t][n][c] (coalesced writes); gather from [n][c][t]
+        const int c = (int)(i % Cin);
+        const long r = i / Cin;
+        const int n = (int)(r % Cout), t = (int)(r / Cout);
+        float v = w[((long)n * Cin + c) * RS + t];
+        if (gamma) v *= gamma[n] * rsqrtf(var[n] + eps);
+        const bf16_t h = f32_to_bf16(v);
+        if (wp) wp[i] = h;
+        if (wpt) wpt[((long)t * Cin + c) * Cout + n] = h;
+    }
+    if (bias_out && blockIdx.x == 0)
+        for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
+            if (gamma) bias_out[n] = beta[n] - mean[n] * gamma[n] * rsqrtf(var[n] + eps);
+            else bias_out[n] = cbias ? cbias[n] : 0.f;
+        }
+}
+LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
+                               const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad,
+                               float* bias_out, void* stream) {
+    const long total = (long)Cout * Cin * RS;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(fold_pack_kernel, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta, mean, var,
+                       eps, Cout, Cin, RS, (bf16_t*)wp_fwd, (bf16_t*)wp_dgrad, bias_out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// one block per output channel n
+__global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ db,
+                                                              const float* __restrict__ w, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ var,
+                                                              float eps, int Cout, int Cin, int RS, float* __restrict__ dw,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int n = blockIdx.x;
+    const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
+    const float scale = gamma ? gamma[n] * rs : 1.f;
+    float acc = 0.f;
+    const int per = Cin * RS;
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+        const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
+        const float g = dwp[((long)t * Cout + n) * Cin + c];
+        const long wi = (long)n * per + j;
+        if (dw) dw[wi] = g * scale;
+        if (gamma) acc += g * w[wi];
+    }
+    if (gamma) {
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float s = part[0] + part[1] + part[2] + part[3];
+            const float dbn = db ? db[n] : 0.f;
+            if (dgamma) dgamma[n] = s * rs - dbn * mean[n] * rs;
+            if (dbeta) dbeta[n] = dbn;
+        }
+    }
+}
+LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
+                                     const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma,
+                                     float* dbeta, void* stream) {
+    if (Cout <= 0) return 0;
+    hipLaunchKernelGGL(fold_unpack_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dwp, db, w, gamma, mean, var, eps,
+                       Cout, Cin, RS, dw, dgamma, dbeta);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -632,3 +632,44 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
     L.check(lib.loft_mask_paste(L.ptr(logits), L.ptr(boxes), N, S, int(img_h), int(img_w), c_float(thr), L.ptr(out),
                                 L.stream()), 'loft_mask_paste')
     return out
+
+
+# ------------------------------------------------------------------ weight fold + pack
+
+def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None,
+              out_bias=None):
+    """w fp32 [Cout,Cin,R,S]; bn = (gamma, beta, mean, var) or None -> (wp_fwd bf16 [T,Cout,Cin] | None,
+    wp_dgrad bf16 [T,Cin,Cout] | None, bias fp32 [Cout])."""
+    lib = L.load()
+    L.dev_check(w, conv_bias)
+    w = w.contiguous()
+    Cout, Cin, R, S = w.shape
+    T = R * S
+    dev = w.device
+    wp = out_fwd if out_fwd is not None else (torch.empty(T, Cout, Cin, dtype=torch.bfloat16, device=dev) if want_fwd else None)
+    wpt = out_dgrad if out_dgrad is not None else (torch.empty(T, Cin, Cout, dtype=torch.bfloat16, device=dev) if want_dgrad else None)
+    bias = out_bias if out_bias is not None else torch.empty(Cout, dtype=torch.float32, device=dev)
+    g = b = m = v = None
+    if bn is not None:
+        g, b, m, v = [t.contiguous() for t in bn]
+    cb = conv_bias.contiguous() if conv_bias is not None else None
+    L.check(lib.loft_fold_pack(L.ptr(w), L.ptr(cb), L.ptr(g), L.ptr(b), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin, T,
+                               L.ptr(wp), L.ptr(wpt), L.ptr(bias), L.stream()), 'loft_fold_pack')
+    return wp, wpt, bias
+
+
+def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True):
+    """dwp fp32 [T,Cout,Cin], db fp32 [Cout] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None)."""
+    lib = L.load()
+    w = w.contiguous()
+    Cout, Cin, R, S = w.shape
+    dev = w.device
+    dw = torch.empty_like(w) if need_dw else None
+    g = m = v = dg = dbeta = None
+    if bn is not None:
+        g, _, m, v = [t.contiguous() for t in bn]
+        dg = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    L.check(lib.loft_fold_unpack_bwd(L.ptr(dwp), L.ptr(db), L.ptr(w), L.ptr(g), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin,
+                                     R * S, L.ptr(dw), L.ptr(dg), L.ptr(dbeta), L.stream()), 'loft_fold_unpack_bwd')
+    return dw, dg, dbeta

@@ -43,11 +43,6 @@ class ConvW(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
 
-def folded(conv, bn):
-    scale, shift = bn.fold()
-    return conv.weight * scale[:, None, None, None], shift
-
-
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -68,16 +63,12 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x):
-        w, b = folded(self.conv1, self.bn1)
-        out = F2.conv2d(x, w, b, relu=True)
-        w, b = folded(self.conv2, self.bn2)
-        out = F2.conv2d(out, w, b, stride=self.stride, pad=1, relu=True)
+        out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, relu=True)
+        out = F2.conv2d(out, self.conv2.weight, bn=self.bn2, stride=self.stride, pad=1, relu=True)
         identity = x
         if self.downsample is not None:
-            w, b = folded(self.downsample[0], self.downsample[1])
-            identity = F2.conv2d(x, w, b, stride=self.stride)
-        w, b = folded(self.conv3, self.bn3)
-        return F2.conv2d(out, w, b, relu=True, residual=identity)
+            identity = F2.conv2d(x, self.downsample[0].weight, bn=self.downsample[1], stride=self.stride)
+        return F2.conv2d(out, self.conv3.weight, bn=self.bn3, relu=True, residual=identity)
 
 
 @BACKBONES.register_module()

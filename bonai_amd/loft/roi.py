@@ -242,9 +242,8 @@ class OffsetHeadExpandFeature(_OffsetBase):
         if x4.shape[0] == 0:
             return x4.new_zeros(0, 2 * self.expand_feature_num, dtype=torch.float32)  # appendix A.1 quirk
         for i in range(self.num_convs):
-            w = torch.stack([self.expand_convs[k][i].weight for k in range(4)])
-            b = torch.stack([self.expand_convs[k][i].bias for k in range(4)])
-            x4 = F2.conv2d(x4, w, b, pad=1, relu=True, groups=4)
+            x4 = F2.conv2d(x4, [self.expand_convs[k][i].weight for k in range(4)],
+                           [self.expand_convs[k][i].bias for k in range(4)], pad=1, relu=True, groups=4)
         return self._fc_tail(x4)
 
     def forward(self, x):

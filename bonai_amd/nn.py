@@ -14,62 +14,109 @@ def to_nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-class _ConvFn(torch.autograd.Function):
-    """y = act(conv(x, w) + b + residual); w [G?,Cout,Cin,R,S] fp32, x bf16 NHWC.
+_PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
 
-    Backward: relu mask (loft_relu_bwd_bf16) -> dgrad (loft_conv_tap_bf16 with the transposed packing)
-    -> wgrad (loft_conv_wgrad_bf16) -> bias grad (loft_colsum_bf16)."""
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, fold(w, bn)) + bias + residual), bf16 NHWC activations, fp32 master weights [Cout,Cin,R,S].
+
+    forward : loft_fold_pack (BN fold + both operand packings, one launch) -> loft_conv_tap_bf16
+    backward: loft_relu_bwd_bf16 -> loft_conv_tap_bf16 (dgrad) -> loft_conv_wgrad_bf16 (+ fused bias gradient)
+              -> loft_fold_unpack_bwd (dW in the reference layout, dgamma, dbeta, one launch)
+    Tensor arguments after the meta tuple: for each of the G groups (w, b|None), then (gamma, beta) when BN is folded."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, stride, pad, relu, groups, out_f32):
-        grouped = w.dim() == 5
-        wg = w if grouped else w[None]
-        G, Cout, Cin, R, S = wg.shape
-        assert G == groups
-        wp = torch.stack([K.pack_w_fwd(wg[i]) for i in range(G)]) if G > 1 else K.pack_w_fwd(wg[0])[None]
-        bias = None if b is None else b.float().contiguous()
-        y = K.conv2d_fwd(x, wp, bias, R, S, stride, pad, relu=relu, residual=residual,
+    def forward(ctx, x, residual, meta, *tensors):
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen = meta
+        ws = tensors[0:2 * G:2]
+        bs = tensors[1:2 * G:2]
+        gamma, beta = (tensors[2 * G], tensors[2 * G + 1]) if bn_stats is not None else (None, None)
+        Cout, Cin, R, S = ws[0].shape
+        T = R * S
+        dev = x.device
+        key = None
+        if frozen:
+            key = tuple((id(t), t._version) for t in tensors if t is not None)
+        if key is not None and key in _PACK_CACHE:
+            wp, wpt, bias = _PACK_CACHE[key]
+        else:
+            wp = torch.empty(G, T, Cout, Cin, dtype=torch.bfloat16, device=dev)
+            need_dgrad = ctx.needs_input_grad[0]
+            wpt = torch.empty(G, T, Cin, Cout, dtype=torch.bfloat16, device=dev) if need_dgrad else None
+            bias = torch.empty(G, Cout, dtype=torch.float32, device=dev)
+            bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
+            eps = bn_stats[2] if bn_stats is not None else 1e-5
+            for g in range(G):
+                K.fold_pack(ws[g], bs[g], bn, eps, out_fwd=wp[g], out_dgrad=None if wpt is None else wpt[g], out_bias=bias[g],
+                            want_dgrad=need_dgrad)
+            if key is not None:
+                _PACK_CACHE[key] = (wp, wpt, bias)
+        use_bias = has_b or bn_stats is not None
+        y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
                          out_dtype=torch.float32 if out_f32 else torch.bfloat16, groups=G)
-        ctx.cfg = (stride, pad, relu, G, R, S, grouped, tuple(x.shape[2:]), b is not None, residual is not None)
-        ctx.save_for_backward(x, wg, y if relu else None)
+        ctx.meta = meta
+        ctx.in_hw = tuple(x.shape[2:])
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y if relu else None, wpt, *tensors)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        stride, pad, relu, G, R, S, grouped, in_hw, has_b, has_res = ctx.cfg
-        x, wg, y = ctx.saved_tensors
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen = ctx.meta
+        x, y, wpt = ctx.saved_tensors[:3]
+        tensors = ctx.saved_tensors[3:]
+        ws = tensors[0:2 * G:2]
+        Cout, Cin, R, S = ws[0].shape
         g = to_nhwc(g)
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
         if relu:
             g = K.relu_bwd(g, y)
-        Cout, Cin = wg.shape[1], wg.shape[2]
-        gx = gw = gb = None
+        gx = None
         if ctx.needs_input_grad[0]:
-            wpt = torch.stack([K.pack_w_dgrad(wg[i]) for i in range(G)]) if G > 1 else K.pack_w_dgrad(wg[0])[None]
-            gx = K.conv2d_dgrad(g, wpt, in_hw, R, S, stride, pad, groups=G)
-        want_b = has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            if want_b:   # bias gradient rides along in the wgrad kernel (ones-operand MFMA)
-                dwp, gb = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, with_bias=True)
-                gb = gb if grouped else gb[0]
-                want_b = False
+            gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G)
+        ngrads = [None] * len(tensors)
+        need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(G))
+        need_b = (has_b and any(ctx.needs_input_grad[3 + 2 * i + 1] for i in range(G))) or \
+            (bn_stats is not None and (ctx.needs_input_grad[3 + 2 * G] or ctx.needs_input_grad[3 + 2 * G + 1]))
+        if need_w or need_b:
+            if need_b:
+                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, with_bias=True)
             else:
-                dwp = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G)      # [G, R*S, Cout, Cin] fp32
-            gw = dwp.view(G, R, S, Cout, Cin).permute(0, 3, 4, 1, 2)
-            gw = gw if grouped else gw[0]
-        if want_b:
-            if G == 1:
-                gb = K.colsum(g, Cout)
-            else:
-                n = g.shape[0] // G
-                gb = torch.stack([K.colsum(g[i * n:(i + 1) * n], Cout) for i in range(G)])
-        gres = g if (has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None, None, None
+                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G), None
+            bn = None
+            if bn_stats is not None:
+                bn = (tensors[2 * G], tensors[2 * G + 1], bn_stats[0], bn_stats[1])
+            for i in range(G):
+                dw, dg, dbeta = K.fold_unpack_bwd(dwp[i], None if db is None else db[i], ws[i], bn,
+                                                  bn_stats[2] if bn_stats is not None else 1e-5, need_dw=need_w)
+                ngrads[2 * i] = dw
+                if has_b and db is not None:
+                    ngrads[2 * i + 1] = db[i]
+                if bn is not None:
+                    ngrads[2 * G], ngrads[2 * G + 1] = dg, dbeta
+        gres = g if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        return (gx, gres, None) + tuple(ngrads)
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False):
-    return _ConvFn.apply(x, w, b, residual, stride, pad, relu, groups, out_f32)
+def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None):
+    """w: [Cout,Cin,R,S] parameter, or a list of `groups` such parameters (independent branches, one launch);
+    b likewise (or None); bn: a FrozenStatBN-like module folded into the conv (its shift becomes the bias)."""
+    ws = list(w) if isinstance(w, (list, tuple)) else [w]
+    bs = list(b) if isinstance(b, (list, tuple)) else [b] * len(ws)
+    assert len(ws) == groups
+    tensors = []
+    for wi, bi in zip(ws, bs):
+        tensors += [wi, bi]
+    bn_stats = None
+    if bn is not None:
+        tensors += [bn.weight, bn.bias]
+        bn_stats = (bn.running_mean, bn.running_var, bn.eps)
+    # cache packed operands only for parameters that can never change (requires_grad=False: frozen stem/layer1);
+    # the fused SGD kernel updates trainable parameters through raw pointers without bumping tensor versions
+    frozen = not any(t is not None and t.requires_grad for t in tensors)
+    meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen)
+    return _ConvFn.apply(x, residual, meta, *tensors)
 
 
 def linear(x2d, w, b=None, relu=False, out_f32=False):

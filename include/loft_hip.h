@@ -188,6 +188,20 @@ int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_
 int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
                     void* stream);
 
+/* ---- weight fold + pack -----------------------------------------------------------------------------
+ * Per conv and step: fp32 master weight [Cout][Cin][R][S] (the reference/checkpoint layout) -> bf16 operand packings
+ * wp_fwd [R*S][Cout][Cin] and wp_dgrad [R*S][Cin][Cout] (either may be NULL) and the fp32 epilogue bias, folding the
+ * frozen-statistics BatchNorm that follows the conv (norm_eval=True, mmdet/models/backbones/resnet.py:640-649; formula of
+ * tools/fuse_conv_bn.py:10-23) when gamma != NULL; conv_bias is used when there is no BN.  loft_fold_unpack_bwd is its
+ * chain rule: dwp fp32 [R*S][Cout][Cin] (gradient of the folded weight), db fp32 [Cout] (gradient of the folded bias)
+ * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL). */
+int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
+                   const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad, float* bias_out,
+                   void* stream);
+int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
+                         const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@
 // deeper prefetch does; the next step is a 256-row, 8-wave tile with fragment double-buffering, not more stages.
 #include "loft_common.h"
 #include "../../include/loft_hip.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -61,11 +62,12 @@ struct ConvArgs {
 __device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_tap_kernel(const ConvArgs a) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const ConvArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;                 // 4 waves (128-wide tiles) or 8 waves (256x256 tile)
+    constexpr int RPR = NW * 8;                           // tile rows staged per glds round (8 rows per wave)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;  // glds instructions per thread per K step
+    constexpr int A_LOADS = BM / RPR, B_LOADS = BN / RPR;  // glds instructions per thread per K step
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
 
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(const ConvArgs a) {
     const int ohw = a.OH * a.OW;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int row = i * 32 + wave * 8 + lrow;
+        const int row = i * RPR + wave * 8 + lrow;
         const int m = m0 + row;
         a_c[i] = swz(row, lchunk) * 8;
         if (m < a.M) {
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(const ConvArgs a) {
     long b_off[B_LOADS];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-        const int row = i * 32 + wave * 8 + lrow;
+        const int row = i * RPR + wave * 8 + lrow;
         int n = n0 + row;
         b_off[i] = (n < a.Cout) ? ((long)n * a.Cin + swz(row, lchunk) * 8) : -1;
     }
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(const ConvArgs a) {
             const int iy = a_y[i] + dy, ix = a_x[i] + dx;
             const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
             const bf16_t* p = ok ? src + ((long)(a_base[i] + iy * a.IW + ix) * a.Cin + c0 + a_c[i]) : a.zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(abuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(abuf + (i * RPR + wave * 8) * 128), 16, 0, 0);
         }
         const bf16_t* wt = wgt + (long)a.wt[t] * a.Cout * a.Cin + c0;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const bf16_t* p = (b_off[i] >= 0) ? wt + b_off[i] : a.zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(bbuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(bbuf + (i * RPR + wave * 8) * 128), 16, 0, 0);
         }
     };
 
@@ -225,6 +227,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
                                    int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
                                    void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
+    static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;   // A/B switch for benchmarking
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -238,7 +241,13 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
-    if (Cout % 128 == 0) {
+    const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
+    if (Cout % 256 == 0 && big_blocks >= 192 && !force_small_tile) {
+        // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
+        // fills the 256 CUs
+        dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
+        hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
+    } else if (Cout % 128 == 0) {
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
         hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
     } else {

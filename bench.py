@@ -137,9 +137,16 @@ def main():
             one_step(args.warmup + args.steps + it)
         torch.cuda.synchronize()
         fam = {}
-        for name, fl, a, b in K.PROFILE:
+        shapes = {}
+        for name, fl, a, b, tag in K.PROFILE:
             d = fam.setdefault(name, [0.0, 0.0, 0])
-            d[0] += fl; d[1] += a.elapsed_time(b) * 1e-3; d[2] += 1
+            dt = a.elapsed_time(b) * 1e-3
+            d[0] += fl; d[1] += dt; d[2] += 1
+            sd = shapes.setdefault((name, tag), [0.0, 0.0, 0])
+            sd[0] += fl; sd[1] += dt; sd[2] += 1
+        if os.environ.get('LOFT_DUMP_SHAPES') and rank == 0:
+            for (name, tag), v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+                print(f'# {name:10s} (G,B,OH,OW,Cin,Cout,T,ss,os)={tag}  n={v[2] // 2:3d}  ms/step={v[1] / 2 * 1e3:7.3f}  TF={v[0] / v[1] / 1e12:7.1f}', file=sys.stderr)
         K.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
         ach = fam[dom][0] / fam[dom][1] / 1e12

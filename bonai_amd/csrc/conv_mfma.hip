@@ -242,9 +242,11 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
-    if (Cout % 256 == 0 && big_blocks >= 192 && !force_small_tile) {
+    if (Cout % 256 == 0 && big_blocks >= 192 && (long)T * Cin >= 512 && !force_small_tile) {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
-        // fills the 256 CUs
+        // fills the 256 CUs and K is deep enough (>= 8 K-steps) to amortise the one-block-per-CU prologue/epilogue.
+        // (Measured and rejected in round 1: staging the bf16 output tile through LDS for 16-byte coalesced stores --
+        //  neutral on the K-shallow 1x1 convs, which are latency- not store-pattern-bound, and -10..20 % on dgrads.)
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
         hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {
@@ -299,15 +301,16 @@ static inline void fastdiv_setup(unsigned d, unsigned* mul, unsigned* sh) {
     *sh = l;
 }
 
+template <int RB>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
-    // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][128] bf16 tile:
+    // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][RB/2] bf16 tile (RB bytes per pixel row):
     // lane l -> channel col0 + (l&31), pixels kbase + 8*(l>>5) + 0..7
     const int il = lane & 15, gl = lane >> 4;
     const int col = col0 + 16 * (gl & 1) + (il & 3) * 4;
     const int r0 = kbase + 8 * (gl >> 1) + (il >> 2);
     const int r1 = r0 + 4;
-    const char* p0 = tile + r0 * 256 + wswz(r0, col >> 3) * 16 + (col & 7) * 2;
-    const char* p1 = tile + r1 * 256 + wswz(r1, col >> 3) * 16 + (col & 7) * 2;
+    const char* p0 = tile + r0 * RB + wswz(r0, col >> 3) * 16 + (col & 7) * 2;
+    const char* p1 = tile + r1 * RB + wswz(r1, col >> 3) * 16 + (col & 7) * 2;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
     bf16x8 f;
@@ -316,15 +319,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0,
     return f;
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int TILE_BYTES = 64 * 128 * 2;  // 16 KiB
+// TN = output tile edge (n and c), NW = waves.  <128,4>: 2x2 waves of 64x64; <256,8>: 2x4 waves of 128(n)x64(c) --
+// the 256 form halves the LDS-DMA bytes per FLOP and is used when Cout and Cin are multiples of 256.
+template <int TN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int RB = TN * 2;                 // bytes per pixel row of a tile
+    constexpr int CPR = RB / 16;               // 16-byte chunks per row
+    constexpr int RPW = 1024 / RB;             // tile rows covered by one wave-level glds
+    constexpr int TILE_BYTES = 64 * RB;
+    constexpr int WAVES_C = NW / 2;
+    constexpr int NI = TN / 2 / 32, NJ = TN / WAVES_C / 32;
+    static_assert(NJ == 2 && WAVES_C >= NI, "tiling");
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [buf][G|X]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = blockIdx.x / a.ctiles, ct = blockIdx.x - nt * a.ctiles;
     const int t = blockIdx.y % a.T, grp = blockIdx.y / a.T;
-    const int n0 = nt * 128, c0 = ct * 128;
+    const int n0 = nt * TN, c0 = ct * TN;
     const int mbeg = blockIdx.z * a.pix_per_split;
     const int mend = min(a.M, mbeg + a.pix_per_split);
     if (mbeg >= mend) return;
@@ -333,13 +345,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
 
-    const int lrow = lane >> 4, lchunk = lane & 15;
+    const int lrow = lane / CPR, lchunk = lane % CPR;
     auto stage = [&](int m_base, int buf) {
         char* gbuf = lds + buf * 2 * TILE_BYTES;
         char* xbuf = gbuf + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = i * 16 + wave * 4 + lrow;
+            const int row = i * 16 + wave * RPW + lrow;
             const int m = m_base + row;
             const int q = wswz(row, lchunk) * 8;
             const bf16_t* pg = a.zero_page;
@@ -354,24 +366,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                     px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + q;
                 }
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(gbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)px, (lds_ptr_t)(xbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(gbuf + (i * 16 + wave * RPW) * RB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)px, (lds_ptr_t)(xbuf + (i * 16 + wave * RPW) * RB), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wn = wave >> 1, wc = wave & 1;
-    // bias gradient rides along on the blocks of the first channel tile: one extra MFMA per n-tile against an
-    // all-ones operand gives sum_k G[k][n] in every column of the result.
-    // (each of the 4 waves takes ONE of the block's four 32-row n-tiles: n-tile index = wn*2 + wc)
-    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);
+    const int wn = wave / WAVES_C, wc = wave % WAVES_C;
+    // bias gradient rides along on the blocks of the first channel tile: one extra MFMA per K sub-step against an
+    // all-ones operand gives sum_k G[k][n] in every column of the result; wave (wn, wc) takes n-tile wn*NI + wc.
+    const bool do_db = a.db != nullptr && ct == 0 && wc < NI && (a.db_tap == -2 || a.db_tap == t);
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
@@ -388,18 +399,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const char* xbuf = gbuf + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 gf[2], xf[2];
+            bf16x8 gf[NI], xf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) gf[i] = tr_frag(gbuf, ks * 16, wn * 64 + i * 32, lane);
+            for (int i = 0; i < NI; ++i) gf[i] = tr_frag<RB>(gbuf, ks * 16, wn * (TN / 2) + i * 32, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xf[j] = tr_frag(xbuf, ks * 16, wc * 64 + j * 32, lane);
+            for (int j = 0; j < NJ; ++j) xf[j] = tr_frag<RB>(xbuf, ks * 16, wc * (TN / WAVES_C) + j * 32, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
-            if (do_db) {   // static register select (a runtime-indexed fragment array would be demoted to scratch)
-                const bf16x8 gsel = wc ? gf[1] : gf[0];
+            if (do_db) {   // static register selects (a runtime-indexed fragment array would be demoted to scratch)
+                bf16x8 gsel = gf[0];
+#pragma unroll
+                for (int i = 1; i < NI; ++i) gsel = (wc == i) ? gf[i] : gsel;
                 accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gsel, ones, accb, 0, 0, 0);
             }
         }
@@ -409,20 +422,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         float* db = a.db + (long)grp * a.Cout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int n = n0 + wn * (TN / 2) + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             unsafeAtomicAdd(db + n, accb[r]);
         }
     }
 
     float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int c = c0 + wc * (TN / WAVES_C) + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * (TN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[i][j][r]);
             }
         }
@@ -449,10 +462,15 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     a.M = (int)M;
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
     fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
-    a.ctiles = Cin / 128;
-    const int tiles = (Cout / 128) * a.ctiles;
+    static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;
+    // 256x256 tiles only when >= 256 workgroups can each run >= ~32 K-steps (else the 65k-atomic epilogue dominates)
+    const bool big = (Cout % 256 == 0) && (Cin % 256 == 0) && !force_small_tile &&
+                     M * (long)(Cout / 256) * (Cin / 256) * T * groups >= 524288L;
+    const int TNv = big ? 256 : 128;
+    a.ctiles = Cin / TNv;
+    const int tiles = (Cout / TNv) * a.ctiles;
     if (splits <= 0) {  // aim for ~1024 workgroups, at least 4 K-steps each
-        long want = 1024 / ((long)tiles * T * groups);
+        long want = (big ? 512 : 1024) / ((long)tiles * T * groups);
         long maxs = (M + 255) / 256;
         splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     }
@@ -461,7 +479,10 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     a.pix_per_split = pps;
     splits = (int)((M + pps - 1) / pps);
     dim3 grid(tiles, T * groups, splits);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (big)
+        hipLaunchKernelGGL((conv_wgrad_kernel<256, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -189,12 +189,12 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev, family, flops):
+def _prof_end(ev, family, flops, tag=None):
     if ev is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
-    PROFILE.append((family, float(flops) * ALGO_SCALE, ev, end))
+    PROFILE.append((family, float(flops) * ALGO_SCALE, ev, end, tag))
 
 
 def zero_page(device):
@@ -249,7 +249,7 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
                                    oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
                                    c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
             'loft_conv_tap_bf16')
-    _prof_end(_ev, 'conv_tap', 2.0 * groups * B * OH * OW * Cout * Cin * T)
+    _prof_end(_ev, 'conv_tap', 2.0 * groups * B * OH * OW * Cout * Cin * T, (groups, B, OH, OW, Cin, Cout, T, ss, os))
     return out
 
 
@@ -330,7 +330,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                                      c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
                                      int(db_tap), L.stream()),
             'loft_conv_wgrad_bf16')
-    _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps))
+    _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
     return dw
 
 

@@ -79,17 +79,20 @@ class BucketedAllReduce:
 
     def begin(self):
         self._remaining = [len(b['params']) for b in self.buckets]
+        self._next = 0
         self.works = []
 
     def _hook(self, p):
         bi = self.param_bucket[id(p)]
         self._remaining[bi] -= 1
-        if self._remaining[bi] == 0:
-            self._launch(bi)
+        # collectives must be issued in the SAME order on every rank even when a rank's graph lacks some branch
+        # (e.g. no positive RoI -> no mask/FOA gradients there): buckets are launched strictly in index order
+        while self._next < len(self.buckets) and self._remaining[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         b = self.buckets[bi]
-        self._remaining[bi] = -1
         if not self.on_gpu:   # gloo / CPU (tests): same bucket order, no stream juggling
             self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
             return
@@ -103,9 +106,9 @@ class BucketedAllReduce:
         """Make the main stream wait for every outstanding collective (no host sync)."""
         if not self.enabled:
             return
-        for bi, r in enumerate(self._remaining):  # parameters that got no gradient this step
-            if r > 0:
-                self._launch(bi)
+        while self._next < len(self.buckets):   # buckets holding parameters that got no gradient this step
+            self._launch(self._next)
+            self._next += 1
         for w in self.works:
             w.wait()
         if self.on_gpu:

@@ -163,11 +163,17 @@ class _NarrowHeadFn(torch.autograd.Function):
             wt = torch.zeros(1, Cin, P, dtype=torch.bfloat16, device=w.device)
             wt[0, :, :Cout] = w.view(Cout, Cin).t()
             gx = K.conv2d_dgrad(gp, wt[None], (H, W), 1, 1)
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dwp = K.conv2d_wgrad(gp, x, 1, 1)
+            if want_b:   # bias gradient from the same pass (ones-operand MFMA)
+                dwp, db = K.conv2d_wgrad(gp, x, 1, 1, with_bias=True)
+                gb = db[0, :Cout]
+                want_b = False
+            else:
+                dwp = K.conv2d_wgrad(gp, x, 1, 1)
             gw = dwp[0, 0, :Cout].reshape(w.shape)
         K.ALGO_SCALE = 1.0
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if want_b:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
         return gx, gw, gb
 

@@ -1,0 +1,41 @@
+"""GPU edge cases of the training step: images without any ground truth (no positives anywhere -> the mask and
+offset heads see zero RoIs), ragged gt counts across the batch, and the reference's list-of-proposals input form."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model():
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    torch.manual_seed(0)
+    return build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+
+
+def test_no_gt_and_ragged_gt():
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    m = _model()
+    tr = Trainer(m, lr=1e-3)
+    data = make_batch(3, 256, 6, device='cuda')
+    # image 0: no gt at all; image 1: 2 gts; image 2: 6 gts
+    for k in ('gt_bboxes', 'gt_labels', 'gt_masks', 'gt_offsets'):
+        data[k][0] = data[k][0][:0]
+        data[k][1] = data[k][1][:2]
+    out = tr.train_step(data)
+    lv = dict(out['log_vars'].items())
+    assert all(np.isfinite(v) for v in lv.values()), lv
+    # every image empty: zero positives -> mask / offset losses are exactly 0, the step still runs
+    for k in ('gt_bboxes', 'gt_labels', 'gt_masks', 'gt_offsets'):
+        data[k] = [t[:0] for t in data[k]]
+    out = tr.train_step(data)
+    lv = dict(out['log_vars'].items())
+    assert all(np.isfinite(v) for v in lv.values()), lv
+    assert lv['loss_mask'] == 0.0 and lv['loss_offset'] == 0.0 and m.roi_head.last_stats['num_pos'] == 0
+    assert torch.isfinite(tr.arena.data).all()

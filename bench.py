@@ -150,8 +150,13 @@ def main():
         K.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
         ach = fam[dom][0] / fam[dom][1] / 1e12
-        roofline = dict(bound='mfma', kernel='conv_tap_kernel' if dom == 'conv_tap' else 'conv_wgrad_kernel',
-                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=None,
+        kname = 'conv_tap_kernel' if dom == 'conv_tap' else 'conv_wgrad_kernel'
+        traffic = None   # HBM bytes per launch from a separate rocprofv3 --pmc pass of this command (profiles/)
+        pmc = os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')
+        if os.path.exists(pmc) and args.batch == 8 and args.size == 1024:
+            traffic = round(json.load(open(pmc)).get(kname, {}).get('hbm_bytes_per_launch', 0.0)) or None
+        roofline = dict(bound='mfma', kernel=kname,
+                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})

@@ -13,6 +13,8 @@ MI355X sizing: 81.2 M trainable parameters = 325 MB fp32; xGMI gives 7 links x ~
 default 64 MiB buckets keep each collective bandwidth- rather than latency-bound while leaving 5-6 buckets
 to overlap with backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -54,7 +56,9 @@ class BucketedAllReduce:
 
     def __init__(self, arena, bucket_bytes=64 << 20):
         self.arena = arena
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # LOFT_FORCE_REDUCER=1 keeps the whole hook / side-stream / RCCL path active in a 1-rank group (GPU test)
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get('LOFT_FORCE_REDUCER') == '1')
         self.buckets, self.param_bucket = [], {}
         start, pending = 0, []
         for p in arena.order:

@@ -39,3 +39,37 @@ def test_no_gt_and_ragged_gt():
     assert all(np.isfinite(v) for v in lv.values()), lv
     assert lv['loss_mask'] == 0.0 and lv['loss_offset'] == 0.0 and m.roi_head.last_stats['num_pos'] == 0
     assert torch.isfinite(tr.arena.data).all()
+
+
+def test_rccl_reducer_path_single_rank():
+    """The N>1 machinery (autograd hooks -> ordered buckets -> side-stream RCCL all-reduce -> event wait) on one GPU:
+    a 1-rank 'nccl' group with the reducer forced on must reproduce the plain step exactly."""
+    import socket
+    import torch.distributed as dist
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft.core import RandomSampler
+    from bonai_amd.synth import make_batch
+    RandomSampler.choice_mode = 'first'
+    try:
+        data = make_batch(2, 256, 6, device='cuda')
+        m0 = _model()
+        ref = dict(Trainer(m0, lr=1e-3).train_step(data)['log_vars'].items())
+        p_ref = next(p for p in m0.parameters() if p.requires_grad).detach().clone()
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOFT_FORCE_REDUCER='1')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        try:
+            m1 = _model()
+            tr = Trainer(m1, lr=1e-3, bucket_bytes=32 << 20)
+            assert tr.reducer.enabled and len(tr.reducer.buckets) >= 3
+            got = dict(tr.train_step(data)['log_vars'].items())
+            torch.cuda.synchronize()
+            p_got = next(p for p in m1.parameters() if p.requires_grad).detach()
+        finally:
+            dist.destroy_process_group()
+            os.environ.pop('LOFT_FORCE_REDUCER', None)
+        for k in ref:
+            assert abs(ref[k] - got[k]) <= 2e-3 * max(1.0, abs(ref[k])), (k, ref[k], got[k])   # wgrad atomics reorder fp32 sums
+        assert torch.allclose(p_ref, p_got, atol=1e-4)
+    finally:
+        RandomSampler.choice_mode = 'random'

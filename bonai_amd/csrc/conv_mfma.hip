@@ -47,6 +47,7 @@ struct ConvArgs {
     const bf16_t* wgt;
     const float* bias;
     const bf16_t* residual;
+    const bf16_t* mask;      // optional: zero the result where mask <= 0 (ReLU backward of the tensor this gradient is for)
     void* out;
     const bf16_t* zero_page;
     int B, IH, IW, Cin, Cout;
@@ -203,6 +204,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if (a.mask) {
+                    float mv[4];
+                    ld4(a.mask + o, mv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                }
                 if (a.out_f32) {
                     float* op = reinterpret_cast<float*>(a.out) + o;
                     if (a.accumulate) {
@@ -220,7 +227,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     }
 }
 
-LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual, void* out,
+LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
+                                   const void* relu_mask, void* out,
                                    const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
                                    int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
                                    const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
@@ -229,7 +237,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;   // A/B switch for benchmarking
     ConvArgs a;
-    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual;
+    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf;
     a.os = os; a.oo_y = oo_y; a.oo_x = oo_x; a.ss = ss; a.T = T;

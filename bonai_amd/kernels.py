@@ -229,7 +229,7 @@ def _bf16(t):
 
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
-             residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0):
+             residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None):
     """Raw launch of loft_conv_tap_bf16.  taps: list of (dy, dx, weight_tap_index)."""
     lib = L.load()
     L.dev_check(src, wgt, out, bias, residual)
@@ -244,7 +244,7 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
     if not out_f32:
         _bf16(out)
     _ev = _prof_begin()
-    L.check(lib.loft_conv_tap_bf16(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(out),
+    L.check(lib.loft_conv_tap_bf16(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
                                    L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
                                    oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
                                    c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
@@ -273,7 +273,7 @@ def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, ou
 
 
 def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=torch.bfloat16, groups=1,
-                 out=None, accumulate=False):
+                 out=None, accumulate=False, mask=None):
     """g [G*B,Cout,OH,OW] channels_last bf16, wpt [G][R*S,Cin,Cout] -> grad of the conv input [G*B,Cin,IH,IW]."""
     g = _nhwc(g)
     GB, Cout, OH, OW = g.shape
@@ -286,7 +286,7 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
     if stride == 1:
         taps = [(pad - r, pad - s, r * S + s) for r in range(R) for s in range(S)]
         conv_tap(g, wpt, out, B, OH, OW, Cout, Cin, IH, IW, IH, IW, taps, residual=residual, accumulate=accumulate,
-                 **gs)
+                 mask=mask, **gs)
         return out
     # strided: one launch per output-parity class, each with the taps that reach it
     covered = 0
@@ -310,7 +310,7 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
         residual_for_launch = residual
     for py, px, taps, nh, nw in launches:
         conv_tap(g, wpt, out, B, OH, OW, Cout, Cin, nh, nw, IH, IW, taps, ss=1, os=stride, oo=(py, px),
-                 residual=residual_for_launch, accumulate=accumulate, **gs)
+                 residual=residual_for_launch, accumulate=accumulate, mask=mask, **gs)
     return out
 
 

@@ -64,11 +64,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, relu=True)
-        out = F2.conv2d(out, self.conv2.weight, bn=self.bn2, stride=self.stride, pad=1, relu=True)
+        out = F2.conv2d(out, self.conv2.weight, bn=self.bn2, stride=self.stride, pad=1, relu=True, input_relu=True)
         identity = x
         if self.downsample is not None:
             identity = F2.conv2d(x, self.downsample[0].weight, bn=self.downsample[1], stride=self.stride)
-        return F2.conv2d(out, self.conv3.weight, bn=self.bn3, relu=True, residual=identity)
+        return F2.conv2d(out, self.conv3.weight, bn=self.bn3, relu=True, residual=identity, input_relu=True)
 
 
 @BACKBONES.register_module()

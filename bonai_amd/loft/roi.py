@@ -99,7 +99,7 @@ class Shared2FCBBoxHead(nn.Module):
         if N == 0:
             return x.new_zeros(0, ncls, dtype=torch.float32), x.new_zeros(0, nreg, dtype=torch.float32)
         h = _fc_after_flatten(x, self.shared_fcs[0])
-        h = F2.linear(h, self.shared_fcs[1].weight, self.shared_fcs[1].bias, relu=True)
+        h = F2.linear(h, self.shared_fcs[1].weight, self.shared_fcs[1].bias, relu=True, input_relu=True)
         w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0)
         b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)
         o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), w, b).reshape(N, -1)
@@ -158,8 +158,8 @@ class FCNMaskHead(nn.Module):
         nout = self.conv_logits.weight.shape[0]
         if x.shape[0] == 0:
             return x.new_zeros(0, nout, 2 * x.shape[2], 2 * x.shape[3], dtype=torch.float32)
-        for m in self.convs:
-            x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True)
+        for i, m in enumerate(self.convs):
+            x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True, input_relu=i > 0)
         x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias)
         o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias)
         return o[:, :nout]
@@ -197,7 +197,7 @@ class _OffsetBase(nn.Module):
         N = x.shape[0]
         h = _fc_after_flatten(x, self.fcs[0])
         for fc in list(self.fcs)[1:]:
-            h = F2.linear(h, fc.weight, fc.bias, relu=True)
+            h = F2.linear(h, fc.weight, fc.bias, relu=True, input_relu=True)
         o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), self.fc_offset.weight,
                            self.fc_offset.bias)
         return o.reshape(N, -1)[:, :self.reg_num]
@@ -243,7 +243,7 @@ class OffsetHeadExpandFeature(_OffsetBase):
             return x4.new_zeros(0, 2 * self.expand_feature_num, dtype=torch.float32)  # appendix A.1 quirk
         for i in range(self.num_convs):
             x4 = F2.conv2d(x4, [self.expand_convs[k][i].weight for k in range(4)],
-                           [self.expand_convs[k][i].bias for k in range(4)], pad=1, relu=True, groups=4)
+                           [self.expand_convs[k][i].bias for k in range(4)], pad=1, relu=True, groups=4, input_relu=i > 0)
         return self._fc_tail(x4)
 
     def forward(self, x):

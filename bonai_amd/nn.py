@@ -27,7 +27,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, meta, *tensors):
-        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen = meta
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu = meta
         ws = tensors[0:2 * G:2]
         bs = tensors[1:2 * G:2]
         gamma, beta = (tensors[2 * G], tensors[2 * G + 1]) if bn_stats is not None else (None, None)
@@ -62,7 +62,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen = ctx.meta
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu = ctx.meta
         x, y, wpt = ctx.saved_tensors[:3]
         tensors = ctx.saved_tensors[3:]
         ws = tensors[0:2 * G:2]
@@ -70,11 +70,14 @@ class _ConvFn(torch.autograd.Function):
         g = to_nhwc(g)
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
-        if relu:
-            g = K.relu_bwd(g, y)
+        if relu and getattr(g, '_loft_premasked', None) != y.data_ptr():
+            g = K.relu_bwd(g, y)        # (skipped when the consumer's dgrad epilogue already applied this mask)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G)
+            # input_relu: x is a ReLU output, so d/d(pre-activation) = gx * (x > 0): folded into the dgrad epilogue
+            gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G, mask=x if input_relu else None)
+            if input_relu and stride == 1:
+                gx._loft_premasked = x.data_ptr()
         ngrads = [None] * len(tensors)
         need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(G))
         need_b = (has_b and any(ctx.needs_input_grad[3 + 2 * i + 1] for i in range(G))) or \
@@ -99,7 +102,7 @@ class _ConvFn(torch.autograd.Function):
         return (gx, gres, None) + tuple(ngrads)
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None):
+def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None, input_relu=False):
     """w: [Cout,Cin,R,S] parameter, or a list of `groups` such parameters (independent branches, one launch);
     b likewise (or None); bn: a FrozenStatBN-like module folded into the conv (its shift becomes the bias)."""
     ws = list(w) if isinstance(w, (list, tuple)) else [w]
@@ -115,15 +118,15 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
     # cache packed operands only for parameters that can never change (requires_grad=False: frozen stem/layer1);
     # the fused SGD kernel updates trainable parameters through raw pointers without bumping tensor versions
     frozen = not any(t is not None and t.requires_grad for t in tensors)
-    meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen)
+    meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen, input_relu)
     return _ConvFn.apply(x, residual, meta, *tensors)
 
 
-def linear(x2d, w, b=None, relu=False, out_f32=False):
+def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
     """x [N,K] bf16 (row-major), w [O,K] fp32 -> [N,O]."""
     N, Kd = x2d.shape
     y = conv2d(x2d.reshape(N, Kd, 1, 1).contiguous(memory_format=torch.channels_last), w.view(w.shape[0], Kd, 1, 1), b,
-               relu=relu, out_f32=out_f32)
+               relu=relu, out_f32=out_f32, input_relu=input_relu)
     return y.reshape(N, w.shape[0])
 
 

@@ -82,11 +82,14 @@ int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_
  *
  * src [B,IH,IW,Cin] bf16; wgt [taps][Cout][Cin] bf16; bias fp32 [Cout] or NULL; residual bf16 with
  * the layout of out, or NULL; out [B,OHf,OWf,Cout] bf16, or fp32 when out_f32 (accumulate=1 adds to
- * the existing fp32 contents).  The launch iterates oy<OH, ox<OW; source pixels outside
+ * the existing fp32 contents).  relu_mask (bf16, layout of out, or NULL): the result is zeroed where relu_mask <= 0 --
+ * used by data-gradient launches to apply the ReLU backward of the tensor they differentiate (their own saved input)
+ * in the epilogue instead of a separate pass.  The launch iterates oy<OH, ox<OW; source pixels outside
  * [0,IH)x[0,IW) contribute zero.  zero_page: >=256 bytes of device zeros.  Cin % 64 == 0,
  * Cout % 4 == 0, T <= 16.  groups/g: independent problems at the given element strides
  * (FOA rotation branches).  dy/dx/wt are HOST arrays. */
-int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual, void* out,
+int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual, const void* relu_mask,
+                       void* out,
                        const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
                        int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                        const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,

@@ -62,6 +62,16 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
 
+// XCD-aware workgroup order (speed only, never correctness): hardware places linear workgroup L on XCD L % 8, each with
+// a private L2.  Re-label so that every XCD works on ONE contiguous range of the logical tile order -- neighbouring
+// tiles (3x3 halo rows of adjacent pixel tiles; all taps / channel tiles of one pixel range in wgrad) then share an L2
+// instead of being fetched eight times.  Bijective for any workgroup count.
+__device__ __forceinline__ int xcd_remap(int L, int N) {
+    const int xcd = L & 7, q = N >> 3, r = N & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (L >> 3);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const ConvArgs a) {
     constexpr int NW = WAVES_M * WAVES_N;                 // 4 waves (128-wide tiles) or 8 waves (256x256 tile)
@@ -75,8 +85,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int g = blockIdx.z;
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int m0 = bx * BM, n0 = by * BN;
+    const int g = bz;
     const bf16_t* src = a.src + (long)g * a.src_gs;
     const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
 
@@ -342,10 +355,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x / a.ctiles, ct = blockIdx.x - nt * a.ctiles;
-    const int t = blockIdx.y % a.T, grp = blockIdx.y / a.T;
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int nt = bx / a.ctiles, ct = bx - nt * a.ctiles;
+    const int t = by % a.T, grp = by / a.T;
     const int n0 = nt * TN, c0 = ct * TN;
-    const int mbeg = blockIdx.z * a.pix_per_split;
+    const int mbeg = bz * a.pix_per_split;
     const int mend = min(a.M, mbeg + a.pix_per_split);
     if (mbeg >= mend) return;
     const bf16_t* G = a.g + (long)grp * a.g_gs;

@@ -72,7 +72,9 @@ __device__ __forceinline__ int xcd_remap(int L, int N) {
     return base + (L >> 3);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// STAGES = 2: double-buffered K loop.  STAGES = 1: single LDS buffer (half the LDS -> one more resident block per CU) for
+// launches with only 1-2 K-steps (the K-shallow 1x1 convs), which are latency-bound: occupancy hides what a pipeline cannot.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES = 2>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const ConvArgs a) {
     constexpr int NW = WAVES_M * WAVES_N;                 // 4 waves (128-wide tiles) or 8 waves (256x256 tile)
     constexpr int RPR = NW * 8;                           // tile rows staged per glds round (8 rows per wave)
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int A_LOADS = BM / RPR, B_LOADS = BN / RPR;  // glds instructions per thread per K step
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * (A_BYTES + B_BYTES)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     for (int kk = 0; kk < nk; ++kk) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
-        const char* abuf = lds + (kk & 1) * (A_BYTES + B_BYTES);
+        if (STAGES == 2 && kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
+        const char* abuf = lds + (STAGES == 2 ? (kk & 1) : 0) * (A_BYTES + B_BYTES);
         const char* bbuf = abuf + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        if (STAGES == 1 && kk + 1 < nk) {
+            __syncthreads();          // everyone is done reading the single buffer
+            stage(kk + 1, 0);
         }
     }
 
@@ -272,7 +278,10 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
-        hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+        if ((long)T * Cin <= 128 && !force_small_tile)
+            hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
     } else {
         dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 64), groups);
         hipLaunchKernelGGL((conv_tap_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, a);

@@ -612,3 +612,181 @@ LOFT_EXPORT int loft_stem7x7_mfma(const float* img, const void* wgt_packed, cons
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// =====================================================================================
+// fp32 parity mode (forward / data-gradient only).  Same tap-convolution contract as loft_conv_tap_bf16, but every
+// operand is fp32 and the contraction runs on v_mfma_f32_32x32x2_f32 -- bit-for-bit an fp32 fmaf chain (exact fp32,
+// 1/16 of the bf16 MFMA rate).  It exists so that inference outputs (boxes, masks, offsets) can be compared with the
+// fp32 CPU oracle at the north-star tolerance of 1e-3; it is not a performance path (its b32 LDS reads are fully
+// bank-conflicted by construction).  128x128 tile, K-step = 32 channels (the same 128-byte LDS rows).
+// =====================================================================================
+struct ConvArgsF32 {
+    const float* src; const float* wgt; const float* bias; const float* residual; const float* mask; float* out;
+    const float* zero_page;
+    int B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo_y, oo_x, ss, T;
+    int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    int relu, accumulate;
+    long src_gs, wgt_gs, out_gs, bias_gs;
+    int M;
+};
+
+__global__ __launch_bounds__(256) void conv_tap_f32_kernel(const ConvArgsF32 a) {
+    constexpr int BM = 128, BN = 128, BKE = 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, g = blockIdx.z;
+    const float* src = a.src + (long)g * a.src_gs;
+    const float* wgt = a.wgt + (long)g * a.wgt_gs;
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    int a_base[4], a_y[4], a_x[4], a_c[4];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + wave * 8 + lrow;
+        const int m = m0 + row;
+        a_c[i] = swz(row, lchunk) * 4;
+        if (m < a.M) {
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / a.OW, ox = rem - oy * a.OW;
+            a_base[i] = b * a.IH * a.IW; a_y[i] = oy * a.ss; a_x[i] = ox * a.ss;
+        } else { a_base[i] = 0; a_y[i] = -100000; a_x[i] = -100000; }
+    }
+    long b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + wave * 8 + lrow;
+        const int n = n0 + row;
+        b_off[i] = (n < a.Cout) ? ((long)n * a.Cin + swz(row, lchunk) * 4) : -1;
+    }
+    const int kchunks = a.Cin / BKE;
+    const int nk = a.T * kchunks;
+    auto stage = [&](int kk, int buf) {
+        const int t = kk / kchunks, c0 = (kk - t * kchunks) * BKE;
+        const int dy = a.dy[t], dx = a.dx[t];
+        char* abuf = lds + buf * (A_BYTES + B_BYTES);
+        char* bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+            const bool ok = (iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW);
+            const float* p = ok ? src + ((long)(a_base[i] + iy * a.IW + ix) * a.Cin + c0 + a_c[i]) : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(abuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+        const float* wt = wgt + (long)a.wt[t] * a.Cout * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* p = (b_off[i] >= 0) ? wt + b_off[i] : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(bbuf + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fq = lane >> 5;
+    stage(0, 0);
+    for (int kk = 0; kk < nk; ++kk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
+        const char* abuf = lds + (kk & 1) * (A_BYTES + B_BYTES);
+        const char* bbuf = abuf + A_BYTES;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int k = ks * 2 + fq, q = k >> 2, e = k & 3;
+            float wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wn * 64 + i * 32 + frow;
+                wf[i] = *reinterpret_cast<const float*>(bbuf + row * 128 + swz(row, q) * 16 + e * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wm * 64 + j * 32 + frow;
+                xf[j] = *reinterpret_cast<const float*>(abuf + row * 128 + swz(row, q) * 16 + e * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+    const long out_g = (long)g * a.out_gs;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + frow;
+        if (m >= a.M) continue;
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * gq + 4 * fq;
+                if (n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = out_g + opix * a.Cout + n;
+                if (a.residual) {
+                    float rv[4];
+                    ld4(a.residual + o, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.mask) {
+                    float mv[4];
+                    ld4(a.mask + o, mv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                }
+                if (a.accumulate) {
+                    float ov[4];
+                    ld4(a.out + o, ov);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                }
+                st4(a.out + o, v);
+            }
+    }
+}
+
+LOFT_EXPORT int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, const float* residual,
+                                  const float* relu_mask, float* out, const void* zero_page, int B, int IH, int IW, int Cin,
+                                  int Cout, int OH, int OW, int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T,
+                                  const int* dy_host, const int* dx_host, const int* wt_host, int relu, int accumulate,
+                                  int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream) {
+    if (T < 1 || T > CONV_MAX_TAPS || (Cin % 32) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
+    ConvArgsF32 a;
+    a.src = src; a.wgt = wgt; a.bias = bias; a.residual = residual; a.mask = relu_mask; a.out = out;
+    a.zero_page = (const float*)zero_page;
+    a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf;
+    a.os = os; a.oo_y = oo_y; a.oo_x = oo_x; a.ss = ss; a.T = T;
+    for (int t = 0; t < T; ++t) { a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t]; }
+    a.relu = relu; a.accumulate = accumulate;
+    a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
+    const long M = (long)B * OH * OW;
+    if (M <= 0) return 0;
+    if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    a.M = (int)M;
+    dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 128), groups);
+    hipLaunchKernelGGL(conv_tap_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

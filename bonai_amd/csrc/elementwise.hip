@@ -29,6 +29,10 @@ __device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
     *reinterpret_cast<uint4*>(p) = t;
 }
 
+// fp32 parity mode: the same 8-channel groups, as two 16-byte accesses
+__device__ __forceinline__ void ld8(const float* p, float v[8]) { ld4(p, v); ld4(p + 4, v + 4); }
+__device__ __forceinline__ void st8(float* p, const float v[8]) { st4(p, v); st4(p + 4, v + 4); }
+
 static inline dim3 ew_grid(long nvec) {
     long b = (nvec + 255) / 256;
     if (b > 8192) b = 8192;
@@ -105,8 +109,8 @@ LOFT_EXPORT int loft_colsum_bf16(const void* x, int64_t M, int C, float* out, vo
 }
 
 // ---- FPN top-down: fine[b,y,x,:] += coarse[b,y/2,x/2,:] ; adjoint: coarse += sum of the 2x2 block ----
-__global__ void upsample_add_kernel(bf16_t* __restrict__ fine, const bf16_t* __restrict__ coarse, int B, int H, int W,
-                                    int C) {
+template <typename T>
+__global__ void upsample_add_kernel(T* __restrict__ fine, const T* __restrict__ coarse, int B, int H, int W, int C) {
     const long nvec = (long)B * H * W * (C >> 3);
     const int cg = C >> 3;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -125,8 +129,15 @@ __global__ void upsample_add_kernel(bf16_t* __restrict__ fine, const bf16_t* __r
 }
 LOFT_EXPORT int loft_upsample2x_add_bf16(void* fine, const void* coarse, int B, int H, int W, int C, void* stream) {
     if ((C % 8) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(upsample_add_kernel, ew_grid((long)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upsample_add_kernel<bf16_t>, ew_grid((long)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)fine, (const bf16_t*)coarse, B, H, W, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+LOFT_EXPORT int loft_upsample2x_add_f32(float* fine, const float* coarse, int B, int H, int W, int C, void* stream) {
+    if ((C % 8) || (H & 1) || (W & 1)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(upsample_add_kernel<float>, ew_grid((long)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, fine,
+                       coarse, B, H, W, C);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -169,8 +180,9 @@ LOFT_EXPORT int loft_downsum2x_add_bf16(void* coarse, const void* fine, int B, i
 }
 
 // ---- stride-2 subsample (P6) and its adjoint (scatter-add into the even positions) ----
-__global__ void subsample2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int Ho, int Wo, int Hi,
-                                  int Wi, int C, int adjoint) {
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                  int adjoint) {
     const int cg = C >> 3;
     const long nvec = (long)B * Ho * Wo * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -196,15 +208,23 @@ __global__ void subsample2_kernel(const bf16_t* __restrict__ src, bf16_t* __rest
 LOFT_EXPORT int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, int adjoint,
                                      void* stream) {
     if (C % 8) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(subsample2_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(subsample2_kernel<bf16_t>, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, (bf16_t*)dst, B, Ho, Wo, Hi, Wi, C, adjoint);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+LOFT_EXPORT int loft_subsample2_f32(const float* src, float* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(subsample2_kernel<float>, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       B, Ho, Wo, Hi, Wi, C, 0);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
 
 // ---- max pool 3x3 stride 2 pad 1 (forward only: it sits in the frozen stem) ----
-__global__ void maxpool3x3s2_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int B, int Hi, int Wi, int Ho,
-                                    int Wo, int C) {
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int Hi, int Wi, int Ho, int Wo,
+                                    int C) {
     const int cg = C >> 3;
     const long nvec = (long)B * Ho * Wo * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -234,8 +254,16 @@ __global__ void maxpool3x3s2_kernel(const bf16_t* __restrict__ src, bf16_t* __re
 LOFT_EXPORT int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream) {
     if (C % 8) return (int)hipErrorInvalidValue;
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, (bf16_t*)dst, B, Hi, Wi, Ho, Wo, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+LOFT_EXPORT int loft_maxpool3x3s2_f32(const float* src, float* dst, int B, int Hi, int Wi, int C, void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, ew_grid((long)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, B, Hi, Wi, Ho, Wo, C);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -244,9 +272,10 @@ LOFT_EXPORT int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi
 // img fp32 NCHW [B,3,H,W] (what the reference's data pipeline hands over); w fp32 [64][3][7][7];
 // out bf16 NHWC [B,H/2,W/2,64].  Block = 16x16 output pixels; the 37x37x3 input patch and the
 // 64x147 weights live in LDS; each thread produces one pixel x 64 channels in 4 passes of 16.
+template <typename T>
 __global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      bf16_t* __restrict__ out, int B, int H, int W, int Ho, int Wo) {
+                                                      T* __restrict__ out, int B, int H, int W, int Ho, int Wo) {
     __shared__ float patch[3][37][38];
     __shared__ float wl[147][64];  // [k][oc]
     const int tid = threadIdx.x;
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ 
     const int ty = tid >> 4, tx = tid & 15;
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= Ho || ox >= Wo) return;
-    bf16_t* op = out + (((long)b * Ho + oy) * Wo + ox) * 64;
+    T* op = out + (((long)b * Ho + oy) * Wo + ox) * 64;
     for (int pass = 0; pass < 4; ++pass) {
         float acc[16];
 #pragma unroll
@@ -294,11 +323,15 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const float* __restrict__ 
     }
 }
 LOFT_EXPORT int loft_stem7x7_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out,
-                                     int B, int H, int W, void* stream) {
+                                     int B, int H, int W, int out_f32, void* stream) {
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     dim3 grid(loft_cdiv(Wo, 16), loft_cdiv(Ho, 16), B);
-    hipLaunchKernelGGL(stem7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, w, scale, shift, (bf16_t*)out, B, H, W,
-                       Ho, Wo);
+    if (out_f32)
+        hipLaunchKernelGGL(stem7x7_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img, w, scale, shift, (float*)out, B, H,
+                           W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem7x7_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, img, w, scale, shift, (bf16_t*)out, B,
+                           H, W, Ho, Wo);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -396,9 +429,13 @@ LOFT_EXPORT int loft_sgd_momentum_f32(float* p, const float* g, float* m, int64_
 // consume: fwd [R*S][Cout][Cin], dgrad [R*S][Cin][Cout] (either may be NULL), and the fp32 epilogue bias
 // (BN shift, or the conv bias).  Backward: from the packed fp32 weight gradient of the folded weight and the bias
 // gradient produce dW in the reference layout, dgamma, dbeta.
+template <typename OT> __device__ __forceinline__ OT fold_cvt(float v);
+template <> __device__ __forceinline__ bf16_t fold_cvt<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ float fold_cvt<float>(float v) { return v; }
+template <typename OT>
 __global__ void fold_pack_kernel(const float* __restrict__ w, const float* __restrict__ cbias, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
-                                 float eps, int Cout, int Cin, int RS, bf16_t* __restrict__ wp, bf16_t* __restrict__ wpt,
+                                 float eps, int Cout, int Cin, int RS, OT* __restrict__ wp, OT* __restrict__ wpt,
                                  float* __restrict__ bias_out) {
     const long total = (long)Cout * Cin * RS;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -408,7 +445,7 @@ __global__ void fold_pack_kernel(const float* __restrict__ w, const float* __res
         const int n = (int)(r % Cout), t = (int)(r / Cout);
         float v = w[((long)n * Cin + c) * RS + t];
         if (gamma) v *= gamma[n] * rsqrtf(var[n] + eps);
-        const bf16_t h = f32_to_bf16(v);
+        const OT h = fold_cvt<OT>(v);
         if (wp) wp[i] = h;
         if (wpt) wpt[((long)t * Cin + c) * Cout + n] = h;
     }
@@ -420,11 +457,15 @@ __global__ void fold_pack_kernel(const float* __restrict__ w, const float* __res
 }
 LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                                const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad,
-                               float* bias_out, void* stream) {
+                               float* bias_out, int pack_f32, void* stream) {
     const long total = (long)Cout * Cin * RS;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(fold_pack_kernel, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta, mean, var,
-                       eps, Cout, Cin, RS, (bf16_t*)wp_fwd, (bf16_t*)wp_dgrad, bias_out);
+    if (pack_f32)
+        hipLaunchKernelGGL(fold_pack_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta,
+                           mean, var, eps, Cout, Cin, RS, (float*)wp_fwd, (float*)wp_dgrad, bias_out);
+    else
+        hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta,
+                           mean, var, eps, Cout, Cin, RS, (bf16_t*)wp_fwd, (bf16_t*)wp_dgrad, bias_out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -204,10 +204,10 @@ def zero_page(device):
     return _ZERO_PAGES[key]
 
 
-def pack_w_fwd(w):
+def pack_w_fwd(w, dtype=torch.bfloat16):
     """[Cout,Cin,R,S] (reference / checkpoint layout) -> bf16 [R*S, Cout, Cin]."""
     co, ci, r, s = w.shape
-    return w.permute(2, 3, 0, 1).reshape(r * s, co, ci).to(torch.bfloat16).contiguous()
+    return w.permute(2, 3, 0, 1).reshape(r * s, co, ci).to(dtype).contiguous()
 
 
 def pack_w_dgrad(w):
@@ -230,9 +230,22 @@ def _bf16(t):
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
              residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None):
-    """Raw launch of loft_conv_tap_bf16.  taps: list of (dy, dx, weight_tap_index)."""
+    """Raw launch of loft_conv_tap_bf16 (or loft_conv_tap_f32 when every operand is fp32: the forward-only parity mode).
+    taps: list of (dy, dx, weight_tap_index)."""
     lib = L.load()
     L.dev_check(src, wgt, out, bias, residual)
+    if src.dtype == torch.float32:
+        for t in (wgt, out, residual, mask):
+            if t is not None and t.dtype != torch.float32:
+                raise L.LoftHipError(f'fp32 parity mode needs every operand in fp32, got {t.dtype}')
+        T = len(taps)
+        L.check(lib.loft_conv_tap_f32(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
+                                      L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
+                                      oo[1], ss, T, L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
+                                      L.arr(c_int, [t[2] for t in taps]), int(relu), int(accumulate), groups,
+                                      c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
+                'loft_conv_tap_f32')
+        return out
     _bf16(src), _bf16(wgt)
     if residual is not None:
         _bf16(residual)
@@ -377,6 +390,9 @@ def upsample2x_add_(fine, coarse):
     lib = L.load()
     fine, coarse = _nhwc(fine), _nhwc(coarse)
     B, C, H, W = fine.shape
+    if fine.dtype == torch.float32 and coarse.dtype == torch.float32:
+        L.check(lib.loft_upsample2x_add_f32(L.ptr(fine), L.ptr(coarse), B, H, W, C, L.stream()), 'loft_upsample2x_add_f32')
+        return fine
     L.check(lib.loft_upsample2x_add_bf16(L.ptr(_bf16(fine)), L.ptr(_bf16(coarse)), B, H, W, C, L.stream()),
             'loft_upsample2x_add_bf16')
     return fine
@@ -397,6 +413,9 @@ def subsample2(x):
     B, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = empty_nhwc(B, C, Ho, Wo, x.dtype, x.device)
+    if x.dtype == torch.float32:
+        L.check(lib.loft_subsample2_f32(L.ptr(x), L.ptr(out), B, Ho, Wo, H, W, C, L.stream()), 'loft_subsample2_f32')
+        return out
     L.check(lib.loft_subsample2_bf16(L.ptr(_bf16(x)), L.ptr(out), B, Ho, Wo, H, W, C, 0, L.stream()),
             'loft_subsample2_bf16')
     return out
@@ -416,20 +435,23 @@ def maxpool3x3s2(x):
     x = _nhwc(x)
     B, C, H, W = x.shape
     out = empty_nhwc(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, x.dtype, x.device)
+    if x.dtype == torch.float32:
+        L.check(lib.loft_maxpool3x3s2_f32(L.ptr(x), L.ptr(out), B, H, W, C, L.stream()), 'loft_maxpool3x3s2_f32')
+        return out
     L.check(lib.loft_maxpool3x3s2_bf16(L.ptr(_bf16(x)), L.ptr(out), B, H, W, C, L.stream()), 'loft_maxpool3x3s2_bf16')
     return out
 
 
-def stem7x7_bn_relu(img, w, scale, shift):
-    """img fp32 NCHW [B,3,H,W] -> bf16 channels_last [B,64,H/2,W/2]."""
+def stem7x7_bn_relu(img, w, scale, shift, out_dtype=torch.bfloat16):
+    """img fp32 NCHW [B,3,H,W] -> bf16 (or fp32: parity mode) channels_last [B,64,H/2,W/2]."""
     lib = L.load()
     L.dev_check(img, w, scale, shift)
     img = img.float().contiguous()
     w, scale, shift = w.float().contiguous(), scale.float().contiguous(), shift.float().contiguous()
     B, _, H, W = img.shape
-    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, torch.bfloat16, img.device)
+    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, out_dtype, img.device)
     L.check(lib.loft_stem7x7_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale),
-                                     L.ptr(shift), L.ptr(out), B, H, W, L.stream()),
+                                     L.ptr(shift), L.ptr(out), B, H, W, int(out_dtype == torch.float32), L.stream()),
             'loft_stem7x7_bn_relu')
     return out
 
@@ -637,7 +659,7 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
 # ------------------------------------------------------------------ weight fold + pack
 
 def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None,
-              out_bias=None):
+              out_bias=None, dtype=torch.bfloat16):
     """w fp32 [Cout,Cin,R,S]; bn = (gamma, beta, mean, var) or None -> (wp_fwd bf16 [T,Cout,Cin] | None,
     wp_dgrad bf16 [T,Cin,Cout] | None, bias fp32 [Cout])."""
     lib = L.load()
@@ -646,15 +668,16 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
     Cout, Cin, R, S = w.shape
     T = R * S
     dev = w.device
-    wp = out_fwd if out_fwd is not None else (torch.empty(T, Cout, Cin, dtype=torch.bfloat16, device=dev) if want_fwd else None)
-    wpt = out_dgrad if out_dgrad is not None else (torch.empty(T, Cin, Cout, dtype=torch.bfloat16, device=dev) if want_dgrad else None)
+    wp = out_fwd if out_fwd is not None else (torch.empty(T, Cout, Cin, dtype=dtype, device=dev) if want_fwd else None)
+    wpt = out_dgrad if out_dgrad is not None else (torch.empty(T, Cin, Cout, dtype=dtype, device=dev) if want_dgrad else None)
     bias = out_bias if out_bias is not None else torch.empty(Cout, dtype=torch.float32, device=dev)
     g = b = m = v = None
     if bn is not None:
         g, b, m, v = [t.contiguous() for t in bn]
     cb = conv_bias.contiguous() if conv_bias is not None else None
     L.check(lib.loft_fold_pack(L.ptr(w), L.ptr(cb), L.ptr(g), L.ptr(b), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin, T,
-                               L.ptr(wp), L.ptr(wpt), L.ptr(bias), L.stream()), 'loft_fold_pack')
+                               L.ptr(wp), L.ptr(wpt), L.ptr(bias), int(dtype == torch.float32), L.stream()),
+            'loft_fold_pack')
     return wp, wpt, bias
 
 

@@ -141,7 +141,10 @@ class ResNet(nn.Module):
         """img fp32 NCHW [B,3,H,W] -> tuple of bf16 NHWC-in-memory maps (C2..C5)."""
         with torch.set_grad_enabled(self.frozen_stages < 0 and torch.is_grad_enabled()):
             scale, shift = self.bn1.fold()
-            x = K.stem7x7_mfma(img, self.conv1.weight, scale, shift)
+            if getattr(self, 'compute_dtype', torch.bfloat16) == torch.float32:   # forward-only parity mode
+                x = K.stem7x7_bn_relu(img, self.conv1.weight, scale, shift, out_dtype=torch.float32)
+            else:
+                x = K.stem7x7_mfma(img, self.conv1.weight, scale, shift)
             x = K.maxpool3x3s2(x)
         outs = []
         for i, name in enumerate(self.res_layers):

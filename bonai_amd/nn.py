@@ -4,6 +4,10 @@ torch.autograd is used as bookkeeping only (which saved tensor feeds which backw
 forward and backward body is a hand-written gfx950 kernel from bonai_amd.kernels.  Activations are
 bf16 NHWC, master weights fp32 in the reference's [Cout,Cin,R,S] layout (so reference checkpoints
 load unchanged), accumulation fp32.
+
+fp32 parity mode: when the activation handed to conv2d / narrow_head / deconv2x2_relu is fp32, the same layers run
+forward-only on the fp32 MFMA kernel (loft_conv_tap_f32) with fp32 operand packings -- used to compare inference results
+with the fp32 reference at 1e-3; the backward of these functions refuses fp32 activations.
 """
 import torch
 
@@ -34,26 +38,27 @@ class _ConvFn(torch.autograd.Function):
         Cout, Cin, R, S = ws[0].shape
         T = R * S
         dev = x.device
+        pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
         key = None
         if frozen:
-            key = tuple((id(t), t._version) for t in tensors if t is not None)
+            key = (pdt,) + tuple((id(t), t._version) for t in tensors if t is not None)
         if key is not None and key in _PACK_CACHE:
             wp, wpt, bias = _PACK_CACHE[key]
         else:
-            wp = torch.empty(G, T, Cout, Cin, dtype=torch.bfloat16, device=dev)
+            wp = torch.empty(G, T, Cout, Cin, dtype=pdt, device=dev)
             need_dgrad = ctx.needs_input_grad[0]
-            wpt = torch.empty(G, T, Cin, Cout, dtype=torch.bfloat16, device=dev) if need_dgrad else None
+            wpt = torch.empty(G, T, Cin, Cout, dtype=pdt, device=dev) if need_dgrad else None
             bias = torch.empty(G, Cout, dtype=torch.float32, device=dev)
             bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
             eps = bn_stats[2] if bn_stats is not None else 1e-5
             for g in range(G):
                 K.fold_pack(ws[g], bs[g], bn, eps, out_fwd=wp[g], out_dgrad=None if wpt is None else wpt[g], out_bias=bias[g],
-                            want_dgrad=need_dgrad)
+                            want_dgrad=need_dgrad, dtype=pdt)
             if key is not None:
                 _PACK_CACHE[key] = (wp, wpt, bias)
         use_bias = has_b or bn_stats is not None
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
-                         out_dtype=torch.float32 if out_f32 else torch.bfloat16, groups=G)
+                         out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else torch.bfloat16, groups=G)
         ctx.meta = meta
         ctx.in_hw = tuple(x.shape[2:])
         ctx.has_res = residual is not None
@@ -64,6 +69,8 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu = ctx.meta
         x, y, wpt = ctx.saved_tensors[:3]
+        if x.dtype != torch.bfloat16:
+            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         tensors = ctx.saved_tensors[3:]
         ws = tensors[0:2 * G:2]
         Cout, Cin, R, S = ws[0].shape
@@ -146,7 +153,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         if b is not None:
             bpad[:Cout] = b
         K.ALGO_SCALE = Cout / c4
-        y = K.conv2d_fwd(x, K.pack_w_fwd(wpad)[None], bpad, 1, 1, out_dtype=torch.float32)
+        y = K.conv2d_fwd(x, K.pack_w_fwd(wpad, x.dtype)[None], bpad, 1, 1, out_dtype=torch.float32)
         K.ALGO_SCALE = 1.0
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -155,6 +162,8 @@ class _NarrowHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        if x.dtype != torch.bfloat16:
+            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         Cout, Cin = w.shape[0], w.shape[1]
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
@@ -193,8 +202,8 @@ class _DeconvFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
-        wp = w.permute(2, 3, 1, 0).reshape(4, Cout, Cin).to(torch.bfloat16).contiguous()
-        y = K.empty_nhwc(N, Cout, 2 * H, 2 * W, torch.bfloat16, x.device)
+        wp = w.permute(2, 3, 1, 0).reshape(4, Cout, Cin).to(x.dtype).contiguous()
+        y = K.empty_nhwc(N, Cout, 2 * H, 2 * W, x.dtype, x.device)
         bias = b.float().contiguous()
         for py in range(2):
             for px in range(2):
@@ -206,6 +215,8 @@ class _DeconvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
+        if x.dtype != torch.bfloat16:
+            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
         g = K.relu_bwd(to_nhwc(g), y)

@@ -94,6 +94,14 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
                        int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                        const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
                        int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream);
+/* loft_conv_tap_f32: the fp32 parity mode of the same contract (all operands and the output fp32, contraction on
+ * v_mfma_f32_32x32x2_f32 = exact fp32 products and sums).  Forward / data-gradient only; it exists so inference results can
+ * be checked against the reference's fp32 outputs at the north-star tolerance (1e-3), not for speed.  Cin % 32 == 0. */
+int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, const float* residual, const float* relu_mask,
+                      float* out, const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
+                      int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
+                      const int* wt_host, int relu, int accumulate, int groups, int64_t src_gs, int64_t wgt_gs,
+                      int64_t out_gs, int64_t bias_gs, void* stream);
 /* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32
@@ -126,7 +134,11 @@ int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int 
                          void* stream);
 int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream);
 int loft_stem7x7_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out, int B,
-                         int H, int W, void* stream);
+                         int H, int W, int out_f32, void* stream);
+/* fp32 parity-mode forms of the three forward glue kernels above (same reference lines). */
+int loft_upsample2x_add_f32(float* fine, const float* coarse, int B, int H, int W, int C, void* stream);
+int loft_subsample2_f32(const float* src, float* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
+int loft_maxpool3x3s2_f32(const float* src, float* dst, int B, int Hi, int Wi, int C, void* stream);
 /* MFMA form of the stem (same reference lines): wgt_packed bf16 [64][192], row n = the 147 weights of output
  * channel n in (c, r, s) order times the folded BN scale, zero padded; bias fp32 [64] = folded BN shift. */
 int loft_stem7x7_mfma(const float* img, const void* wgt_packed, const float* bias, void* out, int B, int H, int W,
@@ -197,10 +209,10 @@ int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int i
  * frozen-statistics BatchNorm that follows the conv (norm_eval=True, mmdet/models/backbones/resnet.py:640-649; formula of
  * tools/fuse_conv_bn.py:10-23) when gamma != NULL; conv_bias is used when there is no BN.  loft_fold_unpack_bwd is its
  * chain rule: dwp fp32 [R*S][Cout][Cin] (gradient of the folded weight), db fp32 [Cout] (gradient of the folded bias)
- * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL). */
+ * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL).  pack_f32 != 0 writes fp32 packings (parity mode). */
 int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad, float* bias_out,
-                   void* stream);
+                   int pack_f32, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
                          void* stream);

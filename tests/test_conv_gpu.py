@@ -101,3 +101,22 @@ def test_linear_as_conv():
     out = K.conv2d_fwd(_cl(x.view(N, Kd, 1, 1)), K.pack_w_fwd(w.view(O, Kd, 1, 1).cuda()), b.cuda(), 1, 1, relu=True,
                        out_dtype=torch.float32)
     assert (out.view(N, O).cpu() - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,hw', [(64, 64, 3, 1, 1, 20), (256, 128, 1, 2, 0, 17), (32, 36, 3, 2, 1, 9),
+                                               (96, 256, 1, 1, 0, 7)])
+def test_conv_tap_f32_parity_mode(cin, cout, k, s, p, hw):
+    """loft_conv_tap_f32 (fp32 MFMA) vs an fp64 CPU convolution: fp32 rounding only (1e-5 relative to the output scale)."""
+    import torch.nn.functional as F
+    from bonai_amd import kernels as K
+    torch.manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, hw, hw)
+    w = torch.randn(cout, cin, k, k) * 0.05
+    b = torch.randn(cout)
+    res = torch.randn(2, cout, (hw + 2 * p - k) // s + 1, (hw + 2 * p - k) // s + 1)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), s, p) + res.double()).float()
+    y = K.conv2d_fwd(x.cuda().contiguous(memory_format=torch.channels_last), K.pack_w_fwd(w.cuda(), torch.float32)[None],
+                     b.cuda(), k, k, s, p, relu=True, residual=res.cuda().contiguous(memory_format=torch.channels_last),
+                     out_dtype=torch.float32)
+    assert y.dtype == torch.float32
+    assert (y.cpu() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())

@@ -87,3 +87,34 @@ def test_e2e_vs_oracle_proposals_and_targets():
         rb = rb[((rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1])) > 4.0]     # zero-area (clamped) boxes have IoU 0 with anything
         iou = R.bbox_overlaps(rb, got[:, :4])
         assert (iou.max(dim=1)[0] > 0.85).float().mean().item() > 0.9
+
+
+def test_e2e_fp32_parity_mode_vs_reference_fixture():
+    """North-star tolerance (1e-3) on the forward quantities: the same fixture as above with the fp32 parity mode
+    (fp32 MFMA contraction, fp32 activations, forward only) -- features and all seven losses at 1e-3."""
+    from bonai_amd.synth import make_batch
+    gd = np.load(os.path.join(GOLD, 'e2e_256.npz'))
+    size, batch, num_gt = [int(v) for v in gd['meta']]
+    m = _build()
+    m.backbone.compute_dtype = torch.float32
+    data = make_batch(batch, size, num_gt, device='cuda')
+    with torch.no_grad():
+        feats = m.extract_feat(data['img'])
+        for i, f in enumerate(feats):
+            assert f.dtype == torch.float32
+            want = torch.from_numpy(gd[f'feat_{i}_crop'])
+            got = f[:, :8, :6, :6].cpu()
+            scale = float(gd[f'feat_{i}_absmean'])
+            assert (got - want).abs().max().item() < 1e-3 * scale, (i, (got - want).abs().max().item(), scale)
+        out = m.train_step(data)
+    lv = dict(out['log_vars'].items())
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'loss_mask', 'loss_offset', 'loss'):
+        want = float(gd['log_' + k])
+        assert abs(lv[k] - want) <= 1e-3 * max(1.0, abs(want)), (k, lv[k], want)
+    assert abs(lv['acc'] - float(gd['log_acc'])) <= 0.2     # one of 1024 sampled RoIs flipping is 0.1
+    # the parity mode refuses to train
+    m2 = _build()
+    m2.backbone.compute_dtype = torch.float32
+    from bonai_amd.lib import LoftHipError
+    with pytest.raises(LoftHipError):
+        m2.train_step(data)['loss'].backward()

@@ -87,3 +87,38 @@ def test_simple_test_vs_reference_fixture():
     off = torch.from_numpy(offset_results)[arg]
     rel = (off[ok] - off_ref[ok]).abs() / (off_ref[ok].abs() + 5.0)
     assert rel.median().item() < 0.1
+
+
+def test_simple_test_fp32_parity_mode_vs_reference_fixture():
+    """North-star tolerance on the inference 3-tuple: with the fp32 parity mode (fp32 MFMA contraction, forward only)
+    every one of the reference's 2000 soft-NMS detections has a twin of ours within 5e-3 px / 1e-4 score (1e-3 relative
+    on a 256 px tile is 0.256 px), offsets within 1e-2 px with a mean end-point error < 1e-3 px, mask areas within 4 px.
+    The comparison is order-insensitive: score near-ties (1e-5 apart) swap rows."""
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import make_batch
+    from oracle.synth_weights import synth_tensor
+    gd = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_test_256.npz'))
+    size = int(gd['meta'][0])
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    m = m.cuda().eval()
+    m.backbone.compute_dtype = torch.float32
+    data = make_batch(1, size, 4, device='cuda')
+    with torch.no_grad():
+        bbox_results, segm_results, offset_results = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False,
+                                                       rescale=True)
+    det, want = torch.from_numpy(bbox_results[0]), torch.from_numpy(gd['det'])
+    assert det.shape == want.shape
+    assert (det[:, 4] - want[:, 4]).abs().max().item() < 1e-4            # sorted score lists agree row by row
+    dbox = (want[:, None, :4] - det[None, :, :4]).abs().amax(-1)
+    dbox = torch.where((want[:, None, 4] - det[None, :, 4]).abs() < 1e-4, dbox, torch.full_like(dbox, 1e9))
+    best, arg = dbox.min(1)
+    assert best.max().item() < 5e-3, best.max().item()
+    off, off_ref = torch.from_numpy(offset_results)[arg], torch.from_numpy(gd['offsets'])
+    epe = (off - off_ref).norm(dim=1)
+    print('box max diff', best.max().item(), 'offset EPE mean', epe.mean().item(), 'max', epe.max().item())
+    assert epe.max().item() < 1e-2 and epe.mean().item() < 1e-3
+    areas = torch.tensor([int(s.sum()) for s in segm_results[0]])[arg]
+    assert (areas - torch.from_numpy(gd['mask_area'])).abs().max().item() <= 4

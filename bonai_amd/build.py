@@ -20,6 +20,7 @@ FLAGS = {
     'roi_align.hip': ['-ffp-contract=off'],
     'nms.hip': ['-ffp-contract=off'],
     'boxes.hip': ['-ffp-contract=off'],
+    'deform.hip': ['-ffp-contract=off'],
 }
 
 

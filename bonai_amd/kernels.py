@@ -656,6 +656,41 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
     return out
 
 
+# ------------------------------------------------------------------ DCNv2 sampling
+
+def mdcn_sample_fwd(x, om, kh, kw, stride=1, pad=0, dil=1, deform_groups=1):
+    """x [B,C,IH,IW] channels_last (bf16 | fp32), om fp32 [B,OMC,OH,OW] channels_last = raw conv_offset output
+    -> col [B, kh*kw*C, OH, OW] channels_last (memory [B,OH,OW,K,C]), dtype of x."""
+    lib = L.load()
+    L.dev_check(x, om)
+    x, om = _nhwc(x), _nhwc(om)
+    if om.dtype != torch.float32:
+        raise L.LoftHipError('conv_offset output must be fp32')
+    B, C, IH, IW = x.shape
+    _, omc, OH, OW = om.shape
+    col = empty_nhwc(B, kh * kw * C, OH, OW, x.dtype, x.device)
+    L.check(lib.loft_mdcn_sample_fwd(L.ptr(x), L.ptr(om), L.ptr(col), L.dtype_code(x), B, IH, IW, C, OH, OW, kh, kw, stride,
+                                     pad, dil, deform_groups, omc, L.stream()), 'loft_mdcn_sample_fwd')
+    return col
+
+
+def mdcn_sample_bwd(x, om, dcol, kh, kw, stride=1, pad=0, dil=1, deform_groups=1):
+    """-> (dx fp32 [B,C,IH,IW] channels_last, dom fp32 like om)."""
+    lib = L.load()
+    L.dev_check(x, om, dcol)
+    x, om, dcol = _nhwc(x), _nhwc(om), _nhwc(dcol)
+    if dcol.dtype != x.dtype:
+        raise L.LoftHipError('dcol must have the dtype of x')
+    B, C, IH, IW = x.shape
+    _, omc, OH, OW = om.shape
+    dx = zeros_nhwc(B, C, IH, IW, torch.float32, x.device)
+    dom = zeros_nhwc(B, omc, OH, OW, torch.float32, x.device)
+    L.check(lib.loft_mdcn_sample_bwd(L.ptr(x), L.ptr(om), L.ptr(dcol), L.ptr(dx), L.ptr(dom), L.dtype_code(x), B, IH, IW, C,
+                                     OH, OW, kh, kw, stride, pad, dil, deform_groups, omc, L.stream()),
+            'loft_mdcn_sample_bwd')
+    return dx, dom
+
+
 # ------------------------------------------------------------------ weight fold + pack
 
 def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None,

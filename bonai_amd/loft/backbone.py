@@ -43,14 +43,53 @@ class ConvW(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
 
 
+class ModulatedDeformConvPack(nn.Module):
+    """Parameter holder with the names of mmcv's ModulatedDeformConv2dPack [mmcv==1.0.5]: ``weight`` [Cout,Cin,k,k],
+    optional ``bias``, ``conv_offset.{weight,bias}`` [3*DG*k*k, Cin, k, k].  Compute: bonai_amd.nn.modulated_deform_conv2d
+    (conv_offset -> loft_mdcn_sample -> 1x1 MFMA contraction).  Built where the reference builds conv type 'DCNv2'
+    (resnet.py:171-194; fpn.py:116-132 through ConvModule's conv_cfg)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, deform_groups=1, bias=True):
+        super().__init__()
+        self.k, self.stride, self.padding, self.deform_groups = k, stride, padding, deform_groups
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self.conv_offset = ConvW(cin, deform_groups * 3 * k * k, k, bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        """mmcv ModulatedDeformConv2d.init_weights: U(-1/sqrt(fan_in), +), zero bias; conv_offset zero (resnet.py:608-612)."""
+        stdv = 1.0 / (self.weight.shape[1] * self.k * self.k) ** 0.5
+        nn.init.uniform_(self.weight, -stdv, stdv)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x, bn=None, relu=False):
+        return F2.modulated_deform_conv2d(x, self.weight, self.bias, self.conv_offset.weight, self.conv_offset.bias,
+                                          stride=self.stride, pad=self.padding, deform_groups=self.deform_groups, bn=bn,
+                                          relu=relu)
+
+
+def _dcn_groups(dcn):
+    if dcn.get('type') != 'DCNv2':
+        raise NotImplementedError(f"conv type {dcn.get('type')!r}: only DCNv2 (modulated) has a native kernel")
+    return dcn.get('deform_groups', dcn.get('deformable_groups', 1))
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=False, bn_grad=True):
+    def __init__(self, inplanes, planes, stride=1, downsample=False, bn_grad=True, dcn=None):
         super().__init__()
         self.conv1 = ConvW(inplanes, planes, 1)
         self.bn1 = FrozenStatBN(planes, requires_grad=bn_grad)
-        self.conv2 = ConvW(planes, planes, 3)
+        if dcn is not None and not (dcn.get('fallback_on_stride', False) and stride > 1):   # resnet.py:171-194
+            self.conv2 = ModulatedDeformConvPack(planes, planes, 3, stride=stride, padding=1,
+                                                 deform_groups=_dcn_groups(dcn), bias=False)
+        else:
+            self.conv2 = ConvW(planes, planes, 3)
         self.bn2 = FrozenStatBN(planes, requires_grad=bn_grad)
         self.conv3 = ConvW(planes, planes * 4, 1)
         self.bn3 = FrozenStatBN(planes * 4, requires_grad=bn_grad)
@@ -64,7 +103,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, relu=True)
-        out = F2.conv2d(out, self.conv2.weight, bn=self.bn2, stride=self.stride, pad=1, relu=True, input_relu=True)
+        if isinstance(self.conv2, ModulatedDeformConvPack):
+            out = self.conv2(out, bn=self.bn2, relu=True)
+        else:
+            out = F2.conv2d(out, self.conv2.weight, bn=self.bn2, stride=self.stride, pad=1, relu=True, input_relu=True)
         identity = x
         if self.downsample is not None:
             identity = F2.conv2d(x, self.downsample[0].weight, bn=self.downsample[1], stride=self.stride)
@@ -85,7 +127,7 @@ class ResNet(nn.Module):
             raise KeyError(f'invalid depth {depth} for resnet')
         if not norm_eval:
             raise NotImplementedError('the MI355X path folds frozen-statistics BN (norm_eval=True), as configs/loft_foa use')
-        if style != 'pytorch' or deep_stem or avg_down or dcn is not None or plugins is not None or conv_cfg is not None:
+        if style != 'pytorch' or deep_stem or avg_down or plugins is not None or conv_cfg is not None:
             raise NotImplementedError('only the plain pytorch-style ResNet of configs/loft_foa is built natively')
         if in_channels != 3 or stem_channels != 64 or tuple(dilations) != (1, 1, 1, 1):
             raise NotImplementedError('stem kernel is specialised for 3->64, dilation 1')
@@ -103,7 +145,7 @@ class ResNet(nn.Module):
             for j in range(nb):
                 stride = strides[i] if j == 0 else 1
                 blocks.append(block(inplanes, planes, stride, downsample=(j == 0 and (stride != 1 or inplanes != planes * 4)),
-                                    bn_grad=bn_grad))
+                                    bn_grad=bn_grad, dcn=dict(dcn) if (dcn is not None and stage_with_dcn[i]) else None))
                 inplanes = planes * 4
             name = f'layer{i + 1}'
             self.add_module(name, nn.Sequential(*blocks))
@@ -132,6 +174,10 @@ class ResNet(nn.Module):
             elif isinstance(m, FrozenStatBN):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        for m in self.modules():                      # resnet.py:608-612
+            if isinstance(m, ModulatedDeformConvPack):
+                nn.init.zeros_(m.conv_offset.weight)
+                nn.init.zeros_(m.conv_offset.bias)
         if self.zero_init_residual:
             for m in self.modules():
                 if isinstance(m, Bottleneck):
@@ -164,12 +210,17 @@ class ResNet(nn.Module):
 class _ConvModule(nn.Module):
     """`.conv.weight/.bias` naming of mmcv ConvModule (no norm, optional ReLU)."""
 
-    def __init__(self, cin, cout, k, relu=False):
+    def __init__(self, cin, cout, k, relu=False, conv_cfg=None):
         super().__init__()
-        self.conv = ConvW(cin, cout, k, bias=True)
+        if conv_cfg is not None:
+            self.conv = ModulatedDeformConvPack(cin, cout, k, padding=k // 2, deform_groups=_dcn_groups(conv_cfg), bias=True)
+        else:
+            self.conv = ConvW(cin, cout, k, bias=True)
         self.k, self.relu = k, relu
 
     def forward(self, x):
+        if isinstance(self.conv, ModulatedDeformConvPack):
+            return self.conv(x, relu=self.relu)
         return F2.conv2d(x, self.conv.weight, self.conv.bias, pad=self.k // 2, relu=self.relu)
 
 
@@ -179,13 +230,13 @@ class FPN(nn.Module):
                  extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
                  norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest')):
         super().__init__()
-        if add_extra_convs or conv_cfg is not None or norm_cfg is not None or act_cfg is not None or start_level != 0 \
+        if add_extra_convs or norm_cfg is not None or act_cfg is not None or start_level != 0 \
                 or end_level != -1 or upsample_cfg.get('mode', 'nearest') != 'nearest':
             raise NotImplementedError('only the plain FPN of configs/loft_foa (no extra convs / norm / act) is built natively')
         self.in_channels, self.out_channels, self.num_outs = list(in_channels), out_channels, num_outs
         self.num_ins = len(in_channels)
-        self.lateral_convs = nn.ModuleList([_ConvModule(c, out_channels, 1) for c in in_channels])
-        self.fpn_convs = nn.ModuleList([_ConvModule(out_channels, out_channels, 3) for _ in in_channels])
+        self.lateral_convs = nn.ModuleList([_ConvModule(c, out_channels, 1, conv_cfg=conv_cfg) for c in in_channels])
+        self.fpn_convs = nn.ModuleList([_ConvModule(out_channels, out_channels, 3, conv_cfg=conv_cfg) for _ in in_channels])
 
     def init_weights(self):
         """fpn.py:149-154."""

@@ -41,7 +41,9 @@ class _ConvFn(torch.autograd.Function):
         pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
         key = None
         if frozen:
-            key = (pdt,) + tuple((id(t), t._version) for t in tensors if t is not None)
+            key = (pdt,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
+            if bn_stats is not None:
+                key += tuple((t.data_ptr(), t._version) for t in bn_stats[:2])
         if key is not None and key in _PACK_CACHE:
             wp, wpt, bias = _PACK_CACHE[key]
         else:
@@ -109,6 +111,13 @@ class _ConvFn(torch.autograd.Function):
         return (gx, gres, None) + tuple(ngrads)
 
 
+def _cacheable(t):
+    if t is None:
+        return True
+    base = t._base if t._base is not None else t
+    return isinstance(base, torch.nn.Parameter) and not base.requires_grad and not t.requires_grad
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None, input_relu=False):
     """w: [Cout,Cin,R,S] parameter, or a list of `groups` such parameters (independent branches, one launch);
     b likewise (or None); bn: a FrozenStatBN-like module folded into the conv (its shift becomes the bias)."""
@@ -123,8 +132,9 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
         tensors += [bn.weight, bn.bias]
         bn_stats = (bn.running_mean, bn.running_var, bn.eps)
     # cache packed operands only for parameters that can never change (requires_grad=False: frozen stem/layer1);
-    # the fused SGD kernel updates trainable parameters through raw pointers without bumping tensor versions
-    frozen = not any(t is not None and t.requires_grad for t in tensors)
+    # the fused SGD kernel updates trainable parameters through raw pointers without bumping tensor versions.
+    # Temporaries (e.g. a permuted weight) are never cached: their storage address can be recycled.
+    frozen = all(_cacheable(t) for t in tensors)
     meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen, input_relu)
     return _ConvFn.apply(x, residual, meta, *tensors)
 
@@ -138,25 +148,26 @@ def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
 
 
 class _NarrowHeadFn(torch.autograd.Function):
-    """1x1 conv / linear with a handful of outputs (RPN cls+reg, fc_cls+fc_reg, fc_offset, mask logits),
+    """Conv / linear with a handful of outputs (RPN cls+reg, fc_cls+fc_reg, fc_offset, mask logits, DCNv2 conv_offset),
     fp32 output [.., Cout4] (Cout rounded up to a multiple of 4).  The backward zero-pads the output
     gradient to 128 channels so the same MFMA dgrad / wgrad kernels apply."""
     PADW = 128
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        Cout, Cin = w.shape[0], w.shape[1]
+    def forward(ctx, x, w, b, stride, pad):
+        Cout, Cin, R, S = w.shape
         c4 = (Cout + 3) // 4 * 4
-        wpad = torch.zeros(c4, Cin, 1, 1, dtype=w.dtype, device=w.device)
-        wpad[:Cout] = w.view(Cout, Cin, 1, 1)
+        wpad = torch.zeros(c4, Cin, R, S, dtype=w.dtype, device=w.device)
+        wpad[:Cout] = w
         bpad = torch.zeros(c4, dtype=torch.float32, device=w.device)
         if b is not None:
             bpad[:Cout] = b
         K.ALGO_SCALE = Cout / c4
-        y = K.conv2d_fwd(x, K.pack_w_fwd(wpad, x.dtype)[None], bpad, 1, 1, out_dtype=torch.float32)
+        y = K.conv2d_fwd(x, K.pack_w_fwd(wpad, x.dtype)[None], bpad, R, S, stride, pad, out_dtype=torch.float32)
         K.ALGO_SCALE = 1.0
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.sp = (stride, pad)
         return y
 
     @staticmethod
@@ -164,7 +175,8 @@ class _NarrowHeadFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if x.dtype != torch.bfloat16:
             raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
-        Cout, Cin = w.shape[0], w.shape[1]
+        stride, pad = ctx.sp
+        Cout, Cin, R, S = w.shape
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
         gp = torch.zeros(N, P, H, W, dtype=torch.bfloat16, device=g.device).contiguous(memory_format=torch.channels_last)
@@ -172,27 +184,69 @@ class _NarrowHeadFn(torch.autograd.Function):
         gx = gw = gb = None
         K.ALGO_SCALE = Cout / P
         if ctx.needs_input_grad[0]:
-            wt = torch.zeros(1, Cin, P, dtype=torch.bfloat16, device=w.device)
-            wt[0, :, :Cout] = w.view(Cout, Cin).t()
-            gx = K.conv2d_dgrad(gp, wt[None], (H, W), 1, 1)
+            wt = torch.zeros(R * S, Cin, P, dtype=torch.bfloat16, device=w.device)
+            wt[:, :, :Cout] = w.permute(2, 3, 1, 0).reshape(R * S, Cin, Cout)
+            gx = K.conv2d_dgrad(gp, wt[None], tuple(x.shape[2:]), R, S, stride, pad)
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_b:   # bias gradient from the same pass (ones-operand MFMA)
-                dwp, db = K.conv2d_wgrad(gp, x, 1, 1, with_bias=True)
+                dwp, db = K.conv2d_wgrad(gp, x, R, S, stride, pad, with_bias=True)
                 gb = db[0, :Cout]
                 want_b = False
             else:
-                dwp = K.conv2d_wgrad(gp, x, 1, 1)
-            gw = dwp[0, 0, :Cout].reshape(w.shape)
+                dwp = K.conv2d_wgrad(gp, x, R, S, stride, pad)
+            gw = dwp[0, :, :Cout].permute(1, 2, 0).reshape(w.shape)
         K.ALGO_SCALE = 1.0
         if want_b:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
-        return gx, gw, gb
+        return gx, gw, gb, None, None
 
 
-def narrow_head(x, w, b=None):
-    """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,1,1)] with small Cout -> fp32 [N,ceil4(Cout),H,W]."""
-    return _NarrowHeadFn.apply(x, w, b)
+def narrow_head(x, w, b=None, stride=1, pad=0):
+    """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW]."""
+    if w.dim() == 2:
+        w = w.view(w.shape[0], w.shape[1], 1, 1)
+    return _NarrowHeadFn.apply(x, w, b, stride, pad)
+
+
+class _MdcnSampleFn(torch.autograd.Function):
+    """DCNv2 sampling: (x, raw conv_offset output) -> modulated, bilinearly sampled columns [B, K*C, OH, OW]
+    (loft_mdcn_sample_fwd / _bwd).  The contraction with the weight is an ordinary 1x1 conv2d over K*C channels."""
+
+    @staticmethod
+    def forward(ctx, x, om, meta):
+        kh, kw, stride, pad, dil, dg = meta
+        ctx.meta = meta
+        ctx.save_for_backward(x, om)
+        return K.mdcn_sample_fwd(x, om, kh, kw, stride, pad, dil, dg)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, om = ctx.saved_tensors
+        kh, kw, stride, pad, dil, dg = ctx.meta
+        g = to_nhwc(g)
+        if g.dtype != x.dtype:
+            g = g.to(x.dtype)
+        dx, dom = K.mdcn_sample_bwd(x, om, g, kh, kw, stride, pad, dil, dg)
+        return (K.cast_bf16(dx) if x.dtype == torch.bfloat16 else dx), dom, None
+
+
+def mdcn_sample(x, om, kh, kw, stride=1, pad=0, dil=1, deform_groups=1):
+    return _MdcnSampleFn.apply(x, om, (kh, kw, stride, pad, dil, deform_groups))
+
+
+def modulated_deform_conv2d(x, w, b, w_off, b_off, stride=1, pad=0, dil=1, deform_groups=1, bn=None, relu=False,
+                            residual=None, input_relu=False):
+    """mmcv ModulatedDeformConv2dPack.forward [mmcv==1.0.5] (used at resnet.py:171-194, fpn.py:116-132):
+    conv_offset (a plain conv, fp32 output) -> sampling -> 1x1 contraction with w viewed as [Cout, K*Cin] in (tap, c) order
+    (+ the folded frozen BN / bias / residual / ReLU epilogue of conv2d)."""
+    if dil != 1:
+        raise NotImplementedError('conv_offset runs on the dilation-1 tap kernel')
+    Cout, Cin, kh, kw = w.shape
+    om = narrow_head(x, w_off, b_off, stride=stride, pad=pad)
+    col = mdcn_sample(x, om, kh, kw, stride, pad, dil, deform_groups)
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin, 1, 1)
+    return conv2d(col, w2, b, relu=relu, residual=residual, bn=bn)
 
 
 class _DeconvFn(torch.autograd.Function):

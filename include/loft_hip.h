@@ -203,6 +203,23 @@ int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_
 int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
                     void* stream);
 
+/* ---- modulated deformable convolution (DCNv2) sampling ------------------------------------------
+ * Replaces mmcv.ops.ModulatedDeformConv2dPack / modulated_deform_conv2d [mmcv==1.0.5, not in tree] at the call sites
+ * mmdet/models/backbones/resnet.py:171-194 (Bottleneck.conv2 when dcn=dict(type='DCNv2')) and
+ * mmdet/models/necks/fpn.py:116-132 (conv_cfg=dict(type='DCNv2')).
+ * x: NHWC [B,IH,IW,C] (dtype: LOFT_F32 | LOFT_BF16); offmask: fp32 NHWC [B,OH,OW,offmask_stride], the RAW conv_offset output
+ * (channels [0, 2*DG*K) = offsets, channel g*2K+2k = dy and +1 = dx of tap k in group g; [2*DG*K, 3*DG*K) = mask logits,
+ * sigmoid applied here).  col: [B*OH*OW][K][C] (same dtype as x) = mask * zero-padded bilinear sample, i.e. the A operand of
+ * the 1x1 contraction with the weight packed as [Cout][K*C] that loft_conv_tap_* then runs.
+ * bwd: dcol (layout of col) -> dx fp32 [B,IH,IW,C] (ACCUMULATED with atomics: caller zeroes), doffmask fp32 (layout of offmask;
+ * channels >= 3*DG*K untouched).  K = kh*kw <= 9, DG <= 4, C % (8*DG) == 0 and C/(8*DG) a power of two. */
+int loft_mdcn_sample_fwd(const void* x, const float* offmask, void* col, int dtype, int B, int IH, int IW, int C, int OH,
+                         int OW, int kh, int kw, int stride, int pad, int dil, int deform_groups, int offmask_stride,
+                         void* stream);
+int loft_mdcn_sample_bwd(const void* x, const float* offmask, const void* dcol, float* dx, float* doffmask, int dtype, int B,
+                         int IH, int IW, int C, int OH, int OW, int kh, int kw, int stride, int pad, int dil,
+                         int deform_groups, int offmask_stride, void* stream);
+
 /* ---- weight fold + pack -----------------------------------------------------------------------------
  * Per conv and step: fp32 master weight [Cout][Cin][R][S] (the reference/checkpoint layout) -> bf16 operand packings
  * wp_fwd [R*S][Cout][Cin] and wp_dgrad [R*S][Cin][Cout] (either may be NULL) and the fp32 epilogue bias, folding the

@@ -38,7 +38,12 @@ def backbone(sd, img, prefix='backbone.'):
             p = f'{prefix}layer{li + 1}.{bi}.'
             stride = 2 if (bi == 0 and li > 0) else 1
             out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
-            out = F.relu(_bn(F.conv2d(out, sd[p + 'conv2.weight'], None, stride, 1), sd, p + 'bn2'))
+            if (p + 'conv2.conv_offset.weight') in sd:      # DCNv2 (resnet.py:171-194)
+                c2 = R.mdcn_pack(out, sd[p + 'conv2.weight'], None, sd[p + 'conv2.conv_offset.weight'],
+                                 sd[p + 'conv2.conv_offset.bias'], stride, 1)
+            else:
+                c2 = F.conv2d(out, sd[p + 'conv2.weight'], None, stride, 1)
+            out = F.relu(_bn(c2, sd, p + 'bn2'))
             out = _bn(F.conv2d(out, sd[p + 'conv3.weight']), sd, p + 'bn3')
             idt = x
             if (p + 'downsample.0.weight') in sd:
@@ -48,13 +53,18 @@ def backbone(sd, img, prefix='backbone.'):
     return outs
 
 
+def _fpn_conv(sd, p, x, pad):
+    """ConvModule of the neck: plain conv, or DCNv2 when conv_cfg=dict(type='DCNv2') (fpn.py:116-132)."""
+    if (p + 'conv_offset.weight') in sd:
+        return R.mdcn_pack(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'conv_offset.weight'], sd[p + 'conv_offset.bias'], 1, pad)
+    return F.conv2d(x, sd[p + 'weight'], sd[p + 'bias'], padding=pad)
+
+
 def fpn(sd, feats, prefix='neck.'):
-    lats = [F.conv2d(f, sd[f'{prefix}lateral_convs.{i}.conv.weight'], sd[f'{prefix}lateral_convs.{i}.conv.bias'])
-            for i, f in enumerate(feats)]
+    lats = [_fpn_conv(sd, f'{prefix}lateral_convs.{i}.conv.', f, 0) for i, f in enumerate(feats)]
     for i in range(len(lats) - 1, 0, -1):
         lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
-    outs = [F.conv2d(l, sd[f'{prefix}fpn_convs.{i}.conv.weight'], sd[f'{prefix}fpn_convs.{i}.conv.bias'], padding=1)
-            for i, l in enumerate(lats)]
+    outs = [_fpn_conv(sd, f'{prefix}fpn_convs.{i}.conv.', l, 1) for i, l in enumerate(lats)]
     outs.append(F.max_pool2d(outs[-1], 1, stride=2))
     return outs
 

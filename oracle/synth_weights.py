@@ -32,6 +32,8 @@ def synth_tensor(name, shape, dtype=torch.float32):
         return torch.randn(shape, generator=g) * 0.02
     final = any(t in name for t in ('rpn_cls', 'rpn_reg', 'fc_cls', 'fc_reg', 'fc_offset', 'conv_logits'))
     gain = 0.01 if final else (1.0 if ('lateral' in name or 'fpn_convs' in name) else 2.0)
+    if 'conv_offset' in name:   # DCNv2 offsets of ~0.3 px: keeps 20 stacked data-dependent samplers well conditioned
+        gain = 0.1
     if len(shape) == 4:       # conv / deconv weight
         fan_in = shape[1] * shape[2] * shape[3]
         if 'upsample' in name:

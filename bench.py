@@ -33,6 +33,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU (BASELINE configs[1]: 8)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--num-gt', type=int, default=80)
+    ap.add_argument('--config', default='loft_foa_r50_fpn_2x_bonai.py',
+                    help='file under configs/loft_foa (default: the headline BASELINE configs[1] model; '
+                         'loft_foa_r50_fpn_mdconv_c3-c5_2x_bonai.py = configs[3], DCNv2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -89,7 +92,8 @@ def main():
     from bonai_amd.loft import build_detector
     from bonai_amd.synth import make_batch
     K.L.load()
-    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', args.config))
+    headline = args.config == 'loft_foa_r50_fpn_2x_bonai.py' 
     torch.manual_seed(0)                                   # same random-init weights on every rank
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
     trainer = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
@@ -166,7 +170,7 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
                    config=dict(workload=f'LOFT R50-FPN + FOA, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
-                                        f'(BASELINE configs[1]), {args.num_gt} gt/img, full train step '
+                                        f'({"BASELINE configs[1]" if headline else args.config}), {args.num_gt} gt/img, full train step '
                                         '(fwd+losses+bwd+allreduce+clip+SGD), random-init weights',
                                global_batch=args.batch * world, per_gpu_batch=args.batch, parallelism=f'dp{world}',
                                mean_num_pos_per_img=round(mean_pos, 1), mean_num_rois_per_img=round(mean_roi, 1),

@@ -685,8 +685,10 @@ def mdcn_sample_bwd(x, om, dcol, kh, kw, stride=1, pad=0, dil=1, deform_groups=1
     _, omc, OH, OW = om.shape
     dx = zeros_nhwc(B, C, IH, IW, torch.float32, x.device)
     dom = zeros_nhwc(B, omc, OH, OW, torch.float32, x.device)
+    nws = lib.loft_mdcn_bwd_workspace_bytes(B, C, OH, OW, kh, kw, stride, dil, deform_groups, omc)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws > 0 else None
     L.check(lib.loft_mdcn_sample_bwd(L.ptr(x), L.ptr(om), L.ptr(dcol), L.ptr(dx), L.ptr(dom), L.dtype_code(x), B, IH, IW, C,
-                                     OH, OW, kh, kw, stride, pad, dil, deform_groups, omc, L.stream()),
+                                     OH, OW, kh, kw, stride, pad, dil, deform_groups, omc, L.ptr(ws), L.stream()),
             'loft_mdcn_sample_bwd')
     return dx, dom
 

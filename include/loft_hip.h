@@ -212,13 +212,18 @@ int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int i
  * sigmoid applied here).  col: [B*OH*OW][K][C] (same dtype as x) = mask * zero-padded bilinear sample, i.e. the A operand of
  * the 1x1 contraction with the weight packed as [Cout][K*C] that loft_conv_tap_* then runs.
  * bwd: dcol (layout of col) -> dx fp32 [B,IH,IW,C] (ACCUMULATED with atomics: caller zeroes), doffmask fp32 (layout of offmask;
- * channels >= 3*DG*K untouched).  K = kh*kw <= 9, DG <= 4, C % (8*DG) == 0 and C/(8*DG) a power of two. */
+ * channels >= 3*DG*K untouched).  K = kh*kw <= 9, DG <= 4, C % (8*DG) == 0 and C/(8*DG) a power of two.
+ * workspace: loft_mdcn_bwd_workspace_bytes() bytes; 0 / NULL = the generic kernel that scatters with global fp32 atomics
+ * (deform_groups > 1, C % 64 != 0).  With a workspace the tiled, atomic-free path runs (LDS gradient windows per output
+ * tile, stored to the workspace and summed per input pixel by a second pass; doffmask is fully overwritten). */
 int loft_mdcn_sample_fwd(const void* x, const float* offmask, void* col, int dtype, int B, int IH, int IW, int C, int OH,
                          int OW, int kh, int kw, int stride, int pad, int dil, int deform_groups, int offmask_stride,
                          void* stream);
 int loft_mdcn_sample_bwd(const void* x, const float* offmask, const void* dcol, float* dx, float* doffmask, int dtype, int B,
                          int IH, int IW, int C, int OH, int OW, int kh, int kw, int stride, int pad, int dil,
-                         int deform_groups, int offmask_stride, void* stream);
+                         int deform_groups, int offmask_stride, void* workspace, void* stream);
+int64_t loft_mdcn_bwd_workspace_bytes(int B, int C, int OH, int OW, int kh, int kw, int stride, int dil, int deform_groups,
+                                      int offmask_stride);
 
 /* ---- weight fold + pack -----------------------------------------------------------------------------
  * Per conv and step: fp32 master weight [Cout][Cin][R][S] (the reference/checkpoint layout) -> bf16 operand packings

@@ -474,12 +474,103 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
         }
 }
 
+
+// Narrow-channel form (Cout or Cin not a multiple of 128: HRNet branches of 32/64 channels, its 64-channel stem).  One 256-byte
+// LDS row per pixel holds BOTH operands side by side -- columns 0..63 = 64 channels of G, columns 64..127 = 64 channels of X --
+// so the same bank-conflict-free swizzle and the same transposing fragment reader apply.  2 x 2 waves of one 32 x 32 MFMA tile;
+// channels past Cout / Cin read the zero page and are masked in the epilogue.
+__global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
+    constexpr int RB = 256, TILE_BYTES = 64 * RB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int nt = bx / a.ctiles, ct = bx - nt * a.ctiles;
+    const int t = by % a.T, grp = by / a.T;
+    const int n0 = nt * 64, c0 = ct * 64;
+    const int mbeg = bz * a.pix_per_split;
+    const int mend = min(a.M, mbeg + a.pix_per_split);
+    if (mbeg >= mend) return;
+    const bf16_t* G = a.g + (long)grp * a.g_gs;
+    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const int ohw = a.OH * a.OW;
+    const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
+    const int lrow = lane >> 4, lchunk = lane & 15;
+    auto stage = [&](int m_base, int buf) {
+        char* tb = lds + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + wave * 4 + lrow;
+            const int m = m_base + row;
+            const int q = wswz(row, lchunk);                    // logical 16-byte chunk held at this physical position
+            const bf16_t* p = a.zero_page;
+            if (m < mend) {
+                const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
+                const int iy = oy * a.ss + dy, ix = ox * a.ss + dx;
+                if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                    if (q < 8) {
+                        if (n0 + q * 8 < a.Cout) p = G + ((long)(b * a.GH + gy) * a.GW + gx) * a.Cout + n0 + q * 8;
+                    } else {
+                        if (c0 + (q - 8) * 8 < a.Cin) p = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + (q - 8) * 8;
+                    }
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(tb + (i * 16 + wave * 4) * RB), 16, 0, 0);
+        }
+    };
+    f32x16 acc, accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
+    const int wn = wave >> 1, wc = wave & 1;
+    const bool do_db = a.db != nullptr && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    const int nsteps = (mend - mbeg + 63) / 64;
+    stage(mbeg, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) stage(mbeg + (s + 1) * 64, (s + 1) & 1);
+        const char* tb = lds + (s & 1) * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 gf = tr_frag<RB>(tb, ks * 16, wn * 32, lane);
+            const bf16x8 xf = tr_frag<RB>(tb, ks * 16, 64 + wc * 32, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc, 0, 0, 0);
+            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ones, accb, 0, 0, 0);
+        }
+    }
+    if (do_db && (lane & 31) == 0) {
+        float* db = a.db + (long)grp * a.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < a.Cout) unsafeAtomicAdd(db + n, accb[r]);
+        }
+    }
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < a.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < a.Cout) unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[r]);
+        }
+    }
+}
+
 LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
                                      int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                                      const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                                      const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
                                      int splits, float* db, int db_tap, void* stream) {
-    if (T < 1 || T > CONV_MAX_TAPS || (Cin % 128) || (Cout % 128) || groups < 1) return (int)hipErrorInvalidValue;
+    if (T < 1 || T > CONV_MAX_TAPS || (Cin % 8) || (Cout % 8) || groups < 1) return (int)hipErrorInvalidValue;
+    const bool narrow = (Cin % 128) || (Cout % 128);
     WgradArgs a;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = GH; a.GW = GW; a.Cout = Cout; a.XH = XH; a.XW = XW; a.Cin = Cin; a.OH = OH; a.OW = OW;
@@ -499,9 +590,9 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     // 256x256 tiles only when >= 256 workgroups can each run >= ~32 K-steps (else the 65k-atomic epilogue dominates)
     const bool big = (Cout % 256 == 0) && (Cin % 256 == 0) && !force_small_tile &&
                      M * (long)(Cout / 256) * (Cin / 256) * T * groups >= 524288L;
-    const int TNv = big ? 256 : 128;
-    a.ctiles = Cin / TNv;
-    const int tiles = (Cout / TNv) * a.ctiles;
+    const int TNv = narrow ? 64 : (big ? 256 : 128);
+    a.ctiles = (Cin + TNv - 1) / TNv;
+    const int tiles = ((Cout + TNv - 1) / TNv) * a.ctiles;
     if (splits <= 0) {  // aim for ~1024 workgroups, at least 4 K-steps each
         long want = (big ? 512 : 1024) / ((long)tiles * T * groups);
         long maxs = (M + 255) / 256;
@@ -512,7 +603,9 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     a.pix_per_split = pps;
     splits = (int)((M + pps - 1) / pps);
     dim3 grid(tiles, T * groups, splits);
-    if (big)
+    if (narrow)
+        hipLaunchKernelGGL(conv_wgrad64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (big)
         hipLaunchKernelGGL((conv_wgrad_kernel<256, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -436,36 +436,41 @@ template <typename OT>
 __global__ void fold_pack_kernel(const float* __restrict__ w, const float* __restrict__ cbias, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
                                  float eps, int Cout, int Cin, int RS, OT* __restrict__ wp, OT* __restrict__ wpt,
-                                 float* __restrict__ bias_out) {
-    const long total = (long)Cout * Cin * RS;
+                                 float* __restrict__ bias_out, int CoutP, int CinP) {
+    const long total = (long)CoutP * CinP * RS;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // i indexes the fwd packing [t][n][c] (coalesced writes); gather from [n][c][t]
-        const int c = (int)(i % Cin);
-        const long r = i / Cin;
-        const int n = (int)(r % Cout), t = (int)(r / Cout);
-        float v = w[((long)n * Cin + c) * RS + t];
-        if (gamma) v *= gamma[n] * rsqrtf(var[n] + eps);
+        // i indexes the (channel-padded) fwd packing [t][n][c] (coalesced writes); gather from [n][c][t]
+        const int c = (int)(i % CinP);
+        const long r = i / CinP;
+        const int n = (int)(r % CoutP), t = (int)(r / CoutP);
+        float v = 0.f;
+        if (n < Cout && c < Cin) {
+            v = w[((long)n * Cin + c) * RS + t];
+            if (gamma) v *= gamma[n] * rsqrtf(var[n] + eps);
+        }
         const OT h = fold_cvt<OT>(v);
         if (wp) wp[i] = h;
-        if (wpt) wpt[((long)t * Cin + c) * Cout + n] = h;
+        if (wpt) wpt[((long)t * CinP + c) * CoutP + n] = h;
     }
     if (bias_out && blockIdx.x == 0)
-        for (int n = threadIdx.x; n < Cout; n += blockDim.x) {
-            if (gamma) bias_out[n] = beta[n] - mean[n] * gamma[n] * rsqrtf(var[n] + eps);
+        for (int n = threadIdx.x; n < CoutP; n += blockDim.x) {
+            if (n >= Cout) bias_out[n] = 0.f;
+            else if (gamma) bias_out[n] = beta[n] - mean[n] * gamma[n] * rsqrtf(var[n] + eps);
             else bias_out[n] = cbias ? cbias[n] : 0.f;
         }
 }
 LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                                const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad,
-                               float* bias_out, int pack_f32, void* stream) {
-    const long total = (long)Cout * Cin * RS;
+                               float* bias_out, int pack_f32, int CoutP, int CinP, void* stream) {
+    if (CoutP < Cout || CinP < Cin) return (int)hipErrorInvalidValue;
+    const long total = (long)CoutP * CinP * RS;
     if (total <= 0) return 0;
     if (pack_f32)
         hipLaunchKernelGGL(fold_pack_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta,
-                           mean, var, eps, Cout, Cin, RS, (float*)wp_fwd, (float*)wp_dgrad, bias_out);
+                           mean, var, eps, Cout, Cin, RS, (float*)wp_fwd, (float*)wp_dgrad, bias_out, CoutP, CinP);
     else
         hipLaunchKernelGGL(fold_pack_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, conv_bias, gamma, beta,
-                           mean, var, eps, Cout, Cin, RS, (bf16_t*)wp_fwd, (bf16_t*)wp_dgrad, bias_out);
+                           mean, var, eps, Cout, Cin, RS, (bf16_t*)wp_fwd, (bf16_t*)wp_dgrad, bias_out, CoutP, CinP);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -475,7 +480,8 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
                                                               const float* __restrict__ w, const float* __restrict__ gamma,
                                                               const float* __restrict__ mean, const float* __restrict__ var,
                                                               float eps, int Cout, int Cin, int RS, float* __restrict__ dw,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int CoutP,
+                                                              int CinP) {
     const int n = blockIdx.x;
     const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
     const float scale = gamma ? gamma[n] * rs : 1.f;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
     const int per = Cin * RS;
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
-        const float g = dwp[((long)t * Cout + n) * Cin + c];
+        const float g = dwp[((long)t * CoutP + n) * CinP + c];
         const long wi = (long)n * per + j;
         if (dw) dw[wi] = g * scale;
         if (gamma) acc += g * w[wi];
@@ -503,10 +509,11 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
 }
 LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                                      const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma,
-                                     float* dbeta, void* stream) {
+                                     float* dbeta, int CoutP, int CinP, void* stream) {
     if (Cout <= 0) return 0;
+    if (CoutP < Cout || CinP < Cin) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_unpack_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dwp, db, w, gamma, mean, var, eps,
-                       Cout, Cin, RS, dw, dgamma, dbeta);
+                       Cout, Cin, RS, dw, dgamma, dbeta, CoutP, CinP);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -696,7 +696,7 @@ def mdcn_sample_bwd(x, om, dcol, kh, kw, stride=1, pad=0, dil=1, deform_groups=1
 # ------------------------------------------------------------------ weight fold + pack
 
 def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None,
-              out_bias=None, dtype=torch.bfloat16):
+              out_bias=None, dtype=torch.bfloat16, cout_pad=None, cin_pad=None):
     """w fp32 [Cout,Cin,R,S]; bn = (gamma, beta, mean, var) or None -> (wp_fwd bf16 [T,Cout,Cin] | None,
     wp_dgrad bf16 [T,Cin,Cout] | None, bias fp32 [Cout])."""
     lib = L.load()
@@ -705,21 +705,22 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
     Cout, Cin, R, S = w.shape
     T = R * S
     dev = w.device
-    wp = out_fwd if out_fwd is not None else (torch.empty(T, Cout, Cin, dtype=dtype, device=dev) if want_fwd else None)
-    wpt = out_dgrad if out_dgrad is not None else (torch.empty(T, Cin, Cout, dtype=dtype, device=dev) if want_dgrad else None)
-    bias = out_bias if out_bias is not None else torch.empty(Cout, dtype=torch.float32, device=dev)
+    CoutP, CinP = cout_pad or Cout, cin_pad or Cin       # channel-padded packings (zeros in the padding)
+    wp = out_fwd if out_fwd is not None else (torch.empty(T, CoutP, CinP, dtype=dtype, device=dev) if want_fwd else None)
+    wpt = out_dgrad if out_dgrad is not None else (torch.empty(T, CinP, CoutP, dtype=dtype, device=dev) if want_dgrad else None)
+    bias = out_bias if out_bias is not None else torch.empty(CoutP, dtype=torch.float32, device=dev)
     g = b = m = v = None
     if bn is not None:
         g, b, m, v = [t.contiguous() for t in bn]
     cb = conv_bias.contiguous() if conv_bias is not None else None
     L.check(lib.loft_fold_pack(L.ptr(w), L.ptr(cb), L.ptr(g), L.ptr(b), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin, T,
-                               L.ptr(wp), L.ptr(wpt), L.ptr(bias), int(dtype == torch.float32), L.stream()),
+                               L.ptr(wp), L.ptr(wpt), L.ptr(bias), int(dtype == torch.float32), CoutP, CinP, L.stream()),
             'loft_fold_pack')
     return wp, wpt, bias
 
 
 def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True):
-    """dwp fp32 [T,Cout,Cin], db fp32 [Cout] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None)."""
+    """dwp fp32 [T,CoutP,CinP], db fp32 [CoutP] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None)."""
     lib = L.load()
     w = w.contiguous()
     Cout, Cin, R, S = w.shape
@@ -731,5 +732,6 @@ def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True):
         dg = torch.empty(Cout, dtype=torch.float32, device=dev)
         dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
     L.check(lib.loft_fold_unpack_bwd(L.ptr(dwp), L.ptr(db), L.ptr(w), L.ptr(g), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin,
-                                     R * S, L.ptr(dw), L.ptr(dg), L.ptr(dbeta), L.stream()), 'loft_fold_unpack_bwd')
+                                     R * S, L.ptr(dw), L.ptr(dg), L.ptr(dbeta), dwp.shape[-2], dwp.shape[-1], L.stream()),
+            'loft_fold_unpack_bwd')
     return dw, dg, dbeta

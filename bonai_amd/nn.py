@@ -31,12 +31,15 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, meta, *tensors):
-        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu = meta
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu, cout_pad = meta
         ws = tensors[0:2 * G:2]
         bs = tensors[1:2 * G:2]
         gamma, beta = (tensors[2 * G], tensors[2 * G + 1]) if bn_stats is not None else (None, None)
         Cout, Cin, R, S = ws[0].shape
         T = R * S
+        if x.shape[1] != Cin or cout_pad:           # channel-padded activations: pad the packings with zeros to match
+            Cin = x.shape[1]
+            Cout = cout_pad or Cout
         dev = x.device
         pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
         key = None
@@ -55,7 +58,7 @@ class _ConvFn(torch.autograd.Function):
             eps = bn_stats[2] if bn_stats is not None else 1e-5
             for g in range(G):
                 K.fold_pack(ws[g], bs[g], bn, eps, out_fwd=wp[g], out_dgrad=None if wpt is None else wpt[g], out_bias=bias[g],
-                            want_dgrad=need_dgrad, dtype=pdt)
+                            want_dgrad=need_dgrad, dtype=pdt, cout_pad=Cout, cin_pad=Cin)
             if key is not None:
                 _PACK_CACHE[key] = (wp, wpt, bias)
         use_bias = has_b or bn_stats is not None
@@ -69,7 +72,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu = ctx.meta
+        stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu, cout_pad = ctx.meta
         x, y, wpt = ctx.saved_tensors[:3]
         if x.dtype != torch.bfloat16:
             raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
@@ -104,7 +107,7 @@ class _ConvFn(torch.autograd.Function):
                                                   bn_stats[2] if bn_stats is not None else 1e-5, need_dw=need_w)
                 ngrads[2 * i] = dw
                 if has_b and db is not None:
-                    ngrads[2 * i + 1] = db[i]
+                    ngrads[2 * i + 1] = db[i][:ws[i].shape[0]]
                 if bn is not None:
                     ngrads[2 * G], ngrads[2 * G + 1] = dg, dbeta
         gres = g if (ctx.has_res and ctx.needs_input_grad[1]) else None
@@ -118,9 +121,12 @@ def _cacheable(t):
     return isinstance(base, torch.nn.Parameter) and not base.requires_grad and not t.requires_grad
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None, input_relu=False):
+def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, out_f32=False, bn=None, input_relu=False,
+           cout_pad=None):
     """w: [Cout,Cin,R,S] parameter, or a list of `groups` such parameters (independent branches, one launch);
-    b likewise (or None); bn: a FrozenStatBN-like module folded into the conv (its shift becomes the bias)."""
+    b likewise (or None); bn: a FrozenStatBN-like module folded into the conv (its shift becomes the bias).
+    x may carry more channels than Cin and cout_pad may exceed Cout: the packed weights are zero-padded to match, so the
+    extra input channels are ignored and the extra output channels are exactly zero."""
     ws = list(w) if isinstance(w, (list, tuple)) else [w]
     bs = list(b) if isinstance(b, (list, tuple)) else [b] * len(ws)
     assert len(ws) == groups
@@ -135,7 +141,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
     # the fused SGD kernel updates trainable parameters through raw pointers without bumping tensor versions.
     # Temporaries (e.g. a permuted weight) are never cached: their storage address can be recycled.
     frozen = all(_cacheable(t) for t in tensors)
-    meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen, input_relu)
+    meta = (stride, pad, relu, groups, out_f32, b is not None, bn_stats, frozen, input_relu, cout_pad)
     return _ConvFn.apply(x, residual, meta, *tensors)
 
 

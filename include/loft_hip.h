@@ -105,7 +105,8 @@ int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, con
 /* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32
- * [taps][Cout][Cin] accumulated with atomics (caller zeroes).  Cin % 128 == 0, Cout % 128 == 0.
+ * [taps][Cout][Cin] accumulated with atomics (caller zeroes).  Cin % 8 == 0, Cout % 8 == 0 (multiples of 128 run the wide tiles;
+ * anything else the 64-channel narrow kernel, e.g. HRNet's 32/64-channel branches).
  * splits <= 0 lets the library choose the split-K factor.  db (may be NULL): fp32 [groups][Cout] bias
  * gradient sum_pixels G, accumulated in the same pass from tap db_tap (a tap whose X gather never
  * leaves the image, e.g. the centre tap; -2 = from every tap, for the transposed-conv case where the
@@ -231,13 +232,15 @@ int64_t loft_mdcn_bwd_workspace_bytes(int B, int C, int OH, int OW, int kh, int 
  * frozen-statistics BatchNorm that follows the conv (norm_eval=True, mmdet/models/backbones/resnet.py:640-649; formula of
  * tools/fuse_conv_bn.py:10-23) when gamma != NULL; conv_bias is used when there is no BN.  loft_fold_unpack_bwd is its
  * chain rule: dwp fp32 [R*S][Cout][Cin] (gradient of the folded weight), db fp32 [Cout] (gradient of the folded bias)
- * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL).  pack_f32 != 0 writes fp32 packings (parity mode). */
+ * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL).  pack_f32 != 0 writes fp32 packings (parity mode).
+ * CoutP >= Cout, CinP >= Cin: channel-padded packings [R*S][CoutP][CinP] / [R*S][CinP][CoutP] / bias [CoutP] with zeros in
+ * the padding (HRNet's 32-channel branch is carried in 64-channel tensors whose upper half stays zero). */
 int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad, float* bias_out,
-                   int pack_f32, void* stream);
+                   int pack_f32, int CoutP, int CinP, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
-                         void* stream);
+                         int CoutP, int CinP, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,3 +120,46 @@ def test_conv_tap_f32_parity_mode(cin, cout, k, s, p, hw):
                      out_dtype=torch.float32)
     assert y.dtype == torch.float32
     assert (y.cpu() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,xpad,opad', [(64, 64, 3, 1, None, None), (64, 192, 1, 1, None, None),
+                                                         (32, 32, 3, 1, 64, 64), (32, 64, 3, 2, 64, None),
+                                                         (64, 32, 1, 1, None, 64), (256, 64, 3, 1, None, None),
+                                                         (64, 256, 1, 1, None, None)])
+def test_narrow_channel_conv_fwd_bwd(cin, cout, k, stride, xpad, opad):
+    """HRNet-sized convs (channels not multiples of 128): the 64-channel wgrad kernel, and 32-channel tensors carried in
+    64-channel buffers through zero-padded weight packings (bonai_amd.nn.conv2d cout_pad / wider x)."""
+    import torch.nn.functional as F
+    from bonai_amd import nn as F2
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    B, H = 2, 20
+    pad = k // 2
+    x = torch.randn(B, cin, H, H, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(cout, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.relu(F.conv2d(xr, wr, br, stride, pad))
+    gout = torch.randn(ref.shape, generator=g).to(torch.bfloat16).float()
+    ref.backward(gout)
+    xin = x
+    if xpad:
+        xin = torch.zeros(B, xpad, H, H)
+        xin[:, :cin] = x
+    xg = xin.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = F2.conv2d(xg, wg, bg, stride=stride, pad=pad, relu=True, cout_pad=opad)
+    assert y.shape[1] == (opad or cout)
+    if opad:
+        assert y[:, cout:].abs().max().item() == 0
+    scale = ref.abs().max().item()
+    assert (y[:, :cout].float().cpu() - ref.detach()).abs().max().item() < 0.02 * scale
+    gfull = torch.zeros(y.shape)
+    gfull[:, :cout] = gout
+    if opad:
+        gfull[:, cout:] = 1.0       # gradient arriving on padded channels must not leak anywhere (y there is 0 -> relu masks it)
+    y.backward(gfull.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    for name, got, want in (('x', xg.grad.float().cpu()[:, :cin], xr.grad), ('w', wg.grad.cpu(), wr.grad), ('b', bg.grad.cpu(), br.grad)):
+        rel = (got - want).norm().item() / max(1e-6, want.norm().item())
+        assert rel < 0.02, (name, rel)
+    if xpad:
+        assert xg.grad[:, cin:].abs().max().item() == 0

@@ -656,6 +656,109 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
     return out
 
 
+# ------------------------------------------------------------------ HRNet / HRFPN resampling and fusion
+
+def fuse_sum_relu(terms, shifts, relu=True):
+    """out = relu(sum_j nearest_up(terms[j], 1 << shifts[j])); the shift-0 terms define the output shape."""
+    lib = L.load()
+    terms = [_nhwc(t) for t in terms]
+    L.dev_check(*terms)
+    ref = terms[list(shifts).index(0)]
+    B, C, H, W = ref.shape
+    for t, s in zip(terms, shifts):
+        if t.dtype != ref.dtype or tuple(t.shape) != (B, C, H >> s, W >> s):
+            raise L.LoftHipError(f'fuse term {tuple(t.shape)} does not match {tuple(ref.shape)} >> {s}')
+    out = empty_nhwc(B, C, H, W, ref.dtype, ref.device)
+    ptrs = (c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    L.check(lib.loft_fuse_sum_relu(ptrs, L.arr(c_int, list(shifts)), len(terms), L.ptr(out), L.dtype_code(ref), B, H, W, C,
+                                   int(relu), L.stream()), 'loft_fuse_sum_relu')
+    return out
+
+
+def blocksum_masked(g, y, shift):
+    """[B,C,H,W] -> [B,C,H>>shift,W>>shift]: sum of g * (y > 0) over each block (y None: no mask)."""
+    lib = L.load()
+    g = _nhwc(g)
+    y = _nhwc(y) if y is not None else None
+    L.dev_check(g, y)
+    B, C, H, W = g.shape
+    out = empty_nhwc(B, C, H >> shift, W >> shift, g.dtype, g.device)
+    L.check(lib.loft_blocksum_masked(L.ptr(g), L.ptr(y), L.ptr(out), L.dtype_code(g), B, H >> shift, W >> shift, C, shift,
+                                     L.stream()), 'loft_blocksum_masked')
+    return out
+
+
+def bilinear_up_slot_(src, dst, shift, coff):
+    """dst[:, coff:coff+C] = bilinear_up(src, 1 << shift) (align_corners=False); dst [B,Ctot,h<<shift,w<<shift]."""
+    lib = L.load()
+    src, dst = _nhwc(src), _nhwc(dst)
+    L.dev_check(src, dst)
+    B, C, h, w = src.shape
+    if dst.dtype != src.dtype or tuple(dst.shape[2:]) != (h << shift, w << shift):
+        raise L.LoftHipError('bilinear_up_slot_: destination does not match')
+    L.check(lib.loft_bilinear_up_slot(L.ptr(src), L.ptr(dst), L.dtype_code(src), B, h, w, C, shift, dst.shape[1], coff, 0,
+                                      L.stream()), 'loft_bilinear_up_slot')
+    return dst
+
+
+def bilinear_up_slot_bwd(gdst, C, shift, coff):
+    """gradient of the slotted tensor [B,Ctot,H,W] -> gradient of the small map [B,C,H>>shift,W>>shift]."""
+    lib = L.load()
+    gdst = _nhwc(gdst)
+    B, Ctot, H, W = gdst.shape
+    out = empty_nhwc(B, C, H >> shift, W >> shift, gdst.dtype, gdst.device)
+    L.check(lib.loft_bilinear_up_slot(L.ptr(gdst), L.ptr(out), L.dtype_code(gdst), B, H >> shift, W >> shift, C, shift, Ctot,
+                                      coff, 1, L.stream()), 'loft_bilinear_up_slot(bwd)')
+    return out
+
+
+def avgpool(x, shift):
+    lib = L.load()
+    x = _nhwc(x)
+    L.dev_check(x)
+    B, C, H, W = x.shape
+    out = empty_nhwc(B, C, H >> shift, W >> shift, x.dtype, x.device)
+    L.check(lib.loft_avgpool(L.ptr(x), L.ptr(out), L.dtype_code(x), B, H >> shift, W >> shift, C, shift, 0, 0, L.stream()),
+            'loft_avgpool')
+    return out
+
+
+def avgpool_bwd(g, shift):
+    lib = L.load()
+    g = _nhwc(g)
+    B, C, Ho, Wo = g.shape
+    out = empty_nhwc(B, C, Ho << shift, Wo << shift, g.dtype, g.device)
+    L.check(lib.loft_avgpool(L.ptr(g), L.ptr(out), L.dtype_code(g), B, Ho, Wo, C, shift, 1, 0, L.stream()), 'loft_avgpool(bwd)')
+    return out
+
+
+def stem3x3s2_bn_relu(img, w, scale, shift, out_dtype=torch.bfloat16):
+    """img fp32 NCHW [B,3,H,W], w fp32 [64,3,3,3] -> channels_last [B,64,H/2,W/2] = relu(conv * scale + shift)."""
+    lib = L.load()
+    L.dev_check(img, w, scale, shift)
+    img = img.float().contiguous()
+    w, scale, shift = w.float().contiguous(), scale.float().contiguous(), shift.float().contiguous()
+    B, _, H, W = img.shape
+    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, out_dtype, img.device)
+    L.check(lib.loft_stem3x3s2_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale), L.ptr(shift), L.ptr(out), L.dtype_code(out), B, H, W,
+                                       L.stream()), 'loft_stem3x3s2_bn_relu')
+    return out
+
+
+def stem3x3s2_wgrad(img, g, y):
+    """-> (dwp fp32 [9,64,3] gradient of the BN-folded weight in the tap packing, db fp32 [64])."""
+    lib = L.load()
+    img = img.float().contiguous()
+    g, y = _nhwc(g), _nhwc(y)
+    L.dev_check(img, g, y)
+    B, _, H, W = img.shape
+    dwp = torch.zeros(9, 64, 3, dtype=torch.float32, device=img.device)
+    db = torch.zeros(64, dtype=torch.float32, device=img.device)
+    L.check(lib.loft_stem3x3s2_wgrad(L.ptr(img), L.ptr(g), L.ptr(y), L.ptr(dwp), L.ptr(db), L.dtype_code(g), B, H, W, L.stream()),
+            'loft_stem3x3s2_wgrad')
+    return dwp, db
+
+
 # ------------------------------------------------------------------ DCNv2 sampling
 
 def mdcn_sample_fwd(x, om, kh, kw, stride=1, pad=0, dil=1, deform_groups=1):

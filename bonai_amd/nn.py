@@ -358,3 +358,108 @@ class _Subsample2Fn(torch.autograd.Function):
 
 def subsample2(x):
     return _Subsample2Fn.apply(x)
+
+
+# ------------------------------------------------------------------ HRNet / HRFPN pieces (BASELINE config 5)
+
+class _FuseSumReluFn(torch.autograd.Function):
+    """y = relu(sum_j nearest_up(term_j, 2^shift_j)) -- HRModule fuse (mmdet/models/backbones/hrnet.py:177-195)."""
+
+    @staticmethod
+    def forward(ctx, shifts, *terms):
+        y = K.fuse_sum_relu(list(terms), shifts, relu=True)
+        ctx.shifts = shifts
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = to_nhwc(g)
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        cache = {}
+        grads = []
+        for j, s in enumerate(ctx.shifts):
+            if not ctx.needs_input_grad[1 + j]:
+                grads.append(None)
+                continue
+            if s not in cache:
+                cache[s] = K.blocksum_masked(g, y, s)
+            grads.append(cache[s])
+        return (None,) + tuple(grads)
+
+
+def fuse_sum_relu(terms, shifts):
+    return _FuseSumReluFn.apply(tuple(shifts), *terms)
+
+
+class _HRFPNConcatFn(torch.autograd.Function):
+    """torch.cat([x0] + [F.interpolate(x_i, scale_factor=2^i, mode='bilinear')], 1) (mmdet/models/necks/hrfpn.py:79-85),
+    each term written straight into its channel slot."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H, W = xs[0].shape
+        ctot = sum(x.shape[1] for x in xs)
+        out = K.empty_nhwc(B, ctot, H, W, xs[0].dtype, xs[0].device)
+        off = 0
+        for i, x in enumerate(xs):
+            K.bilinear_up_slot_(x, out, i, off)
+            off += x.shape[1]
+        ctx.chans = [x.shape[1] for x in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = to_nhwc(g)
+        grads, off = [], 0
+        for i, c in enumerate(ctx.chans):
+            grads.append(K.bilinear_up_slot_bwd(g, c, i, off) if ctx.needs_input_grad[i] else None)
+            off += c
+        return tuple(grads)
+
+
+def hrfpn_concat(xs):
+    return _HRFPNConcatFn.apply(*xs)
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shift):
+        ctx.shift = shift
+        return K.avgpool(x, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.avgpool_bwd(to_nhwc(g), ctx.shift), None
+
+
+def avgpool(x, shift):
+    return _AvgPoolFn.apply(x, shift)
+
+
+class _Stem3x3Fn(torch.autograd.Function):
+    """relu(bn(conv3x3/2(img))) for the 3-channel image (HRNet conv1/norm1, hrnet.py:273-281,481-483)."""
+
+    @staticmethod
+    def forward(ctx, img, w, gamma, beta, mean, var, eps, out_dtype):
+        scale = gamma * torch.rsqrt(var + eps)
+        y = K.stem3x3s2_bn_relu(img, w, scale, beta - mean * scale, out_dtype)
+        ctx.save_for_backward(img, w, gamma, beta, mean, var, y)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        img, w, gamma, beta, mean, var, y = ctx.saved_tensors
+        g = to_nhwc(g)
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        dwp, db = K.stem3x3s2_wgrad(img, g, y)
+        dw, dg, dbeta = K.fold_unpack_bwd(dwp, db, w, (gamma, beta, mean, var), ctx.eps)
+        return None, dw, dg, dbeta, None, None, None, None
+
+
+def stem3x3s2(img, w, bn, out_dtype=torch.bfloat16):
+    return _Stem3x3Fn.apply(img, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, out_dtype)

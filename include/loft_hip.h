@@ -204,6 +204,34 @@ int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_
 int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
                     void* stream);
 
+/* ---- HRNet-W32 / HRFPN resampling and fusion (BASELINE config 5) ----------------------------------
+ * All tensors NHWC, dtype LOFT_F32 | LOFT_BF16, C % 8 == 0, scale factors are 1 << shift.
+ * loft_fuse_sum_relu: out = relu?(sum_j nearest_up(terms[j], 1 << shifts[j])) -- the fuse step of HRModule.forward
+ *   (mmdet/models/backbones/hrnet.py:177-195; nn.Upsample(mode='nearest') of :141-143); terms[j] is [B, H>>s_j, W>>s_j, C];
+ *   terms / shifts are HOST arrays, n_terms <= 4.
+ * loft_blocksum_masked: out[B,Hc,Wc,C] = sum over each (1<<shift)^2 block of g * (y > 0) (y may be NULL): its backward.
+ * loft_bilinear_up_slot: F.interpolate(x, scale_factor=1<<shift, mode='bilinear') (align_corners=False) written into
+ *   channels [coff, coff+C) of a [B, h<<shift, w<<shift, Ctot] tensor -- HRFPN.forward's upsample + torch.cat
+ *   (mmdet/models/necks/hrfpn.py:79-85); backward != 0: src is the gradient of the slotted tensor, dst the gradient of x.
+ * loft_avgpool: F.avg_pool2d(x, 1<<shift, 1<<shift) (hrfpn.py:90-92); backward != 0: src = gradient of the pooled map,
+ *   dst = gradient of x (accumulate != 0 adds to dst).
+ * loft_stem3x3s2_bn_relu: HRNet stem conv1 3x3/2 (3 -> 64) + frozen-stat BN (scale/shift) + ReLU from the fp32 NCHW image
+ *   (hrnet.py:273-281, 481-483).  loft_stem3x3s2_wgrad: dwp fp32 [9][64][3] += gradient of the BN-folded weight, db fp32
+ *   [64] += gradient of the folded bias, from g and the saved output y (ReLU mask applied here); caller zeroes both and
+ *   feeds them to loft_fold_unpack_bwd. */
+int loft_fuse_sum_relu(const void* const* terms, const int* shifts, int n_terms, void* out, int dtype, int B, int H, int W,
+                       int C, int relu, void* stream);
+int loft_blocksum_masked(const void* g, const void* y, void* out, int dtype, int B, int Hc, int Wc, int C, int shift,
+                         void* stream);
+int loft_bilinear_up_slot(const void* src, void* dst, int dtype, int B, int h, int w, int C, int shift, int Ctot, int coff,
+                          int backward, void* stream);
+int loft_avgpool(const void* src, void* dst, int dtype, int B, int Ho, int Wo, int C, int shift, int backward, int accumulate,
+                 void* stream);
+int loft_stem3x3s2_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out, int dtype,
+                           int B, int H, int W, void* stream);
+int loft_stem3x3s2_wgrad(const float* img, const void* g, const void* y, float* dwp, float* db, int dtype, int B, int H, int W,
+                         void* stream);
+
 /* ---- modulated deformable convolution (DCNv2) sampling ------------------------------------------
  * Replaces mmcv.ops.ModulatedDeformConv2dPack / modulated_deform_conv2d [mmcv==1.0.5, not in tree] at the call sites
  * mmdet/models/backbones/resnet.py:171-194 (Bottleneck.conv2 when dcn=dict(type='DCNv2')) and

@@ -53,6 +53,107 @@ def backbone(sd, img, prefix='backbone.'):
     return outs
 
 
+# ---- HRNet-W32 + HRFPN (BASELINE config 5): mmdet/models/backbones/hrnet.py:12-537, mmdet/models/necks/hrfpn.py:11-102
+HRNET_W32 = dict(stage1=dict(num_modules=1, num_branches=1, block='BOTTLENECK', num_blocks=(4,), num_channels=(64,)),
+                 stage2=dict(num_modules=1, num_branches=2, block='BASIC', num_blocks=(4, 4), num_channels=(32, 64)),
+                 stage3=dict(num_modules=4, num_branches=3, block='BASIC', num_blocks=(4, 4, 4), num_channels=(32, 64, 128)),
+                 stage4=dict(num_modules=3, num_branches=4, block='BASIC', num_blocks=(4, 4, 4, 4),
+                             num_channels=(32, 64, 128, 256)))
+
+
+def _cb(sd, p, x, stride=1, pad=0, relu=False):
+    """Sequential(conv '0', bn '1'[, relu]) (hrnet.py:130-172, 345-391)."""
+    y = _bn(F.conv2d(x, sd[p + '0.weight'], None, stride, pad), sd, p + '1')
+    return F.relu(y) if relu else y
+
+
+def _basic_block(sd, p, x):
+    """resnet.py:65-92 (BasicBlock.forward), stride 1."""
+    out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight'], None, 1, 1), sd, p + 'bn1'))
+    out = _bn(F.conv2d(out, sd[p + 'conv2.weight'], None, 1, 1), sd, p + 'bn2')
+    idt = _cb(sd, p + 'downsample.', x) if (p + 'downsample.0.weight') in sd else x
+    return F.relu(out + idt)
+
+
+def _bottleneck(sd, p, x):
+    out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
+    out = F.relu(_bn(F.conv2d(out, sd[p + 'conv2.weight'], None, 1, 1), sd, p + 'bn2'))
+    out = _bn(F.conv2d(out, sd[p + 'conv3.weight']), sd, p + 'bn3')
+    idt = _cb(sd, p + 'downsample.', x) if (p + 'downsample.0.weight') in sd else x
+    return F.relu(out + idt)
+
+
+def _hr_module(sd, p, xs, num_blocks):
+    """HRModule.forward (hrnet.py:177-195)."""
+    nb = len(xs)
+    xs = list(xs)
+    for i in range(nb):
+        for k in range(num_blocks[i]):
+            xs[i] = _basic_block(sd, f'{p}branches.{i}.{k}.', xs[i])
+    if nb == 1:
+        return xs
+    outs = []
+    for i in range(nb):
+        y = 0
+        for j in range(nb):
+            if i == j:
+                y = y + xs[j]
+            elif j > i:
+                t = _cb(sd, f'{p}fuse_layers.{i}.{j}.', xs[j])
+                y = y + F.interpolate(t, scale_factor=2 ** (j - i), mode='nearest')
+            else:
+                t = xs[j]
+                for k in range(i - j):
+                    t = _cb(sd, f'{p}fuse_layers.{i}.{j}.{k}.', t, 2, 1, relu=(k != i - j - 1))
+                y = y + t
+        outs.append(F.relu(y))
+    return outs
+
+
+def hrnet_backbone(sd, img, extra=HRNET_W32, prefix='backbone.'):
+    """HRNet.forward (hrnet.py:480-515)."""
+    x = F.relu(_bn(F.conv2d(img, sd[prefix + 'conv1.weight'], None, 2, 1), sd, prefix + 'bn1'))
+    x = F.relu(_bn(F.conv2d(x, sd[prefix + 'conv2.weight'], None, 2, 1), sd, prefix + 'bn2'))
+    for k in range(extra['stage1']['num_blocks'][0]):
+        x = _bottleneck(sd, f'{prefix}layer1.{k}.', x)
+    y = [x]
+    for si in (2, 3, 4):
+        cfg = extra[f'stage{si}']
+        xs = []
+        for i in range(cfg['num_branches']):
+            tp = f'{prefix}transition{si - 1}.{i}.'
+            if (tp + '0.weight') in sd:                    # existing branch, channel change: Sequential(conv, bn, relu)
+                xs.append(_cb(sd, tp, y[-1], 1, 1, relu=True))
+            elif (tp + '0.0.weight') in sd:                # new branch: chain of stride-2 conv-bn-relu
+                t, j = y[-1], 0
+                while (f'{tp}{j}.0.weight') in sd:
+                    t = _cb(sd, f'{tp}{j}.', t, 2, 1, relu=True)
+                    j += 1
+                xs.append(t)
+            else:
+                xs.append(y[i])
+        for m in range(cfg['num_modules']):
+            xs = _hr_module(sd, f'{prefix}stage{si}.{m}.', xs, cfg['num_blocks'])
+        y = xs
+    return y
+
+
+def hrfpn(sd, feats, num_outs=5, prefix='neck.'):
+    """HRFPN.forward (hrfpn.py:78-102)."""
+    outs = [feats[0]] + [F.interpolate(f, scale_factor=2 ** i, mode='bilinear') for i, f in enumerate(feats) if i > 0]
+    out = F.conv2d(torch.cat(outs, 1), sd[prefix + 'reduction_conv.conv.weight'], sd[prefix + 'reduction_conv.conv.bias'])
+    pyr = [out] + [F.avg_pool2d(out, 2 ** i, 2 ** i) for i in range(1, num_outs)]
+    return [F.conv2d(o, sd[f'{prefix}fpn_convs.{i}.conv.weight'], sd[f'{prefix}fpn_convs.{i}.conv.bias'], padding=1)
+            for i, o in enumerate(pyr)]
+
+
+def extract_feat(sd, img):
+    """backbone + neck by the checkpoint's key set (ResNet-50 + FPN, or HRNet + HRFPN)."""
+    if 'backbone.stage2.0.branches.0.0.conv1.weight' in sd:
+        return hrfpn(sd, hrnet_backbone(sd, img))
+    return fpn(sd, backbone(sd, img))
+
+
 def _fpn_conv(sd, p, x, pad):
     """ConvModule of the neck: plain conv, or DCNv2 when conv_cfg=dict(type='DCNv2') (fpn.py:116-132)."""
     if (p + 'conv_offset.weight') in sd:
@@ -223,7 +324,7 @@ def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_o
 def forward_train(sd, img, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.choose_first, return_extras=False):
     """-> OrderedDict of the 7 losses + acc (+ 'loss'), keys as base.py:_parse_losses logs them."""
     H, W = img.shape[2:]
-    feats = fpn(sd, backbone(sd, img))
+    feats = extract_feat(sd, img)
     cls, reg = rpn_forward(sd, feats)
     l_cls, l_box = rpn_loss(cls, reg, gt_bboxes, choose)
     props = rpn_proposals(cls, reg, (H, W, 3))
@@ -241,7 +342,7 @@ def simple_test(sd, img, rescale=False, scale_factor=(1., 1., 1., 1.), score_thr
     """two_stage.py:187-199 -> loft_roi_head.py:196-227 for ONE image (test_cfg of bonai_loft_foa_r50_fpn_basic.py:127-140).
     -> (det_bboxes [n,5], det_labels [n], masks bool [n,H,W], offsets [n,2])."""
     H, W = img.shape[2:]
-    feats = fpn(sd, backbone(sd, img))
+    feats = extract_feat(sd, img)
     cls, reg = rpn_forward(sd, feats)
     props = rpn_proposals(cls, reg, (H, W, 3))[0]
     rois = R.bbox2roi([props])

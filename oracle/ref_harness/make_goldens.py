@@ -197,8 +197,56 @@ def e2e_test(size=256):
     print(f'e2e_test_{size}.npz dets', det.shape, 'top', det[:2], 'offsets', out['offsets'][:2], 'areas', out['mask_area'][:5])
 
 
+def hrnet(size=128):
+    """Reference HRNetV2p-W32 backbone + HRFPN neck (mmdet/models/backbones/hrnet.py, necks/hrfpn.py) on a seeded tile with
+    name-keyed synthetic weights: outputs (crops + sums) and a few parameter gradients of sum(neck outputs * ramp)."""
+    from mmdet.models.backbones.hrnet import HRNet
+    from mmdet.models.necks.hrfpn import HRFPN
+    from bonai_amd.synth import make_batch
+    from oracle.loft_model_ref import HRNET_W32
+    from oracle.synth_weights import synth_tensor
+    bb = HRNet(extra={k: dict(v) for k, v in HRNET_W32.items()})
+    neck = HRFPN(in_channels=[32, 64, 128, 256], out_channels=256)
+    bb.load_state_dict({k: synth_tensor('backbone.' + k, v.shape) for k, v in bb.state_dict().items()})
+    neck.load_state_dict({k: synth_tensor('neck.' + k, v.shape) for k, v in neck.state_dict().items()})
+    bb.train(); neck.train()                  # norm_eval=True keeps the BN statistics frozen (hrnet.py:527-537)
+    img = make_batch(1, size, 4)['img']
+    ys = bb(img)
+    outs = neck(ys)
+    out = dict(meta=np.array([size]), n_backbone_keys=np.array([len(bb.state_dict())]), n_neck_keys=np.array([len(neck.state_dict())]))
+    for i, y in enumerate(ys):
+        out[f'bb_{i}_shape'] = np.array(y.shape)
+        out[f'bb_{i}_crop'] = T(y[:, :8, :6, :6])
+        out[f'bb_{i}_absmean'] = T(y.abs().mean())
+        out[f'bb_{i}_sum'] = T(y.double().sum())
+    for i, o in enumerate(outs):
+        out[f'neck_{i}_shape'] = np.array(o.shape)
+        out[f'neck_{i}_crop'] = T(o[:, :8, :6, :6])
+        out[f'neck_{i}_absmean'] = T(o.abs().mean())
+        out[f'neck_{i}_sum'] = T(o.double().sum())
+    loss = sum((o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for o in outs) / 1000.0
+    loss.backward()
+    out['loss'] = T(loss)
+    names = ['backbone.conv1.weight', 'backbone.bn1.weight', 'backbone.conv2.weight', 'backbone.layer1.0.conv1.weight',
+             'backbone.transition1.0.0.weight', 'backbone.stage2.0.branches.0.0.conv1.weight',
+             'backbone.stage2.0.fuse_layers.0.1.0.weight', 'backbone.stage3.1.fuse_layers.2.0.1.0.weight',
+             'backbone.stage3.0.branches.2.3.bn2.bias', 'backbone.stage4.2.branches.3.3.conv2.weight',
+             'backbone.stage4.0.fuse_layers.0.3.1.weight', 'neck.reduction_conv.conv.weight', 'neck.fpn_convs.4.conv.bias']
+    params = {('backbone.' + k): v for k, v in bb.named_parameters()}
+    params.update({('neck.' + k): v for k, v in neck.named_parameters()})
+    for n in names:
+        out['gradnorm_' + n] = T(params[n].grad.norm())
+        out['gradhead_' + n] = T(params[n].grad.reshape(-1)[:16])
+    np.savez_compressed(os.path.join(GOLD, f'hrnet_{size}.npz'), **out)
+    print(f'hrnet_{size}.npz', [tuple(y.shape) for y in ys], [float(out[f'neck_{i}_absmean']) for i in range(5)], float(loss))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'hrnet':
+        hrnet()
+        sys.exit(0)
     core_ops()
     e2e()
     e2e_test()
+    hrnet()

@@ -24,8 +24,11 @@ def synth_tensor(name, shape, dtype=torch.float32):
         return torch.randn(shape, generator=g) * 0.1
     leaf = name.rsplit('.', 2)
     is_bn = len(leaf) >= 2 and (leaf[-2].startswith('bn') or (leaf[-2] == '1' and 'downsample' in name))
+    hr_seq_bn = len(shape) == 1 and ('fuse_layers' in name or 'transition' in name) and leaf[-2] == '1'   # HRNet Sequential(conv, bn)
+    if hr_seq_bn and name.endswith('weight'):
+        return torch.rand(shape, generator=g) * 0.3 + 0.3
     if is_bn and name.endswith('weight'):
-        if leaf[-2] == 'bn3':   # residual branch: keep the 16-block sum well conditioned
+        if leaf[-2] == 'bn3' or (leaf[-2] == 'bn2' and 'branches' in name):   # residual branch: keep the stacked sums well conditioned
             return torch.rand(shape, generator=g) * 0.2 + 0.2
         return torch.rand(shape, generator=g) * 0.4 + 0.8
     if name.endswith('bias'):

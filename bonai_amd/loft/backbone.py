@@ -164,9 +164,8 @@ class ResNet(nn.Module):
     def init_weights(self, pretrained=None):
         """resnet.py:591-621 (pretrained checkpoints load through load_state_dict by key)."""
         if isinstance(pretrained, str):
-            sd = torch.load(pretrained, map_location='cpu')
-            sd = sd.get('state_dict', sd)
-            self.load_state_dict({k.replace('backbone.', '', 1): v for k, v in sd.items()}, strict=False)
+            from ..checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
             return
         for m in self.modules():
             if isinstance(m, ConvW):

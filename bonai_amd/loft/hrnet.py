@@ -192,9 +192,8 @@ class HRNet(nn.Module):
     def init_weights(self, pretrained=None):
         """hrnet.py:461-484."""
         if isinstance(pretrained, str):
-            sd = torch.load(pretrained, map_location='cpu')
-            sd = sd.get('state_dict', sd)
-            self.load_state_dict({k.replace('backbone.', '', 1): v for k, v in sd.items()}, strict=False)
+            from ..checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
             return
         for m in self.modules():
             if isinstance(m, ConvW):

@@ -32,9 +32,8 @@ def main():
     torch.manual_seed(0)
     model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     if args.checkpoint:
-        sd = torch.load(args.checkpoint, map_location='cpu')
-        sd = sd.get('state_dict', sd)
-        model.load_state_dict({k[7:] if k.startswith('module.') else k: v for k, v in sd.items()})
+        from bonai_amd.checkpoint import load_checkpoint
+        load_checkpoint(model, args.checkpoint, strict=True)
     model = model.cuda().eval()
     results = []
     t0 = time.time()

@@ -46,7 +46,8 @@ def main():
     torch.manual_seed(args.seed)
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
     if args.resume_from:
-        model.load_state_dict(torch.load(args.resume_from, map_location='cpu')['state_dict'])
+        from bonai_amd.checkpoint import load_checkpoint
+        load_checkpoint(model, args.resume_from, strict=True)
     tr = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
                  max_norm=cfg.optimizer_config.grad_clip.max_norm)
     bs = cfg.data.get('samples_per_gpu', 8)
@@ -61,7 +62,8 @@ def main():
             print(f'Iter [{it + 1}/{args.iters}] time: {(time.time() - t0) / (it + 1):.3f}, {lv}', flush=True)
     if args.work_dir and rank == 0:
         os.makedirs(args.work_dir, exist_ok=True)
-        torch.save(dict(meta=dict(config=cfg.filename), state_dict=model.state_dict()), os.path.join(args.work_dir, 'latest.pth'))
+        from bonai_amd.checkpoint import save_checkpoint
+        save_checkpoint(model, os.path.join(args.work_dir, 'latest.pth'), meta=dict(config=cfg.filename, iter=args.iters))
     if world > 1:
         dist.destroy_process_group()
 

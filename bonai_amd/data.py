@@ -1,0 +1,154 @@
+"""BONAI sample contract on the host side of the path: annotation schema -> training sample -> device batch.
+
+What the hot path consumes is the batch dict ``img, img_metas, gt_bboxes, gt_labels, gt_masks, gt_offsets``
+(mmdet/models/detectors/two_stage.py:105-167).  This module mirrors the pieces of the reference's data pipeline that
+define the *values* in that dict -- the BONAI annotation parser (mmdet/datasets/bonai.py:105-256), the flip rules for
+boxes and offsets (mmdet/datasets/pipelines/transforms.py:379-404, 458-466), Normalize and DefaultFormatBundle / Collect
+(pipelines/formating.py) -- and ends in ``to_device_batch``, which uploads once: images normalised on the GPU, instance
+masks as uint8 device tensors (the device-side mask_target kernel crops them; no per-step CPU round trip as in
+mmdet/core/mask/structures.py:261-291).  Image decoding / polygon rasterisation (cv2, pycocotools) stay outside: they are
+not in this image and not on the path.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def parse_bonai_annotations(img_info, ann_info, cat_ids=(1,), cat2label=None, bbox_type='roof', mask_type='roof',
+                            offset_coordinate='rectangle', resolution=0.6, ignore_buildings=True):
+    """BONAI._parse_ann_info (bonai.py:105-256): list of COCO-style BONAI annotation dicts -> ann dict of arrays.
+    Keys and dtypes follow the reference, including its empty-image conventions (angle 0.0001, heights (0, 2))."""
+    cat2label = cat2label or {c: i for i, c in enumerate(cat_ids)}
+    key = {'roof': 'bbox', 'building': 'building_bbox', 'footprint': 'footprint_bbox'}
+    if bbox_type not in key:
+        raise TypeError(f"don't support bbox_type={bbox_type}")
+    if mask_type not in ('roof', 'footprint'):
+        raise TypeError(f"don't support mask_type={mask_type}")
+    if offset_coordinate not in ('rectangle', 'polar'):
+        raise RuntimeError(f'do not support this coordinate: {offset_coordinate}')
+    bboxes, labels, ignore, masks, roof_masks, fp_masks = [], [], [], [], [], []
+    offsets, heights, angles, roof_bboxes, fp_bboxes = [], [], [], [], []
+    only_fp = 0
+    for ann in ann_info:
+        if ann.get('ignore', False):
+            continue
+        x1, y1, w, h = ann[key[bbox_type]]
+        inter_w = max(0, min(x1 + w, img_info['width']) - max(x1, 0))
+        inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
+        if inter_w * inter_h == 0 or ann['area'] <= 0 or w < 1 or h < 1 or ann['category_id'] not in cat_ids:
+            continue
+        bbox = [x1, y1, x1 + w, y1 + h]
+        if ann.get('iscrowd', False) and ignore_buildings:
+            ignore.append(bbox)
+            continue
+        if 'roof_bbox' in ann:
+            rx, ry, rw, rh = ann['roof_bbox']
+            roof_bboxes.append([rx, ry, rx + rw, ry + rh])
+        if 'footprint_bbox' in ann:
+            fx, fy, fw, fh = ann['footprint_bbox']
+            fp_bboxes.append([fx, fy, fx + fw, fy + fh])
+        if 'only_footprint' in ann:
+            only_fp = 1 if ann['only_footprint'] == 1 else 0
+        bboxes.append(bbox)
+        labels.append(cat2label[ann['category_id']])
+        if only_fp == 0 and mask_type == 'roof':
+            masks.append(ann['segmentation'])
+        else:
+            masks.append([ann['footprint_mask']])
+        roof_masks.append(ann['segmentation'])
+        fp_masks.append([ann['footprint_mask']])
+        if 'offset' in ann:
+            if offset_coordinate == 'rectangle':
+                offsets.append(ann['offset'])
+            else:
+                ox, oy = ann['offset']
+                offsets.append([math.sqrt(ox ** 2 + oy ** 2), math.atan2(oy, ox)])
+        else:
+            offsets.append([0, 0])
+        heights.append(ann.get('building_height', 0.0))
+        if 'offset' in ann and 'building_height' in ann:
+            ox, oy = ann['offset']
+            angles.append(math.atan2(math.sqrt(ox ** 2 + oy ** 2) * resolution, ann['building_height']))
+    if bboxes:
+        out = dict(bboxes=np.array(bboxes, dtype=np.float32), labels=np.array(labels, dtype=np.int64),
+                   offsets=np.array(offsets, dtype=np.float32), building_heights=np.array(heights, dtype=np.float32),
+                   angle=float(np.array(angles, dtype=np.float32).mean()) if angles else float('nan'),
+                   roof_bboxes=np.array(roof_bboxes, dtype=np.float32), footprint_bboxes=np.array(fp_bboxes, dtype=np.float32),
+                   only_footprint_flag=float(only_fp))
+    else:
+        out = dict(bboxes=np.zeros((0, 4), np.float32), labels=np.array([], dtype=np.int64), offsets=np.zeros((0, 2), np.float32),
+                   building_heights=np.zeros((0, 2), np.float32), angle=0.0001, roof_bboxes=np.zeros((0, 4), np.float32),
+                   footprint_bboxes=np.zeros((0, 4), np.float32), only_footprint_flag=0)
+    out['bboxes_ignore'] = np.array(ignore, dtype=np.float32) if ignore else np.zeros((0, 4), np.float32)
+    out.update(masks=masks, roof_masks=roof_masks, footprint_masks=fp_masks)
+    fn = img_info['filename']
+    out.update(seg_map=fn.replace('jpg', 'png'), edge_map=fn.replace('jpg', 'png'), side_face_map=fn.replace('jpg', 'png'),
+               offset_field=fn.replace('png', 'npy'))
+    return out
+
+
+def flip_bboxes(bboxes, img_shape, direction):
+    """RandomFlip.bbox_flip (transforms.py:379-404)."""
+    out = bboxes.copy()
+    if direction == 'horizontal':
+        w = img_shape[1]
+        out[..., 0::4] = w - bboxes[..., 2::4]
+        out[..., 2::4] = w - bboxes[..., 0::4]
+    elif direction == 'vertical':
+        h = img_shape[0]
+        out[..., 1::4] = h - bboxes[..., 3::4]
+        out[..., 3::4] = h - bboxes[..., 1::4]
+    else:
+        raise ValueError(f"Invalid flipping direction '{direction}'")
+    return out
+
+
+def flip_offsets(offsets, direction):
+    """RandomFlip.offset_flip (transforms.py:458-466): horizontal negates x, vertical negates y."""
+    off = np.asarray(offsets, dtype=np.float32).reshape(-1, 2).copy()
+    if direction == 'horizontal':
+        off[:, 0] = -off[:, 0]
+    elif direction == 'vertical':
+        off[:, 1] = -off[:, 1]
+    else:
+        raise ValueError(f"Invalid flipping direction '{direction}'")
+    return off
+
+
+def flip_sample(sample, direction='horizontal'):
+    """One training sample (img HxWx3, gt_bboxes, gt_masks [K,H,W] u8, gt_offsets) flipped as RandomFlip.__call__ does."""
+    h, w = sample['img'].shape[:2]
+    ax = 1 if direction == 'horizontal' else 0
+    out = dict(sample)
+    out['img'] = np.flip(sample['img'], axis=ax).copy()
+    out['gt_bboxes'] = flip_bboxes(sample['gt_bboxes'], (h, w), direction)
+    out['gt_masks'] = np.flip(sample['gt_masks'], axis=ax + 1).copy()
+    out['gt_offsets'] = flip_offsets(sample['gt_offsets'], direction)
+    out['flip'], out['flip_direction'] = True, direction
+    return out
+
+
+def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True):
+    """Collate + DefaultFormatBundle + Normalize, on the device: list of samples (img uint8/float HxWx3 BGR, gt_* numpy) ->
+    the batch dict of forward_train.  Images are stacked (same size: BONAI tiles are 1024x1024), normalised on the GPU;
+    masks go up once as uint8 [K,H,W] tensors."""
+    dev = torch.device(device)
+    imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(s['img'])) for s in samples]).to(dev)
+    x = imgs.float()
+    if to_rgb:
+        x = x.flip(-1)
+    x = (x - torch.tensor(mean, device=dev)) / torch.tensor(std, device=dev)
+    img = x.permute(0, 3, 1, 2).contiguous()
+    metas = []
+    for s in samples:
+        h, w = s['img'].shape[:2]
+        metas.append(dict(filename=s.get('filename'), ori_shape=(h, w, 3), img_shape=(h, w, 3), pad_shape=(h, w, 3),
+                          scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), flip=bool(s.get('flip', False)),
+                          flip_direction=s.get('flip_direction'),
+                          img_norm_cfg=dict(mean=np.array(mean, np.float32), std=np.array(std, np.float32), to_rgb=to_rgb)))
+    return dict(img=img, img_metas=metas,
+                gt_bboxes=[torch.from_numpy(np.asarray(s['gt_bboxes'], np.float32)).to(dev) for s in samples],
+                gt_labels=[torch.from_numpy(np.asarray(s['gt_labels'], np.int64)).to(dev) for s in samples],
+                gt_masks=[torch.from_numpy(np.ascontiguousarray(s['gt_masks'], dtype=np.uint8)).to(dev) for s in samples],
+                gt_offsets=[torch.from_numpy(np.asarray(s['gt_offsets'], np.float32).reshape(-1, 2)).to(dev) for s in samples])

@@ -40,3 +40,36 @@ def make_batch(batch_size, size=1024, num_gt=80, rank=0, step=0, device='cpu'):
                   scale_factor=np.ones(4, np.float32), flip=False) for _ in range(batch_size)]
     return dict(img=img.to(device), img_metas=metas, gt_bboxes=gt_bboxes, gt_labels=gt_labels, gt_masks=gt_masks,
                 gt_offsets=gt_offsets)
+
+
+def synth_bonai_anns(seed=0, n=12, size=1024):
+    """Synthetic BONAI annotation dicts exercising every branch of the parser (ignore, crowd, zero-area, outside, missing
+    optional keys, only_footprint)."""
+    rng = np.random.RandomState(seed)
+    anns = []
+    for i in range(n):
+        w, h = rng.uniform(8, 200, 2)
+        x, y = rng.uniform(-20, size - 30, 2)
+        ox, oy = rng.uniform(-40, 40, 2)
+        a = dict(bbox=[float(x), float(y), float(w), float(h)],
+                 building_bbox=[float(x - 5), float(y - 5), float(w + 10 + abs(ox)), float(h + 10 + abs(oy))],
+                 footprint_bbox=[float(x + ox), float(y + oy), float(w), float(h)],
+                 roof_bbox=[float(x), float(y), float(w), float(h)],
+                 segmentation=[[float(x), float(y), float(x + w), float(y), float(x + w), float(y + h), float(x), float(y + h)]],
+                 footprint_mask=[float(x + ox), float(y + oy), float(x + ox + w), float(y + oy), float(x + ox + w), float(y + oy + h),
+                                 float(x + ox), float(y + oy + h)],
+                 area=float(w * h), category_id=1, iscrowd=0, offset=[float(ox), float(oy)], building_height=float(rng.uniform(3, 90)))
+        anns.append(a)
+    anns[1]['ignore'] = True
+    anns[2]['iscrowd'] = 1
+    anns[3]['area'] = 0.0
+    anns[4]['bbox'] = [2000.0, 2000.0, 50.0, 50.0]
+    anns[4]['building_bbox'] = [2000.0, 2000.0, 50.0, 50.0]
+    anns[4]['footprint_bbox'] = [2000.0, 2000.0, 50.0, 50.0]
+    anns[5]['category_id'] = 7
+    del anns[6]['offset']
+    del anns[7]['building_height']
+    anns[8]['only_footprint'] = 1
+    anns[9]['only_footprint'] = 0
+    anns[10]['bbox'][2] = 0.5
+    return anns

@@ -241,8 +241,47 @@ def hrnet(size=128):
     print(f'hrnet_{size}.npz', [tuple(y.shape) for y in ys], [float(out[f'neck_{i}_absmean']) for i in range(5)], float(loss))
 
 
+def data_pipeline():
+    """Reference BONAI._parse_ann_info (bonai.py:105-256) and RandomFlip.bbox_flip/offset_flip (transforms.py:379-466) on
+    synthetic annotations; the expected outputs are stored, the inputs are regenerated by synth_bonai_anns()."""
+    from mmdet.datasets.bonai import BONAI
+    from mmdet.datasets.pipelines.transforms import RandomFlip
+    from bonai_amd.synth import synth_bonai_anns
+    out = {}
+    img_info = dict(width=1024, height=1024, filename='L18_104400_210392.png')
+    for tag, kw in (('roof', dict(bbox_type='roof', mask_type='roof', offset_coordinate='rectangle')),
+                    ('building_polar', dict(bbox_type='building', mask_type='footprint', offset_coordinate='polar')),
+                    ('footprint', dict(bbox_type='footprint', mask_type='roof', offset_coordinate='rectangle'))):
+        ds = BONAI.__new__(BONAI)
+        ds.cat_ids, ds.cat2label, ds.resolution, ds.ignore_buildings = [1], {1: 0}, 0.6, True
+        for k, v in kw.items():
+            setattr(ds, k, v)
+        ann = ds._parse_ann_info(img_info, synth_bonai_anns())
+        for k in ('bboxes', 'labels', 'bboxes_ignore', 'offsets', 'building_heights', 'roof_bboxes', 'footprint_bboxes'):
+            out[f'{tag}_{k}'] = np.asarray(ann[k])
+        out[f'{tag}_angle'] = np.array(ann['angle'], dtype=np.float64)
+        out[f'{tag}_only_footprint_flag'] = np.array(ann['only_footprint_flag'], dtype=np.float64)
+        out[f'{tag}_n_masks'] = np.array([len(ann['masks']), len(ann['roof_masks']), len(ann['footprint_masks'])])
+        out[f'{tag}_mask0'] = np.asarray(ann['masks'][0], dtype=np.float64).reshape(-1)
+        out[f'{tag}_mask_of_only_fp'] = np.asarray(ann['masks'][-3], dtype=np.float64).reshape(-1)
+    empty = ds._parse_ann_info(img_info, [])
+    out['empty_heights_shape'] = np.array(empty['building_heights'].shape)
+    out['empty_angle'] = np.array(empty['angle'])
+    rf = RandomFlip(flip_ratio=0.5)
+    bb = out['roof_bboxes']
+    off = out['roof_offsets']
+    for d in ('horizontal', 'vertical'):
+        out[f'flip_{d}_bboxes'] = rf.bbox_flip(bb, (1024, 1024, 3), d)
+        out[f'flip_{d}_offsets'] = rf.offset_flip(off, (1024, 1024, 3), d)
+    np.savez_compressed(os.path.join(GOLD, 'data_pipeline.npz'), **out)
+    print('data_pipeline.npz', out['roof_bboxes'].shape, out['building_polar_offsets'][:2], float(out['roof_angle']))
+
+
 if __name__ == '__main__':
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'data':
+        data_pipeline()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hrnet':
         hrnet()
         sys.exit(0)
@@ -250,3 +289,4 @@ if __name__ == '__main__':
     e2e()
     e2e_test()
     hrnet()
+    data_pipeline()

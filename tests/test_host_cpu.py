@@ -95,3 +95,49 @@ def test_checkpoint_formats(tmp_path):
     assert load_checkpoint(c, p3, strict=True)['meta']['iter'] == 7
     with pytest.raises(RuntimeError):
         load_checkpoint(c, {'state_dict': {'backbone.conv1.weight': torch.zeros(1, 1)}})
+
+
+def test_bonai_data_contract_vs_reference_fixture():
+    """bonai_amd.data vs the reference's own BONAI._parse_ann_info / RandomFlip (tests/golden/data_pipeline.npz, generated by
+    oracle/ref_harness/make_goldens.py data): every parser branch, both flip directions, and the device-batch layout."""
+    import numpy as np
+    from bonai_amd import data as D
+    from bonai_amd.synth import synth_bonai_anns
+    gd = np.load(os.path.join(ROOT, 'tests', 'golden', 'data_pipeline.npz'))
+    img_info = dict(width=1024, height=1024, filename='L18_104400_210392.png')
+    for tag, kw in (('roof', dict(bbox_type='roof', mask_type='roof', offset_coordinate='rectangle')),
+                    ('building_polar', dict(bbox_type='building', mask_type='footprint', offset_coordinate='polar')),
+                    ('footprint', dict(bbox_type='footprint', mask_type='roof', offset_coordinate='rectangle'))):
+        ann = D.parse_bonai_annotations(img_info, synth_bonai_anns(), **kw)
+        for k in ('bboxes', 'labels', 'bboxes_ignore', 'offsets', 'building_heights', 'roof_bboxes', 'footprint_bboxes'):
+            want = gd[f'{tag}_{k}']
+            assert ann[k].dtype == want.dtype and ann[k].shape == want.shape and np.array_equal(ann[k], want), (tag, k)
+        assert abs(ann['angle'] - float(gd[f'{tag}_angle'])) < 1e-7
+        assert float(ann['only_footprint_flag']) == float(gd[f'{tag}_only_footprint_flag'])
+        assert [len(ann['masks']), len(ann['roof_masks']), len(ann['footprint_masks'])] == list(gd[f'{tag}_n_masks'])
+        assert np.array_equal(np.asarray(ann['masks'][0], dtype=np.float64).reshape(-1), gd[f'{tag}_mask0'])
+        assert np.array_equal(np.asarray(ann['masks'][-3], dtype=np.float64).reshape(-1), gd[f'{tag}_mask_of_only_fp'])
+    empty = D.parse_bonai_annotations(img_info, [])
+    assert tuple(empty['building_heights'].shape) == tuple(gd['empty_heights_shape']) and empty['angle'] == float(gd['empty_angle'])
+    bb, off = gd['roof_bboxes'], gd['roof_offsets']
+    for d in ('horizontal', 'vertical'):
+        assert np.array_equal(D.flip_bboxes(bb, (1024, 1024, 3), d), gd[f'flip_{d}_bboxes'])
+        assert np.array_equal(D.flip_offsets(off, d), gd[f'flip_{d}_offsets'])
+    # sample -> flipped sample -> batch dict (CPU device here): keys, dtypes, flip consistency of masks vs boxes
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 255, (64, 96, 3)).astype(np.uint8)
+    boxes = np.array([[10, 8, 40, 30], [50, 20, 90, 60]], np.float32)
+    masks = np.zeros((2, 64, 96), np.uint8)
+    for i, (x1, y1, x2, y2) in enumerate(boxes.astype(int)):
+        masks[i, y1:y2, x1:x2] = 1
+    s = dict(img=img, gt_bboxes=boxes, gt_labels=np.zeros(2, np.int64), gt_masks=masks, gt_offsets=np.array([[3, -4], [0, 5]], np.float32))
+    f = D.flip_sample(s, 'horizontal')
+    for i, (x1, y1, x2, y2) in enumerate(f['gt_bboxes'].astype(int)):
+        assert f['gt_masks'][i, y1:y2, x1:x2].all() and f['gt_masks'][i].sum() == masks[i].sum()
+    assert np.array_equal(f['gt_offsets'], np.array([[-3, -4], [0, 5]], np.float32))
+    batch = D.to_device_batch([s, f], device='cpu')
+    assert batch['img'].shape == (2, 3, 64, 96) and batch['img'].dtype == torch.float32
+    assert batch['gt_masks'][0].dtype == torch.uint8 and batch['gt_offsets'][1].shape == (2, 2)
+    assert batch['img_metas'][1]['flip'] and batch['img_metas'][0]['img_shape'] == (64, 96, 3)
+    want0 = (img[..., ::-1].astype(np.float32) - np.array([123.675, 116.28, 103.53], np.float32)) / np.array([58.395, 57.12, 57.375], np.float32)
+    assert np.allclose(batch['img'][0].permute(1, 2, 0).numpy(), want0, atol=1e-5)

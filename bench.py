@@ -155,12 +155,14 @@ def main():
         dom = max(fam, key=lambda k: fam[k][1])
         ach = fam[dom][0] / fam[dom][1] / 1e12
         kname = 'conv_tap_kernel' if dom == 'conv_tap' else 'conv_wgrad_kernel'
-        traffic = None   # HBM bytes per launch from a separate rocprofv3 --pmc pass of this command (profiles/)
+        traffic = mfma_util = None   # from separate rocprofv3 --pmc passes of this command (tools/pmc_collect.py -> profiles/)
         pmc = os.path.join(ROOT, 'profiles', 'round1_pmc_traffic.json')
-        if os.path.exists(pmc) and args.batch == 8 and args.size == 1024:
-            traffic = round(json.load(open(pmc)).get(kname, {}).get('hbm_bytes_per_launch', 0.0)) or None
+        if os.path.exists(pmc) and args.batch == 8 and args.size == 1024 and headline:
+            ent = json.load(open(pmc)).get(kname, {})
+            traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
+            mfma_util = round(ent['mfma_util'], 4) if 'mfma_util' in ent else None
         roofline = dict(bound='mfma', kernel=kname,
-                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic,
+                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})

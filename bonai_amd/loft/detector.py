@@ -55,6 +55,15 @@ class LOFT(nn.Module):
             x = self.neck(x)
         return x
 
+    def forward_dummy(self, img):
+        """two_stage.py:87-103 (used by tools/get_flops.py): backbone + neck + RPN + RoI heads on 1000 random proposals."""
+        outs = ()
+        x = self.extract_feat(img)
+        if self.with_rpn:
+            outs = outs + (self.rpn_head(x),)
+        proposals = torch.randn(1000, 4, device=img.device)
+        return outs + (self.roi_head.forward_dummy(x, proposals),)
+
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       gt_offsets=None, **kwargs):
         x = self.extract_feat(img)

@@ -503,6 +503,14 @@ class LoftRoIHead(nn.Module):
             offset_results = (offset_pred * offset_pred.new_tensor(s) * wh).clamp(-1024, 1024).cpu().numpy().astype(np.float32)
         return bbox_results, segm_results, offset_results
 
+    def forward_dummy(self, x, proposals):
+        """standard_roi_head.py:54-68: (cls_score, bbox_pred, mask_pred of the first 100 RoIs)."""
+        rois = torch.cat([proposals.new_zeros(proposals.shape[0], 1), proposals[:, :4]], 1).contiguous()
+        outs = tuple(self.bbox_head(self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)))
+        if self.with_mask:
+            outs = outs + (self.mask_head(self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], rois[:100].contiguous())),)
+        return outs
+
     def _offset_forward(self, x, rois):
         feats = x[:self.offset_roi_extractor.num_inputs]
         if isinstance(self.offset_head, OffsetHeadExpandFeature):

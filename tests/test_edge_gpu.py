@@ -73,3 +73,15 @@ def test_rccl_reducer_path_single_rank():
         assert torch.allclose(p_ref, p_got, atol=1e-4)
     finally:
         RandomSampler.choice_mode = 'random'
+
+
+def test_forward_dummy_shapes():
+    """two_stage.py:87-103 / standard_roi_head.py:54-68 contract used by tools/get_flops.py."""
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().eval()
+    with torch.no_grad():
+        (cls, reg), (cls_score, bbox_pred, mask_pred) = m.forward_dummy(torch.randn(1, 3, 256, 256, device='cuda'))
+    assert len(cls) == 5 and cls[0].shape[1] == 3 and reg[0].shape[1] == 12 and cls[0].shape[2:] == (64, 64)
+    assert cls_score.shape == (1000, 2) and bbox_pred.shape == (1000, 4) and mask_pred.shape[0] == 100 and mask_pred.shape[2:] == (28, 28)

@@ -66,3 +66,71 @@ def test_nms_full_size_properties():
     # and the first box of every non-empty segment always survives
     for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
         assert b == a or bool(keep[a])
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def test_resample_adjoints_fullsize():
+    """HRFPN / HRModule resampling kernels at BASELINE config-5 sizes (8 x 1024^2 input -> 256^2 maps): each backward is
+    the exact adjoint of its forward, <F(x), g> == <x, F^T(g)> (fp32, relative 1e-4), and the fuse kernel is linear where its
+    ReLU is inactive."""
+    from bonai_amd import kernels as K
+    g = torch.Generator(device='cuda').manual_seed(0)
+    B, H = 8, 256
+
+    def rnd(*shape):
+        return torch.randn(*shape, device='cuda', generator=g).contiguous(memory_format=torch.channels_last)
+    # bilinear x4 into a slot of a 512-channel tensor
+    x = rnd(B, 128, H // 4, H // 4)
+    gout = rnd(B, 512, H, H)
+    dst = torch.zeros_like(gout)
+    K.bilinear_up_slot_(x, dst, 2, 128)
+    gx = K.bilinear_up_slot_bwd(gout, 128, 2, 128)
+    lhs, rhs = _dot(dst, gout), _dot(x, gx)
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    assert dst[:, :128].abs().max().item() == 0 and dst[:, 256:].abs().max().item() == 0      # only its slot is written
+    # avg-pool x8
+    x = rnd(B, 256, H, H)
+    y = K.avgpool(x, 3)
+    gy = torch.randn_like(y)
+    lhs, rhs = _dot(y, gy), _dot(x, K.avgpool_bwd(gy, 3))
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+    # fuse: sum of a fine and a x4-coarser term, shifted so the ReLU never clips -> linear; backward = adjoint
+    a, b = rnd(B, 64, H, H).abs() + 5.0, rnd(B, 64, H // 4, H // 4).abs() + 5.0
+    y = K.fuse_sum_relu([a, b], [0, 2])
+    gy = torch.randn_like(y)
+    lhs = _dot(y, gy)
+    rhs = _dot(a, K.blocksum_masked(gy, y, 0)) + _dot(b, K.blocksum_masked(gy, y, 2))
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_dcn_sampling_adjoint_fullsize():
+    """DCNv2 sampling at the config-4 layer3 shape (8 x 256 x 64^2, 3x3), bf16 binned backward: for fixed offsets the map
+    x -> col is linear, so <col(x), g> == <x, dx(g)> up to bf16 rounding of the operands (1e-2 relative); the offset
+    gradient matches a central finite difference of <col, g> along a random direction."""
+    from bonai_amd import kernels as K
+    g = torch.Generator(device='cuda').manual_seed(1)
+    B, C, H = 8, 256, 64
+    x = torch.randn(B, C, H, H, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    om = torch.zeros(B, 28, H, H, device='cuda').contiguous(memory_format=torch.channels_last)
+    om[:, :27] = torch.randn(B, 27, H, H, device='cuda', generator=g) * 0.7
+    # offsets = integer + fraction in [0.25, 0.75]: +-eps never crosses a pixel boundary, where the bilinear sample has a kink
+    om[:, :18] = torch.randint(-1, 2, (B, 18, H, H), device='cuda', generator=g).float() + \
+        0.25 + 0.5 * torch.rand(B, 18, H, H, device='cuda', generator=g)
+    col = K.mdcn_sample_fwd(x, om, 3, 3, 1, 1)
+    gcol = torch.randn(col.shape, device='cuda', generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dx, dom = K.mdcn_sample_bwd(x, om, gcol, 3, 3, 1, 1)
+    lhs, rhs = _dot(col, gcol), _dot(x, dx)
+    assert abs(lhs - rhs) <= 1e-2 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    # directional derivative w.r.t. the raw conv_offset output (fp32 sampling of the same bf16-valued x for a clean difference)
+    xf, gf = x.float(), gcol.float()
+    d = torch.zeros_like(om)
+    d[:, :27] = torch.rand(B, 27, H, H, device='cuda', generator=g) * 2 - 1
+    eps = 1e-2
+    fp = _dot(K.mdcn_sample_fwd(xf, om + eps * d, 3, 3, 1, 1), gf)
+    fm = _dot(K.mdcn_sample_fwd(xf, om - eps * d, 3, 3, 1, 1), gf)
+    fd = (fp - fm) / (2 * eps)
+    an = _dot(dom, d)
+    assert abs(fd - an) <= 0.03 * max(abs(fd), abs(an), 1.0), (fd, an)

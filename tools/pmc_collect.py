@@ -1,0 +1,77 @@
+"""Collect per-kernel hardware counters for one bench step with rocprofv3 and aggregate them per kernel family.
+
+Run ON the GPU box (gpurun):  cd /tmp && export TMPDIR=/tmp && python $GRAFT_REPO_ROOT/tools/pmc_collect.py
+Passes (separate runs, --pmc with --kernel-trace only, as the pool requires):
+  1. FETCH_SIZE   2. WRITE_SIZE   3. SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
+Writes gpurun_out/pmc/summary.json: per family launches, HBM bytes per launch (FETCH_SIZE x2 per
+/opt/skills/guides/MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 B; counter unit KiB) and
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs; 32 cycles per 32x32x16 bf16 MFMA) /
+((GRBM_GUI_ACTIVE / 8 XCDs) x 256 CUs x 4 SIMDs) -- checked against FLOPs / 2.5 PFLOP/s from the event timings (0.238 vs 0.24)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, 'gpurun_out', 'pmc')
+FAMILIES = ['conv_tap_kernel', 'conv_wgrad_kernel', 'conv_wgrad64_kernel', 'roi_align_fwd_kernel', 'roi_align_bwd_tile_kernel',
+            'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
+            'fuse_sum_relu_kernel', 'stem_mfma_kernel']
+PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE'])]
+
+
+def run_pass(tag, counters, extra):
+    d = os.path.join(OUT, tag)
+    cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
+                                               os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
+                                               '--no-roofline'] + extra
+    subprocess.run(cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+    rows = []
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+        os.remove(f)                    # raw per-dispatch rows are large; only the aggregate is kept
+    for f in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True):
+        os.remove(f)
+    return rows
+
+
+def main():
+    extra = sys.argv[1:]
+    os.makedirs(OUT, exist_ok=True)
+    agg = {}
+    for tag, counters in PASSES:
+        for r in run_pass(tag, counters, extra):
+            name = r.get('Kernel_Name', '')
+            fam = next((f for f in FAMILIES if f in name), None)
+            if fam is None:
+                continue
+            a = agg.setdefault(fam, {})
+            c = r.get('Counter_Name')
+            a.setdefault(c, [0.0, set()])
+            a[c][0] += float(r.get('Counter_Value', 0.0))
+            a[c][1].add(r.get('Dispatch_Id'))
+    out = {'_how': __doc__.strip().split('\n\n')[0], '_args': extra}
+    for fam, a in agg.items():
+        n = max((len(v[1]) for v in a.values()), default=0)
+        e = dict(launches=n)
+        if 'FETCH_SIZE' in a:
+            e['fetch_bytes_corrected_per_launch'] = a['FETCH_SIZE'][0] * 1024 * 2 / max(1, len(a['FETCH_SIZE'][1]))
+        if 'WRITE_SIZE' in a:
+            e['write_bytes_per_launch'] = a['WRITE_SIZE'][0] * 1024 / max(1, len(a['WRITE_SIZE'][1]))
+        if 'fetch_bytes_corrected_per_launch' in e and 'write_bytes_per_launch' in e:
+            e['hbm_bytes_per_launch'] = e['fetch_bytes_corrected_per_launch'] + e['write_bytes_per_launch']
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in a and 'GRBM_GUI_ACTIVE' in a and a['GRBM_GUI_ACTIVE'][0] > 0:
+            e['mfma_busy_cycles'] = a['SQ_VALU_MFMA_BUSY_CYCLES'][0]
+            e['gui_active_cycles'] = a['GRBM_GUI_ACTIVE'][0]
+            e['mfma_util'] = a['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (a['GRBM_GUI_ACTIVE'][0] / 8 * 256 * 4)   # GUI_ACTIVE is summed over the 8 XCDs
+        if 'SQ_BUSY_CU_CYCLES' in a:
+            e['sq_busy_cu_cycles'] = a['SQ_BUSY_CU_CYCLES'][0]
+        out[fam] = e
+    json.dump(out, open(os.path.join(OUT, 'summary.json'), 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()

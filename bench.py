@@ -41,9 +41,12 @@ def parse():
     return ap.parse_args()
 
 
-def f_train_gflop(n_roi, n_pos):
-    """Algorithmic training FLOPs per image, SURVEY.md section 8(d)."""
-    return 32.8 + 3.0 * (360.3 + 0.0278 * n_roi + 3.451 * n_pos)
+def f_train_gflop(n_roi, n_pos, sparse_rpn_backward=True):
+    """Algorithmic training FLOPs per image, SURVEY.md section 8(d): 32.8 (frozen stem + layer1, forward only) +
+    3 x (trainable dense part 360.3 + RoI heads).  With the sparse RPN backward the head's 103.6 GFLOP forward has no dense
+    backward (its output gradient is non-zero at <= 256 anchors per image), so only its forward is counted."""
+    f = 32.8 + 3.0 * (360.3 + 0.0278 * n_roi + 3.451 * n_pos)
+    return f - 2.0 * 103.6 if sparse_rpn_backward else f
 
 
 def cpu_baseline(size, num_gt):
@@ -167,7 +170,7 @@ def main():
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     if rank == 0:
-        f_img = f_train_gflop(mean_roi, mean_pos)
+        f_img = f_train_gflop(mean_roi, mean_pos, sparse_rpn_backward=model.rpn_head.sparse_backward)
         res = dict(metric='training img/s at 1024x1024 LOFT R50-FPN', value=round(value, 3), unit='img/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',

@@ -1,0 +1,104 @@
+// rpn_sparse.hip -- row gather / scatter for the sparse backward of the RPN head (gfx950).
+//
+// The RPN losses (mmdet/models/dense_heads/anchor_head.py:429-497 via rpn_head.py:56-80) touch only the sampled anchors --
+// at most 256 per image (RandomSampler num=256, cfg train_cfg.rpn.sampler) of 261 888 at 1024^2 -- so the gradient of the
+// head's outputs is zero everywhere else.  Instead of running dense data/weight-gradient convolutions over five pyramid
+// levels for a gradient that is >99.8 % zeros, the backward works on the selected pixels only:
+//   gather   : rows x[level][b, y+dy, x+dx, :] of the K x K neighbourhood of every selected pixel -> [nsel][K*K][C]
+//              (the A operand of a dense [nsel x K*K*C] GEMM for the weight gradient)
+//   scatter  : dx[level][b, y+dy, x+dx, :] += src[i][tap][:]  (packed bf16 atomics: neighbourhoods of nearby anchors overlap)
+// Both are HBM/L2-bound row copies of 512 B (C = 256 bf16); nsel * K*K rows in total (<= 36 864 per step).
+#include "loft_common.h"
+#include "../../include/loft_hip.h"
+
+namespace {
+
+struct SparseLevels {
+    void* ptr[8];
+    int H[8], W[8];
+    int n;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// rows: int32 [nsel][4] = (b, level, y, x); level < 0 marks an inactive row (output zeros / no scatter)
+__global__ void rpn_gather_rows_kernel(const SparseLevels lv, const int* __restrict__ rows, int nsel, int C, int K,
+                                       bf16_t* __restrict__ out) {
+    const int cg = C >> 3, T = K * K, half = K >> 1;
+    const long total = (long)nsel * T * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cg);
+        const long r = i / cg;
+        const int t = (int)(r % T), s = (int)(r / T);
+        const int4 rw = *reinterpret_cast<const int4*>(rows + (long)s * 4);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (rw.y >= 0 && rw.y < lv.n) {
+            const int y = rw.z + t / K - half, x = rw.w + t % K - half;
+            const int H = lv.H[rw.y], W = lv.W[rw.y];
+            if (y >= 0 && y < H && x >= 0 && x < W)
+                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(lv.ptr[rw.y]) +
+                                                    (((long)rw.x * H + y) * W + x) * C + c8 * 8);
+        }
+        *reinterpret_cast<uint4*>(out + i * 8) = v;
+    }
+}
+
+__global__ void rpn_scatter_add_kernel(const SparseLevels lv, const int* __restrict__ rows, int nsel, int C, int K,
+                                       const bf16_t* __restrict__ src) {
+    const int cp = C >> 1, T = K * K, half = K >> 1;
+    const long total = (long)nsel * T * cp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c2 = (int)(i % cp);
+        const long r = i / cp;
+        const int t = (int)(r % T), s = (int)(r / T);
+        const int4 rw = *reinterpret_cast<const int4*>(rows + (long)s * 4);
+        if (rw.y < 0 || rw.y >= lv.n) continue;
+        const int y = rw.z + t / K - half, x = rw.w + t % K - half;
+        const int H = lv.H[rw.y], W = lv.W[rw.y];
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(src + i * 2);
+        if (v == 0u) continue;
+        bf16_t* dst = reinterpret_cast<bf16_t*>(lv.ptr[rw.y]) + (((long)rw.x * H + y) * W + x) * C + c2 * 2;
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2_t*)dst,
+                                                   __builtin_bit_cast(bf16x2_t, v));
+    }
+}
+
+int fill_levels(SparseLevels* lv, void* const* ptrs, const int* H, const int* W, int n) {
+    if (n < 1 || n > 8) return (int)hipErrorInvalidValue;
+    lv->n = n;
+    for (int i = 0; i < 8; ++i) { lv->ptr[i] = i < n ? ptrs[i] : nullptr; lv->H[i] = i < n ? H[i] : 0; lv->W[i] = i < n ? W[i] : 0; }
+    return 0;
+}
+
+}  // namespace
+
+LOFT_EXPORT int loft_rpn_gather_rows(void* const* level_ptrs, const int* H, const int* W, int n_levels, const int* rows, int nsel,
+                                     int C, int K, void* out, void* stream) {
+    SparseLevels lv;
+    if (int e = fill_levels(&lv, level_ptrs, H, W, n_levels)) return e;
+    if ((C % 8) || !(K & 1)) return (int)hipErrorInvalidValue;
+    const long total = (long)nsel * K * K * (C / 8);
+    if (total <= 0) return 0;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rpn_gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lv, rows, nsel, C, K,
+                       (bf16_t*)out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+LOFT_EXPORT int loft_rpn_scatter_add_rows(void* const* level_ptrs, const int* H, const int* W, int n_levels, const int* rows,
+                                          int nsel, int C, int K, const void* src, void* stream) {
+    SparseLevels lv;
+    if (int e = fill_levels(&lv, level_ptrs, H, W, n_levels)) return e;
+    if ((C % 2) || !(K & 1)) return (int)hipErrorInvalidValue;
+    const long total = (long)nsel * K * K * (C / 2);
+    if (total <= 0) return 0;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rpn_scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lv, rows, nsel, C, K,
+                       (const bf16_t*)src);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -656,6 +656,42 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
     return out
 
 
+# ------------------------------------------------------------------ sparse RPN backward helpers
+
+def _sparse_levels(maps):
+    maps = [_nhwc(m) for m in maps]
+    for m in maps:
+        if m.dtype != torch.bfloat16 or m.shape[1] != maps[0].shape[1]:
+            raise L.LoftHipError('sparse RPN rows: bf16 maps with one channel count')
+    ptrs = (c_void_p * len(maps))(*[m.data_ptr() for m in maps])
+    return maps, ptrs, L.arr(c_int, [m.shape[2] for m in maps]), L.arr(c_int, [m.shape[3] for m in maps])
+
+
+def rpn_gather_rows(maps, rows, K=3):
+    """maps: list of bf16 channels_last [B,C,H_l,W_l]; rows int32 [nsel,4] (b, level, y, x) -> bf16 [nsel, K*K*C]."""
+    lib = L.load()
+    maps, ptrs, H, W = _sparse_levels(maps)
+    L.dev_check(rows, *maps)
+    C = maps[0].shape[1]
+    out = torch.empty(rows.shape[0], K * K * C, dtype=torch.bfloat16, device=rows.device)
+    L.check(lib.loft_rpn_gather_rows(ptrs, H, W, len(maps), L.ptr(rows), rows.shape[0], C, K, L.ptr(out), L.stream()),
+            'loft_rpn_gather_rows')
+    return out
+
+
+def rpn_scatter_add_rows_(maps, rows, src, K=3):
+    """maps[level][b, y+dy, x+dx, :] += src[nsel, K*K*C] (in place, packed bf16 atomics)."""
+    lib = L.load()
+    maps, ptrs, H, W = _sparse_levels(maps)
+    L.dev_check(rows, src)
+    C = maps[0].shape[1]
+    if src.dtype != torch.bfloat16 or tuple(src.shape) != (rows.shape[0], K * K * C) or not src.is_contiguous():
+        raise L.LoftHipError('rpn_scatter_add_rows_: src must be contiguous bf16 [nsel, K*K*C]')
+    L.check(lib.loft_rpn_scatter_add_rows(ptrs, H, W, len(maps), L.ptr(rows), rows.shape[0], C, K, L.ptr(src), L.stream()),
+            'loft_rpn_scatter_add_rows')
+    return maps
+
+
 # ------------------------------------------------------------------ HRNet / HRFPN resampling and fusion
 
 def fuse_sum_relu(terms, shifts, relu=True):

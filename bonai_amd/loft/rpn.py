@@ -13,6 +13,8 @@ proposal semantics.  What changed underneath:
   * the losses are evaluated on the <=512 sampled anchors per image only (identical value: all other
     anchors carry weight 0 in anchor_head.py:180-245).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -54,16 +56,17 @@ class RPNHead(nn.Module):
             nn.init.constant_(m.bias, 0)
 
     # ---------------------------------------------------------------- forward
-    def forward_fused(self, feats):
+    def forward_fused(self, feats, keep_hidden=False):
         """-> per level fp32 [B,16,H,W] NHWC: channels [0,A) objectness, [A,5A) deltas (anchor-major)."""
         A = self.num_anchors
         w = torch.cat([self.rpn_cls.weight.view(A, -1), self.rpn_reg.weight.view(4 * A, -1)], 0)
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
-        outs = []
+        outs, hs = [], []
         for x in feats:
             h = F2.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, pad=1, relu=True)
             outs.append(F2.narrow_head(h, w, b))
-        return outs
+            hs.append(h)
+        return (outs, hs) if keep_hidden else outs
 
     def forward(self, feats):
         """Reference signature: (cls_scores, bbox_preds), NCHW-shaped views of the fused outputs."""
@@ -98,7 +101,7 @@ class RPNHead(nn.Module):
         return cls, reg
 
     # ---------------------------------------------------------------- loss
-    def loss_fused(self, fused, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+    def loss_fused(self, fused, gt_bboxes, img_metas, gt_bboxes_ignore=None, sparse=None):
         dev = fused[0].device
         geo = self._geometry(fused, dev)
         if self.train_cfg.get('allowed_border', -1) >= 0:
@@ -118,13 +121,34 @@ class RPNHead(nn.Module):
             pos_gt = torch.gather(gts, 1, pos_gt_i[..., None].expand(-1, -1, 4)).reshape(-1, 4)
             tgt = self.bbox_coder.encode(pos_anchor, pos_gt).view(B, -1, 4)
             tgt = torch.where(pval[..., None], tgt, torch.zeros_like(tgt))
-        cls, reg = self._flatten(fused)
         sel = torch.cat([pidx, nidx], 1)
-        logit = torch.gather(cls, 1, sel)
+        if sparse is None:
+            cls, reg = self._flatten(fused)
+            logit = torch.gather(cls, 1, sel)
+            pred = torch.gather(reg, 1, pidx[..., None].expand(-1, -1, 4))
+        else:       # autograd sees only the sampled anchors (bonai_amd.nn._SparseRPNFn); fused was computed without a graph
+            xs, hs = sparse
+            with torch.no_grad():
+                cls, reg = self._flatten(fused)
+                vals = torch.cat([torch.gather(cls, 1, sel)[..., None], torch.gather(reg, 1, sel[..., None].expand(-1, -1, 4))], 2)
+                A = self.num_anchors
+                off = torch.tensor(geo['lvl_off'], device=dev)
+                lvl = torch.bucketize(sel, off[1:], right=True)
+                local = sel - off[lvl]
+                pix, slot = local // A, local % A
+                wl = torch.tensor([s[1] for s in geo['sizes']], device=dev)[lvl]
+                valid = torch.cat([pval, nval], 1)
+                rows = torch.stack([torch.arange(B, device=dev)[:, None].expand_as(sel), torch.where(valid, lvl, torch.full_like(lvl, -1)),
+                                    pix // wl, pix % wl], -1).reshape(-1, 4).int().contiguous()
+            S = sel.shape[1]
+            vals = F2.rpn_sparse_outputs(vals.reshape(-1, 5), rows, slot.reshape(-1), A, list(xs), list(hs), self.rpn_conv.weight,
+                                         self.rpn_conv.bias, self.rpn_cls.weight, self.rpn_cls.bias, self.rpn_reg.weight,
+                                         self.rpn_reg.bias).view(B, S, 5)
+            logit = vals[..., 0]
+            pred = vals[:, :pidx.shape[1], 1:5]
         label = torch.cat([pval.long(), torch.zeros_like(nval, dtype=torch.long)], 1)
         w = torch.cat([pval, nval], 1).float()
         loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
-        pred = torch.gather(reg, 1, pidx[..., None].expand(-1, -1, 4))
         loss_bbox = self.loss_bbox(pred, tgt, pval[..., None].float().expand_as(pred), avg_factor=avg)
         return dict(loss_rpn_cls=loss_cls, loss_rpn_bbox=loss_bbox)
 
@@ -191,9 +215,16 @@ class RPNHead(nn.Module):
         return [props[i, :int(n)] for i, n in enumerate(counts.tolist())]
 
     # ---------------------------------------------------------------- train / test entry points
+    sparse_backward = os.environ.get('LOFT_RPN_DENSE_BWD') is None      # A/B switch; the dense path is the plain autograd one
+
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
-        fused = self.forward_fused(x)
-        losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore)
+        if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == torch.bfloat16 and x[0].shape[1] % 128 == 0:
+            with torch.no_grad():
+                fused, hs = self.forward_fused(x, keep_hidden=True)
+            losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore, sparse=(x, hs))
+        else:
+            fused = self.forward_fused(x)
+            losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore)
         if proposal_cfg is None:
             return losses
         return losses, self.get_bboxes_fused([f.detach() for f in fused], img_metas, proposal_cfg)

@@ -463,3 +463,67 @@ class _Stem3x3Fn(torch.autograd.Function):
 
 def stem3x3s2(img, w, bn, out_dtype=torch.bfloat16):
     return _Stem3x3Fn.apply(img, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, out_dtype)
+
+
+# ------------------------------------------------------------------ sparse backward of the RPN head
+
+def _as_img(t2d):
+    """[n, C] row-major -> a channels_last [1, C, n, 1] view (what the tap / wgrad kernels index as n pixels of C channels)."""
+    return t2d.view(1, t2d.shape[0], 1, t2d.shape[1]).permute(0, 3, 1, 2)
+
+
+class _SparseRPNFn(torch.autograd.Function):
+    """Differentiable handle on the RPN head outputs AT THE SAMPLED ANCHORS only.
+
+    forward : returns ``vals`` [nsel, 5] (objectness logit + 4 deltas of each sampled anchor), gathered by the caller from the
+              dense head outputs it computed without autograd (those also feed proposal generation).
+    backward: the gradient of the dense outputs is zero except at <= 256 anchors per image, so instead of dense dgrad / wgrad
+              launches over five pyramid levels (3.5 ms per step at 8 x 1024^2) it runs four small dense GEMMs over the nsel
+              selected pixels on the same MFMA kernels, with loft_rpn_gather_rows / loft_rpn_scatter_add_rows moving the rows:
+                gh   = relu'(h_sel) * (g_rows x W_head)                    [nsel,256]
+                dW_head, db_head = g_rows^T x h_sel                         (cls + reg 1x1 convs)
+                dW_conv, db_conv = gh^T x gather3x3(x)                      [256, 9*256]
+                dx[level][pixel + tap] += gh x W_conv[tap]                  (scatter, bf16 packed atomics)
+    Reference semantics: autograd of rpn_head.py:38-54 under the losses of anchor_head.py:429-497."""
+
+    @staticmethod
+    def forward(ctx, vals, rows, slot, A, nlev, w_conv, b_conv, w_cls, b_cls, w_reg, b_reg, *maps):
+        xs, hs = maps[:nlev], maps[nlev:]
+        h_sel = K.rpn_gather_rows(list(hs), rows, 1)
+        ctx.save_for_backward(rows, slot, w_conv, w_cls, w_reg, h_sel, *xs)
+        ctx.A = A
+        return vals.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, slot, w_conv, w_cls, w_reg, h_sel = ctx.saved_tensors[:6]
+        xs = ctx.saved_tensors[6:]
+        A, nsel, dev = ctx.A, rows.shape[0], rows.device
+        P = _NarrowHeadFn.PADW
+        C = w_conv.shape[0]
+        # output-gradient rows in the fused head's channel order (cls 0..A-1, reg A..5A-1), zero padded to 128 channels
+        idx = torch.cat([slot[:, None], A + 4 * slot[:, None] + torch.arange(4, device=dev)[None]], 1)
+        g_rows = torch.zeros(nsel, P, dtype=torch.float32, device=dev).scatter_(1, idx, g.float()).to(torch.bfloat16)
+        w_head = torch.zeros(P, C, dtype=torch.float32, device=dev)
+        w_head[:A] = w_cls.view(A, C)
+        w_head[A:5 * A] = w_reg.view(4 * A, C)
+        gimg = _as_img(g_rows)
+        # gh = relu'(h) * (g_rows x W_head): data gradient of the 1x1 heads with the ReLU mask in the epilogue
+        gh = K.conv2d_dgrad(gimg, w_head.t().contiguous().to(torch.bfloat16)[None, None], (nsel, 1), 1, 1, mask=_as_img(h_sel))
+        dwp, db = K.conv2d_wgrad(gimg, _as_img(h_sel), 1, 1, with_bias=True)
+        g_wcls, g_wreg = dwp[0, 0, :A].reshape(w_cls.shape), dwp[0, 0, A:5 * A].reshape(w_reg.shape)
+        g_bcls, g_breg = db[0, :A], db[0, A:5 * A]
+        gh2d = gh.permute(0, 2, 3, 1).reshape(nsel, C)
+        xg = K.rpn_gather_rows(list(xs), rows, 3)
+        dwc, dbc = K.conv2d_wgrad(gh, _as_img(xg), 1, 1, with_bias=True)
+        g_wconv = dwc[0, 0].view(C, 9, C).permute(0, 2, 1).reshape(w_conv.shape)
+        wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(torch.bfloat16).contiguous()     # [(tap, cin), cout]
+        dxs = K.conv2d_fwd(_as_img(gh2d), wd[None, None], None, 1, 1)
+        dxs = dxs.permute(0, 2, 3, 1).reshape(nsel, 9 * C)
+        dxl = [torch.zeros_like(x) for x in xs]
+        K.rpn_scatter_add_rows_(dxl, rows, dxs, 3)
+        return (None, None, None, None, None, g_wconv, dbc[0], g_wcls, g_bcls, g_wreg, g_breg) + tuple(dxl) + (None,) * len(xs)
+
+
+def rpn_sparse_outputs(vals, rows, slot, A, xs, hs, w_conv, b_conv, w_cls, b_cls, w_reg, b_reg):
+    return _SparseRPNFn.apply(vals, rows, slot, A, len(xs), w_conv, b_conv, w_cls, b_cls, w_reg, b_reg, *xs, *hs)

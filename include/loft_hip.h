@@ -204,6 +204,18 @@ int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_
 int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
                     void* stream);
 
+/* ---- sparse backward of the RPN head -------------------------------------------------------------
+ * The RPN losses (anchor_head.py:429-497, rpn_head.py:56-80) read the head outputs only at the sampled anchors (<= 256 per
+ * image of 261 888), so its backward runs on the selected pixels: level_ptrs/H/W (HOST arrays, n_levels <= 8) describe the
+ * bf16 NHWC pyramid maps [B,H_l,W_l,C]; rows int32 [nsel][4] = (b, level, y, x) on the device, level < 0 = inactive.
+ * gather: out bf16 [nsel][K*K][C] = the K x K neighbourhood rows (zeros outside the map): the A operand of the dense
+ * weight-gradient GEMM.  scatter_add: map[level][b, y+dy, x+dx, :] += src[nsel][K*K][C] with packed bf16 atomics: the
+ * data gradient.  K odd. */
+int loft_rpn_gather_rows(void* const* level_ptrs, const int* H, const int* W, int n_levels, const int* rows, int nsel, int C,
+                         int K, void* out, void* stream);
+int loft_rpn_scatter_add_rows(void* const* level_ptrs, const int* H, const int* W, int n_levels, const int* rows, int nsel,
+                              int C, int K, const void* src, void* stream);
+
 /* ---- HRNet-W32 / HRFPN resampling and fusion (BASELINE config 5) ----------------------------------
  * All tensors NHWC, dtype LOFT_F32 | LOFT_BF16, C % 8 == 0, scale factors are 1 << shift.
  * loft_fuse_sum_relu: out = relu?(sum_j nearest_up(terms[j], 1 << shifts[j])) -- the fuse step of HRModule.forward

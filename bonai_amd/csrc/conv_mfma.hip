@@ -276,7 +276,10 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
         // fills the 256 CUs and K is deep enough (>= 8 K-steps) to amortise the one-block-per-CU prologue/epilogue.
         // (Measured and rejected in round 1: staging the bf16 output tile through LDS for 16-byte coalesced stores --
-        //  neutral on the K-shallow 1x1 convs, which are latency- not store-pattern-bound, and -10..20 % on dgrads.)
+        //  neutral on the K-shallow 1x1 convs, which are latency- not store-pattern-bound, and -10..20 % on dgrads;
+        //  4 waves of 128x128 (16 accumulator tiles per wave, 0.5 instead of 0.75 fragment reads per MFMA, one wave per
+        //  SIMD) -- 12 % slower than the 8-wave form with or without explicit fragment double-buffering + sched_group_barrier
+        //  hints: with one wave per SIMD the per-K-step vmcnt(0)+barrier is fully exposed.)
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
         hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {

@@ -317,10 +317,11 @@ LOFT_EXPORT int loft_foa_fuse_decode(const float* pred, const float* boxes, int6
 // out[i][S][S] = (RoIAlign_avg_aligned(mask, box, S, scale 1, adaptive grid) >= 0.5) as fp32 0/1.
 __global__ __launch_bounds__(256) void mask_target_kernel(const uint8_t* __restrict__ masks, int H, int W,
                                                           const float* __restrict__ boxes, const int64_t* __restrict__ gt_idx, int S,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const int64_t* __restrict__ mask_addr) {
     const int i = blockIdx.x;
     const float4 r = reinterpret_cast<const float4*>(boxes)[i];
-    const uint8_t* m = masks + (long)gt_idx[i] * H * W;
+    // mask_addr (optional): device address of every instance mask, so per-image mask tensors need no concatenation
+    const uint8_t* m = mask_addr ? reinterpret_cast<const uint8_t*>(mask_addr[gt_idx[i]]) : masks + (long)gt_idx[i] * H * W;
     const float start_w = r.x - 0.5f, start_h = r.y - 0.5f;
     const float rw = (r.z - 0.5f) - start_w, rh = (r.w - 0.5f) - start_h;
     const float bin_h = rh / (float)S, bin_w = rw / (float)S;
@@ -349,10 +350,11 @@ __global__ __launch_bounds__(256) void mask_target_kernel(const uint8_t* __restr
     }
 }
 LOFT_EXPORT int loft_mask_target(const uint8_t* masks, int H, int W, const float* boxes, const int64_t* gt_idx, int64_t n,
-                                 int S, float* out, void* stream) {
+                                 int S, float* out, const int64_t* mask_addr, void* stream) {
     if (n <= 0) return 0;
+    if (!masks && !mask_addr) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(mask_target_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, masks, H, W, boxes, gt_idx, S,
-                       out);
+                       out, mask_addr);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

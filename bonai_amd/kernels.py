@@ -590,16 +590,30 @@ def foa_fuse_decode(pred, boxes, stds=(0.5, 0.5), max_shape=(1024, 1024)):
 
 
 def mask_target(masks_u8, boxes, gt_idx, S=28):
-    """masks uint8 [K,H,W] (device), boxes [n,4] already clipped to the image, gt_idx int64 [n]."""
+    """masks: uint8 [K,H,W] (device), or a LIST of per-image uint8 [K_b,H,W] tensors (gt_idx then indexes their
+    concatenation; no copy is made: the kernel gets a table of instance addresses); boxes [n,4] already clipped to the
+    image, gt_idx int64 [n]."""
     lib = L.load()
-    L.dev_check(masks_u8, boxes, gt_idx)
-    masks_u8 = masks_u8.contiguous()
     boxes = boxes.float().contiguous()
     n = boxes.shape[0]
     gt_idx = gt_idx.long().contiguous()
     out = torch.empty(n, S, S, dtype=torch.float32, device=boxes.device)
+    if isinstance(masks_u8, (list, tuple)):
+        ms = [m.contiguous() for m in masks_u8]
+        L.dev_check(boxes, gt_idx, *ms)
+        H, W = ms[0].shape[1], ms[0].shape[2]
+        if any(m.dtype != torch.uint8 or tuple(m.shape[1:]) != (H, W) for m in ms):
+            raise L.LoftHipError('mask_target: per-image masks must be uint8 [K,H,W] of one size')
+        addr = torch.tensor([m.data_ptr() + k * H * W for m in ms for k in range(m.shape[0])], dtype=torch.int64).to(
+            boxes.device, non_blocking=True)
+        L.check(lib.loft_mask_target(None, H, W, L.ptr(boxes), L.ptr(gt_idx), c_int64(n), S, L.ptr(out), L.ptr(addr), L.stream()),
+                'loft_mask_target')
+        out._keep = ms      # the address table points into these tensors
+        return out
+    L.dev_check(masks_u8, boxes, gt_idx)
+    masks_u8 = masks_u8.contiguous()
     L.check(lib.loft_mask_target(L.ptr(masks_u8), masks_u8.shape[1], masks_u8.shape[2], L.ptr(boxes),
-                                 L.ptr(gt_idx), c_int64(n), S, L.ptr(out), L.stream()),
+                                 L.ptr(gt_idx), c_int64(n), S, L.ptr(out), None, L.stream()),
             'loft_mask_target')
     return out
 

@@ -288,7 +288,8 @@ class OffsetHead(_OffsetBase):
 
 
 def _masks_to_device(gt_masks, device):
-    """list of BitmapMasks-like (``.masks`` ndarray [K,H,W]) / ndarrays / uint8 tensors -> (uint8 [sumK,H,W], offsets)."""
+    """list of BitmapMasks-like (``.masks`` ndarray [K,H,W]) / ndarrays / uint8 tensors -> (list of uint8 device tensors
+    [K_b,H,W], instance offsets); the mask-target kernel addresses the instances in place (no concatenation)."""
     ts = []
     for m in gt_masks:
         a = getattr(m, 'masks', m)
@@ -297,7 +298,7 @@ def _masks_to_device(gt_masks, device):
     offs = [0]
     for t in ts:
         offs.append(offs[-1] + int(t.shape[0]))
-    return torch.cat(ts, 0), offs
+    return ts, offs
 
 
 @HEADS.register_module()
@@ -399,7 +400,7 @@ class LoftRoIHead(nn.Module):
             mask_pred = self.mask_head(mask_feats)
             with torch.no_grad():
                 masks, moffs = _masks_to_device(gt_masks, dev)
-                H, W = masks.shape[1], masks.shape[2]
+                H, W = masks[0].shape[1], masks[0].shape[2]
                 pb = pos_rois[:, 1:].clone()
                 pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
                 pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)

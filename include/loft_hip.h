@@ -187,9 +187,10 @@ int loft_foa_fuse_decode(const float* pred, const float* boxes, int64_t n, float
                          float max_w, float* out, void* stream);
 /* Mask targets on device (mmdet/core/mask/mask_target.py:33-62 -> structures.py:261-291):
  * masks u8 [K,H,W]; RoI i crops mask gt_idx[i] with box boxes[i] (clipped to the image) to SxS,
- * RoIAlign(avg, aligned, adaptive grid) >= 0.5 -> out fp32 {0,1} [n,S,S]. */
+ * RoIAlign(avg, aligned, adaptive grid) >= 0.5 -> out fp32 {0,1} [n,S,S].  mask_addr (optional, device int64 [#instances]): the address of every instance mask -- gt_idx then
+ * indexes it and per-image mask tensors need no concatenation (masks may be NULL). */
 int loft_mask_target(const uint8_t* masks, int H, int W, const float* boxes, const int64_t* gt_idx, int64_t n, int S,
-                     float* out, void* stream);
+                     float* out, const int64_t* mask_addr, void* stream);
 
 /* ---- inference post-processing --------------------------------------------------------------------
  * loft_soft_nms: mmcv.ops.soft_nms (CPU-only in mmcv 1.0.5), reached from multiclass_nms

@@ -162,3 +162,18 @@ def test_mask_target():
     ref = (cops.roi_align_fwd(sel, rois, 28, 1.0, 0, True).squeeze(1) >= 0.5).float()
     got = K.mask_target(torch.from_numpy(masks).cuda(), boxes.cuda(), idx.cuda(), 28).cpu()
     assert (got != ref).float().mean().item() < 1e-4
+
+
+def test_mask_target_per_image_list_matches_concatenated():
+    """Per-image mask tensors addressed in place (instance address table) == the concatenated form, bit for bit."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(9)
+    H, W, n = 96, 128, 300
+    parts = [torch.from_numpy((rng.rand(k, H, W) > 0.6).astype(np.uint8)).cuda() for k in (3, 0, 5, 1)]
+    boxes = _boxes(rng, n, 90.)
+    boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, W)
+    boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, H)
+    idx = torch.tensor(rng.randint(0, 9, n)).cuda()
+    a = K.mask_target(parts, boxes.cuda(), idx, 28)
+    b = K.mask_target(torch.cat(parts, 0), boxes.cuda(), idx, 28)
+    assert torch.equal(a, b)

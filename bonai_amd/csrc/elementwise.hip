@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
                                                               const float* __restrict__ mean, const float* __restrict__ var,
                                                               float eps, int Cout, int Cin, int RS, float* __restrict__ dw,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int CoutP,
-                                                              int CinP) {
+                                                              int CinP, int accumulate) {
     const int n = blockIdx.x;
     const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
     const float scale = gamma ? gamma[n] * rs : 1.f;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
         const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
         const float g = dwp[((long)t * CoutP + n) * CinP + c];
         const long wi = (long)n * per + j;
-        if (dw) dw[wi] = g * scale;
+        if (dw) dw[wi] = (accumulate ? dw[wi] : 0.f) + g * scale;
         if (gamma) acc += g * w[wi];
     }
     if (gamma) {
@@ -502,18 +502,18 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
         if (threadIdx.x == 0) {
             const float s = part[0] + part[1] + part[2] + part[3];
             const float dbn = db ? db[n] : 0.f;
-            if (dgamma) dgamma[n] = s * rs - dbn * mean[n] * rs;
-            if (dbeta) dbeta[n] = dbn;
+            if (dgamma) dgamma[n] = (accumulate ? dgamma[n] : 0.f) + (s * rs - dbn * mean[n] * rs);
+            if (dbeta) dbeta[n] = (accumulate ? dbeta[n] : 0.f) + dbn;
         }
     }
 }
 LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                                      const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma,
-                                     float* dbeta, int CoutP, int CinP, void* stream) {
+                                     float* dbeta, int CoutP, int CinP, int accumulate, void* stream) {
     if (Cout <= 0) return 0;
     if (CoutP < Cout || CinP < Cin) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_unpack_bwd_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dwp, db, w, gamma, mean, var, eps,
-                       Cout, Cin, RS, dw, dgamma, dbeta, CoutP, CinP);
+                       Cout, Cin, RS, dw, dgamma, dbeta, CoutP, CinP, accumulate);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

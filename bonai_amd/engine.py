@@ -137,14 +137,24 @@ class Trainer:
         self.world = dist.get_world_size() if self.reducer.enabled else 1
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=self.arena.data.device)
         self.iter = 0
+        # kernels accumulate weight / BN gradients straight into the arena slots (bonai_amd.nn.GRAD_SINK); the callback
+        # replaces the post-accumulate-grad hook for those parameters
+        self._sink = self.reducer._hook if self.reducer.enabled else (lambda p: None)
 
     def train_step(self, data, lr=None):
         """One full optimisation step: forward, losses, backward, gradient all-reduce, clip, SGD."""
         self.arena.grad.zero_()
         self.arena.rebind_grads()
         self.reducer.begin()
+        for p in self.arena.params:
+            p._loft_pending = 0
         out = self.model.train_step(data)
-        out['loss'].backward()
+        from . import nn as F2
+        prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
+        try:
+            out['loss'].backward()
+        finally:
+            F2.GRAD_SINK = prev
         self.reducer.finish()
         self.gnorm_sq.zero_()
         K.sumsq_(self.arena.grad, self.gnorm_sq)

@@ -872,19 +872,26 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
     return wp, wpt, bias
 
 
-def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True):
-    """dwp fp32 [T,CoutP,CinP], db fp32 [CoutP] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None)."""
+def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True, out=None):
+    """dwp fp32 [T,CoutP,CinP], db fp32 [CoutP] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None).
+    out = (dw, dgamma, dbeta) existing fp32 contiguous tensors (e.g. slots of a flat gradient arena): ACCUMULATE into them."""
     lib = L.load()
     w = w.contiguous()
     Cout, Cin, R, S = w.shape
     dev = w.device
-    dw = torch.empty_like(w) if need_dw else None
     g = m = v = dg = dbeta = None
-    if bn is not None:
-        g, _, m, v = [t.contiguous() for t in bn]
-        dg = torch.empty(Cout, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+    if out is not None:
+        dw, dg, dbeta = out
+        if bn is not None:
+            g, _, m, v = [t.contiguous() for t in bn]
+    else:
+        dw = torch.empty_like(w) if need_dw else None
+        if bn is not None:
+            g, _, m, v = [t.contiguous() for t in bn]
+            dg = torch.empty(Cout, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
     L.check(lib.loft_fold_unpack_bwd(L.ptr(dwp), L.ptr(db), L.ptr(w), L.ptr(g), L.ptr(m), L.ptr(v), c_float(eps), Cout, Cin,
-                                     R * S, L.ptr(dw), L.ptr(dg), L.ptr(dbeta), dwp.shape[-2], dwp.shape[-1], L.stream()),
+                                     R * S, L.ptr(dw), L.ptr(dg), L.ptr(dbeta), dwp.shape[-2], dwp.shape[-1], int(out is not None),
+                                     L.stream()),
             'loft_fold_unpack_bwd')
     return dw, dg, dbeta

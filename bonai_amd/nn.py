@@ -18,6 +18,29 @@ def to_nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+# Set by bonai_amd.engine.Trainer: callable(param) invoked after a kernel has ACCUMULATED a parameter's gradient straight
+# into ``param.grad`` (a slot of the flat gradient arena).  The autograd Function then returns None for that parameter, so
+# no per-parameter accumulation launch (267 tiny adds per step) happens; the callback stands in for the
+# post-accumulate-grad hook that drives the bucketed all-reduce.  None (default): gradients are returned to autograd.
+GRAD_SINK = None
+
+
+def _direct_slot(p):
+    """The arena slot of a leaf parameter, if the trainer bound one."""
+    if GRAD_SINK is None or not isinstance(p, torch.nn.Parameter) or p.grad is None:
+        return None
+    g = p.grad
+    return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape) else None
+
+
+def _sink_done(p):
+    """One use of ``p`` has deposited its gradient in the arena; tell the trainer once the last use of this step has."""
+    p._loft_pending = getattr(p, '_loft_pending', 1) - 1
+    if p._loft_pending <= 0:
+        p._loft_pending = 0
+        GRAD_SINK(p)
+
+
 _PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
 
 
@@ -65,6 +88,10 @@ class _ConvFn(torch.autograd.Function):
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
                          out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else torch.bfloat16, groups=G)
         ctx.meta = meta
+        ctx.params = tensors            # the Parameter objects themselves (their .grad may be an arena slot)
+        for k, t in enumerate(tensors):  # uses per step of each parameter: the gradient sink fires after the last one
+            if t is not None and ctx.needs_input_grad[3 + k] and isinstance(t, torch.nn.Parameter):
+                t._loft_pending = getattr(t, '_loft_pending', 0) + 1
         ctx.in_hw = tuple(x.shape[2:])
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if relu else None, wpt, *tensors)
@@ -103,6 +130,22 @@ class _ConvFn(torch.autograd.Function):
             if bn_stats is not None:
                 bn = (tensors[2 * G], tensors[2 * G + 1], bn_stats[0], bn_stats[1])
             for i in range(G):
+                pw = ctx.params[2 * i]
+                slot_w = _direct_slot(pw) if need_w else None
+                slot_g = slot_b = None
+                if bn is not None and slot_w is not None:
+                    slot_g, slot_b = _direct_slot(ctx.params[2 * G]), _direct_slot(ctx.params[2 * G + 1])
+                if slot_w is not None and (bn is None or (slot_g is not None and slot_b is not None)):
+                    # accumulate straight into the flat gradient arena; autograd gets None for these inputs
+                    K.fold_unpack_bwd(dwp[i], None if db is None else db[i], ws[i], bn,
+                                      bn_stats[2] if bn_stats is not None else 1e-5, out=(slot_w, slot_g, slot_b))
+                    _sink_done(pw)
+                    if bn is not None and i == G - 1:
+                        _sink_done(ctx.params[2 * G])
+                        _sink_done(ctx.params[2 * G + 1])
+                    if has_b and db is not None:
+                        ngrads[2 * i + 1] = db[i][:ws[i].shape[0]]
+                    continue
                 dw, dg, dbeta = K.fold_unpack_bwd(dwp[i], None if db is None else db[i], ws[i], bn,
                                                   bn_stats[2] if bn_stats is not None else 1e-5, need_dw=need_w)
                 ngrads[2 * i] = dw

@@ -275,13 +275,15 @@ int64_t loft_mdcn_bwd_workspace_bytes(int B, int C, int OH, int OW, int kh, int 
  * chain rule: dwp fp32 [R*S][Cout][Cin] (gradient of the folded weight), db fp32 [Cout] (gradient of the folded bias)
  * -> dw [Cout][Cin][R][S], dgamma, dbeta (any of them may be NULL).  pack_f32 != 0 writes fp32 packings (parity mode).
  * CoutP >= Cout, CinP >= Cin: channel-padded packings [R*S][CoutP][CinP] / [R*S][CinP][CoutP] / bias [CoutP] with zeros in
- * the padding (HRNet's 32-channel branch is carried in 64-channel tensors whose upper half stays zero). */
+ * the padding (HRNet's 32-channel branch is carried in 64-channel tensors whose upper half stays zero).
+ * loft_fold_unpack_bwd accumulate != 0: dw / dgamma / dbeta are ADDED to (the trainer passes the parameters' slots of its
+ * flat gradient arena, so no separate per-parameter accumulation launch is needed). */
 int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad, float* bias_out,
                    int pack_f32, int CoutP, int CinP, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
-                         int CoutP, int CinP, void* stream);
+                         int CoutP, int CinP, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,10 +83,15 @@ class BucketedAllReduce:
 
     def begin(self):
         self._remaining = [len(b['params']) for b in self.buckets]
+        self._seen = set()
         self._next = 0
         self.works = []
 
     def _hook(self, p):
+        """Gradient of ``p`` is final for this step (autograd post-accumulate hook, or the kernels' direct arena sink)."""
+        if id(p) in self._seen:       # idempotent: a parameter must never release its bucket twice
+            return
+        self._seen.add(id(p))
         bi = self.param_bucket[id(p)]
         self._remaining[bi] -= 1
         # collectives must be issued in the SAME order on every rank even when a rank's graph lacks some branch

@@ -31,6 +31,7 @@
 // 2-stage / 2-blocks-per-CU form (fpn P2 3x3: 538 vs 649 TFLOP/s) -- the second resident block hides more than the
 // deeper prefetch does; the next step is a 256-row, 8-wave tile with fragment double-buffering, not more stages.
 #include "loft_common.h"
+#include <type_traits>
 #include "../../include/loft_hip.h"
 #include <stdlib.h>
 
@@ -199,36 +200,65 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int frow = lane & 31, fq = lane >> 5;
 
-    stage(0, 0);
-    for (int kk = 0; kk < nk; ++kk) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (STAGES == 2 && kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
-        const char* abuf = lds + (STAGES == 2 ? (kk & 1) : 0) * (A_BYTES + B_BYTES);
-        const char* bbuf = abuf + A_BYTES;
+    // Fragment addresses are loop invariant: row r+32 has the same swizzle as row r, so the NT / MT fragments of a sub-step sit
+    // at fixed 4 KiB strides (ds_read immediate offsets) from one per-(buffer, sub-step) base.  The 16 bases live in VGPRs and
+    // the K loop is unrolled by two so the buffer index is a compile-time constant: no address VALU between the MFMAs
+    // (the SQ counters showed ~5 VALU instructions per MFMA before, mostly this address math, competing for the issue port).
+    const char* wbase[STAGES][4];
+    const char* xbase[STAGES][4];
+    {
+        const int rw = wn * WN + frow, rx = wm * WM + frow;
+#pragma unroll
+        for (int bsel = 0; bsel < STAGES; ++bsel)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int q = ks * 2 + fq;
+                xbase[bsel][ks] = lds + bsel * (A_BYTES + B_BYTES) + rx * 128 + swz(rx, q) * 16;
+                wbase[bsel][ks] = lds + bsel * (A_BYTES + B_BYTES) + A_BYTES + rw * 128 + swz(rw, q) * 16;
+            }
+    }
+    auto compute = [&](auto bufc) {
+        constexpr int bsel = decltype(bufc)::value;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int q = ks * 2 + fq;
             bf16x8 wf[NT], xf[MT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int row = wn * WN + i * 32 + frow;
-                wf[i] = *reinterpret_cast<const bf16x8*>(bbuf + row * 128 + swz(row, q) * 16);
-            }
+            for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wbase[bsel][ks] + i * 4096);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int row = wm * WM + j * 32 + frow;
-                xf[j] = *reinterpret_cast<const bf16x8*>(abuf + row * 128 + swz(row, q) * 16);
-            }
+            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xbase[bsel][ks] + j * 4096);
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        if (STAGES == 1 && kk + 1 < nk) {
-            __syncthreads();          // everyone is done reading the single buffer
-            stage(kk + 1, 0);
+    };
+    using buf0_t = std::integral_constant<int, 0>;
+    using buf1_t = std::integral_constant<int, STAGES - 1>;
+
+    stage(0, 0);
+    if constexpr (STAGES == 2) {
+        for (int kk = 0; kk < nk; kk += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kk + 1 < nk) stage(kk + 1, 1);
+            compute(buf0_t{});
+            if (kk + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kk + 2 < nk) stage(kk + 2, 0);
+                compute(buf1_t{});
+            }
+        }
+    } else {
+        for (int kk = 0; kk < nk; ++kk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(buf0_t{});
+            if (kk + 1 < nk) {
+                __syncthreads();          // everyone is done reading the single buffer
+                stage(kk + 1, 0);
+            }
         }
     }
 

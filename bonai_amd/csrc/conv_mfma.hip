@@ -73,6 +73,70 @@ __device__ __forceinline__ int xcd_remap(int L, int N) {
     return base + (L >> 3);
 }
 
+// Shared epilogue of the tap-conv kernels: bias (= folded BN shift) + residual + ReLU + ReLU-backward mask + bf16/fp32 store.
+template <int NT, int MT, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], int g, int m0, int n0, int wm, int wn,
+                                              int frow, int fq, int ohw) {
+    // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
+    // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
+    //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
+    //  64-byte runs -- 8 % slower end to end: store width per lane matters more than run contiguity, L2 merges the lines.)
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+    const long out_g = (long)g * a.out_gs;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * WM + j * 32 + frow;
+        if (m >= a.M) continue;
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * WN + i * 32 + 8 * gq + 4 * fq;
+                if (n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = out_g + opix * a.Cout + n;
+                if (a.residual) {
+                    float rv[4];
+                    ld4(a.residual + o, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.mask) {
+                    float mv[4];
+                    ld4(a.mask + o, mv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                }
+                if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out) + o;
+                    if (a.accumulate) {
+                        float ov[4];
+                        ld4(op, ov);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                    }
+                    st4(op, v);
+                } else {
+                    st4(reinterpret_cast<bf16_t*>(a.out) + o, v);
+                }
+            }
+        }
+    }
+}
+
 // STAGES = 2: double-buffered K loop.  STAGES = 1: single LDS buffer (half the LDS -> one more resident block per CU) for
 // launches with only 1-2 K-steps (the K-shallow 1x1 convs), which are latency-bound: occupancy hides what a pipeline cannot.
 // FAST: pixel-dependent address work hoisted out of the K loop (pays off from ~32 K-steps on; measured +9..12 % on the
@@ -262,65 +326,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
         }
     }
 
-    // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
-    // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
-    //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
-    //  64-byte runs -- 8 % slower end to end: store width per lane matters more than run contiguity, L2 merges the lines.)
-    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
-    const long out_g = (long)g * a.out_gs;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m0 + wm * WM + j * 32 + frow;
-        if (m >= a.M) continue;
-        const int b = m / ohw, rem = m - b * ohw;
-        const int oy = rem / a.OW, ox = rem - oy * a.OW;
-        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int n = n0 + wn * WN + i * 32 + 8 * gq + 4 * fq;
-                if (n >= a.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
-                if (bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                const long o = out_g + opix * a.Cout + n;
-                if (a.residual) {
-                    float rv[4];
-                    ld4(a.residual + o, rv);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (a.mask) {
-                    float mv[4];
-                    ld4(a.mask + o, mv);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-                }
-                if (a.out_f32) {
-                    float* op = reinterpret_cast<float*>(a.out) + o;
-                    if (a.accumulate) {
-                        float ov[4];
-                        ld4(op, ov);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += ov[e];
-                    }
-                    st4(op, v);
-                } else {
-                    st4(reinterpret_cast<bf16_t*>(a.out) + o, v);
-                }
-            }
-        }
-    }
+    conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw);
 }
+
 
 LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
                                    const void* relu_mask, void* out,
@@ -353,7 +361,12 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         //  neutral on the K-shallow 1x1 convs, which are latency- not store-pattern-bound, and -10..20 % on dgrads;
         //  4 waves of 128x128 (16 accumulator tiles per wave, 0.5 instead of 0.75 fragment reads per MFMA, one wave per
         //  SIMD) -- 12 % slower than the 8-wave form with or without explicit fragment double-buffering + sched_group_barrier
-        //  hints: with one wave per SIMD the per-K-step vmcnt(0)+barrier is fully exposed.)
+        //  hints: with one wave per SIMD the per-K-step vmcnt(0)+barrier is fully exposed;
+        //  a 4-stage pipeline with 32-channel K-steps (same 128 KiB of LDS, three global->LDS copies in flight, counted vmcnt
+        //  waits) -- correct, 4 % slower: the copies' latency is not what parks the waves.  SQ counters of the 8-wave form on
+        //  the P2 3x3: MFMA pipe busy 40 % of the SIMD cycles, waves parked on waitcnt/barrier 37 %, issue-stalled 39 %, LDS
+        //  bank conflicts 0, LDS array active 8 %: the remaining loss is barrier skew between the two waves of a SIMD plus the
+        //  un-overlapped prologue/epilogue of a one-block-per-CU kernel -- a persistent, software-pipelined rewrite is the fix.)
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
         if (deepk) hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);

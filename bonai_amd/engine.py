@@ -134,9 +134,15 @@ def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16,
 
 
 class Trainer:
-    def __init__(self, model, lr=0.005, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_bytes=64 << 20):
+    def __init__(self, model, lr=0.005, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_bytes=64 << 20,
+                 loss_scale=1.0):
+        """loss_scale: the static scale of the reference's Fp16OptimizerHook (``fp16 = dict(loss_scale=512.)``,
+        mmdet/core/fp16/hooks.py:64-96): the loss is multiplied before backward and the gradients are divided again inside
+        the fused clip + SGD kernel (after the all-reduce, before the norm), exactly the hook's order.  bf16 activations have
+        fp32's exponent range, so the scale is not needed for range here; it is honoured for runner parity."""
         self.model = model
         self.lr, self.mu, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
+        self.loss_scale = float(loss_scale)
         self.arena = FlatArena(model)
         self.reducer = BucketedAllReduce(self.arena, bucket_bytes)
         self.world = dist.get_world_size() if self.reducer.enabled else 1
@@ -157,13 +163,13 @@ class Trainer:
         from . import nn as F2
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
         try:
-            out['loss'].backward()
+            (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
         finally:
             F2.GRAD_SINK = prev
         self.reducer.finish()
         self.gnorm_sq.zero_()
         K.sumsq_(self.arena.grad, self.gnorm_sq)
         K.sgd_momentum_(self.arena.data, self.arena.grad, self.arena.momentum, self.gnorm_sq, self.max_norm,
-                        self.lr if lr is None else lr, self.mu, self.wd, grad_scale=1.0 / self.world)
+                        self.lr if lr is None else lr, self.mu, self.wd, grad_scale=1.0 / (self.world * self.loss_scale))
         self.iter += 1
         return out

@@ -13,3 +13,6 @@ model = dict(
             stage4=dict(num_modules=3, num_branches=4, block='BASIC', num_blocks=(4, 4, 4, 4),
                         num_channels=(32, 64, 128, 256)))),
     neck=dict(_delete_=True, type='HRFPN', in_channels=[32, 64, 128, 256], out_channels=256))
+# BASELINE config 5 is the reference's fp16 recipe (configs/fp16/*: Fp16OptimizerHook, static loss scale).  Activations run
+# in bf16 here (dtype >= the reference's fp16); the static loss scale is honoured by bonai_amd.engine.Trainer.
+fp16 = dict(loss_scale=512.)

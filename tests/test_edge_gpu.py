@@ -118,3 +118,29 @@ def test_trainer_direct_grad_sink_matches_autograd_accumulation():
     for n, g in got.items():
         if n not in want:
             assert g.abs().max().item() == 0, n
+
+
+def test_static_loss_scale_is_transparent():
+    """Fp16OptimizerHook semantics (hooks.py:64-96): scaling the loss by 512 and un-scaling inside the fused clip+SGD kernel
+    leaves the update unchanged (up to bf16 rounding of the scaled gradients flowing through the backward)."""
+    from bonai_amd.config import Config
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft import build_detector
+    from bonai_amd.loft.core import RandomSampler
+    from bonai_amd.synth import make_batch
+    from oracle.synth_weights import synth_tensor
+    RandomSampler.choice_mode = 'first'
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    data = make_batch(1, 256, 6, device='cuda')
+    res = []
+    for scale in (1.0, 512.0):
+        m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        sd0 = {k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd0)
+        m = m.cuda().train()
+        tr = Trainer(m, lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=35.0, loss_scale=scale)
+        tr.train_step(data)
+        res.append({n: (p.detach().cpu() - sd0[n]) for n, p in m.named_parameters() if p.requires_grad})
+    for n in res[0]:
+        a, b = res[0][n], res[1][n]
+        assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-9, (n, (a - b).norm().item(), b.norm().item())

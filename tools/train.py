@@ -49,7 +49,8 @@ def main():
         from bonai_amd.checkpoint import load_checkpoint
         load_checkpoint(model, args.resume_from, strict=True)
     tr = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
-                 max_norm=cfg.optimizer_config.grad_clip.max_norm)
+                 max_norm=cfg.optimizer_config.grad_clip.max_norm,
+                 loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0))
     bs = cfg.data.get('samples_per_gpu', 8)
     interval = cfg.log_config.get('interval', 10)
     t0 = time.time()

@@ -491,10 +491,18 @@ class LoftRoIHead(nn.Module):
                 img_h = int(np.round(ori_shape[0] * float(np.asarray(scale_factor).reshape(-1)[1 if np.size(scale_factor) > 1 else 0])))
                 img_w = int(np.round(ori_shape[1] * float(np.asarray(scale_factor).reshape(-1)[0])))
                 pb = _bboxes
-            im = K.mask_paste(sel, pb.contiguous(), img_h, img_w, cfg.mask_thr_binary).bool().cpu().numpy()
+            pasted = K.mask_paste(sel, pb.contiguous(), img_h, img_w, cfg.mask_thr_binary)
             segm_results = [[] for _ in range(ncls)]
-            for i in range(im.shape[0]):
-                segm_results[int(dl[i])].append(im[i])
+            if cfg.get('rle_masks', False):
+                # what apis/test.py:59-67 (encode_mask_results) produces from the bool arrays, without moving them to the host:
+                # run boundaries are extracted on the device (bonai_amd.rle)
+                from ..rle import rle_encode_masks
+                for i, r in enumerate(rle_encode_masks(pasted)):
+                    segm_results[int(dl[i])].append(r)
+            else:
+                im = pasted.bool().cpu().numpy()
+                for i in range(im.shape[0]):
+                    segm_results[int(dl[i])].append(im[i])
         offset_pred = self._offset_forward(x, det_rois)
         if isinstance(self.offset_head, OffsetHeadExpandFeature):
             offset_results = self.offset_head.get_offsets(offset_pred, _bboxes.contiguous(), scale_factor, rescale)

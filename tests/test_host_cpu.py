@@ -141,3 +141,28 @@ def test_bonai_data_contract_vs_reference_fixture():
     assert batch['img_metas'][1]['flip'] and batch['img_metas'][0]['img_shape'] == (64, 96, 3)
     want0 = (img[..., ::-1].astype(np.float32) - np.array([123.675, 116.28, 103.53], np.float32)) / np.array([58.395, 57.12, 57.375], np.float32)
     assert np.allclose(batch['img'][0].permute(1, 2, 0).numpy(), want0, atol=1e-5)
+
+
+def test_coco_rle_coder():
+    """bonai_amd.rle: cocoapi rleToString / rleFrString restated -- hand-derived strings of the published algorithm (5 data
+    bits per char, 0x20 continuation, 0x10 sign, delta to the count two back from the 4th count on, +48) and round trips."""
+    import numpy as np
+    from bonai_amd import rle as R
+    assert R.counts_to_string([2, 2]) == b'22'
+    assert R.counts_to_string([0, 4]) == b'04'
+    assert R.counts_to_string([1073]) == b'aQ1'                   # 1073 = 17 + 32*(1 + 32*1): 'a' = 48+17+32, 'Q' = 48+1+32, '1'
+    assert R.counts_to_string([3, 1, 1, 1]) == b'3110'            # 4th count stored as 1 - 1 = 0
+    assert R.counts_to_string([5, 2, 3, 1]) == b'523O'            # 1 - 2 = -1 -> 0x1f with sign bit, no continuation: 48 + 31 = 'O'
+    for cs in ([0, 4], [5, 40, 1000, 3], [3, 1, 1, 1, 70000, 2, 1], [1000000, 5, 3, 999999], [1, 1] * 50):
+        assert R.string_to_counts(R.counts_to_string(cs)) == cs
+    rng = np.random.RandomState(0)
+    m = rng.rand(6, 37, 29) > 0.5
+    m[1] = False
+    m[2] = True
+    m[3] = False
+    m[3, 5:20, 3:9] = True
+    enc = R.rle_encode_masks(torch.from_numpy(m), chunk=4)
+    for i, e in enumerate(enc):
+        assert e['size'] == [37, 29] and np.array_equal(R.rle_decode(e), m[i])
+    assert enc[1]['counts'] == b'aQ1' and enc[2]['counts'] == b'0aQ1'
+    assert R.encode_mask_results([[m[0], m[3]], []])[0][1] == enc[3]

@@ -122,3 +122,26 @@ def test_simple_test_fp32_parity_mode_vs_reference_fixture():
     assert epe.max().item() < 1e-2 and epe.mean().item() < 1e-3
     areas = torch.tensor([int(s.sum()) for s in segm_results[0]])[arg]
     assert (areas - torch.from_numpy(gd['mask_area'])).abs().max().item() <= 4
+
+
+def test_simple_test_rle_masks_equal_bitmaps():
+    """test_cfg.rcnn.rle_masks: segm_results as COCO RLE dicts encoded from the device (what encode_mask_results gives the
+    reference's test loop, apis/test.py:59-67) decode to exactly the bool masks of the default path."""
+    from bonai_amd import rle as RL
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import make_batch
+    from oracle.synth_weights import synth_tensor
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    m = m.cuda().eval()
+    data = make_batch(1, 256, 4, device='cuda')
+    with torch.no_grad():
+        _, segm_bitmap, _ = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
+        m.roi_head.test_cfg['rle_masks'] = True
+        _, segm_rle, _ = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
+    assert len(segm_rle[0]) == len(segm_bitmap[0]) > 0
+    for r, b in list(zip(segm_rle[0], segm_bitmap[0]))[:200]:
+        assert r['size'] == [256, 256] and isinstance(r['counts'], bytes)
+        assert np.array_equal(RL.rle_decode(r), b)

@@ -24,11 +24,16 @@ def main():
     ap.add_argument('--out')
     ap.add_argument('--num', type=int, default=4)
     ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--bitmap-masks', action='store_true',
+                    help='return full-image bool masks like simple_test; default: COCO RLE dicts, i.e. what the reference\'s '
+                         'single_gpu_test hands on after encode_mask_results (apis/test.py:59-67), encoded from the device')
     args = ap.parse_args()
     from bonai_amd.config import Config
     from bonai_amd.loft import build_detector
     from bonai_amd.synth import make_batch
     cfg = Config.fromfile(args.config)
+    if not args.bitmap_masks:
+        cfg.test_cfg.rcnn['rle_masks'] = True
     torch.manual_seed(0)
     model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     if args.checkpoint:
@@ -44,7 +49,7 @@ def main():
         results.append(res)
         print(f'[{i + 1}/{args.num}] dets={res[0][0].shape[0]} offsets={res[2].shape if hasattr(res[2], "shape") else 0}', flush=True)
     torch.cuda.synchronize()
-    print(f'{args.num / (time.time() - t0):.2f} img/s (incl. mask paste + host copies)')
+    print(f'{args.num / (time.time() - t0):.2f} img/s (incl. mask paste + result encoding)')
     if args.out:
         with open(args.out, 'wb') as f:
             pickle.dump(results, f)

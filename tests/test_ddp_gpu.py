@@ -1,0 +1,101 @@
+"""GPU, world_size 2: the REAL LOFT training step under data parallelism on the one available GPU.
+
+Both ranks share cuda:0 and talk over gloo (RCCL cannot put two ranks on one device); everything else is the production
+N>1 path: flat arena, kernels depositing gradients straight into it (GRAD_SINK) and releasing buckets, bucketed all-reduce
+on the side stream from autograd hooks, fused log-var all-reduce, clip + SGD with 1/world scaling.  Checks: the ranks see
+different data, finish with bit-identical parameters, the averaged gradient equals the mean of the ranks' local gradients
+(recomputed without the reducer), and the step changes the weights."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from bonai_amd.config import Config
+        from bonai_amd.engine import Trainer
+        from bonai_amd.loft import build_detector
+        from bonai_amd.loft.core import RandomSampler
+        from bonai_amd.synth import make_batch
+        RandomSampler.choice_mode = 'first'
+        cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+
+        def build():
+            torch.manual_seed(0)
+            return build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        data = make_batch(1, 256, 6, rank=rank, device='cuda')
+        # local gradient of this rank, no reducer (plain autograd)
+        ref = build()
+        ref.train_step(data)['loss'].backward()
+        local = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        del ref
+        m = build()
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        tr = Trainer(m, lr=0.01, momentum=0.0, weight_decay=0.0, max_norm=0.0, bucket_bytes=16 << 20)
+        assert tr.reducer.enabled and tr.reducer.on_gpu and len(tr.reducer.buckets) >= 4 and tr.world == 2
+        out = tr.train_step(data)
+        torch.cuda.synchronize()
+        # (1) the summed gradient in the arena equals the sum of both ranks' local gradients
+        names = [n for n, p in m.named_parameters() if p.requires_grad]
+        for n, p in m.named_parameters():
+            if not p.requires_grad:
+                continue
+            mine = local.get(n, torch.zeros_like(p))
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            want = both[0] + both[1]
+            got = p.grad
+            assert (got - want).norm().item() <= 2e-2 * want.norm().item() + 1e-7, (n, (got - want).norm().item(), want.norm().item())
+        # (2) parameters identical on both ranks after the step, and changed
+        for n, p in m.named_parameters():
+            both = [torch.zeros_like(p) for _ in range(world)]
+            dist.all_gather(both, p.detach())
+            assert torch.equal(both[0], both[1]), n
+        moved = sum(float((p.detach() - before[n]).abs().sum()) for n, p in m.named_parameters() if p.requires_grad)
+        assert moved > 0
+        # (3) the logged losses are the mean over ranks (fused all-reduce) -> identical on both ranks
+        lv = torch.tensor([float(v) for v in out['log_vars'].values()], device='cuda')
+        both = [torch.zeros_like(lv) for _ in range(world)]
+        dist.all_gather(both, lv)
+        assert torch.equal(both[0], both[1])
+        q.put((rank, 'ok', len(names)))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_loft_trainer_two_ranks_one_gpu():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg, _ in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'

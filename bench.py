@@ -85,10 +85,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs MI355X GPUs: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    # LOFT_BENCH_SHARED_GPU=1 (tests only): every rank on device 0 over gloo, to exercise this exact launch path on a 1-GPU box
+    shared = os.environ.get('LOFT_BENCH_SHARED_GPU') == '1'
+    torch.cuda.set_device(0 if shared else local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # 'nccl' is RCCL on ROCm
+        dist.init_process_group('gloo' if shared else 'nccl', rank=rank, world_size=world)   # 'nccl' is RCCL on ROCm
     from bonai_amd import kernels as K
     from bonai_amd.config import Config
     from bonai_amd.engine import Trainer, step_lr

@@ -99,3 +99,25 @@ def test_loft_trainer_two_ranks_one_gpu():
         p.join(60)
     for rank, msg, _ in res:
         assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+@pytest.mark.timeout(900)
+def test_bench_launch_contract_two_ranks():
+    """The driver's multi-GPU command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...) end to end with N = 2 ranks sharing the one GPU (gloo instead of RCCL):
+    exactly one JSON line from rank 0, whole-job value, weak scaling fields."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, LOFT_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '2', '--size', '512', '--num-gt', '20']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 2 and j['warmup'] == 1
+    assert j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
+    assert 'roofline' in j and 'cpu_baseline' not in j

@@ -17,6 +17,16 @@ from . import lib as L
 c_int, c_int64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
 
+def h2d(values, dtype, device):
+    """Small host list -> device tensor WITHOUT stalling the host: a pageable-memory H2D copy is stream-ordered and blocks the
+    launching thread until every kernel queued before it has run (an implicit device sync per call -- six per step before);
+    from pinned memory (PyTorch's caching pinned allocator) it is asynchronous."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _nhwc(t):
     if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
         raise L.LoftHipError('expected a 4-D channels_last (NHWC-in-memory) tensor, got strides '
@@ -604,8 +614,7 @@ def mask_target(masks_u8, boxes, gt_idx, S=28):
         H, W = ms[0].shape[1], ms[0].shape[2]
         if any(m.dtype != torch.uint8 or tuple(m.shape[1:]) != (H, W) for m in ms):
             raise L.LoftHipError('mask_target: per-image masks must be uint8 [K,H,W] of one size')
-        addr = torch.tensor([m.data_ptr() + k * H * W for m in ms for k in range(m.shape[0])], dtype=torch.int64).to(
-            boxes.device, non_blocking=True)
+        addr = h2d([m.data_ptr() + k * H * W for m in ms for k in range(m.shape[0])], torch.int64, boxes.device)
         L.check(lib.loft_mask_target(None, H, W, L.ptr(boxes), L.ptr(gt_idx), c_int64(n), S, L.ptr(out), L.ptr(addr), L.stream()),
                 'loft_mask_target')
         out._keep = ms      # the address table points into these tensors

@@ -152,5 +152,5 @@ def pad_gts(gt_bboxes, device):
     for i, g in enumerate(gt_bboxes):
         if g.shape[0]:
             gts[i, :g.shape[0]] = g.to(device=device, dtype=torch.float32)
-    ngt = torch.tensor([int(g.shape[0]) for g in gt_bboxes], dtype=torch.int32, device=device)
+    ngt = K.h2d([int(g.shape[0]) for g in gt_bboxes], torch.int32, device)
     return gts, ngt

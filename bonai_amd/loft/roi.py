@@ -346,7 +346,7 @@ class LoftRoIHead(nn.Module):
             props = torch.zeros(B, P, 5, device=dev)
             for i, p in enumerate(proposal_list):
                 props[i, :p.shape[0], :p.shape[1]] = p
-            nprop = torch.tensor([int(p.shape[0]) for p in proposal_list], device=dev)
+            nprop = K.h2d([int(p.shape[0]) for p in proposal_list], torch.int64, dev)
         else:
             props, nprop = proposal_list
         with torch.no_grad():
@@ -404,7 +404,7 @@ class LoftRoIHead(nn.Module):
                 pb = pos_rois[:, 1:].clone()
                 pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
                 pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
-                gidx = pos_gt_i + torch.tensor(moffs[:-1], device=dev)[pos_b]
+                gidx = pos_gt_i + K.h2d(moffs[:-1], torch.int64, dev)[pos_b]
                 mask_targets = K.mask_target(masks, pb, gidx, int(self.train_cfg.mask_size))
             losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel]))
 

@@ -132,11 +132,14 @@ class RPNHead(nn.Module):
                 cls, reg = self._flatten(fused)
                 vals = torch.cat([torch.gather(cls, 1, sel)[..., None], torch.gather(reg, 1, sel[..., None].expand(-1, -1, 4))], 2)
                 A = self.num_anchors
-                off = torch.tensor(geo['lvl_off'], device=dev)
+                if 'lvl_off_t' not in geo:      # static geometry, uploaded once
+                    geo['lvl_off_t'] = torch.tensor(geo['lvl_off'], device=dev)
+                    geo['lvl_w_t'] = torch.tensor([s[1] for s in geo['sizes']], device=dev)
+                off = geo['lvl_off_t']
                 lvl = torch.bucketize(sel, off[1:], right=True)
                 local = sel - off[lvl]
                 pix, slot = local // A, local % A
-                wl = torch.tensor([s[1] for s in geo['sizes']], device=dev)[lvl]
+                wl = geo['lvl_w_t'][lvl]
                 valid = torch.cat([pval, nval], 1)
                 rows = torch.stack([torch.arange(B, device=dev)[:, None].expand_as(sel), torch.where(valid, lvl, torch.full_like(lvl, -1)),
                                     pix // wl, pix % wl], -1).reshape(-1, 4).int().contiguous()

@@ -57,8 +57,17 @@ def ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+_DEV_INDEX = None
+
+
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's CURRENT stream on this process's device (one device per process: one process per GPU).
+    torch.cuda.current_stream() builds a Stream object through several python layers (~10 us; 900-3000 calls per step);
+    the raw-pointer query is the same information in well under a microsecond and still follows torch.cuda.stream(...)."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
 def dev_check(*tensors):

@@ -9,6 +9,8 @@ frozen-statistics BatchNorm folded into the conv weights each step (tools/fuse_c
 formula, kept differentiable w.r.t. gamma/beta), BN shift + residual add + ReLU applied in the
 conv epilogue, and the stem as one fused kernel.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -101,7 +103,14 @@ class Bottleneck(nn.Module):
         else:
             self.downsample = None
 
+    fused = os.environ.get('LOFT_NO_BLOCK_FUSION') is None     # A/B switch: one autograd node per block (nn.res_block)
+
     def forward(self, x):
+        if self.fused and not isinstance(self.conv2, ModulatedDeformConvPack):
+            main = [(self.conv1.weight, self.bn1, 1, 1, 0, None), (self.conv2.weight, self.bn2, 3, self.stride, 1, None),
+                    (self.conv3.weight, self.bn3, 1, 1, 0, None)]
+            sc = None if self.downsample is None else (self.downsample[0].weight, self.downsample[1], 1, self.stride, 0, None)
+            return F2.res_block(x, main, sc)
         out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, relu=True)
         if isinstance(self.conv2, ModulatedDeformConvPack):
             out = self.conv2(out, bn=self.bn2, relu=True)

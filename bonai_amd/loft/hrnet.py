@@ -54,6 +54,12 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if Bottleneck.fused:     # one autograd node per block: no aten add / separate ReLU-backward per block
+            cp = _p(self.planes)
+            main = [(self.conv1.weight, self.bn1, 3, self.stride, 1, cp), (self.conv2.weight, self.bn2, 3, 1, 1, cp)]
+            ds = self.downsample
+            sc = None if ds is None else (ds[0].weight, ds[1], ds.k, ds.stride, ds.k // 2, _p(ds.cout))
+            return F2.res_block(x, main, sc)
         out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, stride=self.stride, pad=1, relu=True, cout_pad=_p(self.planes))
         identity = x if self.downsample is None else self.downsample(x)
         return F2.conv2d(out, self.conv2.weight, bn=self.bn2, pad=1, relu=True, residual=identity, cout_pad=_p(self.planes))

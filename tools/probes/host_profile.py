@@ -23,4 +23,4 @@ for _ in range(4):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(22); st.sort_stats('cumulative').print_stats('bonai_amd', 30)

@@ -689,8 +689,13 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     const int TNv = narrow ? 64 : (big ? 256 : 128);
     a.ctiles = (Cin + TNv - 1) / TNv;
     const int tiles = ((Cout + TNv - 1) / TNv) * a.ctiles;
-    if (splits <= 0) {  // aim for ~1024 workgroups, at least 4 K-steps each
-        long want = (big ? 512 : 1024) / ((long)tiles * T * groups);
+    if (splits <= 0) {
+        // split-K factor: ~512 workgroups (two resident 128-tile workgroups per CU).  More splits only add fp32 atomic
+        // traffic to dW -- measured on the 1x1 shapes: 1024 workgroups 202-222 TFLOP/s, 512: 279-305, 256: 261-274.
+        static const long tgt_small = getenv("LOFT_WGRAD_TARGET") ? atol(getenv("LOFT_WGRAD_TARGET")) : 512;
+        static const long tgt_big = getenv("LOFT_WGRAD_TARGET_BIG") ? atol(getenv("LOFT_WGRAD_TARGET_BIG")) : 256;   // 256-tile: one workgroup per CU
+        // (big tile, measured: 256 workgroups 708-791 TFLOP/s on the FOA / mask / P2-P3 3x3 shapes, 512: 606-754, 1024: 474-719)
+        long want = (big ? tgt_big : tgt_small) / ((long)tiles * T * groups);
         long maxs = (M + 255) / 256;
         splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
     }

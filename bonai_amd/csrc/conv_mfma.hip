@@ -354,7 +354,9 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     hipStream_t s = (hipStream_t)stream;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
     const bool deepk = (long)T * Cin >= 2048;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
-    if (Cout % 256 == 0 && big_blocks >= 192 && (long)T * Cin >= 512 && !force_small_tile) {
+    static const long big_min = getenv("LOFT_CONV_BIG_MIN") ? atol(getenv("LOFT_CONV_BIG_MIN")) : 192;
+    static const long big_k = getenv("LOFT_CONV_BIG_K") ? atol(getenv("LOFT_CONV_BIG_K")) : 512;
+    if (Cout % 256 == 0 && big_blocks >= big_min && (long)T * Cin >= big_k && !force_small_tile) {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
         // fills the 256 CUs and K is deep enough (>= 8 K-steps) to amortise the one-block-per-CU prologue/epilogue.
         // (Measured and rejected in round 1: staging the bf16 output tile through LDS for 16-byte coalesced stores --
@@ -685,7 +687,8 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;
     // 256x256 tiles only when >= 256 workgroups can each run >= ~32 K-steps (else the 65k-atomic epilogue dominates)
     const bool big = (Cout % 256 == 0) && (Cin % 256 == 0) && !force_small_tile &&
-                     M * (long)(Cout / 256) * (Cin / 256) * T * groups >= 524288L;
+                     M * (long)(Cout / 256) * (Cin / 256) * T * groups >=
+                         (getenv("LOFT_WGRAD_BIG_MIN") ? atol(getenv("LOFT_WGRAD_BIG_MIN")) : 524288L);
     const int TNv = narrow ? 64 : (big ? 256 : 128);
     a.ctiles = (Cin + TNv - 1) / TNv;
     const int tiles = ((Cout + TNv - 1) / TNv) * a.ctiles;

@@ -353,7 +353,9 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
-    const bool deepk = (long)T * Cin >= 2048;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
+    static const long deepk_min = getenv("LOFT_CONV_DEEPK") ? atol(getenv("LOFT_CONV_DEEPK")) : 2048;
+    static const long single_max = getenv("LOFT_CONV_SINGLE") ? atol(getenv("LOFT_CONV_SINGLE")) : 128;
+    const bool deepk = (long)T * Cin >= deepk_min;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
     static const long big_min = getenv("LOFT_CONV_BIG_MIN") ? atol(getenv("LOFT_CONV_BIG_MIN")) : 192;
     static const long big_k = getenv("LOFT_CONV_BIG_K") ? atol(getenv("LOFT_CONV_BIG_K")) : 512;
     if (Cout % 256 == 0 && big_blocks >= big_min && (long)T * Cin >= big_k && !force_small_tile) {
@@ -374,7 +376,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
-        if ((long)T * Cin <= 128 && !force_small_tile)
+        if ((long)T * Cin <= single_max && !force_small_tile)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
         else if (deepk)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 2, true>), grid, dim3(256), 0, s, a);

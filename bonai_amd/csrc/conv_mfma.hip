@@ -74,9 +74,13 @@ __device__ __forceinline__ int xcd_remap(int L, int N) {
 }
 
 // Shared epilogue of the tap-conv kernels: bias (= folded BN shift) + residual + ReLU + ReLU-backward mask + bf16/fp32 store.
+// res_t / mask_t (optional): the 128x128 bf16 tiles of a.residual / a.mask staged in LDS by conv_stage_tile() with coalesced
+// 16-byte global->LDS copies (row r, logical 16-byte chunk c at r*256 + ((c ^ (r & 15)) * 16)); the per-lane 8-byte reads then
+// hit LDS instead of scattering 8-byte loads over 32 different 64-byte sectors of HBM/L2 per instruction.
 template <int NT, int MT, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], int g, int m0, int n0, int wm, int wn,
-                                              int frow, int fq, int ohw) {
+                                              int frow, int fq, int ohw, const char* res_t = nullptr,
+                                              const char* mask_t = nullptr) {
     // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
     // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
     //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
@@ -104,9 +108,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
                 const long o = out_g + opix * a.Cout + n;
+                const int trow = wm * WM + j * 32 + frow;                      // position inside a staged 128x128 tile
+                const int tcol = (((wn * WN + i * 32 + 8 * gq) >> 3) ^ (trow & 15)) * 16 + 8 * fq;
                 if (a.residual) {
                     float rv[4];
-                    ld4(a.residual + o, rv);
+                    if (res_t) ld4(reinterpret_cast<const bf16_t*>(res_t + trow * 256 + tcol), rv);
+                    else ld4(a.residual + o, rv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rv[e];
                 }
@@ -116,7 +123,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                 }
                 if (a.mask) {
                     float mv[4];
-                    ld4(a.mask + o, mv);
+                    if (mask_t) ld4(reinterpret_cast<const bf16_t*>(mask_t + trow * 256 + tcol), mv);
+                    else ld4(a.mask + o, mv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
                 }
@@ -134,6 +142,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                 }
             }
         }
+    }
+}
+
+// Coalesced copy of the [128 pixels][128 channels] bf16 tile of an output-shaped tensor (dense placement: pixel index == m)
+// into LDS, 4 waves, swizzled as conv_epilogue expects.
+__device__ __forceinline__ void conv_stage_tile(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int wave, int lane,
+                                                char* dst) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 16 + wave * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ (row & 15);
+        const int m = m0 + row, n = n0 + lc * 8;
+        const bf16_t* p = (m < a.M && n < a.Cout) ? t + out_g + (long)m * a.Cout + n : a.zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(dst + (it * 16 + wave * 4) * 256), 16, 0, 0);
     }
 }
 
@@ -326,6 +348,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
         }
     }
 
+    if constexpr (BM == 128 && BN == 128 && STAGES == 2) {
+        // memory-bound launches (residual add of a bottleneck's conv3, shortcut + ReLU mask of a fused block's first dgrad):
+        // bring the residual / mask tiles in through the (now idle) stage buffers with coalesced copies
+        const bool dense = a.os == 1 && a.OHf == a.OH && a.OWf == a.OW && !a.out_f32;
+        if (dense && (a.residual || a.mask)) {
+            __syncthreads();                                    // all fragment reads of the last K-step are done
+            const long out_g = (long)g * a.out_gs;
+            char* rt = lds;
+            char* mt = lds + 32768;
+            if (a.residual) conv_stage_tile(a, a.residual, out_g, m0, n0, wave, lane, rt);
+            if (a.mask) conv_stage_tile(a, a.mask, out_g, m0, n0, wave, lane, mt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw, a.residual ? rt : nullptr,
+                                          a.mask ? mt : nullptr);
+            return;
+        }
+    }
     conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw);
 }
 
@@ -376,7 +416,8 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
-        if ((long)T * Cin <= single_max && !force_small_tile)
+        const bool staged_epi = (residual || relu_mask) && !out_f32 && os == 1 && OHf == OH && OWf == OW;
+        if ((long)T * Cin <= single_max && !force_small_tile && !staged_epi)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
         else if (deepk)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 2, true>), grid, dim3(256), 0, s, a);

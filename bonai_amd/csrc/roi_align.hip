@@ -173,10 +173,12 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
     return w;
 }
 
-template <typename T>
+// GT: type of the gradient map (fp32, or bf16 written directly: every pixel is written exactly once from fp32 registers, so
+// no fp32 staging map + cast pass is needed when the features are bf16)
+template <typename T, typename GT>
 __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, int level, const float* __restrict__ rois,
                                                                  int K, int C, int P, int n_rot,
-                                                                 const T* __restrict__ gout, float* __restrict__ grad,
+                                                                 const T* __restrict__ gout, GT* __restrict__ grad,
                                                                  int accumulate, const int4* __restrict__ rec, int sorted) {
     __shared__ int list[RB_LIST];
     __shared__ int wcnt[4];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, in
             for (int i = 0; i < 16; ++i) {
                 const int y = ty0 + 2 * wave + (i >> 3), x = tx0 + (i & 7);
                 if (y >= H || x >= W) continue;
-                float* gp = grad + (((size_t)b * H + y) * W + x) * C + c0;
+                GT* gp = grad + (((size_t)b * H + y) * W + x) * C + c0;
                 float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
                 if (accumulate) {
                     float o[4];
@@ -327,12 +329,13 @@ LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const
     return 0;
 }
 
-LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const int* W, const float* scales,
+LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const int* W, const float* scales,
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
                                    int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
-                                   void* workspace, void* stream) {
+                                   void* workspace, int grad_dtype, void* stream) {
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || P > RB_MAXP)
         return (int)hipErrorInvalidValue;
+    if (grad_dtype != LOFT_F32 && !(grad_dtype == LOFT_BF16 && dtype == LOFT_BF16)) return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(nullptr, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
     int4* rec = (int4*)workspace;
@@ -342,12 +345,15 @@ LOFT_EXPORT int loft_roi_align_bwd(float* const* grad_feats, const int* H, const
     }
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
-        if (dtype == LOFT_BF16)
-            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<bf16_t>, grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
-                               (const bf16_t*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
+        if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16)
+            hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
+                               (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
+        else if (dtype == LOFT_BF16)
+            hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, float>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
+                               (const bf16_t*)grad_out, (float*)grad_feats[l], accumulate, rec, rois_sorted);
         else if (dtype == LOFT_F32)
-            hipLaunchKernelGGL(roi_align_bwd_tile_kernel<float>, grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
-                               (const float*)grad_out, grad_feats[l], accumulate, rec, rois_sorted);
+            hipLaunchKernelGGL((roi_align_bwd_tile_kernel<float, float>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
+                               (const float*)grad_out, (float*)grad_feats[l], accumulate, rec, rois_sorted);
         else
             return (int)hipErrorInvalidValue;
         LOFT_LAUNCH_CHECK();

@@ -68,8 +68,8 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
 
 
 def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_rot=1, grad_feats=None,
-                  rois_sorted=False):
-    """Accumulates into fp32 NHWC buffers (created zeroed when not supplied) and returns them."""
+                  rois_sorted=False, out_dtype=torch.float32):
+    """Writes (or, with grad_feats supplied, accumulates into) NHWC gradient maps of out_dtype and returns them."""
     lib = L.load()
     L.dev_check(grad_out, rois)
     grad_out = _nhwc(grad_out)
@@ -78,7 +78,7 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     accumulate = grad_feats is not None
     if grad_feats is None:
         mk = zeros_nhwc if K == 0 else empty_nhwc
-        grad_feats = [mk(s[0], s[1], s[2], s[3], torch.float32, rois.device) for s in feat_shapes]
+        grad_feats = [mk(s[0], s[1], s[2], s[3], out_dtype, rois.device) for s in feat_shapes]
     if K == 0:
         return grad_feats
     H = L.arr(c_int, [s[2] for s in feat_shapes])
@@ -88,7 +88,7 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     ws = torch.empty(16 * K, dtype=torch.uint8, device=rois.device)
     L.check(lib.loft_roi_align_bwd(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
                                    L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
-                                   int(accumulate), int(rois_sorted), L.ptr(ws), L.stream()),
+                                   int(accumulate), int(rois_sorted), L.ptr(ws), L.dtype_code(grad_feats[0]), L.stream()),
             'loft_roi_align_bwd')
     return grad_feats
 
@@ -105,7 +105,8 @@ class _RoIAlign(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         P, strides, fs, n_rot, shapes, dt = ctx.meta
         g = g.contiguous(memory_format=torch.channels_last)
-        grads = roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot)
+        grads = roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot,
+                              out_dtype=dt if (dt == torch.bfloat16 and g.dtype == torch.bfloat16) else torch.float32)
         return (None, None, None, None, None) + tuple(x.to(dt) for x in grads)
 
 

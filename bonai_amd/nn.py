@@ -9,6 +9,8 @@ fp32 parity mode: when the activation handed to conv2d / narrow_head / deconv2x2
 forward-only on the fp32 MFMA kernel (loft_conv_tap_f32) with fp32 operand packings -- used to compare inference results
 with the fp32 reference at 1e-3; the backward of these functions refuses fp32 activations.
 """
+import os as _os
+
 import torch
 
 from . import kernels as K
@@ -355,8 +357,11 @@ class _RoIAlignFn(torch.autograd.Function):
     def backward(ctx, g):
         (rois,) = ctx.saved_tensors
         P, strides, fs, n_rot, shapes, dt = ctx.meta
-        grads = K.roi_align_bwd(to_nhwc(g), rois, shapes, P, strides, fs, n_rot, rois_sorted=True)  # bbox2roi order
-        return (None, None, None, None, None) + tuple(K.cast_bf16(x) if dt == torch.bfloat16 else x for x in grads)
+        g = to_nhwc(g)
+        direct = dt == torch.bfloat16 and g.dtype == torch.bfloat16 and not _os.environ.get('LOFT_ROI_FP32_BWD')   # bf16 maps straight from fp32 registers
+        grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True,       # (rois in bbox2roi order)
+                                out_dtype=torch.bfloat16 if direct else torch.float32)
+        return (None, None, None, None, None) + tuple(x if x.dtype == dt else K.cast_bf16(x) for x in grads)
 
 
 def roi_align(feats, rois, P, strides, finest_scale=56, n_rot=1):

@@ -40,14 +40,15 @@ extern "C" {
  * bwd: grad_out has the layout of out; grad_feats[l] are fp32 NHWC maps [B,H[l],W[l],C], every pixel
  * of which is written (accumulate=0) or added to (accumulate=1) exactly once -- no atomics reach HBM.
  * rois_sorted=1 promises the RoIs are ordered by batch index (bbox2roi order) so each tile scans only its
- * image's RoIs; workspace: 16*K bytes.  H/W/scales are HOST arrays of num_levels entries. */
+ * image's RoIs; workspace: 16*K bytes.  H/W/scales are HOST arrays of num_levels entries.  grad_dtype: LOFT_F32, or LOFT_BF16 (only with dtype ==
+ * LOFT_BF16): the gradient maps are written directly in bf16 (each pixel exactly once from fp32 registers). */
 int loft_roi_align_fwd(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                        int n_rot, void* out, void* stream);
-int loft_roi_align_bwd(float* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
+int loft_roi_align_bwd(void* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                        int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,
-                       void* stream);
+                       int grad_dtype, void* stream);
 /* map_roi_levels alone (single_level_roi_extractor.py:32-51) -> int32 [K]. */
 int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out, void* stream);
 

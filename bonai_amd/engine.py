@@ -162,10 +162,13 @@ class Trainer:
         out = self.model.train_step(data)
         from . import nn as F2
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
+        if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
+            K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
         try:
             (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
         finally:
             F2.GRAD_SINK = prev
+            K.zero_pool_end()
         self.reducer.finish()
         self.gnorm_sq.zero_()
         K.sumsq_(self.arena.grad, self.gnorm_sq)

@@ -27,6 +27,46 @@ def h2d(values, dtype, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+class _ZeroPool:
+    """One zeroed fp32 slab per training step for the many small accumulation buffers of the backward (every weight-gradient
+    launch accumulates into a zeroed [taps, Cout, Cin] buffer with atomics: ~190 separate fill launches per step otherwise).
+    The trainer calls zero_pool_begin() at the start of a step: ONE memset of the slab; pooled_zeros() then hands out views.
+    The slab is sized from the previous step's requests; anything that does not fit falls back to torch.zeros."""
+    buf = None
+    off = 0
+    need = 0
+    active = False
+
+
+def zero_pool_begin(device):
+    zp = _ZeroPool
+    if zp.buf is None or zp.need > zp.buf.numel() or zp.buf.device != torch.device(device):
+        if zp.need > 0:
+            zp.buf = torch.empty(int(zp.need * 1.05) + 1024, dtype=torch.float32, device=device)
+    if zp.buf is not None:
+        zp.buf.zero_()
+    zp.off, zp.need, zp.active = 0, 0, zp.buf is not None
+
+
+def zero_pool_end():
+    _ZeroPool.active = False
+
+
+def pooled_zeros(shape, device):
+    """fp32 zeros of `shape`: a view of the step's pre-zeroed slab when the trainer opened one, else torch.zeros."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    n64 = (n + 63) // 64 * 64
+    zp = _ZeroPool
+    zp.need += n64
+    if zp.active and zp.buf.device == torch.device(device) and zp.off + n64 <= zp.buf.numel():
+        v = zp.buf[zp.off:zp.off + n].view(*shape)
+        zp.off += n64
+        return v
+    return torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
 def _nhwc(t):
     if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
         raise L.LoftHipError('expected a 4-D channels_last (NHWC-in-memory) tensor, got strides '
@@ -346,7 +386,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     L.dev_check(g, x)
     _bf16(g), _bf16(x)
     if dw is None:
-        dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
+        dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
     A = lambda i: L.arr(c_int, [t[i] for t in taps])
     _ev = _prof_begin()
     L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
@@ -370,7 +410,7 @@ def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0, with_bias=Fals
         centre = [i for i, t in enumerate(taps) if t[2] == 0 and t[3] == 0]
         if not centre:
             raise L.LoftHipError('fused bias gradient needs a tap with zero offset')
-        db, db_tap = torch.zeros(groups, Cout, dtype=torch.float32, device=g.device), centre[0]
+        db, db_tap = pooled_zeros((groups, Cout), g.device), centre[0]
     dw = conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
                     g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits, db=db, db_tap=db_tap)
     return (dw, db) if with_bias else dw

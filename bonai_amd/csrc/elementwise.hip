@@ -475,6 +475,63 @@ LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const flo
     return 0;
 }
 
+// Batched form: ONE launch packs every registered conv of the model (the trainer knows the full list after the first step;
+// weights only change in the SGD kernel, so all packings of a step can be produced up front).  desc: n records of 16 int64
+// {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_chunk};
+// the work is cut into chunks of FOLD_CHUNK packed elements, chunk c belongs to the record with the largest first_chunk <= c.
+constexpr int FOLD_CHUNK = 2048;
+__global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __restrict__ desc, int n, long nchunks) {
+    for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        int lo = 0, hi = n - 1;                                  // binary search once per chunk (block-uniform)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (desc[(long)mid * 16 + 15] <= c) lo = mid; else hi = mid - 1;
+        }
+        const long* d = desc + (long)lo * 16;
+        const float* w = reinterpret_cast<const float*>(d[0]);
+        const float* cbias = reinterpret_cast<const float*>(d[1]);
+        const float* gamma = reinterpret_cast<const float*>(d[2]);
+        const float* beta = reinterpret_cast<const float*>(d[3]);
+        const float* mean = reinterpret_cast<const float*>(d[4]);
+        const float* var = reinterpret_cast<const float*>(d[5]);
+        bf16_t* wp = reinterpret_cast<bf16_t*>(d[6]);
+        bf16_t* wpt = reinterpret_cast<bf16_t*>(d[7]);
+        float* bias_out = reinterpret_cast<float*>(d[8]);
+        const float eps = __int_as_float((int)d[9]);
+        const int Cout = (int)d[10], Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
+        const long local_chunk = c - d[15];
+        const long total = (long)CoutP * CinP * RS;
+        const long i0 = local_chunk * FOLD_CHUNK;
+        for (long i = i0 + threadIdx.x; i < i0 + FOLD_CHUNK && i < total; i += blockDim.x) {
+            const int cc = (int)(i % CinP);
+            const long r = i / CinP;
+            const int nn = (int)(r % CoutP), t = (int)(r / CoutP);
+            float v = 0.f;
+            if (nn < Cout && cc < Cin) {
+                v = w[((long)nn * Cin + cc) * RS + t];
+                if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+            }
+            const bf16_t h = f32_to_bf16(v);
+            if (wp) wp[i] = h;
+            if (wpt) wpt[((long)t * CinP + cc) * CoutP + nn] = h;
+        }
+        if (local_chunk == 0 && bias_out)
+            for (int nn = threadIdx.x; nn < CoutP; nn += blockDim.x) {
+                if (nn >= Cout) bias_out[nn] = 0.f;
+                else if (gamma) bias_out[nn] = beta[nn] - mean[nn] * gamma[nn] * rsqrtf(var[nn] + eps);
+                else bias_out[nn] = cbias ? cbias[nn] : 0.f;
+            }
+    }
+}
+LOFT_EXPORT int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream) {
+    if (n <= 0 || nchunks <= 0) return 0;
+    long blocks = nchunks < 16384 ? nchunks : 16384;
+    hipLaunchKernelGGL(fold_pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const long*)desc, n,
+                       (long)nchunks);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // one block per output channel n
 __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ db,
                                                               const float* __restrict__ w, const float* __restrict__ gamma,

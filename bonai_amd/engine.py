@@ -148,6 +148,7 @@ class Trainer:
         self.world = dist.get_world_size() if self.reducer.enabled else 1
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=self.arena.data.device)
         self.iter = 0
+        self.prepack = K.PrepackRegistry()
         # kernels accumulate weight / BN gradients straight into the arena slots (bonai_amd.nn.GRAD_SINK); the callback
         # replaces the post-accumulate-grad hook for those parameters
         self._sink = self.reducer._hook if self.reducer.enabled else (lambda p: None)
@@ -159,8 +160,15 @@ class Trainer:
         self.reducer.begin()
         for p in self.arena.params:
             p._loft_pending = 0
-        out = self.model.train_step(data)
         from . import nn as F2
+        prev_pp = F2.PREPACK
+        if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_PREPACK'):
+            F2.PREPACK = self.prepack
+            self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
+        try:
+            out = self.model.train_step(data)
+        finally:
+            F2.PREPACK = prev_pp
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers

@@ -922,6 +922,70 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
     return wp, wpt, bias
 
 
+FOLD_CHUNK = 2048
+
+
+class PrepackRegistry:
+    """All BN-fold + operand-packing jobs of a model as ONE launch per step (loft_fold_pack_multi).
+
+    Jobs register themselves the first time a conv runs under the trainer (request()); from the next step on the trainer calls
+    run() once at the start of the step -- the weights only change in the SGD kernel -- and request() just returns the buffers.
+    Keys are the parameter storage addresses (stable: parameters live in the trainer's flat arena)."""
+
+    def __init__(self):
+        self.jobs, self.order = {}, []
+        self.desc = None
+        self.nchunks = 0
+        self.step = -1
+
+    def request(self, w, conv_bias, bn, eps, cout_p, cin_p, want_dgrad):
+        """-> (wp [T,CoutP,CinP], wpt | None, bias [CoutP]) bf16 packings valid for the current step."""
+        key = (w.data_ptr(), 0 if conv_bias is None else conv_bias.data_ptr(),
+               0 if bn is None else (bn[0].data_ptr(), bn[2].data_ptr()), cout_p, cin_p, bool(want_dgrad))
+        job = self.jobs.get(key)
+        if job is None:
+            Cout, Cin, R, S = w.shape
+            dev = w.device
+            job = dict(w=w, cb=conv_bias, bn=bn, eps=float(eps), dims=(Cout, Cin, R * S, cout_p, cin_p),
+                       wp=torch.empty(R * S, cout_p, cin_p, dtype=torch.bfloat16, device=dev),
+                       wpt=torch.empty(R * S, cin_p, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
+                       bias=torch.empty(cout_p, dtype=torch.float32, device=dev), step=-2)
+            self.jobs[key] = job
+            self.order.append(key)
+            self.desc = None
+        if job['step'] != self.step:          # registered after this step's batched launch (first step): pack it now
+            fold_pack(job['w'], job['cb'], job['bn'], job['eps'], want_dgrad=job['wpt'] is not None, out_fwd=job['wp'],
+                      out_dgrad=job['wpt'], out_bias=job['bias'], cout_pad=job['dims'][3], cin_pad=job['dims'][4])
+            job['step'] = self.step
+        return job['wp'], job['wpt'], job['bias']
+
+    def run(self, step):
+        """One launch for every registered job; afterwards request() is a dictionary lookup."""
+        self.step = step
+        if not self.order:
+            return
+        lib = L.load()
+        if self.desc is None:
+            import struct
+            rows, chunk = [], 0
+            for key in self.order:
+                j = self.jobs[key]
+                Cout, Cin, RS, CoutP, CinP = j['dims']
+                bn = j['bn']
+                p = lambda t: 0 if t is None else t.data_ptr()
+                eps_bits = struct.unpack('<i', struct.pack('<f', j['eps']))[0]
+                rows.append([p(j['w']), p(j['cb']), p(bn[0]) if bn else 0, p(bn[1]) if bn else 0, p(bn[2]) if bn else 0,
+                             p(bn[3]) if bn else 0, p(j['wp']), p(j['wpt']), p(j['bias']), eps_bits, Cout, Cin, RS, CoutP, CinP, chunk])
+                chunk += (CoutP * CinP * RS + FOLD_CHUNK - 1) // FOLD_CHUNK
+            self.nchunks = chunk
+            dev = self.jobs[self.order[0]]['w'].device
+            self.desc = h2d(rows, torch.int64, dev)
+        L.check(lib.loft_fold_pack_multi(L.ptr(self.desc), len(self.order), c_int64(self.nchunks), L.stream()), 'loft_fold_pack_multi')
+        for key in self.order:
+            self.jobs[key]['step'] = step
+
+
+
 def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True, out=None):
     """dwp fp32 [T,CoutP,CinP], db fp32 [CoutP] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None).
     out = (dw, dgamma, dbeta) existing fp32 contiguous tensors (e.g. slots of a flat gradient arena): ACCUMULATE into them."""

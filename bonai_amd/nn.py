@@ -43,6 +43,7 @@ def _sink_done(p):
         GRAD_SINK(p)
 
 
+PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
 _PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
 
 
@@ -74,6 +75,11 @@ class _ConvFn(torch.autograd.Function):
                 key += tuple((t.data_ptr(), t._version) for t in bn_stats[:2])
         if key is not None and key in _PACK_CACHE:
             wp, wpt, bias = _PACK_CACHE[key]
+        elif PREPACK is not None and key is None and G == 1 and pdt == torch.bfloat16 and isinstance(ws[0], torch.nn.Parameter):
+            bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
+            wp, wpt, bias = PREPACK.request(ws[0], bs[0], bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
+                                            ctx.needs_input_grad[0])
+            wp, wpt, bias = wp[None], None if wpt is None else wpt[None], bias[None]
         else:
             wp = torch.empty(G, T, Cout, Cin, dtype=pdt, device=dev)
             need_dgrad = ctx.needs_input_grad[0]
@@ -590,6 +596,9 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
             tuple((t.data_ptr(), t._version) for t in stats)
         if key in _PACK_CACHE:
             return _PACK_CACHE[key]
+    if PREPACK is not None and key is None and pdt == torch.bfloat16 and isinstance(w, torch.nn.Parameter):
+        out = PREPACK.request(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
+        return out[0][None], None if out[1] is None else out[1][None], out[2][None]
     out = K.fold_pack(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, want_fwd=True, want_dgrad=need_dgrad, dtype=pdt,
                       cout_pad=cout_p, cin_pad=cin_p)
     out = (out[0][None], None if out[1] is None else out[1][None], out[2][None])

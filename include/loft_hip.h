@@ -282,6 +282,10 @@ int64_t loft_mdcn_bwd_workspace_bytes(int B, int C, int OH, int OW, int kh, int 
 int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, int Cout, int Cin, int RS, void* wp_fwd, void* wp_dgrad, float* bias_out,
                    int pack_f32, int CoutP, int CinP, void* stream);
+/* loft_fold_pack_multi: the bf16 packings of MANY convs in one launch.  desc (device): n records of 16 int64 {w, conv_bias,
+ * gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out (device addresses, 0 = absent), eps as float bits, Cout, Cin, RS, CoutP,
+ * CinP, first_chunk}; record i covers chunks [first_chunk_i, first_chunk_{i+1}) of 2048 packed elements; nchunks = their total. */
+int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
                          int CoutP, int CinP, int accumulate, void* stream);

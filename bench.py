@@ -78,6 +78,48 @@ def cpu_baseline(size, num_gt):
                        f'the CPU oracle (fp32, {cores} threads of {os.cpu_count()} host cores), {dt:.1f} s')
 
 
+def offset_epe_vs_ref():
+    """BASELINE.json's second metric, 'offset EPE vs ref' (EPE = sqrt(dx^2 + dy^2), tools/bonai/bonai_evaluation.py:276): the
+    offsets of ``simple_test`` on the committed fixture tests/golden/e2e_test_256.npz (outputs of the reference's own python
+    for a seeded 256 px tile and name-seeded weights) against ours -- the checker leg, rank 0 at N=1 only, after the timed
+    region.  fp32 parity mode: every reference detection paired with ours by score (order-insensitive); bf16 (the training
+    dtype): the reference's 100 best detections paired by box IoU > 0.7."""
+    import numpy as np
+    from bonai_amd.config import Config
+    from bonai_amd.evaluation import offset_error_vector
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import make_batch
+    from oracle import ops_ref as R
+    from oracle.synth_weights import synth_tensor
+    gd = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_test_256.npz'))
+    size = int(gd['meta'][0])
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    m = m.cuda().eval()
+    data = make_batch(1, size, 4, device='cuda')
+    want, off_ref = torch.from_numpy(gd['det']), torch.from_numpy(gd['offsets'])
+    out = dict(fixture='tests/golden/e2e_test_256.npz', unit='px')
+    for mode, dt in (('fp32_parity', torch.float32), ('bf16', torch.bfloat16)):
+        m.backbone.compute_dtype = dt
+        with torch.no_grad():
+            bbox_results, _, offs = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
+        det, offs = torch.from_numpy(bbox_results[0]), torch.from_numpy(offs)
+        if dt == torch.float32 and det.shape == want.shape:
+            dbox = (want[:, None, :4] - det[None, :, :4]).abs().amax(-1)
+            dbox = torch.where((want[:, None, 4] - det[None, :, 4]).abs() < 1e-4, dbox, torch.full_like(dbox, 1e9))
+            arg = dbox.min(1)[1]
+            ev = offset_error_vector(off_ref.numpy(), offs[arg].numpy())
+            n = int(want.shape[0])
+        else:
+            best, arg = R.bbox_overlaps(want[:100, :4], det[:, :4]).max(dim=1)
+            ok = best > 0.7
+            ev = offset_error_vector(off_ref[:100][ok].numpy(), offs[arg[ok]].numpy())
+            n = int(ok.sum())
+        out[mode] = dict(aEPE=round(float(ev['aEPE']), 6), max_EPE=round(float(ev['max_EPE']), 6), pairs=n)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,6 +228,10 @@ def main():
                    roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.size, args.num_gt)
+            if headline:
+                del trainer, model
+                torch.cuda.empty_cache()
+                res['offset_epe_vs_ref'] = offset_epe_vs_ref()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -478,9 +478,16 @@ LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const flo
 // Batched form: ONE launch packs every registered conv of the model (the trainer knows the full list after the first step;
 // weights only change in the SGD kernel, so all packings of a step can be produced up front).  desc: n records of 16 int64
 // {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_chunk};
-// the work is cut into chunks of FOLD_CHUNK packed elements, chunk c belongs to the record with the largest first_chunk <= c.
+// chunk c belongs to the record with the largest first_chunk <= c.  A chunk is one [NT output channels] x [64 input channels]
+// tile with all RS taps (NT = 64 for RS == 1, else 16; RS <= FOLD_TILE_MAX_RS): the fp32 source rows are read coalesced
+// (64*RS contiguous floats per output channel) into LDS, then written out as 128-byte runs of wp_fwd [T][CoutP][CinP] and
+// 2*NT-byte runs of wp_dgrad [T][CinP][CoutP] -- the per-element form of loft_fold_pack scatters 2-byte stores for the
+// transposed packing.  Records with more taps use chunks of FOLD_CHUNK elements of the per-element form.
 constexpr int FOLD_CHUNK = 2048;
+constexpr int FOLD_TILE_MAX_RS = 9;
+constexpr int FOLD_TILE_FLOATS = 16 * (64 * FOLD_TILE_MAX_RS + 1);      // >= 64 * 65 (the RS == 1 tile)
 __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __restrict__ desc, int n, long nchunks) {
+    __shared__ float tile[FOLD_TILE_FLOATS];
     for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
         int lo = 0, hi = n - 1;                                  // binary search once per chunk (block-uniform)
         while (lo < hi) {
@@ -499,28 +506,69 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
         float* bias_out = reinterpret_cast<float*>(d[8]);
         const float eps = __int_as_float((int)d[9]);
         const int Cout = (int)d[10], Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
-        const long local_chunk = c - d[15];
-        const long total = (long)CoutP * CinP * RS;
-        const long i0 = local_chunk * FOLD_CHUNK;
-        for (long i = i0 + threadIdx.x; i < i0 + FOLD_CHUNK && i < total; i += blockDim.x) {
-            const int cc = (int)(i % CinP);
-            const long r = i / CinP;
-            const int nn = (int)(r % CoutP), t = (int)(r / CoutP);
-            float v = 0.f;
-            if (nn < Cout && cc < Cin) {
-                v = w[((long)nn * Cin + cc) * RS + t];
-                if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
-            }
-            const bf16_t h = f32_to_bf16(v);
-            if (wp) wp[i] = h;
-            if (wpt) wpt[((long)t * CinP + cc) * CoutP + nn] = h;
-        }
+        const int local_chunk = (int)(c - d[15]);
         if (local_chunk == 0 && bias_out)
             for (int nn = threadIdx.x; nn < CoutP; nn += blockDim.x) {
                 if (nn >= Cout) bias_out[nn] = 0.f;
                 else if (gamma) bias_out[nn] = beta[nn] - mean[nn] * gamma[nn] * rsqrtf(var[nn] + eps);
                 else bias_out[nn] = cbias ? cbias[nn] : 0.f;
             }
+        if (RS > FOLD_TILE_MAX_RS) {                             // per-element form
+            const long total = (long)CoutP * CinP * RS;
+            const long i0 = (long)local_chunk * FOLD_CHUNK;
+            for (long i = i0 + threadIdx.x; i < i0 + FOLD_CHUNK && i < total; i += blockDim.x) {
+                const int cc = (int)(i % CinP);
+                const long r = i / CinP;
+                const int nn = (int)(r % CoutP), t = (int)(r / CoutP);
+                float v = 0.f;
+                if (nn < Cout && cc < Cin) {
+                    v = w[((long)nn * Cin + cc) * RS + t];
+                    if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+                }
+                const bf16_t h = f32_to_bf16(v);
+                if (wp) wp[i] = h;
+                if (wpt) wpt[((long)t * CinP + cc) * CoutP + nn] = h;
+            }
+            continue;
+        }
+        const int NT = RS == 1 ? 64 : 16;
+        const int tc = (CinP + 63) >> 6;
+        const int n0 = (local_chunk / tc) * NT, c0 = (local_chunk % tc) * 64;
+        const int span = 64 * RS, ldw = span + 1;
+        __syncthreads();                                         // the previous chunk's readers are done with the tile
+        for (int i = threadIdx.x; i < NT * span; i += 256) {
+            const int row = i / span, off = i - row * span;
+            const int nn = n0 + row, cc = c0 + off / RS;
+            float v = 0.f;
+            if (nn < Cout && cc < Cin) {
+                v = w[((long)nn * Cin + c0) * RS + off];
+                if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+            }
+            tile[row * ldw + off] = v;
+        }
+        __syncthreads();
+        if (wp)                                                  // [t][nn][cc pair]: 32 lanes = one 128-byte run
+            for (int i = threadIdx.x; i < RS * NT * 32; i += 256) {
+                const int cp = i & 31, row = (i >> 5) % NT, t = (i >> 5) / NT;
+                const int nn = n0 + row, cc = c0 + 2 * cp;
+                if (nn < CoutP && cc < CinP) {
+                    const float* tp = tile + row * ldw + 2 * cp * RS + t;
+                    const uint32_t pk = (uint32_t)f32_to_bf16(tp[0]) | ((uint32_t)f32_to_bf16(tp[RS]) << 16);
+                    *reinterpret_cast<uint32_t*>(wp + ((long)t * CoutP + nn) * CinP + cc) = pk;
+                }
+            }
+        if (wpt) {                                               // [t][cc][nn pair]: NT/2 lanes = one 2*NT-byte run
+            const int hp = NT >> 1;
+            for (int i = threadIdx.x; i < RS * 64 * hp; i += 256) {
+                const int np = i % hp, ccl = (i / hp) & 63, t = i / (hp * 64);
+                const int nn = n0 + 2 * np, cc = c0 + ccl;
+                if (nn < CoutP && cc < CinP) {
+                    const float* tp = tile + 2 * np * ldw + ccl * RS + t;
+                    const uint32_t pk = (uint32_t)f32_to_bf16(tp[0]) | ((uint32_t)f32_to_bf16(tp[ldw]) << 16);
+                    *reinterpret_cast<uint32_t*>(wpt + ((long)t * CinP + cc) * CoutP + nn) = pk;
+                }
+            }
+        }
     }
 }
 LOFT_EXPORT int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream) {

@@ -923,6 +923,7 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
 
 
 FOLD_CHUNK = 2048
+FOLD_TILE_MAX_RS = 9        # mirrors elementwise.hip
 
 
 class PrepackRegistry:
@@ -938,26 +939,31 @@ class PrepackRegistry:
         self.nchunks = 0
         self.step = -1
 
-    def request(self, w, conv_bias, bn, eps, cout_p, cin_p, want_dgrad):
-        """-> (wp [T,CoutP,CinP], wpt | None, bias [CoutP]) bf16 packings valid for the current step."""
-        key = (w.data_ptr(), 0 if conv_bias is None else conv_bias.data_ptr(),
+    def request(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad):
+        """ws / conv_biases: the G parameters of a grouped launch (G = 1 for a plain conv).
+        -> (wp [G,T,CoutP,CinP], wpt [G,T,CinP,CoutP] | None, bias [G,CoutP]) bf16 packings valid for the current step."""
+        key = (tuple(w.data_ptr() for w in ws), tuple(0 if b is None else b.data_ptr() for b in conv_biases),
                0 if bn is None else (bn[0].data_ptr(), bn[2].data_ptr()), cout_p, cin_p, bool(want_dgrad))
-        job = self.jobs.get(key)
-        if job is None:
-            Cout, Cin, R, S = w.shape
-            dev = w.device
-            job = dict(w=w, cb=conv_bias, bn=bn, eps=float(eps), dims=(Cout, Cin, R * S, cout_p, cin_p),
-                       wp=torch.empty(R * S, cout_p, cin_p, dtype=torch.bfloat16, device=dev),
-                       wpt=torch.empty(R * S, cin_p, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
-                       bias=torch.empty(cout_p, dtype=torch.float32, device=dev), step=-2)
-            self.jobs[key] = job
+        grp = self.jobs.get(key)
+        if grp is None:
+            G = len(ws)
+            Cout, Cin, R, S = ws[0].shape
+            dev = ws[0].device
+            grp = dict(wp=torch.empty(G, R * S, cout_p, cin_p, dtype=torch.bfloat16, device=dev),
+                       wpt=torch.empty(G, R * S, cin_p, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
+                       bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2, members=[])
+            for g in range(G):
+                grp['members'].append(dict(w=ws[g], cb=conv_biases[g], bn=bn, eps=float(eps), dims=(Cout, Cin, R * S, cout_p, cin_p),
+                                           wp=grp['wp'][g], wpt=None if grp['wpt'] is None else grp['wpt'][g], bias=grp['bias'][g]))
+            self.jobs[key] = grp
             self.order.append(key)
             self.desc = None
-        if job['step'] != self.step:          # registered after this step's batched launch (first step): pack it now
-            fold_pack(job['w'], job['cb'], job['bn'], job['eps'], want_dgrad=job['wpt'] is not None, out_fwd=job['wp'],
-                      out_dgrad=job['wpt'], out_bias=job['bias'], cout_pad=job['dims'][3], cin_pad=job['dims'][4])
-            job['step'] = self.step
-        return job['wp'], job['wpt'], job['bias']
+        if grp['step'] != self.step:          # registered after this step's batched launch (first step): pack it now
+            for j in grp['members']:
+                fold_pack(j['w'], j['cb'], j['bn'], j['eps'], want_dgrad=j['wpt'] is not None, out_fwd=j['wp'], out_dgrad=j['wpt'],
+                          out_bias=j['bias'], cout_pad=j['dims'][3], cin_pad=j['dims'][4])
+            grp['step'] = self.step
+        return grp['wp'], grp['wpt'], grp['bias']
 
     def run(self, step):
         """One launch for every registered job; afterwards request() is a dictionary lookup."""
@@ -968,19 +974,23 @@ class PrepackRegistry:
         if self.desc is None:
             import struct
             rows, chunk = [], 0
-            for key in self.order:
-                j = self.jobs[key]
+            for j in (m for key in self.order for m in self.jobs[key]['members']):
                 Cout, Cin, RS, CoutP, CinP = j['dims']
                 bn = j['bn']
                 p = lambda t: 0 if t is None else t.data_ptr()
                 eps_bits = struct.unpack('<i', struct.pack('<f', j['eps']))[0]
                 rows.append([p(j['w']), p(j['cb']), p(bn[0]) if bn else 0, p(bn[1]) if bn else 0, p(bn[2]) if bn else 0,
                              p(bn[3]) if bn else 0, p(j['wp']), p(j['wpt']), p(j['bias']), eps_bits, Cout, Cin, RS, CoutP, CinP, chunk])
-                chunk += (CoutP * CinP * RS + FOLD_CHUNK - 1) // FOLD_CHUNK
+                if RS > FOLD_TILE_MAX_RS:
+                    chunk += (CoutP * CinP * RS + FOLD_CHUNK - 1) // FOLD_CHUNK
+                else:                         # one chunk per [NT output channels] x [64 input channels] tile, all taps
+                    nt = 64 if RS == 1 else 16
+                    chunk += ((CoutP + nt - 1) // nt) * ((CinP + 63) // 64)
             self.nchunks = chunk
-            dev = self.jobs[self.order[0]]['w'].device
+            dev = self.jobs[self.order[0]]['wp'].device
             self.desc = h2d(rows, torch.int64, dev)
-        L.check(lib.loft_fold_pack_multi(L.ptr(self.desc), len(self.order), c_int64(self.nchunks), L.stream()), 'loft_fold_pack_multi')
+            self.nrows = len(rows)
+        L.check(lib.loft_fold_pack_multi(L.ptr(self.desc), self.nrows, c_int64(self.nchunks), L.stream()), 'loft_fold_pack_multi')
         for key in self.order:
             self.jobs[key]['step'] = step
 

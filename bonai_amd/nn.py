@@ -75,11 +75,11 @@ class _ConvFn(torch.autograd.Function):
                 key += tuple((t.data_ptr(), t._version) for t in bn_stats[:2])
         if key is not None and key in _PACK_CACHE:
             wp, wpt, bias = _PACK_CACHE[key]
-        elif PREPACK is not None and key is None and G == 1 and pdt == torch.bfloat16 and isinstance(ws[0], torch.nn.Parameter):
+        elif PREPACK is not None and key is None and pdt == torch.bfloat16 and Cout % 2 == 0 and Cin % 2 == 0 and \
+                all(isinstance(w, torch.nn.Parameter) for w in ws):
             bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
-            wp, wpt, bias = PREPACK.request(ws[0], bs[0], bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
+            wp, wpt, bias = PREPACK.request(ws, bs, bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
                                             ctx.needs_input_grad[0])
-            wp, wpt, bias = wp[None], None if wpt is None else wpt[None], bias[None]
         else:
             wp = torch.empty(G, T, Cout, Cin, dtype=pdt, device=dev)
             need_dgrad = ctx.needs_input_grad[0]
@@ -596,9 +596,9 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
             tuple((t.data_ptr(), t._version) for t in stats)
         if key in _PACK_CACHE:
             return _PACK_CACHE[key]
-    if PREPACK is not None and key is None and pdt == torch.bfloat16 and isinstance(w, torch.nn.Parameter):
-        out = PREPACK.request(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
-        return out[0][None], None if out[1] is None else out[1][None], out[2][None]
+    if PREPACK is not None and key is None and pdt == torch.bfloat16 and cout_p % 2 == 0 and cin_p % 2 == 0 and \
+            isinstance(w, torch.nn.Parameter):
+        return PREPACK.request((w,), (None,), (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
     out = K.fold_pack(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, want_fwd=True, want_dgrad=need_dgrad, dtype=pdt,
                       cout_pad=cout_p, cin_pad=cin_p)
     out = (out[0][None], None if out[1] is None else out[1][None], out[2][None])

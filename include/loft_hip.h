@@ -284,7 +284,9 @@ int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, c
                    int pack_f32, int CoutP, int CinP, void* stream);
 /* loft_fold_pack_multi: the bf16 packings of MANY convs in one launch.  desc (device): n records of 16 int64 {w, conv_bias,
  * gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out (device addresses, 0 = absent), eps as float bits, Cout, Cin, RS, CoutP,
- * CinP, first_chunk}; record i covers chunks [first_chunk_i, first_chunk_{i+1}) of 2048 packed elements; nchunks = their total. */
+ * CinP, first_chunk}; record i covers chunks [first_chunk_i, first_chunk_{i+1}); nchunks = their total.  A record with RS <= 9
+ * has ceil(CoutP / NT) * ceil(CinP / 64) chunks (NT = 64 when RS == 1, else 16; chunk = one channel tile, all taps), a record
+ * with more taps ceil(CoutP * CinP * RS / 2048).  CoutP and CinP must be even. */
 int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,

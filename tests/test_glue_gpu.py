@@ -177,3 +177,40 @@ def test_mask_target_per_image_list_matches_concatenated():
     a = K.mask_target(parts, boxes.cuda(), idx, 28)
     b = K.mask_target(torch.cat(parts, 0), boxes.cuda(), idx, 28)
     assert torch.equal(a, b)
+
+
+def test_fold_pack_multi_equals_per_conv_packing():
+    """loft_fold_pack_multi (one launch for all trainable convs of a step) writes bit-identical packings to loft_fold_pack:
+    3x3 / 1x1 / 2x2-deconv / 5x5 (per-element form) taps, BN-folded and biased, channel-padded, grouped, with and without the
+    transposed (dgrad) packing."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(5)
+    dev = 'cuda'
+    reg = K.PrepackRegistry()
+    reg.run(0)
+    cases = []   # (Cout, Cin, k, bn?, bias?, cout_p, cin_p, dgrad, groups)
+    for spec in [(256, 256, 3, True, False, 256, 256, True, 1), (64, 256, 1, True, False, 64, 256, True, 1),
+                 (1024, 1000, 1, False, True, 1024, 1000, True, 1), (256, 256, 2, False, True, 256, 256, True, 1),
+                 (32, 48, 3, True, False, 64, 64, True, 1), (18, 30, 3, False, False, 18, 30, False, 1),
+                 (64, 64, 5, True, False, 64, 64, True, 1), (128, 128, 3, False, True, 128, 128, True, 4),
+                 (2, 1024, 1, False, True, 2, 1024, True, 1)]:
+        Cout, Cin, k, has_bn, has_b, cop, cip, dgrad, G = spec
+        ws = tuple(torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev)) for _ in range(G))
+        bs = tuple(torch.nn.Parameter(torch.randn(Cout, device=dev)) if has_b else None for _ in range(G))
+        bn = tuple(torch.rand(Cout, device=dev) + 0.5 for _ in range(4)) if has_bn else None
+        cases.append((ws, bs, bn, cop, cip, dgrad))
+        reg.request(ws, bs, bn, 1e-5, cop, cip, dgrad)          # registers (and packs per conv: first step)
+    for ws, bs, bn, *_ in cases:                                 # new weights: only the batched launch can produce these
+        for w in ws:
+            w.data.normal_()
+    reg.run(1)
+    for ws, bs, bn, cop, cip, dgrad in cases:
+        wp, wpt, bias = reg.request(ws, bs, bn, 1e-5, cop, cip, dgrad)
+        for g in range(len(ws)):
+            rwp, rwpt, rb = K.fold_pack(ws[g], bs[g], bn, 1e-5, want_dgrad=dgrad, cout_pad=cop, cin_pad=cip)
+            assert torch.equal(wp[g].view(torch.int16), rwp.view(torch.int16))
+            assert torch.equal(bias[g], rb)
+            if dgrad:
+                assert torch.equal(wpt[g].view(torch.int16), rwpt.view(torch.int16))
+            else:
+                assert wpt is None

@@ -1,6 +1,7 @@
 """CPU: config loader, registry, model construction / parameter naming (no kernels launched)."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -166,3 +167,24 @@ def test_coco_rle_coder():
         assert e['size'] == [37, 29] and np.array_equal(R.rle_decode(e), m[i])
     assert enc[1]['counts'] == b'aQ1' and enc[2]['counts'] == b'0aQ1'
     assert R.encode_mask_results([[m[0], m[3]], []])[0][1] == enc[3]
+
+
+def test_offset_error_vector_statistics():
+    """aEPE / aAE / cosine distance exactly as tools/bonai/bonai_evaluation.py:241-290 computes them."""
+    from bonai_amd.evaluation import cosine_distance, match_by_iou, offset_error_vector
+    gt = np.array([[3., 4.], [0., 10.], [-6., 8.]])
+    pr = np.array([[0., 0.], [10., 0.], [-6., 8.]])
+    ev = offset_error_vector(gt, pr)
+    assert np.allclose(ev['EPE'], [5., np.sqrt(200.), 0.])
+    assert np.isclose(ev['aEPE'], (5. + np.sqrt(200.)) / 3)
+    want_ae = np.abs(np.arctan2(gt[:, 1], gt[:, 0]) - np.arctan2(pr[:, 1], pr[:, 0])).mean()
+    assert np.isclose(ev['aAE'], want_ae)
+    cd = cosine_distance(gt[1:], pr[1:])
+    assert np.allclose(cd, [1.0, 0.0])
+    assert np.isnan(offset_error_vector(np.zeros((0, 2)), np.zeros((0, 2)))['aEPE'])
+    with pytest.raises(ValueError):
+        offset_error_vector(gt, pr[:2])
+    g, p = match_by_iou(np.array([[0.9, 0.6, 0.], [0.8, 0.1, 0.], [0., 0., 0.3]]), 0.5)
+    assert dict(zip(g.tolist(), p.tolist())) == {0: 0}             # gt 1's only candidate is taken, gt 2 is below the bar
+    g, p = match_by_iou(np.array([[0.6, 0.9], [0.7, 0.2]]), 0.5)
+    assert dict(zip(g.tolist(), p.tolist())) == {0: 1, 1: 0}

@@ -59,6 +59,8 @@ struct ConvArgs {
     int relu, out_f32, accumulate;
     long src_gs, wgt_gs, out_gs, bias_gs;
     int M;
+    int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
+    int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
 };
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
@@ -80,7 +82,7 @@ __device__ __forceinline__ int xcd_remap(int L, int N) {
 template <int NT, int MT, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], int g, int m0, int n0, int wm, int wn,
                                               int frow, int fq, int ohw, const char* res_t = nullptr,
-                                              const char* mask_t = nullptr) {
+                                              const char* mask_t = nullptr, char* out_t = nullptr) {
     // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
     // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
     //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
@@ -128,7 +130,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
                 }
-                if (a.out_f32) {
+                if (out_t) {              // bf16 tile collected in LDS (same swizzle), written out by conv_unstage_tile
+                    st4(reinterpret_cast<bf16_t*>(out_t + trow * 256 + tcol), v);
+                } else if (a.out_f32) {
                     float* op = reinterpret_cast<float*>(a.out) + o;
                     if (a.accumulate) {
                         float ov[4];
@@ -159,6 +163,20 @@ __device__ __forceinline__ void conv_stage_tile(const ConvArgs& a, const bf16_t*
     }
 }
 
+// The reverse: the finished [128][128] bf16 tile from LDS to the (dense) output, 16 bytes per lane, 16 lanes per 256-byte row.
+__device__ __forceinline__ void conv_unstage_tile(const ConvArgs& a, long out_g, int m0, int n0, int wave, int lane, const char* srct) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 16 + wave * 4 + (lane >> 4);
+        const int lc = (lane & 15) ^ (row & 15);
+        const int m = m0 + row, n = n0 + lc * 8;
+        if (m < a.M && n < a.Cout) {
+            const uint4 v = *reinterpret_cast<const uint4*>(srct + row * 256 + (lane & 15) * 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + out_g + (long)m * a.Cout + n) = v;
+        }
+    }
+}
+
 // STAGES = 2: double-buffered K loop.  STAGES = 1: single LDS buffer (half the LDS -> one more resident block per CU) for
 // launches with only 1-2 K-steps (the K-shallow 1x1 convs), which are latency-bound: occupancy hides what a pipeline cannot.
 // FAST: pixel-dependent address work hoisted out of the K loop (pays off from ~32 K-steps on; measured +9..12 % on the
@@ -178,7 +196,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = gridDim.x * gridDim.y * gridDim.z;
     const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
-    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int bz = V / (gridDim.x * gridDim.y), Vg = V - bz * (gridDim.x * gridDim.y);
+    const int bx = a.nfast ? Vg / gridDim.y : Vg % gridDim.x, by = a.nfast ? Vg % gridDim.y : Vg / gridDim.x;
     const int m0 = bx * BM, n0 = by * BN;
     const int g = bz;
     const bf16_t* src = a.src + (long)g * a.src_gs;
@@ -348,21 +367,30 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
         }
     }
 
-    if constexpr (BM == 128 && BN == 128 && STAGES == 2) {
+    if constexpr (BM == 128 && BN == 128) {
         // memory-bound launches (residual add of a bottleneck's conv3, shortcut + ReLU mask of a fused block's first dgrad):
         // bring the residual / mask tiles in through the (now idle) stage buffers with coalesced copies
         const bool dense = a.os == 1 && a.OHf == a.OH && a.OWf == a.OW && !a.out_f32;
-        if (dense && (a.residual || a.mask)) {
+        // (the single-stage form has room for the output tile only: the dispatcher never gives it a residual or a mask)
+        if (dense && (STAGES == 2 ? (a.residual || a.mask || a.staged_out) : (a.staged_out && !a.residual && !a.mask))) {
             __syncthreads();                                    // all fragment reads of the last K-step are done
             const long out_g = (long)g * a.out_gs;
             char* rt = lds;
             char* mt = lds + 32768;
             if (a.residual) conv_stage_tile(a, a.residual, out_g, m0, n0, wave, lane, rt);
             if (a.mask) conv_stage_tile(a, a.mask, out_g, m0, n0, wave, lane, mt);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (a.residual || a.mask) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // staged_out: the results replace the residual tile in place (each lane rewrites exactly the 8 bytes it read) and
+            // leave as 16-byte-per-lane row-contiguous stores instead of 8-byte stores to 32 different rows per instruction
             conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw, a.residual ? rt : nullptr,
-                                          a.mask ? mt : nullptr);
+                                          a.mask ? mt : nullptr, a.staged_out ? rt : nullptr);
+            if (a.staged_out) {
+                __syncthreads();
+                conv_unstage_tile(a, out_g, m0, n0, wave, lane, rt);
+            }
             return;
         }
     }
@@ -392,6 +420,13 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
+    // Channel-tile-fastest order when the activation is the big operand (it does not fit the 4 MiB L2 of an XCD but the packed
+    // weights do): every channel tile of a pixel tile then runs back to back on one XCD and the pixel tile comes from HBM once
+    // instead of once per channel tile.
+    static const int staged_out_mode = getenv("LOFT_CONV_STAGED_OUT") ? atoi(getenv("LOFT_CONV_STAGED_OUT")) : 1;
+    a.staged_out = staged_out_mode && !accumulate;
+    static const int nfast_mode = getenv("LOFT_CONV_NFAST") ? atoi(getenv("LOFT_CONV_NFAST")) : 1;
+    a.nfast = nfast_mode == 2 ? ((long)T * Cin * Cout * 2 <= (3L << 20)) : nfast_mode;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
     static const long deepk_min = getenv("LOFT_CONV_DEEPK") ? atol(getenv("LOFT_CONV_DEEPK")) : 2048;
     static const long single_max = getenv("LOFT_CONV_SINGLE") ? atol(getenv("LOFT_CONV_SINGLE")) : 128;

@@ -165,10 +165,13 @@ class Trainer:
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_PREPACK'):
             F2.PREPACK = self.prepack
             self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
+        prev_hub = F2.HUB_ENABLED
+        F2.HUB_ENABLED = self.arena.data.is_cuda and not os.environ.get('LOFT_NO_FEAT_HUB')
         try:
             out = self.model.train_step(data)
         finally:
             F2.PREPACK = prev_pp
+            F2.HUB_ENABLED = prev_hub
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
@@ -176,6 +179,7 @@ class Trainer:
             (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
         finally:
             F2.GRAD_SINK = prev
+            F2.HUB = None
             K.zero_pool_end()
         self.reducer.finish()
         self.gnorm_sq.zero_()

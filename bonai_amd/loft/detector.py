@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from .. import nn as F2
+
 from .builder import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -67,6 +69,9 @@ class LOFT(nn.Module):
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       gt_offsets=None, **kwargs):
         x = self.extract_feat(img)
+        if F2.HUB_ENABLED and x[0].is_cuda and x[0].dtype == torch.bfloat16:
+            # one shared gradient map per pyramid level for the RPN head and the three RoI extractors (nn.feat_hub)
+            x = F2.feat_hub(x, 4)
         losses = dict()
         if self.with_rpn:
             proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)

@@ -390,13 +390,16 @@ class LoftRoIHead(nn.Module):
         self.last_stats = dict(num_rois=int(M), num_pos=int(pos_sel.numel()))
 
         losses = dict()
-        feats = x[:self.bbox_roi_extractor.num_inputs]
+        xb = xm = xo = x
+        if isinstance(x, F2.FeatFork):       # own aliases per extractor: their backward kernels share one gradient map per level
+            xb, xm, xo = x.branches[1], x.branches[2], x.branches[3]
+        feats = xb[:self.bbox_roi_extractor.num_inputs]
         bbox_feats = self.bbox_roi_extractor(feats, rois)
         cls_score, bbox_pred = self.bbox_head(bbox_feats)
         losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights))
 
         if self.with_mask:
-            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+            mask_feats = self.mask_roi_extractor(xm[:self.mask_roi_extractor.num_inputs], pos_rois)
             mask_pred = self.mask_head(mask_feats)
             with torch.no_grad():
                 masks, moffs = _masks_to_device(gt_masks, dev)
@@ -413,7 +416,7 @@ class LoftRoIHead(nn.Module):
             for i, o in enumerate(gt_offsets):
                 off_pad[i, :o.shape[0]] = o.to(dev)
             pos_gt_off = off_pad[pos_b, pos_gt_i]
-        offset_pred = self._offset_forward(x, pos_rois)
+        offset_pred = self._offset_forward(xo, pos_rois)
         if hasattr(self.offset_head, 'get_targets') and isinstance(self.offset_head, OffsetHeadExpandFeature):
             offset_targets = self.offset_head.get_targets(pos_rois[:, 1:].contiguous(), pos_gt_off)
         else:

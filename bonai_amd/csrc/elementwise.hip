@@ -612,6 +612,62 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
         }
     }
 }
+// Batched form for the trainer's direct gradient sink: n records of 16 int64 {dwp, db, w, gamma, mean, var, dw, dgamma,
+// dbeta_or_dbias, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_block}; block b serves output channel
+// b - first_block of the record with the largest first_block <= b and ACCUMULATES into dw / dgamma / dbeta (slots of the
+// flat gradient arena).  Without BN (gamma == 0) the last slot is the conv's bias gradient: dbias[n] += db[n].
+__global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* __restrict__ desc, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[(long)mid * 16 + 15] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* d = desc + (long)lo * 16;
+    const float* dwp = reinterpret_cast<const float*>(d[0]);
+    const float* db = reinterpret_cast<const float*>(d[1]);
+    const float* w = reinterpret_cast<const float*>(d[2]);
+    const float* gamma = reinterpret_cast<const float*>(d[3]);
+    const float* mean = reinterpret_cast<const float*>(d[4]);
+    const float* var = reinterpret_cast<const float*>(d[5]);
+    float* dw = reinterpret_cast<float*>(d[6]);
+    float* dgamma = reinterpret_cast<float*>(d[7]);
+    float* dbeta = reinterpret_cast<float*>(d[8]);
+    const float eps = __int_as_float((int)d[9]);
+    const int Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
+    const int n = (int)(blockIdx.x - d[15]);
+    const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
+    const float scale = gamma ? gamma[n] * rs : 1.f;
+    float acc = 0.f;
+    const int per = Cin * RS;
+    for (int j = threadIdx.x; j < per; j += blockDim.x) {
+        const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
+        const float g = dwp[((long)t * CoutP + n) * CinP + c];
+        const long wi = (long)n * per + j;
+        if (dw) dw[wi] += g * scale;
+        if (gamma) acc += g * w[wi];
+    }
+    if (gamma) {
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float s = part[0] + part[1] + part[2] + part[3];
+            const float dbn = db ? db[n] : 0.f;
+            if (dgamma) dgamma[n] += s * rs - dbn * mean[n] * rs;
+            if (dbeta) dbeta[n] += dbn;
+        }
+    } else if (threadIdx.x == 0 && dbeta && db) {
+        dbeta[n] += db[n];
+    }
+}
+LOFT_EXPORT int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, void* stream) {
+    if (njobs <= 0 || nblocks <= 0) return 0;
+    hipLaunchKernelGGL(fold_unpack_bwd_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
+                       njobs);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
 LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                                      const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma,
                                      float* dbeta, int CoutP, int CinP, int accumulate, void* stream) {

@@ -78,7 +78,7 @@ class BucketedAllReduce:
         self.works = []
         if self.enabled:
             for p in arena.order:
-                p.register_post_accumulate_grad_hook(self._hook)
+                p.register_post_accumulate_grad_hook(self._autograd_hook)
         self._remaining = None
 
     def begin(self):
@@ -86,6 +86,14 @@ class BucketedAllReduce:
         self._seen = set()
         self._next = 0
         self.works = []
+
+    def _autograd_hook(self, p):
+        """autograd's post-accumulate callback.  It also runs for parameters whose Function returned None because a kernel
+        deposits the gradient in the arena itself -- possibly later, at the next UnpackQueue flush: those report through the
+        gradient sink (Trainer._sink -> _hook) once the deposit has been enqueued, never from here."""
+        if getattr(p, '_loft_sunk', False):
+            return
+        self._hook(p)
 
     def _hook(self, p):
         """Gradient of ``p`` is final for this step (autograd post-accumulate hook, or the kernels' direct arena sink)."""
@@ -160,6 +168,7 @@ class Trainer:
         self.reducer.begin()
         for p in self.arena.params:
             p._loft_pending = 0
+            p._loft_sunk = False
         from . import nn as F2
         prev_pp = F2.PREPACK
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_PREPACK'):
@@ -175,9 +184,14 @@ class Trainer:
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
+        if F2.GRAD_SINK is not None and not os.environ.get('LOFT_NO_UNPACK_QUEUE'):
+            F2.UNPACK_Q = K.UnpackQueue()
         try:
             (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
+            if F2.UNPACK_Q is not None:
+                F2.UNPACK_Q.flush()
         finally:
+            F2.UNPACK_Q = None
             F2.GRAD_SINK = prev
             F2.HUB = None
             K.zero_pool_end()

@@ -996,6 +996,41 @@ class PrepackRegistry:
 
 
 
+class UnpackQueue:
+    """Deferred loft_fold_unpack_bwd jobs of the trainer's direct gradient sink, flushed as ONE launch
+    (loft_fold_unpack_bwd_multi) every ``limit`` jobs and at the end of the backward pass."""
+
+    def __init__(self, limit=48):
+        self.limit = limit
+        self.jobs, self.done = [], []
+
+    def add(self, dwp, db, w, bn, eps, slots, on_done=()):
+        """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
+        launch that served this job has been enqueued (the reducer's gradient-ready notifications)."""
+        self.jobs.append((dwp, db, w, bn, float(eps), slots))
+        self.done.extend(on_done)
+        if len(self.jobs) >= self.limit:
+            self.flush()
+
+    def flush(self):
+        if self.jobs:
+            import struct
+            rows, blk = [], 0
+            p = lambda t: 0 if t is None else t.data_ptr()
+            for dwp, db, w, bn, eps, (dw, dg, dbeta) in self.jobs:
+                Cout, Cin, R, S = w.shape
+                g, _, m, v = bn if bn is not None else (None, None, None, None)
+                rows.append([p(dwp), p(db), p(w), p(g), p(m), p(v), p(dw), p(dg), p(dbeta),
+                             struct.unpack('<i', struct.pack('<f', eps))[0], Cout, Cin, R * S, dwp.shape[-2], dwp.shape[-1], blk])
+                blk += Cout
+            desc = h2d(rows, torch.int64, self.jobs[0][2].device)
+            L.check(L.load().loft_fold_unpack_bwd_multi(L.ptr(desc), len(rows), c_int64(blk), L.stream()), 'loft_fold_unpack_bwd_multi')
+            self.jobs = []
+        done, self.done = self.done, []
+        for f in done:
+            f()
+
+
 def fold_unpack_bwd(dwp, db, w, bn=None, eps=1e-5, need_dw=True, out=None):
     """dwp fp32 [T,CoutP,CinP], db fp32 [CoutP] | None -> (dw [Cout,Cin,R,S] | None, dgamma | None, dbeta | None).
     out = (dw, dgamma, dbeta) existing fp32 contiguous tensors (e.g. slots of a flat gradient arena): ACCUMULATE into them."""

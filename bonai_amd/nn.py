@@ -35,6 +35,14 @@ def _direct_slot(p):
     return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape) else None
 
 
+def _mark_sunk(*ps):
+    """These parameters' gradients of this step reach the arena through the kernels (now or at the next queue flush), not
+    through autograd: the trainer's reducer must not treat autograd's own post-accumulate callback as 'gradient ready'."""
+    for p in ps:
+        if p is not None:
+            p._loft_sunk = True
+
+
 def _sink_done(p):
     """One use of ``p`` has deposited its gradient in the arena; tell the trainer once the last use of this step has."""
     p._loft_pending = getattr(p, '_loft_pending', 1) - 1
@@ -43,6 +51,7 @@ def _sink_done(p):
         GRAD_SINK(p)
 
 
+UNPACK_Q = None    # the running Trainer's kernels.UnpackQueue: weight-gradient unpacking of many convs in one launch
 PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
 _PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
 
@@ -145,8 +154,24 @@ class _ConvFn(torch.autograd.Function):
                     slot_g, slot_b = _direct_slot(ctx.params[2 * G]), _direct_slot(ctx.params[2 * G + 1])
                 if slot_w is not None and (bn is None or (slot_g is not None and slot_b is not None)):
                     # accumulate straight into the flat gradient arena; autograd gets None for these inputs
-                    K.fold_unpack_bwd(dwp[i], None if db is None else db[i], ws[i], bn,
-                                      bn_stats[2] if bn_stats is not None else 1e-5, out=(slot_w, slot_g, slot_b))
+                    eps = bn_stats[2] if bn_stats is not None else 1e-5
+                    if UNPACK_Q is not None:
+                        sinks = [pw]
+                        pb = ctx.params[2 * i + 1] if (bn is None and has_b and db is not None) else None
+                        if pb is not None and ctx.needs_input_grad[3 + 2 * i + 1]:
+                            slot_b = _direct_slot(pb)           # the conv's own bias gradient: db rides in the same launch
+                            if slot_b is not None:
+                                sinks.append(pb)
+                        if bn is not None and i == G - 1:
+                            sinks += [ctx.params[2 * G], ctx.params[2 * G + 1]]
+                        _mark_sunk(*sinks)
+                        UNPACK_Q.add(dwp[i], None if db is None else db[i], ws[i], bn, eps, (slot_w, slot_g, slot_b),
+                                     [(lambda q=q: _sink_done(q)) for q in sinks])
+                        if has_b and db is not None and bn is None and slot_b is None:
+                            ngrads[2 * i + 1] = db[i][:ws[i].shape[0]]
+                        continue
+                    _mark_sunk(pw, *((ctx.params[2 * G], ctx.params[2 * G + 1]) if bn is not None else ()))
+                    K.fold_unpack_bwd(dwp[i], None if db is None else db[i], ws[i], bn, eps, out=(slot_w, slot_g, slot_b))
                     _sink_done(pw)
                     if bn is not None and i == G - 1:
                         _sink_done(ctx.params[2 * G])
@@ -703,6 +728,10 @@ def _rb_param_grads(g, x, w, bn, k, stride, pad, needs):
     bnt = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
     slots = (_direct_slot(w) if need_w else None, _direct_slot(bn.weight) if need_g else None, _direct_slot(bn.bias) if need_b else None)
     if need_w and need_g and need_b and all(s is not None for s in slots):
+        _mark_sunk(w, bn.weight, bn.bias)
+        if UNPACK_Q is not None:
+            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)])
+            return None, None, None
         K.fold_unpack_bwd(dwp[0], db[0], w, bnt, bn.eps, out=slots)
         _sink_done(w), _sink_done(bn.weight), _sink_done(bn.bias)
         return None, None, None

@@ -288,6 +288,11 @@ int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, c
  * has ceil(CoutP / NT) * ceil(CinP / 64) chunks (NT = 64 when RS == 1, else 16; chunk = one channel tile, all taps), a record
  * with more taps ceil(CoutP * CinP * RS / 2048).  CoutP and CinP must be even. */
 int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream);
+/* loft_fold_unpack_bwd_multi: loft_fold_unpack_bwd for MANY convs in one launch, accumulate-only (the trainer's direct gradient
+ * sink).  desc (device): njobs records of 16 int64 {dwp, db, w, gamma, mean, var, dw, dgamma, dbeta_or_dbias (device addresses,
+ * 0 = absent), eps as float bits, Cout, Cin, RS, CoutP, CinP, first_block}; record i owns blocks [first_block_i, first_block_i +
+ * Cout_i); nblocks = their total. */
+int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
                          int CoutP, int CinP, int accumulate, void* stream);

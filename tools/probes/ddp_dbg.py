@@ -1,0 +1,68 @@
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, '/root/repo')
+os.environ['MASTER_ADDR']='127.0.0.1'; os.environ['MASTER_PORT']='29533'
+rank=int(os.environ['RANK']); dist.init_process_group('gloo', rank=rank, world_size=2)
+from bonai_amd.config import Config
+from bonai_amd.engine import Trainer
+from bonai_amd.loft import build_detector
+from bonai_amd.loft.core import RandomSampler
+from bonai_amd.synth import make_batch
+RandomSampler.choice_mode = 'first'
+ROOT='/root/repo'
+cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+def build():
+    torch.manual_seed(0)
+    return build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+data = make_batch(1, 256, 6, rank=rank, device='cuda')
+ref = build()
+ref.train_step(data)['loss'].backward()
+local = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+del ref
+m = build()
+from bonai_amd.engine import BucketedAllReduce
+import traceback
+_orig_hook = BucketedAllReduce._hook
+NAMES = {}
+def dbg_hook(self, p):
+    st = traceback.extract_stack(limit=6)
+    src = 'python:' + '/'.join(f.name for f in st[:-1]) if len(st) > 1 else 'autograd'
+    print(rank, 'hook', NAMES.get(id(p)), 'bucket', self.param_bucket[id(p)], src, flush=True)
+    _orig_hook(self, p)
+BucketedAllReduce._hook = dbg_hook
+tr = Trainer(m, lr=0.01, momentum=0.0, weight_decay=0.0, max_norm=0.0, bucket_bytes=16 << 20)
+NAMES.update({id(p): n for n, p in m.named_parameters()})
+print('buckets', len(tr.reducer.buckets), tr.reducer.enabled)
+from bonai_amd import nn as F2, kernels as K
+orig_launch = tr.reducer._launch
+def dbg_launch(bi):
+    q = F2.UNPACK_Q
+    b = tr.reducer.buckets[bi]
+    base = tr.arena.grad.data_ptr()
+    inb = 0
+    for job in (q.jobs if q else []):
+        for sl in job[5]:
+            if sl is not None and b['start'] <= (sl.data_ptr() - base) // 4 < b['end']:
+                inb += 1
+    print(rank, 'launch bucket', bi, 'pending jobs', len(q.jobs) if q else None, 'slots pending in this bucket', inb, flush=True)
+    if inb:
+        import traceback; traceback.print_stack(limit=12)
+    orig_launch(bi)
+tr.reducer._launch = dbg_launch
+orig_flush = K.UnpackQueue.flush
+def dbg_flush(self):
+    print(rank, 'flush', len(self.jobs), len(self.done), flush=True)
+    orig_flush(self)
+K.UnpackQueue.flush = dbg_flush
+out = tr.train_step(data)
+torch.cuda.synchronize()
+bad = 0
+for n, p in m.named_parameters():
+    if not p.requires_grad: continue
+    mine = local.get(n, torch.zeros_like(p)); both = [torch.zeros_like(mine) for _ in range(2)]
+    dist.all_gather(both, mine); want = both[0] + both[1]; got = p.grad
+    e = (got - want).norm().item(); w = want.norm().item()
+    if e > 2e-2 * w + 1e-7:
+        bad += 1
+        print('BAD', n, e, w, got.norm().item(), 'bucket', tr.reducer.param_bucket[id(p)])
+print('bad', bad)

@@ -445,7 +445,10 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         //  waits) -- correct, 4 % slower: the copies' latency is not what parks the waves.  SQ counters of the 8-wave form on
         //  the P2 3x3: MFMA pipe busy 40 % of the SIMD cycles, waves parked on waitcnt/barrier 37 %, issue-stalled 39 %, LDS
         //  bank conflicts 0, LDS array active 8 %: the remaining loss is barrier skew between the two waves of a SIMD plus the
-        //  un-overlapped prologue/epilogue of a one-block-per-CU kernel -- a persistent, software-pipelined rewrite is the fix.)
+        //  un-overlapped prologue/epilogue of a one-block-per-CU kernel -- a persistent, software-pipelined rewrite is the fix.
+        //  Also rejected: 256x128 tiles with 4 waves (same 128x64 wave tile, 48/96 KiB LDS so two independent blocks share a
+        //  CU and cover each other's barriers), single- and double-buffered: 560 vs 780 TFLOP/s on the P2 / mask / FOA 3x3.
+        //  Reference point: hipBLASLt on the equivalent explicit GEMM (M=524288, N=256, K=2304) reaches 955 TFLOP/s.)
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
         if (deepk) hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);

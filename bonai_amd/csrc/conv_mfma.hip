@@ -182,7 +182,8 @@ __device__ __forceinline__ void conv_unstage_tile(const ConvArgs& a, long out_g,
 // FAST: pixel-dependent address work hoisted out of the K loop (pays off from ~32 K-steps on; measured +9..12 % on the
 // FOA / FC / layer4 shapes, -8 % on the 9-step layer1 3x3, so the dispatcher picks per launch).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES = 2, bool FAST = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 4 : 1)))
+void conv_tap_kernel(const ConvArgs a) {
     constexpr int NW = WAVES_M * WAVES_N;                 // 4 waves (128-wide tiles) or 8 waves (256x256 tile)
     constexpr int RPR = NW * 8;                           // tile rows staged per glds round (8 rows per wave)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -371,12 +372,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
         // memory-bound launches (residual add of a bottleneck's conv3, shortcut + ReLU mask of a fused block's first dgrad):
         // bring the residual / mask tiles in through the (now idle) stage buffers with coalesced copies
         const bool dense = a.os == 1 && a.OHf == a.OH && a.OWf == a.OW && !a.out_f32;
-        // (the single-stage form has room for the output tile only: the dispatcher never gives it a residual or a mask)
-        if (dense && (STAGES == 2 ? (a.residual || a.mask || a.staged_out) : (a.staged_out && !a.residual && !a.mask))) {
+        // (the single-stage form has room for ONE tile: the dispatcher never gives it a residual AND a mask)
+        if (dense && (STAGES == 2 ? (a.residual || a.mask || a.staged_out) : !(a.residual && a.mask))) {
             __syncthreads();                                    // all fragment reads of the last K-step are done
             const long out_g = (long)g * a.out_gs;
             char* rt = lds;
-            char* mt = lds + 32768;
+            char* mt = (STAGES == 2 || a.residual) ? lds + 32768 : lds;
             if (a.residual) conv_stage_tile(a, a.residual, out_g, m0, n0, wave, lane, rt);
             if (a.mask) conv_stage_tile(a, a.mask, out_g, m0, n0, wave, lane, mt);
             if (a.residual || a.mask) {
@@ -385,11 +386,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_tap_kernel(const 
             }
             // staged_out: the results replace the residual tile in place (each lane rewrites exactly the 8 bytes it read) and
             // leave as 16-byte-per-lane row-contiguous stores instead of 8-byte stores to 32 different rows per instruction
+            char* ot = (a.mask && !a.residual) ? mt : rt;
             conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw, a.residual ? rt : nullptr,
-                                          a.mask ? mt : nullptr, a.staged_out ? rt : nullptr);
+                                          a.mask ? mt : nullptr, a.staged_out ? ot : nullptr);
             if (a.staged_out) {
                 __syncthreads();
-                conv_unstage_tile(a, out_g, m0, n0, wave, lane, rt);
+                conv_unstage_tile(a, out_g, m0, n0, wave, lane, ot);
             }
             return;
         }
@@ -429,7 +431,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     a.nfast = nfast_mode == 2 ? ((long)T * Cin * Cout * 2 <= (3L << 20)) : nfast_mode;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
     static const long deepk_min = getenv("LOFT_CONV_DEEPK") ? atol(getenv("LOFT_CONV_DEEPK")) : 2048;
-    static const long single_max = getenv("LOFT_CONV_SINGLE") ? atol(getenv("LOFT_CONV_SINGLE")) : 128;
+    static const long single_max = getenv("LOFT_CONV_SINGLE") ? atol(getenv("LOFT_CONV_SINGLE")) : 256;
     const bool deepk = (long)T * Cin >= deepk_min;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
     static const long big_min = getenv("LOFT_CONV_BIG_MIN") ? atol(getenv("LOFT_CONV_BIG_MIN")) : 192;
     static const long big_k = getenv("LOFT_CONV_BIG_K") ? atol(getenv("LOFT_CONV_BIG_K")) : 512;
@@ -454,8 +456,12 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
-        const bool staged_epi = (residual || relu_mask) && !out_f32 && os == 1 && OHf == OH && OWf == OW;
-        if ((long)T * Cin <= single_max && !force_small_tile && !staged_epi)
+        const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
+        const bool two_tiles = residual && relu_mask && dense_out;        // needs both halves of the double buffer
+        const bool staged_epi = (residual || relu_mask) && dense_out;
+        static const long single_res_max = getenv("LOFT_CONV_SINGLE_RES") ? atol(getenv("LOFT_CONV_SINGLE_RES")) : 256;
+        if (!force_small_tile && !two_tiles && a.staged_out &&
+            (long)T * Cin <= (staged_epi ? single_res_max : single_max))
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
         else if (deepk)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 2, true>), grid, dim3(256), 0, s, a);

@@ -8,7 +8,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libloft_hip.so')
+# LOFT_HIP_LIB: an alternative build of the same library (A/B timing of kernel variants on one box)
+_LIB_PATH = os.environ.get('LOFT_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libloft_hip.so')
 _lib = None
 
 F32, BF16 = 0, 1

@@ -420,6 +420,212 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(RoiLevels L, in
     }
 }
 
+// ---- backward on the matrix cores (bf16 training path, C == 256) ---------------------------------------------------
+// Same tile-owner scheme, but the per-(RoI, tile) scatter is one small GEMM instead of 64 VALU FMAs per bin and lane:
+//     grad_tile[c][pix] += sum_k  gout[bin_k][c] * A[bin_k][pix],   A[bin][pix] = WY[py][y] * WX[px][x] / count
+// over the (<= 64 per chunk) bins that overlap the 8x8 tile.  gout rows are staged bin-major in LDS (summed over the FOA
+// rotations), A is built bin-major next to them as a bf16 hi + lo pair (16 mantissa bits: the fp32 weights of the scalar
+// form to 1e-5), both operands are read with the LDS transpose reader of the weight-gradient kernel
+// (ds_read_tr16_b64: "8 consecutive k for my column"), v_mfma_f32_32x32x16_bf16 accumulates in fp32.
+// Wave w owns channels 64w..64w+63 of all 64 pixels (2 x 2 tiles of 32 x 32 -> 64 accumulator registers).  Per pair
+// this is ~2 x 2 x 2 x ceil(K/16) MFMAs instead of K x 64 FMAs per lane; the VALU form spent 1 ms on the P2 level
+// of the 8192-RoI bbox extractor alone.
+typedef __attribute__((ext_vector_type(8))) short rbf16x8;
+typedef __attribute__((ext_vector_type(16))) float rf32x16;
+typedef __attribute__((ext_vector_type(4))) short rs16x4;
+
+__device__ __forceinline__ int rwswz(int row, int q) { return q ^ ((row & 3) << 2); }
+
+template <int RB>
+__device__ __forceinline__ rbf16x8 roi_tr_frag(const char* tile, int kbase, int col0, int lane) {
+    // lane l -> column col0 + (l&31), rows (k) kbase + 8*(l>>5) + 0..7 of a row-major [k][RB/2] bf16 tile
+    const int il = lane & 15, gl = lane >> 4;
+    const int col = col0 + 16 * (gl & 1) + (il & 3) * 4;
+    const int r0 = kbase + 8 * (gl >> 1) + (il >> 2);
+    const int r1 = r0 + 4;
+    const char* p0 = tile + r0 * RB + rwswz(r0, col >> 3) * 16 + (col & 7) * 2;
+    const char* p1 = tile + r1 * RB + rwswz(r1, col >> 3) * 16 + (col & 7) * 2;
+    rs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)p0);
+    rs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)p1);
+    rbf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, const float* __restrict__ rois,
+                                                                 int K, int P, int n_rot, const bf16_t* __restrict__ gout,
+                                                                 bf16_t* __restrict__ grad, int accumulate,
+                                                                 const int4* __restrict__ rec, int sorted) {
+    constexpr int C = 256;
+    __shared__ __attribute__((aligned(16))) char gbuf[64 * 512];      // [bin][256 ch] bf16, 16-byte chunks swizzled
+    __shared__ __attribute__((aligned(16))) char abuf[64 * 256];      // [bin][64 px hi | 64 px lo] bf16
+    __shared__ int list[RB_LIST];
+    __shared__ int wcnt[4];
+    __shared__ int range[2];
+    __shared__ float WY[RB_MAXP][RB_TILE], WX[RB_MAXP][RB_TILE];
+    __shared__ int pyl[RB_MAXP], pxl[RB_MAXP], npyx[2];
+    const int H = L.H[level], W = L.W[level];
+    const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 2) {
+        int lo = 0, hi = K;
+        const int key = b + tid;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
+        range[tid] = lo;
+    }
+    for (int i = tid; i < 64 * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 64 * 256 / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int kbeg = sorted ? range[0] : 0, kend = sorted ? range[1] : K;
+    rf32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int base = kbeg; base < kend; base += RB_LIST) {
+        // ---- deterministic compaction of the RoIs that touch this tile
+        const int k = base + tid;
+        bool hit = false;
+        if (k < kend) {
+            const int4 r = rec[k];
+            if (r.x == b && r.y == level) {   // (the empty flag lives in bits 8+ of r.y -> empty RoIs never match)
+                const int x0 = r.z & 0xffff, x1 = r.z >> 16, y0 = r.w & 0xffff, y1 = r.w >> 16;
+                hit = x1 >= tx0 && x0 < tx0 + RB_TILE && y1 >= ty0 && y0 < ty0 + RB_TILE;
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w2 = 0; w2 < wave; ++w2) off += wcnt[w2];
+        const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (hit) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        for (int li = 0; li < n; ++li) {
+            const int kk = list[li];
+            const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
+            if (tid < P * RB_TILE) {
+                const int p = tid / RB_TILE, pix = tid % RB_TILE;
+                WY[p][pix] = axis_weight(g.start_h, g.bin_h, g.grid_h, p, ty0 + pix, H);
+            } else if (tid >= 128 && tid < 128 + P * RB_TILE) {
+                const int t = tid - 128, p = t / RB_TILE, pix = t % RB_TILE;
+                WX[p][pix] = axis_weight(g.start_w, g.bin_w, g.grid_w, p, tx0 + pix, W);
+            }
+            __syncthreads();
+            if (tid < 2) {                       // bin rows / columns with any weight inside the tile
+                float (*Wt)[RB_TILE] = tid == 0 ? WY : WX;
+                int* lst = tid == 0 ? pyl : pxl;
+                int cnt = 0;
+                for (int p = 0; p < P; ++p) {
+                    bool any = false;
+                    for (int x = 0; x < RB_TILE; ++x) any |= (Wt[p][x] != 0.f);
+                    if (any) lst[cnt++] = p;
+                }
+                npyx[tid] = cnt;
+            }
+            __syncthreads();
+            const int npy = npyx[0], npx = npyx[1];
+            const int ka = npy * npx;            // active bins of this (RoI, tile) pair
+            const float inv = 1.f / g.count;
+            for (int kc = 0; kc < ka; kc += 64) {                 // chunks of 64 bins (one chunk unless P = 14 with tiny bins)
+                const int kn = min(64, ka - kc);
+                const int kpad = (kn + 15) & ~15;
+                if (kc > 0) __syncthreads();                      // the previous chunk's fragment reads are done
+                // ---- A[bin][pix]: one (bin, tile row) = 8 pixels = one 16-byte chunk of hi and one of lo per task
+                for (int t = tid; t < kpad * 8; t += 256) {
+                    const int kb = t >> 3, y = t & 7;
+                    uint32_t hi4[4] = {0, 0, 0, 0}, lo4[4] = {0, 0, 0, 0};
+                    if (kb < kn) {
+                        const int ab = kc + kb;
+                        const int py = pyl[ab / npx], px = pxl[ab % npx];
+                        const float wy = WY[py][y] * inv;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            const float a = wy * WX[px][x];
+                            const bf16_t h = f32_to_bf16(a);
+                            const bf16_t l = f32_to_bf16(a - bf16_to_f32(h));
+                            hi4[x >> 1] |= (uint32_t)h << (16 * (x & 1));
+                            lo4[x >> 1] |= (uint32_t)l << (16 * (x & 1));
+                        }
+                    }
+                    *reinterpret_cast<uint4*>(abuf + kb * 256 + rwswz(kb, y) * 16) = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
+                    *reinterpret_cast<uint4*>(abuf + kb * 256 + rwswz(kb, 8 + y) * 16) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+                }
+                // ---- gout rows of the active bins (FOA: the four rotations summed in fp32, rounded once)
+                for (int t = tid; t < kn * 32; t += 256) {
+                    const int kb = t >> 5, q = t & 31;
+                    const int ab = kc + kb;
+                    const int py = pyl[ab / npx], px = pxl[ab % npx];
+                    uint4 v;
+                    if (n_rot == 1) {
+                        v = *reinterpret_cast<const uint4*>(gout + ((size_t)kk * P * P + py * P + px) * C + q * 8);
+                    } else {
+                        float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        for (int r = 0; r < n_rot; ++r) {
+                            const bf16_t* gp = gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + q * 8;
+                            float t0[4], t1[4];
+                            ld4(gp, t0); ld4(gp + 4, t1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { sacc[e] += t0[e]; sacc[4 + e] += t1[e]; }
+                        }
+                        v.x = (uint32_t)f32_to_bf16(sacc[0]) | ((uint32_t)f32_to_bf16(sacc[1]) << 16);
+                        v.y = (uint32_t)f32_to_bf16(sacc[2]) | ((uint32_t)f32_to_bf16(sacc[3]) << 16);
+                        v.z = (uint32_t)f32_to_bf16(sacc[4]) | ((uint32_t)f32_to_bf16(sacc[5]) << 16);
+                        v.w = (uint32_t)f32_to_bf16(sacc[6]) | ((uint32_t)f32_to_bf16(sacc[7]) << 16);
+                    }
+                    *reinterpret_cast<uint4*>(gbuf + kb * 512 + rwswz(kb, q) * 16) = v;
+                }
+                __syncthreads();
+                for (int ks = 0; ks < kpad; ks += 16) {
+                    rbf16x8 gf[2], xh[2], xl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) gf[i] = roi_tr_frag<512>(gbuf, ks, wave * 64 + i * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        xh[j] = roi_tr_frag<256>(abuf, ks, j * 32, lane);
+                        xl[j] = roi_tr_frag<256>(abuf, ks, 64 + j * 32, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xl[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();   // tables and operand tiles are rewritten by the next RoI
+        }
+    }
+    // ---- flush: lane holds pixel 32j + (lane & 31) and 4 x 4 consecutive channels per (i, gq)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = j * 32 + (lane & 31);
+        const int y = ty0 + (pix >> 3), x = tx0 + (pix & 7);
+        if (y >= H || x >= W) continue;
+        bf16_t* gp = grad + (((size_t)b * H + y) * W + x) * C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = wave * 64 + i * 32 + 8 * gq + 4 * (lane >> 5);
+                float v[4] = {acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]};
+                if (accumulate) {
+                    float o[4];
+                    ld4(gp + n, o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += o[q];
+                }
+                st4(gp + n, v);
+            }
+    }
+}
+
 __global__ void roi_levels_kernel(const float* __restrict__ rois, int K, int num_levels, int finest_scale,
                                   int32_t* __restrict__ out) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -475,7 +681,11 @@ LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const 
     }
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
-        if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16)
+        static const bool valu_form = getenv("LOFT_ROI_VALU_BWD") != nullptr;          // A/B switch
+        if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16 && C == 256 && !valu_form)
+            hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, rois, K, P, n_rot,
+                               (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
+        else if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16)
             hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
         else if (dtype == LOFT_BF16)

@@ -125,3 +125,35 @@ def test_sort_stability():
     for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
         want = cops.argsort_desc(keys[a:b]) + a
         assert torch.equal(vs[a:b].cpu().long(), want)
+
+
+@pytest.mark.parametrize('P,n_rot', [(7, 1), (14, 1), (7, 4)])
+def test_roi_align_bwd_mfma_matches_scalar_form(P, n_rot):
+    """The matrix-core backward (bf16 maps, C = 256: the training path) against the scalar fp32 form that is pinned to the
+    oracle above: same RoIs incl. zero-size / outside / image-sized boxes, tiny (sub-pixel-bin) and elongated boxes, and the
+    accumulate mode used by the feature-gradient hub."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(5)
+    B, C, size = 2, 256, 256
+    strides = [4, 8, 16, 32]
+    rois = _rand_rois(rng, 400, B, size)
+    rois[0, 1:] = torch.tensor([10., 10., 10., 10.])
+    rois[1, 1:] = torch.tensor([-500., -500., -400., -400.])
+    rois[2, 1:] = torch.tensor([0., 0., float(size), float(size)])
+    rois[3, 1:] = torch.tensor([40., 40., 44., 43.])            # sub-pixel bins at stride 4
+    rois[4, 1:] = torch.tensor([-20., 100., 250., 112.])        # long and thin, partly outside
+    rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous()
+    torch.manual_seed(1)
+    g = torch.randn(n_rot * rois.shape[0], C, P, P).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    shapes = [(B, C, size // s, size // s) for s in strides]
+    want = K.roi_align_bwd(g, rois.cuda(), shapes, P, strides, n_rot=n_rot, rois_sorted=True, out_dtype=torch.float32)
+    got = K.roi_align_bwd(g, rois.cuda(), shapes, P, strides, n_rot=n_rot, rois_sorted=True, out_dtype=torch.bfloat16)
+    for gg, ww in zip(got, want):
+        assert gg.dtype == torch.bfloat16
+        scale = max(1.0, ww.abs().max().item())
+        assert (gg.float() - ww).abs().max().item() <= 6e-3 * scale          # bf16 output rounding (2^-8 of the value)
+        assert (gg.float() - ww).abs().mean().item() <= 6e-4 * scale
+    twice = K.roi_align_bwd(g, rois.cuda(), shapes, P, strides, n_rot=n_rot, rois_sorted=True, grad_feats=[x.clone() for x in got])
+    for tt, ww in zip(twice, want):
+        scale = max(1.0, ww.abs().max().item())
+        assert (tt.float() - 2 * ww).abs().max().item() <= 2e-2 * scale

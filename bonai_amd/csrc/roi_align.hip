@@ -453,18 +453,25 @@ __device__ __forceinline__ rbf16x8 roi_tr_frag(const char* tile, int kbase, int 
     return f;
 }
 
-__global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, const float* __restrict__ rois,
+__device__ __forceinline__ int nth_set_bit(unsigned m, int n) {      // position of the n-th (0-based) set bit of m
+    for (int i = 0; i < n; ++i) m &= m - 1u;
+    return __builtin_ctz(m);
+}
+
+#define RBM_CHUNK 32      // bins per operand chunk: 24 KiB of LDS per block -> 6 blocks per CU hide the staging latency
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, const float* __restrict__ rois,
                                                                  int K, int P, int n_rot, const bf16_t* __restrict__ gout,
                                                                  bf16_t* __restrict__ grad, int accumulate,
                                                                  const int4* __restrict__ rec, int sorted) {
     constexpr int C = 256;
-    __shared__ __attribute__((aligned(16))) char gbuf[64 * 512];      // [bin][256 ch] bf16, 16-byte chunks swizzled
-    __shared__ __attribute__((aligned(16))) char abuf[64 * 256];      // [bin][64 px hi | 64 px lo] bf16
+    __shared__ __attribute__((aligned(16))) char gbuf[RBM_CHUNK * 512];      // [bin][256 ch] bf16, 16-byte chunks swizzled
+    __shared__ __attribute__((aligned(16))) char abuf[RBM_CHUNK * 256];      // [bin][64 px hi | 64 px lo] bf16
     __shared__ int list[RB_LIST];
     __shared__ int wcnt[4];
     __shared__ int range[2];
-    __shared__ float WY[RB_MAXP][RB_TILE], WX[RB_MAXP][RB_TILE];
-    __shared__ int pyl[RB_MAXP], pxl[RB_MAXP], npyx[2];
+    __shared__ float WY[2][RB_MAXP][RB_TILE], WX[2][RB_MAXP][RB_TILE];       // double-buffered per pair
+    __shared__ unsigned long long anyb[2][4];                                // per wave: ballot of "weight != 0"
     const int H = L.H[level], W = L.W[level];
     const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -475,8 +482,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
         range[tid] = lo;
     }
-    for (int i = tid; i < 64 * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < 64 * 256 / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < RBM_CHUNK * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < RBM_CHUNK * 256 / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int kbeg = sorted ? range[0] : 0, kend = sorted ? range[1] : K;
     rf32x16 acc[2][2];
@@ -486,6 +493,27 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // 1-D weight tables of one RoI for this tile + which bin rows / columns have any weight in it (wave ballots: waves 0-1
+    // hold the 8 tile rows of bins 0-7 / 8-13, waves 2-3 the tile columns)
+    auto tables = [&](int kk, int buf) {
+        const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
+        const int t = tid & 127;
+        const int p = t >> 3, pix = t & 7;
+        float w = 0.f;
+        if (p < P) {
+            if (tid < 128) {
+                w = axis_weight(g.start_h, g.bin_h, g.grid_h, p, ty0 + pix, H);
+                WY[buf][p][pix] = w;
+            } else {
+                w = axis_weight(g.start_w, g.bin_w, g.grid_w, p, tx0 + pix, W);
+                WX[buf][p][pix] = w;
+            }
+        }
+        const unsigned long long bal = __ballot(w != 0.f);
+        if (lane == 0) anyb[buf][wave] = bal;
+        return 1.f / g.count;
+    };
 
     for (int base = kbeg; base < kend; base += RB_LIST) {
         // ---- deterministic compaction of the RoIs that touch this tile
@@ -499,6 +527,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
             }
         }
         const unsigned long long bal = __ballot(hit);
+        __syncthreads();                     // (previous batch: its last fragment reads and list reads are done)
         if (lane == 0) wcnt[wave] = __popcll(bal);
         __syncthreads();
         int off = 0;
@@ -506,47 +535,36 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
         const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         if (hit) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
         __syncthreads();
+        float inv = 0.f;
+        if (n > 0) inv = tables(list[0], 0);
         for (int li = 0; li < n; ++li) {
             const int kk = list[li];
-            const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
-            if (tid < P * RB_TILE) {
-                const int p = tid / RB_TILE, pix = tid % RB_TILE;
-                WY[p][pix] = axis_weight(g.start_h, g.bin_h, g.grid_h, p, ty0 + pix, H);
-            } else if (tid >= 128 && tid < 128 + P * RB_TILE) {
-                const int t = tid - 128, p = t / RB_TILE, pix = t % RB_TILE;
-                WX[p][pix] = axis_weight(g.start_w, g.bin_w, g.grid_w, p, tx0 + pix, W);
+            const int buf = li & 1;
+            __syncthreads();                 // tables of this pair are ready; the previous pair's fragment reads are done
+            unsigned rmask = 0u, cmask = 0u;
+            for (int p = 0; p < P; ++p) {
+                rmask |= (((anyb[buf][p >> 3] >> (8 * (p & 7))) & 0xffull) != 0ull) ? (1u << p) : 0u;
+                cmask |= (((anyb[buf][2 + (p >> 3)] >> (8 * (p & 7))) & 0xffull) != 0ull) ? (1u << p) : 0u;
             }
-            __syncthreads();
-            if (tid < 2) {                       // bin rows / columns with any weight inside the tile
-                float (*Wt)[RB_TILE] = tid == 0 ? WY : WX;
-                int* lst = tid == 0 ? pyl : pxl;
-                int cnt = 0;
-                for (int p = 0; p < P; ++p) {
-                    bool any = false;
-                    for (int x = 0; x < RB_TILE; ++x) any |= (Wt[p][x] != 0.f);
-                    if (any) lst[cnt++] = p;
-                }
-                npyx[tid] = cnt;
-            }
-            __syncthreads();
-            const int npy = npyx[0], npx = npyx[1];
+            const int npy = __popc(rmask), npx = __popc(cmask);
             const int ka = npy * npx;            // active bins of this (RoI, tile) pair
-            const float inv = 1.f / g.count;
-            for (int kc = 0; kc < ka; kc += 64) {                 // chunks of 64 bins (one chunk unless P = 14 with tiny bins)
-                const int kn = min(64, ka - kc);
+            const float inv_cur = inv;
+            for (int kc = 0; kc < ka; kc += RBM_CHUNK) {          // one chunk unless P = 14 with small bins
+                const int kn = min(RBM_CHUNK, ka - kc);
                 const int kpad = (kn + 15) & ~15;
                 if (kc > 0) __syncthreads();                      // the previous chunk's fragment reads are done
                 // ---- A[bin][pix]: one (bin, tile row) = 8 pixels = one 16-byte chunk of hi and one of lo per task
+#pragma unroll 1
                 for (int t = tid; t < kpad * 8; t += 256) {
                     const int kb = t >> 3, y = t & 7;
                     uint32_t hi4[4] = {0, 0, 0, 0}, lo4[4] = {0, 0, 0, 0};
                     if (kb < kn) {
                         const int ab = kc + kb;
-                        const int py = pyl[ab / npx], px = pxl[ab % npx];
-                        const float wy = WY[py][y] * inv;
+                        const int py = nth_set_bit(rmask, ab / npx), px = nth_set_bit(cmask, ab % npx);
+                        const float wy = WY[buf][py][y] * inv_cur;
 #pragma unroll
                         for (int x = 0; x < 8; ++x) {
-                            const float a = wy * WX[px][x];
+                            const float a = wy * WX[buf][px][x];
                             const bf16_t h = f32_to_bf16(a);
                             const bf16_t l = f32_to_bf16(a - bf16_to_f32(h));
                             hi4[x >> 1] |= (uint32_t)h << (16 * (x & 1));
@@ -557,15 +575,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
                     *reinterpret_cast<uint4*>(abuf + kb * 256 + rwswz(kb, 8 + y) * 16) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
                 }
                 // ---- gout rows of the active bins (FOA: the four rotations summed in fp32, rounded once)
+#pragma unroll 1
                 for (int t = tid; t < kn * 32; t += 256) {
                     const int kb = t >> 5, q = t & 31;
                     const int ab = kc + kb;
-                    const int py = pyl[ab / npx], px = pxl[ab % npx];
+                    const int py = nth_set_bit(rmask, ab / npx), px = nth_set_bit(cmask, ab % npx);
                     uint4 v;
                     if (n_rot == 1) {
                         v = *reinterpret_cast<const uint4*>(gout + ((size_t)kk * P * P + py * P + px) * C + q * 8);
                     } else {
                         float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
                         for (int r = 0; r < n_rot; ++r) {
                             const bf16_t* gp = gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + q * 8;
                             float t0[4], t1[4];
@@ -581,6 +601,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
                     *reinterpret_cast<uint4*>(gbuf + kb * 512 + rwswz(kb, q) * 16) = v;
                 }
                 __syncthreads();
+#pragma unroll 1
                 for (int ks = 0; ks < kpad; ks += 16) {
                     rbf16x8 gf[2], xh[2], xl[2];
 #pragma unroll
@@ -599,7 +620,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_mfma_kernel(RoiLevels L, in
                         }
                 }
             }
-            __syncthreads();   // tables and operand tiles are rewritten by the next RoI
+            // the next pair's tables ride behind this pair's MFMAs (other buffer; its readers finished two barriers ago)
+            if (li + 1 < n) inv = tables(list[li + 1], buf ^ 1);
         }
     }
     // ---- flush: lane holds pixel 32j + (lane & 31) and 4 x 4 consecutive channels per (i, gq)

@@ -678,3 +678,95 @@ LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const fl
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------- backward of a 1x1 head with a handful of outputs
+// Replaces, for Cout <= 8 (mask logits: 1, fc_cls + fc_reg: 6, fc_offset: 2), the padded-to-128-channels MFMA route
+// (zero fill + strided copy of g, a 128-wide data-gradient GEMM and a weight-gradient GEMM: ~0.6 ms for the 1-channel mask
+// logits at 875 x 28 x 28 pixels) by ONE pass over the input:
+//     gx[m][c] = (x[m][c] > 0 | no mask) * sum_n g[m][n] * w[n][c]         (bf16, 8 bytes per lane)
+//     dw[n][c] += sum_m g[m][n] * x[m][c],   db[n] += sum_m g[m][n]         (fp32 registers -> LDS -> one atomic per entry and block)
+// HBM-bound: reads x once (it is also the ReLU mask of the producer), writes gx once.  g fp32 [M][gs] (gs = Cout rounded up
+// to 4), x bf16 [M][Cin], w fp32 [Cout][Cin]; Cin % 4 == 0, Cin <= 1024.
+template <int NOUT>
+__global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __restrict__ g, int gs, const bf16_t* __restrict__ x,
+                                                              const float* __restrict__ w, long M, int Cin, int relu_in,
+                                                              bf16_t* __restrict__ gx, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+    const int cg = Cin >> 2;                       // column groups of 4 channels
+    const int ppi = 256 / cg > 0 ? 256 / cg : 1;   // pixels per block iteration (Cin = 256 -> 4, Cin = 1024 -> 1)
+    const int tid = threadIdx.x;
+    const int col = tid % cg, sub = tid / cg;
+    const bool act = sub < ppi;
+    const int c0 = col << 2;
+    float wr[NOUT][4], acc[NOUT][4], bacc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        const float4 t = *reinterpret_cast<const float4*>(w + (long)n * Cin + c0);
+        wr[n][0] = t.x; wr[n][1] = t.y; wr[n][2] = t.z; wr[n][3] = t.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[n][q] = 0.f;
+        bacc[n] = 0.f;
+    }
+    if (act)
+        for (long m = (long)blockIdx.x * ppi + sub; m < M; m += (long)gridDim.x * ppi) {
+            float xv[4], gv[NOUT];
+            ld4(x + m * Cin + c0, xv);
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) gv[n] = g[m * gs + n];
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] += gv[n] * wr[n][q];
+                    acc[n][q] += gv[n] * xv[q];
+                }
+                bacc[n] += gv[n];
+            }
+            if (gx) {
+                if (relu_in) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = xv[q] > 0.f ? o[q] : 0.f;
+                }
+                st4(gx + m * Cin + c0, o);
+            }
+        }
+    // block reduction over the ppi pixel sub-streams, then one atomic per (n, c) and block
+    __shared__ float red[NOUT][1024];
+    for (int s2 = 0; s2 < ppi; ++s2) {
+        if (act && sub == s2) {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (s2 == 0) red[n][c0 + q] = acc[n][q];
+                    else red[n][c0 + q] += acc[n][q];
+                }
+        }
+        __syncthreads();
+    }
+    if (dw)
+        for (int i = tid; i < NOUT * Cin; i += 256) unsafeAtomicAdd(dw + i, red[i / Cin][i % Cin]);
+    if (db && col == 0 && act) {
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) unsafeAtomicAdd(db + n, bacc[n]);
+    }
+}
+LOFT_EXPORT int loft_narrow_head_bwd(const float* g, int g_stride, const void* x, const float* w, int64_t M, int Cin, int Cout,
+                                     int relu_in, void* gx, float* dw, float* db, void* stream) {
+    if (M <= 0) return 0;
+    if (Cout < 1 || Cout > 8 || (Cin & 3) || Cin > 1024 || g_stride < Cout) return (int)hipErrorInvalidValue;
+    const int cg = Cin >> 2, ppi = 256 / cg > 0 ? 256 / cg : 1;
+    long blocks = (M + ppi - 1) / ppi;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+#define NHB(N) hipLaunchKernelGGL(narrow_head_bwd_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, s, g, g_stride, (const bf16_t*)x, w, \
+                                  (long)M, Cin, relu_in, (bf16_t*)gx, dw, db)
+    switch (Cout) {
+        case 1: NHB(1); break; case 2: NHB(2); break; case 3: NHB(3); break; case 4: NHB(4); break;
+        case 5: NHB(5); break; case 6: NHB(6); break; case 7: NHB(7); break; default: NHB(8); break;
+    }
+#undef NHB
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -996,6 +996,25 @@ class PrepackRegistry:
 
 
 
+def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=True):
+    """Backward of a 1x1 head with Cout <= 8 outputs in one pass over x (loft_narrow_head_bwd).
+    g fp32 [N,c4,H,W] channels_last (c4 >= Cout), x bf16 NHWC [N,Cin,H,W], w fp32 [Cout,Cin]
+    -> (gx bf16 NHWC | None, dw fp32 [Cout,Cin] | None, db fp32 [Cout] | None)."""
+    lib = L.load()
+    L.dev_check(g, x, w)
+    x = _nhwc(x)
+    g = g.float().contiguous(memory_format=torch.channels_last)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w2 = w.reshape(Cout, Cin).float().contiguous()
+    gx = empty_nhwc(N, Cin, H, W, torch.bfloat16, x.device) if need_gx else None
+    dw = pooled_zeros((Cout, Cin), x.device) if need_dw else None
+    db = pooled_zeros((Cout,), x.device) if need_db else None
+    L.check(lib.loft_narrow_head_bwd(L.ptr(g), int(g.shape[1]), L.ptr(x), L.ptr(w2), c_int64(N * H * W), Cin, Cout, int(relu_in),
+                                     L.ptr(gx), L.ptr(dw), L.ptr(db), L.stream()), 'loft_narrow_head_bwd')
+    return gx, dw, db
+
+
 class UnpackQueue:
     """Deferred loft_fold_unpack_bwd jobs of the trainer's direct gradient sink, flushed as ONE launch
     (loft_fold_unpack_bwd_multi) every ``limit`` jobs and at the end of the backward pass."""

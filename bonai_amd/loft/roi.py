@@ -160,8 +160,8 @@ class FCNMaskHead(nn.Module):
             return x.new_zeros(0, nout, 2 * x.shape[2], 2 * x.shape[3], dtype=torch.float32)
         for i, m in enumerate(self.convs):
             x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True, input_relu=i > 0)
-        x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias)
-        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias)
+        x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias, input_relu=len(self.convs) > 0)
+        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias, input_relu=True)
         return o[:, :nout]
 
     def loss(self, mask_pred, mask_targets, labels):

@@ -236,8 +236,9 @@ class _NarrowHeadFn(torch.autograd.Function):
     PADW = 128
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad):
+    def forward(ctx, x, w, b, stride, pad, input_relu=False):
         Cout, Cin, R, S = w.shape
+        ctx.input_relu = input_relu
         c4 = (Cout + 3) // 4 * 4
         wpad = torch.zeros(c4, Cin, R, S, dtype=w.dtype, device=w.device)
         wpad[:Cout] = w
@@ -259,6 +260,15 @@ class _NarrowHeadFn(torch.autograd.Function):
             raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         stride, pad = ctx.sp
         Cout, Cin, R, S = w.shape
+        if R == 1 and S == 1 and stride == 1 and pad == 0 and Cout <= 8 and Cin % 4 == 0 and Cin <= 1024 and \
+                not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
+            # one pass over x: gx (with the producer's ReLU mask when x is a ReLU output), dW and db together
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=ctx.input_relu, need_gx=ctx.needs_input_grad[0],
+                                           need_dw=ctx.needs_input_grad[1], need_db=want_b)
+            if gx is not None and ctx.input_relu:
+                gx._loft_premasked = x.data_ptr()
+            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
         gp = torch.zeros(N, P, H, W, dtype=torch.bfloat16, device=g.device).contiguous(memory_format=torch.channels_last)
@@ -281,14 +291,15 @@ class _NarrowHeadFn(torch.autograd.Function):
         K.ALGO_SCALE = 1.0
         if want_b:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def narrow_head(x, w, b=None, stride=1, pad=0):
-    """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW]."""
+def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False):
+    """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW].
+    input_relu: x is the output of a ReLU -- the backward folds that ReLU's mask into the data gradient it produces."""
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
-    return _NarrowHeadFn.apply(x, w, b, stride, pad)
+    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu)
 
 
 class _MdcnSampleFn(torch.autograd.Function):
@@ -335,9 +346,10 @@ class _DeconvFn(torch.autograd.Function):
     """ConvTranspose2d(k=2, s=2) + bias + ReLU (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:121-124)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, input_relu=False):
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
+        ctx.input_relu = input_relu
         wp = w.permute(2, 3, 1, 0).reshape(4, Cout, Cin).to(x.dtype).contiguous()
         y = K.empty_nhwc(N, Cout, 2 * H, 2 * W, x.dtype, x.device)
         bias = b.float().contiguous()
@@ -355,13 +367,18 @@ class _DeconvFn(torch.autograd.Function):
             raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
-        g = K.relu_bwd(to_nhwc(g), y)
+        g = to_nhwc(g)
+        if getattr(g, '_loft_premasked', None) != y.data_ptr():   # (the 1x1 logits head already applied this ReLU's mask)
+            g = K.relu_bwd(g, y)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt = w.permute(2, 3, 0, 1).reshape(4, Cin, Cout).to(torch.bfloat16).contiguous()
             gx = K.empty_nhwc(N, Cin, H, W, torch.bfloat16, x.device)
             taps = [(py, px, py * 2 + px) for py in range(2) for px in range(2)]
-            K.conv_tap(g, wt, gx, N, 2 * H, 2 * W, Cout, Cin, H, W, H, W, taps, ss=2)
+            # x is the ReLU output of the last mask conv (fcn_mask_head.py:117-124): its mask rides in this epilogue
+            K.conv_tap(g, wt, gx, N, 2 * H, 2 * W, Cout, Cin, H, W, H, W, taps, ss=2, mask=x if ctx.input_relu else None)
+            if ctx.input_relu:
+                gx._loft_premasked = x.data_ptr()
         if ctx.needs_input_grad[1]:
             taps = [(py, px, 0, 0, py * 2 + px) for py in range(2) for px in range(2)]
             db = torch.zeros(1, Cout, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
@@ -370,11 +387,12 @@ class _DeconvFn(torch.autograd.Function):
             gb = db[0] if db is not None else None
         elif ctx.needs_input_grad[2]:
             gb = K.colsum(g, Cout)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def deconv2x2_relu(x, w, b):
-    return _DeconvFn.apply(x, w, b)
+def deconv2x2_relu(x, w, b, input_relu=False):
+    """input_relu: x is a ReLU output -- the backward folds that mask into the data gradient (no separate pass)."""
+    return _DeconvFn.apply(x, w, b, input_relu)
 
 
 # ------------------------------------------------------------------ feature-gradient hub

@@ -297,6 +297,14 @@ int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, cons
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
                          int CoutP, int CinP, int accumulate, void* stream);
 
+/* loft_narrow_head_bwd: backward of a 1x1 conv / linear layer with Cout <= 8 outputs (FCNMaskHead.conv_logits,
+ * fcn_mask_head.py:102; fc_cls / fc_reg, bbox_head.py:46-56; fc_offset, offset_head_expand_feature.py:104) in one pass:
+ * gx[M,Cin] bf16 = (relu_in ? x > 0 : 1) * g[M,:Cout] . w[Cout,Cin];  dw[Cout,Cin] += g^T x and db[Cout] += colsum(g) with fp32
+ * atomics (caller zeroes them).  g fp32 with row stride g_stride >= Cout, x bf16 [M,Cin], Cin % 4 == 0, Cin <= 1024.
+ * gx / dw / db may be NULL. */
+int loft_narrow_head_bwd(const float* g, int g_stride, const void* x, const float* w, int64_t M, int Cin, int Cout,
+                         int relu_in, void* gx, float* dw, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,3 +163,31 @@ def test_narrow_channel_conv_fwd_bwd(cin, cout, k, stride, xpad, opad):
         assert rel < 0.02, (name, rel)
     if xpad:
         assert xg.grad[:, cin:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('N,Cin,Cout,hw,relu_in', [(37, 256, 1, 28, True), (513, 1024, 6, 1, True), (300, 1024, 2, 1, False),
+                                                    (5, 64, 8, 7, True), (0, 256, 1, 28, True)])
+def test_narrow_head_bwd_one_pass(N, Cin, Cout, hw, relu_in):
+    """loft_narrow_head_bwd (mask logits / fc_cls+fc_reg / fc_offset backward in one pass over x) against the plain fp32
+    formulas: gx = [x > 0] * g W, dW = g^T x, db = colsum(g)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(N + Cout)
+    c4 = (Cout + 3) // 4 * 4
+    x = torch.randn(N, Cin, hw, hw).relu().bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    g = torch.randn(N, c4, hw, hw).cuda().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin).cuda()
+    gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=relu_in)
+    assert gx.shape == x.shape and dw.shape == (Cout, Cin) and db.shape == (Cout,)
+    if N == 0:
+        assert float(dw.abs().sum()) == 0.0
+        return
+    x2 = x.float().permute(0, 2, 3, 1).reshape(-1, Cin)
+    g2 = g.permute(0, 2, 3, 1).reshape(-1, c4)[:, :Cout]
+    want_gx = g2 @ w
+    if relu_in:
+        want_gx = want_gx * (x2 > 0)
+    got_gx = gx.float().permute(0, 2, 3, 1).reshape(-1, Cin)
+    assert (got_gx - want_gx).abs().max().item() <= 1e-2 * max(1.0, want_gx.abs().max().item())     # bf16 output
+    want_dw = g2.t() @ x2
+    assert (dw - want_dw).abs().max().item() <= 1e-4 * max(1.0, want_dw.abs().max().item())
+    assert (db - g2.sum(0)).abs().max().item() <= 1e-4 * max(1.0, g2.sum(0).abs().max().item())

@@ -785,6 +785,9 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
         static const long tgt_small = getenv("LOFT_WGRAD_TARGET") ? atol(getenv("LOFT_WGRAD_TARGET")) : 512;
         static const long tgt_big = getenv("LOFT_WGRAD_TARGET_BIG") ? atol(getenv("LOFT_WGRAD_TARGET_BIG")) : 256;   // 256-tile: one workgroup per CU
         // (big tile, measured: 256 workgroups 708-791 TFLOP/s on the FOA / mask / P2-P3 3x3 shapes, 512: 606-754, 1024: 474-719)
+        // (also measured: a single-stage 128-tile form at four workgroups per CU -- what helped the K-shallow forward convs --
+        //  changes nothing here, with 512 or 1024 workgroups: these launches are bound by the fp32-atomic epilogue and the
+        //  operand re-reads, not by the per-K-step round trip)
         long want = (big ? tgt_big : tgt_small) / ((long)tiles * T * groups);
         long maxs = (M + 255) / 256;
         splits = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));

@@ -505,7 +505,11 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
         bf16_t* wpt = reinterpret_cast<bf16_t*>(d[7]);
         float* bias_out = reinterpret_cast<float*>(d[8]);
         const float eps = __int_as_float((int)d[9]);
-        const int Cout = (int)d[10], Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
+        const int Cout = (int)d[10], Cin = (int)d[11], CoutP = (int)d[13], CinP = (int)d[14];
+        // RS < 0: "n-major" forward packing wp[n][t][c] (a Linear applied to a flattened [C,H,W] map: the K axis of the GEMM is
+        // (t, c) = the NHWC order of the activation, so the weight's (c, t) columns are permuted here instead of the activation)
+        const bool nmajor = d[12] < 0;
+        const int RS = (int)(nmajor ? -d[12] : d[12]);
         const int local_chunk = (int)(c - d[15]);
         if (local_chunk == 0 && bias_out)
             for (int nn = threadIdx.x; nn < CoutP; nn += blockDim.x) {
@@ -513,6 +517,24 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
                 else if (gamma) bias_out[nn] = beta[nn] - mean[nn] * gamma[nn] * rsqrtf(var[nn] + eps);
                 else bias_out[nn] = cbias ? cbias[nn] : 0.f;
             }
+        if (nmajor) {
+            // one output channel per chunk: the fp32 row w[n][c][t] is read contiguously, permuted to (t, c) order through LDS
+            // (as bf16: C * RS * 2 bytes <= the tile array) and written contiguously.  The transposed packing of these
+            // records is produced afterwards by loft_transpose_bf16 (a [O][K] -> [K][O] tiled transpose).
+            bf16_t* row = reinterpret_cast<bf16_t*>(tile);
+            const int nn = local_chunk, per = Cin * RS;
+            const float sc = gamma ? gamma[nn] * rsqrtf(var[nn] + eps) : 1.f;
+            __syncthreads();
+            for (int j = threadIdx.x; j < per; j += 256) {
+                const int cc = j / RS, t = j - cc * RS;
+                row[t * Cin + cc] = f32_to_bf16(w[(long)nn * per + j] * sc);
+            }
+            __syncthreads();
+            if (wp)
+                for (int j = threadIdx.x * 2; j < per; j += 512)
+                    *reinterpret_cast<uint32_t*>(wp + (long)nn * per + j) = *reinterpret_cast<const uint32_t*>(row + j);
+            continue;
+        }
         if (RS > FOLD_TILE_MAX_RS) {                             // per-element form
             const long total = (long)CoutP * CinP * RS;
             const long i0 = (long)local_chunk * FOLD_CHUNK;
@@ -580,6 +602,33 @@ LOFT_EXPORT int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks
     return 0;
 }
 
+// dst[c][r] = src[r][c] for a row-major bf16 matrix [R][Cc] (64 x 64 tiles through LDS, both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int R, int Cc) {
+    __shared__ bf16_t t[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int r = i >> 5, cp = (i & 31) * 2;
+        uint32_t v = 0;
+        if (r0 + r < R && c0 + cp < Cc) v = *reinterpret_cast<const uint32_t*>(src + (long)(r0 + r) * Cc + c0 + cp);
+        t[r][cp] = (bf16_t)(v & 0xffff);
+        t[r][cp + 1] = (bf16_t)(v >> 16);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int c = i >> 5, rp = (i & 31) * 2;
+        if (c0 + c < Cc && r0 + rp < R)
+            *reinterpret_cast<uint32_t*>(dst + (long)(c0 + c) * R + r0 + rp) = (uint32_t)t[rp][c] | ((uint32_t)t[rp + 1][c] << 16);
+    }
+}
+LOFT_EXPORT int loft_transpose_bf16(const void* src, void* dst, int R, int Cc, void* stream) {
+    if (R <= 0 || Cc <= 0) return 0;
+    if ((R & 1) || (Cc & 1)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(loft_cdiv(Cc, 64), loft_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, R, Cc);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // one block per output channel n
 __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __restrict__ dwp, const float* __restrict__ db,
                                                               const float* __restrict__ w, const float* __restrict__ gamma,
@@ -633,12 +682,29 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
     float* dgamma = reinterpret_cast<float*>(d[7]);
     float* dbeta = reinterpret_cast<float*>(d[8]);
     const float eps = __int_as_float((int)d[9]);
-    const int Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
+    const int Cin = (int)d[11], CoutP = (int)d[13], CinP = (int)d[14];
+    const bool nmajor = d[12] < 0;             // dwp is [n][t][c] (weight gradient of a Linear over an NHWC-flattened map)
+    const int RS = (int)(nmajor ? -d[12] : d[12]);
     const int n = (int)(blockIdx.x - d[15]);
     const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
     const float scale = gamma ? gamma[n] * rs : 1.f;
     float acc = 0.f;
     const int per = Cin * RS;
+    if (nmajor) {
+        // dwp row [t][c] read contiguously, permuted to the parameter's (c, t) order through LDS, added contiguously
+        extern __shared__ float urow[];
+        for (int j = threadIdx.x; j < per; j += blockDim.x) {
+            const int t = j / CinP, c = j - t * CinP;
+            urow[c * RS + t] = dwp[(long)n * per + j];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < per; j += blockDim.x) {
+            const long wi = (long)n * per + j;
+            if (dw) dw[wi] += urow[j] * scale;
+        }
+        if (threadIdx.x == 0 && dbeta && db) dbeta[n] += db[n];
+        return;
+    }
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
         const float g = dwp[((long)t * CoutP + n) * CinP + c];
@@ -661,10 +727,11 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         dbeta[n] += db[n];
     }
 }
-LOFT_EXPORT int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, void* stream) {
+LOFT_EXPORT int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, int lds_floats, void* stream) {
     if (njobs <= 0 || nblocks <= 0) return 0;
-    hipLaunchKernelGGL(fold_unpack_bwd_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)desc,
-                       njobs);
+    if (lds_floats < 0 || lds_floats > 16384) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_unpack_bwd_multi_kernel, dim3((unsigned)nblocks), dim3(256), (size_t)lds_floats * 4, (hipStream_t)stream,
+                       (const long*)desc, njobs);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

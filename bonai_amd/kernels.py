@@ -939,29 +939,45 @@ class PrepackRegistry:
         self.nchunks = 0
         self.step = -1
 
-    def request(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad):
+    def request(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad, flat_chw=None):
         """ws / conv_biases: the G parameters of a grouped launch (G = 1 for a plain conv).
-        -> (wp [G,T,CoutP,CinP], wpt [G,T,CinP,CoutP] | None, bias [G,CoutP]) bf16 packings valid for the current step."""
+        -> (wp [G,T,CoutP,CinP], wpt [G,T,CinP,CoutP] | None, bias [G,CoutP]) bf16 packings valid for the current step.
+        flat_chw = (C, H, W): ws[0] is a Linear weight [O, C*H*W] applied to a flattened map that is kept NHWC in memory --
+        the packings come back as the 1x1 operands [1,1,O,H*W*C] / [1,1,H*W*C,O] with the K axis in (h, w, c) order."""
         key = (tuple(w.data_ptr() for w in ws), tuple(0 if b is None else b.data_ptr() for b in conv_biases),
-               0 if bn is None else (bn[0].data_ptr(), bn[2].data_ptr()), cout_p, cin_p, bool(want_dgrad))
+               0 if bn is None else (bn[0].data_ptr(), bn[2].data_ptr()), cout_p, cin_p, bool(want_dgrad), flat_chw)
         grp = self.jobs.get(key)
         if grp is None:
             G = len(ws)
-            Cout, Cin, R, S = ws[0].shape
             dev = ws[0].device
-            grp = dict(wp=torch.empty(G, R * S, cout_p, cin_p, dtype=torch.bfloat16, device=dev),
-                       wpt=torch.empty(G, R * S, cin_p, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
-                       bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2, members=[])
+            if flat_chw is not None:
+                C, H, W = flat_chw
+                Cout, Cin, RS, T, kin = ws[0].shape[0], C, -(H * W), 1, C * H * W      # RS < 0: n-major packing
+                cout_p, cin_p = Cout, C
+            else:
+                Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+                RS = T = (ws[0].shape[2] * ws[0].shape[3]) if ws[0].dim() == 4 else 1
+                kin = cin_p
+            grp = dict(wp=torch.empty(G, T, cout_p, kin, dtype=torch.bfloat16, device=dev),
+                       wpt=torch.empty(G, T, kin, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
+                       bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2, members=[], flat=flat_chw)
             for g in range(G):
-                grp['members'].append(dict(w=ws[g], cb=conv_biases[g], bn=bn, eps=float(eps), dims=(Cout, Cin, R * S, cout_p, cin_p),
+                grp['members'].append(dict(w=ws[g], cb=conv_biases[g], bn=bn, eps=float(eps), dims=(Cout, Cin, RS, cout_p, cin_p),
                                            wp=grp['wp'][g], wpt=None if grp['wpt'] is None else grp['wpt'][g], bias=grp['bias'][g]))
             self.jobs[key] = grp
             self.order.append(key)
             self.desc = None
         if grp['step'] != self.step:          # registered after this step's batched launch (first step): pack it now
             for j in grp['members']:
-                fold_pack(j['w'], j['cb'], j['bn'], j['eps'], want_dgrad=j['wpt'] is not None, out_fwd=j['wp'], out_dgrad=j['wpt'],
-                          out_bias=j['bias'], cout_pad=j['dims'][3], cin_pad=j['dims'][4])
+                w4 = j['w']
+                if grp['flat'] is not None:   # (once: the permuted copy the batched launch avoids from the next step on)
+                    C, H, W = grp['flat']
+                    w4 = w4.detach().view(-1, C, H, W).permute(0, 2, 3, 1).reshape(w4.shape[0], -1)
+                if w4.dim() == 2:
+                    w4 = w4.detach().view(w4.shape[0], w4.shape[1], 1, 1)
+                cop, cip = (j['dims'][3], j['dims'][4]) if grp['flat'] is None else (w4.shape[0], w4.shape[1])
+                fold_pack(w4, j['cb'], j['bn'], j['eps'], want_dgrad=j['wpt'] is not None, out_fwd=j['wp'], out_dgrad=j['wpt'],
+                          out_bias=j['bias'], cout_pad=cop, cin_pad=cip)
             grp['step'] = self.step
         return grp['wp'], grp['wpt'], grp['bias']
 
@@ -981,7 +997,9 @@ class PrepackRegistry:
                 eps_bits = struct.unpack('<i', struct.pack('<f', j['eps']))[0]
                 rows.append([p(j['w']), p(j['cb']), p(bn[0]) if bn else 0, p(bn[1]) if bn else 0, p(bn[2]) if bn else 0,
                              p(bn[3]) if bn else 0, p(j['wp']), p(j['wpt']), p(j['bias']), eps_bits, Cout, Cin, RS, CoutP, CinP, chunk])
-                if RS > FOLD_TILE_MAX_RS:
+                if RS < 0:
+                    chunk += Cout             # n-major record: one output channel per chunk
+                elif RS > FOLD_TILE_MAX_RS:
                     chunk += (CoutP * CinP * RS + FOLD_CHUNK - 1) // FOLD_CHUNK
                 else:                         # one chunk per [NT output channels] x [64 input channels] tile, all taps
                     nt = 64 if RS == 1 else 16
@@ -991,6 +1009,12 @@ class PrepackRegistry:
             self.desc = h2d(rows, torch.int64, dev)
             self.nrows = len(rows)
         L.check(lib.loft_fold_pack_multi(L.ptr(self.desc), self.nrows, c_int64(self.nchunks), L.stream()), 'loft_fold_pack_multi')
+        for key in self.order:                # n-major records: the [K][O] operand is the transpose of the [O][K] one
+            grp = self.jobs[key]
+            if grp['flat'] is not None and grp['wpt'] is not None:
+                for j in grp['members']:
+                    O, Kd = j['wp'].shape[-2], j['wp'].shape[-1]
+                    L.check(lib.loft_transpose_bf16(L.ptr(j['wp']), L.ptr(j['wpt']), O, Kd, L.stream()), 'loft_transpose_bf16')
         for key in self.order:
             self.jobs[key]['step'] = step
 
@@ -1023,10 +1047,11 @@ class UnpackQueue:
         self.limit = limit
         self.jobs, self.done = [], []
 
-    def add(self, dwp, db, w, bn, eps, slots, on_done=()):
+    def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None):
         """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
-        launch that served this job has been enqueued (the reducer's gradient-ready notifications)."""
-        self.jobs.append((dwp, db, w, bn, float(eps), slots))
+        launch that served this job has been enqueued (the reducer's gradient-ready notifications).
+        flat_chw = (C, H, W): w is a Linear weight [O, C*H*W] and dwp [O, H*W*C] its gradient in NHWC-flattened K order."""
+        self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw))
         self.done.extend(on_done)
         if len(self.jobs) >= self.limit:
             self.flush()
@@ -1036,14 +1061,22 @@ class UnpackQueue:
             import struct
             rows, blk = [], 0
             p = lambda t: 0 if t is None else t.data_ptr()
-            for dwp, db, w, bn, eps, (dw, dg, dbeta) in self.jobs:
-                Cout, Cin, R, S = w.shape
+            for dwp, db, w, bn, eps, (dw, dg, dbeta), flat in self.jobs:
+                if flat is not None:
+                    Cout, Cin, RS = w.shape[0], flat[0], -(flat[1] * flat[2])
+                    coutp, cinp = Cout, Cin
+                else:
+                    Cout, Cin = w.shape[0], w.shape[1]
+                    RS = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+                    coutp, cinp = dwp.shape[-2], dwp.shape[-1]
                 g, _, m, v = bn if bn is not None else (None, None, None, None)
                 rows.append([p(dwp), p(db), p(w), p(g), p(m), p(v), p(dw), p(dg), p(dbeta),
-                             struct.unpack('<i', struct.pack('<f', eps))[0], Cout, Cin, R * S, dwp.shape[-2], dwp.shape[-1], blk])
+                             struct.unpack('<i', struct.pack('<f', eps))[0], Cout, Cin, RS, coutp, cinp, blk])
                 blk += Cout
             desc = h2d(rows, torch.int64, self.jobs[0][2].device)
-            L.check(L.load().loft_fold_unpack_bwd_multi(L.ptr(desc), len(rows), c_int64(blk), L.stream()), 'loft_fold_unpack_bwd_multi')
+            lds = max([r[11] * -r[12] for r in rows if r[12] < 0], default=0)
+            L.check(L.load().loft_fold_unpack_bwd_multi(L.ptr(desc), len(rows), c_int64(blk), int(lds), L.stream()),
+                    'loft_fold_unpack_bwd_multi')
             self.jobs = []
         done, self.done = self.done, []
         for f in done:

@@ -54,12 +54,10 @@ class _FC(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
 
 
-def _fc_after_flatten(x, fc, relu=True):
+def _fc_after_flatten(x, fc, relu=True, input_relu=False):
     """``x.flatten(1)`` of an NCHW tensor followed by nn.Linear, on NHWC memory: permute the weight columns
     from (c,y,x) to (y,x,c) order instead of the activations."""
-    N, C, H, W = x.shape
-    w = fc.weight.view(-1, C, H, W).permute(0, 2, 3, 1).reshape(fc.weight.shape[0], -1)
-    return F2.linear(x.permute(0, 2, 3, 1).reshape(N, -1), w, fc.bias, relu=relu)
+    return F2.linear_after_flatten(x, fc.weight, fc.bias, relu=relu, input_relu=input_relu)
 
 
 @HEADS.register_module()
@@ -195,7 +193,7 @@ class _OffsetBase(nn.Module):
 
     def _fc_tail(self, x):
         N = x.shape[0]
-        h = _fc_after_flatten(x, self.fcs[0])
+        h = _fc_after_flatten(x, self.fcs[0], input_relu=self.num_convs > 0)   # x: output of the conv + ReLU chain
         for fc in list(self.fcs)[1:]:
             h = F2.linear(h, fc.weight, fc.bias, relu=True, input_relu=True)
         o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), self.fc_offset.weight,

@@ -221,12 +221,98 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
     return _ConvFn.apply(x, residual, meta, *tensors)
 
 
+_NO_LINEAR_FN = bool(_os.environ.get('LOFT_NO_LINEAR_FN'))     # A/B switch: Linear layers through the generic conv node
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for an nn.Linear whose weight is passed AS THE PARAMETER ([O, K], never a view), so that under the
+    trainer its bf16 packings come from the step's batched launch and its gradient goes straight into the arena.
+    x: [N, K] row-major, or -- with flat_chw = (C, H, W) -- the NHWC map [N, C, H, W] that the reference flattens in (c, h, w)
+    order before the layer (convfc_bbox_head.py:159-166, offset_head_expand_feature.py:150-156): the weight's columns are
+    permuted to (h, w, c) inside the packing kernel instead of permuting activations or copying the weight."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, input_relu, flat_chw):
+        O = w.shape[0]
+        N = x.shape[0]
+        Kd = w.shape[1]
+        x4 = x.permute(0, 2, 3, 1).reshape(N, Kd, 1, 1) if flat_chw is not None else x.reshape(N, Kd, 1, 1)
+        x4 = x4.contiguous(memory_format=torch.channels_last)            # (a view: NHWC memory is already (h, w, c)-flat)
+        need_dgrad = ctx.needs_input_grad[0]
+        if PREPACK is not None and O % 2 == 0 and Kd % 2 == 0 and isinstance(w, torch.nn.Parameter):
+            wp, wpt, bias = PREPACK.request((w,), (b,), None, 1e-5, O, Kd, need_dgrad, flat_chw=flat_chw)
+        else:
+            weff = w if flat_chw is None else w.view(O, *flat_chw).permute(0, 2, 3, 1).reshape(O, Kd)
+            wp, wpt, bias = K.fold_pack(weff.reshape(O, Kd, 1, 1), b, None, 1e-5, want_dgrad=need_dgrad)
+            wp, wpt, bias = wp[None], None if wpt is None else wpt[None], bias[None]
+        y = K.conv2d_fwd(x4, wp, bias if b is not None else None, 1, 1, 1, 0, relu=relu, out_dtype=torch.bfloat16)
+        ctx.cfg = (relu, input_relu, flat_chw, tuple(x.shape))
+        ctx.params = (w, b)
+        for k, t in enumerate((w, b)):
+            if t is not None and ctx.needs_input_grad[1 + k] and isinstance(t, torch.nn.Parameter):
+                t._loft_pending = getattr(t, '_loft_pending', 0) + 1
+        ctx.save_for_backward(x4, y if relu else None, wpt, w)
+        return y.reshape(N, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        relu, input_relu, flat_chw, xshape = ctx.cfg
+        x4, y, wpt, w = ctx.saved_tensors
+        pw, pb = ctx.params
+        N, O = g.shape
+        Kd = w.shape[1]
+        g4 = g.reshape(N, O, 1, 1).contiguous(memory_format=torch.channels_last)
+        if g4.dtype != torch.bfloat16:
+            g4 = g4.to(torch.bfloat16)
+        if relu and getattr(g, '_loft_premasked', None) != y.data_ptr():
+            g4 = K.relu_bwd(g4, y)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = K.conv2d_dgrad(g4, wpt, (1, 1), 1, 1, 1, 0, mask=x4 if input_relu else None)
+            if flat_chw is not None:
+                C, H, W = flat_chw
+                gx = gx.reshape(N, H, W, C).permute(0, 3, 1, 2)          # NHWC memory, NCHW-shaped: what the producer expects
+            else:
+                gx = gx.reshape(xshape)
+            if input_relu:
+                gx._loft_premasked = x4.data_ptr()
+        gw = gb = None
+        need_w, need_b = ctx.needs_input_grad[1], pb is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            dwp, db = K.conv2d_wgrad(g4, x4, 1, 1, 1, 0, with_bias=True)
+            slot_w = _direct_slot(pw) if need_w else None
+            slot_b = _direct_slot(pb) if need_b else None
+            if UNPACK_Q is not None and slot_w is not None and (not need_b or slot_b is not None):
+                sinks = [pw] + ([pb] if need_b else [])
+                _mark_sunk(*sinks)
+                UNPACK_Q.add(dwp[0, 0], db[0], w, None, 1e-5, (slot_w, None, slot_b), [(lambda q=q: _sink_done(q)) for q in sinks],
+                             flat_chw=flat_chw)
+            else:
+                gw = dwp[0, 0, :O, :Kd]
+                if flat_chw is not None:
+                    C, H, W = flat_chw
+                    gw = gw.reshape(O, H * W, C).permute(0, 2, 1).reshape(O, Kd)
+                gb = db[0, :O] if need_b else None
+        return gx, gw, gb, None, None, None
+
+
 def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
     """x [N,K] bf16 (row-major), w [O,K] fp32 -> [N,O]."""
     N, Kd = x2d.shape
+    if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and not out_f32 and x2d.dtype == torch.bfloat16 and not _NO_LINEAR_FN:
+        return _LinearFn.apply(x2d, w, b, relu, input_relu, None)
     y = conv2d(x2d.reshape(N, Kd, 1, 1).contiguous(memory_format=torch.channels_last), w.view(w.shape[0], Kd, 1, 1), b,
                relu=relu, out_f32=out_f32, input_relu=input_relu)
     return y.reshape(N, w.shape[0])
+
+
+def linear_after_flatten(x, w, b=None, relu=True, input_relu=False):
+    """``x.flatten(1)`` of an NCHW-shaped map followed by nn.Linear, on NHWC memory (x bf16 [N,C,H,W] channels_last)."""
+    N, C, H, W = x.shape
+    if isinstance(w, torch.nn.Parameter) and x.dtype == torch.bfloat16 and not _NO_LINEAR_FN:
+        return _LinearFn.apply(x, w, b, relu, input_relu, (C, H, W))
+    wperm = w.view(-1, C, H, W).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    return linear(x.permute(0, 2, 3, 1).reshape(N, -1), wperm, b, relu=relu, input_relu=input_relu)
 
 
 class _NarrowHeadFn(torch.autograd.Function):

@@ -286,13 +286,20 @@ int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, c
  * gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out (device addresses, 0 = absent), eps as float bits, Cout, Cin, RS, CoutP,
  * CinP, first_chunk}; record i covers chunks [first_chunk_i, first_chunk_{i+1}); nchunks = their total.  A record with RS <= 9
  * has ceil(CoutP / NT) * ceil(CinP / 64) chunks (NT = 64 when RS == 1, else 16; chunk = one channel tile, all taps), a record
- * with more taps ceil(CoutP * CinP * RS / 2048).  CoutP and CinP must be even. */
+ * with more taps ceil(CoutP * CinP * RS / 2048).  CoutP and CinP must be even.  RS < 0 selects the "n-major" forward
+ * packing wp[n][t][c] with |RS| taps (a Linear over a flattened [C,H,W] map whose activation is kept NHWC; such records
+ * have Cout chunks, one output channel each, Cin * |RS| <= 18432, and their wp_dgrad is NOT written: the caller
+ * derives it with loft_transpose_bf16); loft_fold_unpack_bwd_multi reads dwp in the same [n][t][c] order for RS < 0. */
 int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream);
 /* loft_fold_unpack_bwd_multi: loft_fold_unpack_bwd for MANY convs in one launch, accumulate-only (the trainer's direct gradient
  * sink).  desc (device): njobs records of 16 int64 {dwp, db, w, gamma, mean, var, dw, dgamma, dbeta_or_dbias (device addresses,
  * 0 = absent), eps as float bits, Cout, Cin, RS, CoutP, CinP, first_block}; record i owns blocks [first_block_i, first_block_i +
- * Cout_i); nblocks = their total. */
-int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, void* stream);
+ * Cout_i); nblocks = their total.  lds_floats: dynamic LDS in floats = max Cin * |RS| over the RS < 0 records (0 if none;
+ * <= 16384). */
+int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, int lds_floats, void* stream);
+/* loft_transpose_bf16: dst[Cc][R] = src[R][Cc]^T (row-major bf16, R and Cc even): the [K][O] data-gradient operand of an
+ * n-major record from its [O][K] forward packing. */
+int loft_transpose_bf16(const void* src, void* dst, int R, int Cc, void* stream);
 int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, const float* gamma, const float* mean,
                          const float* var, float eps, int Cout, int Cin, int RS, float* dw, float* dgamma, float* dbeta,
                          int CoutP, int CinP, int accumulate, void* stream);

@@ -214,3 +214,35 @@ def test_fold_pack_multi_equals_per_conv_packing():
                 assert torch.equal(wpt[g].view(torch.int16), rwpt.view(torch.int16))
             else:
                 assert wpt is None
+
+
+def test_fold_pack_multi_flat_linear_packing():
+    """n-major records (a Linear over a flattened [C,H,W] map kept NHWC): the batched launch + transpose give exactly the
+    packings of the column-permuted weight, and the batched unpack returns the gradient in the parameter's (c, h, w) order."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(11)
+    dev = 'cuda'
+    O, C, H, W = 96, 32, 7, 7
+    w = torch.nn.Parameter(torch.randn(O, C * H * W, device=dev))
+    b = torch.nn.Parameter(torch.randn(O, device=dev))
+    reg = K.PrepackRegistry()
+    reg.run(0)
+    reg.request((w,), (b,), None, 1e-5, O, C * H * W, True, flat_chw=(C, H, W))
+    w.data.normal_()
+    reg.run(1)
+    wp, wpt, bias = reg.request((w,), (b,), None, 1e-5, O, C * H * W, True, flat_chw=(C, H, W))
+    wperm = w.detach().view(O, C, H, W).permute(0, 2, 3, 1).reshape(O, -1, 1, 1).contiguous()
+    rwp, rwpt, rb = K.fold_pack(wperm, b, None, 1e-5, want_dgrad=True)
+    assert torch.equal(wp[0].view(torch.int16), rwp.view(torch.int16))
+    assert torch.equal(wpt[0].view(torch.int16), rwpt.view(torch.int16))
+    assert torch.equal(bias[0], rb)
+    # unpack: dwp in (h, w, c) order -> accumulate into a (c, h, w)-ordered slot
+    dwp = torch.randn(O, H * W * C, device=dev)
+    db = torch.randn(O, device=dev)
+    slot_w, slot_b = torch.ones(O, C * H * W, device=dev), torch.ones(O, device=dev)
+    q = K.UnpackQueue()
+    q.add(dwp, db, w, None, 1e-5, (slot_w, None, slot_b), flat_chw=(C, H, W))
+    q.flush()
+    want = 1.0 + dwp.view(O, H * W, C).permute(0, 2, 1).reshape(O, -1)
+    assert torch.equal(slot_w, want)
+    assert torch.equal(slot_b, 1.0 + db)

@@ -404,3 +404,327 @@ LOFT_EXPORT int loft_mask_paste(const float* logits, const float* boxes, int N, 
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------- RandomSampler on the device
+// mmdet/core/bbox/samplers/random_sampler.py:31-75 + base_sampler.py:34-101 for a whole batch in one launch: per image, up to
+// max_pos of the positives (gt_inds > 0) and then num - #sampled_pos of the negatives (gt_inds == 0), each a uniformly random
+// subset (mode 1) or the first ones in index order (mode 0: the tests' injected sampling), written in ascending index order
+// (base_sampler.py:86,96 `.unique()`), padded with index N-1 / valid 0.  Replaces rand + two top-k over all 261 888 anchors
+// + two sorts + gathers (0.45 ms) by radix-select on hashed keys: one 1024-thread workgroup per image makes <= 6 passes over
+// the image's gt_inds per class -- count, four 8-bit histogram passes that pin down the k-th smallest key exactly, and an
+// ordered compaction (block scan) of the keys below it (ties: first in index order).  Integer path; deterministic for a seed.
+__device__ __forceinline__ unsigned sample_key(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = seed + (i + 1ull) * 0x9E3779B97F4A7C15ull;      // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
+__device__ __forceinline__ int block_sum_1024(int v, int* red) {   // every thread gets the total
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+}
+
+// class code per box: 1 positive, 2 negative, 0 ignored -- 8x fewer bytes than the int64 gt_inds for the sampler's passes
+__global__ void sample_codes_kernel(const int64_t* __restrict__ gt_inds, int N, int Np, uint8_t* __restrict__ code) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= Np) return;
+    uint8_t c = 0;
+    if (i < N) { const int64_t g = gt_inds[(size_t)b * N + i]; c = g > 0 ? 1 : (g == 0 ? 2 : 0); }
+    code[(size_t)b * Np + i] = c;
+}
+
+#define SAMPLE_POOL 4096
+
+// One 1024-thread workgroup per image; every pass reads the image's class codes 16 per lane (uint4), Np = N rounded up to 16.
+__global__ __launch_bounds__(1024) void random_sample_kernel(const uint8_t* __restrict__ code, int N, int Np, int num, int max_pos,
+                                                             int mode, unsigned long long seed, int P, int Q,
+                                                             int64_t* __restrict__ pos_idx, uint8_t* __restrict__ pos_valid,
+                                                             int64_t* __restrict__ neg_idx, uint8_t* __restrict__ neg_valid) {
+    __shared__ int red[16];
+    __shared__ int hist[256];
+    __shared__ int wsum[16];
+    __shared__ int sel[2];
+    __shared__ int pool_idx[SAMPLE_POOL];
+    __shared__ unsigned pool_key[SAMPLE_POOL];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint4* cv = reinterpret_cast<const uint4*>(code + (size_t)b * Np);
+    const int nvec = Np >> 4;
+    const unsigned long long sd = seed ^ ((unsigned long long)(b + 1) * 0xD6E8FEB86659FD93ull);
+    int taken_pos = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+        int64_t* oidx = cls == 0 ? pos_idx + (size_t)b * P : neg_idx + (size_t)b * Q;
+        uint8_t* oval = cls == 0 ? pos_valid + (size_t)b * P : neg_valid + (size_t)b * Q;
+        const int cap = cls == 0 ? P : Q;
+        const int limit = cls == 0 ? min(max_pos, P) : min(max(num - taken_pos, 0), Q);
+        const unsigned want = cls == 0 ? 1u : 2u;
+        const unsigned long long sdc = sd + cls;
+        // ---- pass A: count the candidates and collect them, in index order, into the LDS pool (valid while cnt <= SAMPLE_POOL:
+        // RPN positives, everything in the RoI sampler) -- the selection then never touches the image's codes again
+        int cnt = 0;
+        for (int v0 = 0; v0 < nvec; v0 += 1024) {
+            const int v = v0 + tid;
+            unsigned msk = 0u;
+            if (v < nvec) {
+                const uint4 q = cv[v];
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) msk |= (((w4[e >> 2] >> (8 * (e & 3))) & 255u) == want) ? (1u << e) : 0u;
+            }
+            const int val = __popc(msk);
+            int incl = val;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += u;
+            }
+            __syncthreads();
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+            int at = cnt + incl - val + woff;
+            if (at < SAMPLE_POOL)
+                while (msk) {
+                    const int e = __builtin_ctz(msk);
+                    msk &= msk - 1u;
+                    if (at < SAMPLE_POOL) pool_idx[at] = v * 16 + e;
+                    ++at;
+                }
+            cnt += tot;
+        }
+        __syncthreads();
+        const int k = min(cnt, limit);
+        // ---- threshold key T: the k-th smallest hashed key among the candidates (only when a strict subset is drawn at random)
+        unsigned T = 0xffffffffu;
+        int k_eq = 0;                                // how many candidates with key == T to take
+        const bool thresh = mode == 1 && k < cnt && k > 0;
+        bool pooled = false;
+        int m = 0;
+        if (cnt <= SAMPLE_POOL) {
+            m = cnt;
+            if (!thresh) {                            // everything, or the first k in index order: the head of the pool
+                for (int j = tid; j < k; j += 1024) { oidx[j] = pool_idx[j]; oval[j] = 1; }
+                for (int j = k + tid; j < cap; j += 1024) { oidx[j] = N - 1; oval[j] = 0; }
+                if (cls == 0) taken_pos = k;
+                __syncthreads();
+                continue;
+            }
+            for (int j = tid; j < m; j += 1024) pool_key[j] = sample_key(sdc, (unsigned long long)pool_idx[j]);
+            __syncthreads();
+            pooled = true;
+        } else if (thresh && cnt > 16 * k) {
+            // ---- many candidates, few wanted (the RPN's 256 of ~250 000 negatives): ONE hashed pass keeps only the candidates
+            // whose key is below a cut chosen for ~8k survivors, in index order; the exact selection then runs on that pool.
+            const double cut = 8.0 * (double)k / (double)cnt * 4294967296.0;
+            const unsigned T0 = cut >= 4294967295.0 ? 0xffffffffu : (unsigned)cut;
+            for (int v0 = 0; v0 < nvec; v0 += 1024) {
+                const int v = v0 + tid;
+                unsigned msk = 0u;
+                unsigned keys[16];
+                if (v < nvec) {
+                    const uint4 q = cv[v];
+                    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        keys[e] = 0u;
+                        if (((w4[e >> 2] >> (8 * (e & 3))) & 255u) == want) {
+                            keys[e] = sample_key(sdc, (unsigned long long)(v * 16 + e));
+                            msk |= (keys[e] < T0) ? (1u << e) : 0u;
+                        }
+                    }
+                }
+                const int val = __popc(msk);
+                int incl = val;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += u;
+                }
+                __syncthreads();
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                int woff = 0, tot = 0;
+                for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+                int at = m + incl - val + woff;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if ((msk >> e) & 1u) {
+                        if (at < SAMPLE_POOL) { pool_idx[at] = v * 16 + e; pool_key[at] = keys[e]; }
+                        ++at;
+                    }
+                m += tot;
+            }
+            __syncthreads();
+            pooled = m >= k && m <= SAMPLE_POOL;      // (else: the full passes below; probability ~1e-9 for the 8k cut)
+        }
+        if (pooled) {
+            unsigned prefix = 0u;
+            int krem = k;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+                for (int j = tid; j < m; j += 1024) {
+                    const unsigned key = pool_key[j];
+                    if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0, bkt = 0;
+                    for (; bkt < 256; ++bkt) {
+                        if (acc + hist[bkt] >= krem) break;
+                        acc += hist[bkt];
+                    }
+                    sel[0] = bkt; sel[1] = krem - acc;
+                }
+                __syncthreads();
+                prefix |= (unsigned)sel[0] << shift;
+                krem = sel[1];
+                __syncthreads();
+            }
+            const unsigned Tp = prefix;
+            const int keq = krem;
+            int base_lt = 0, base_eq = 0;
+            for (int j0 = 0; j0 < m; j0 += 1024) {      // the pool is in index order: the same ordered compaction, 1 entry per lane
+                const int j = j0 + tid;
+                int flt = 0, feq = 0;
+                if (j < m) { const unsigned key = pool_key[j]; flt = key < Tp; feq = key == Tp; }
+                const int val = flt | (feq << 16);
+                int incl = val;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += u;
+                }
+                __syncthreads();
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                int woff = 0, tot = 0;
+                for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+                const int excl = incl - val + woff;
+                const int r_lt = base_lt + (excl & 0xffff), r_eq = base_eq + (excl >> 16);
+                int pos = -1;
+                if (flt) pos = r_lt + min(r_eq, keq);
+                else if (feq && r_eq < keq) pos = r_lt + r_eq;
+                if (pos >= 0 && pos < k) { oidx[pos] = pool_idx[j]; oval[pos] = 1; }
+                base_lt += tot & 0xffff; base_eq += tot >> 16;
+            }
+            for (int j = k + tid; j < cap; j += 1024) { oidx[j] = N - 1; oval[j] = 0; }
+            if (cls == 0) taken_pos = k;
+            __syncthreads();
+            continue;
+        }
+        if (thresh) {
+            unsigned prefix = 0u;
+            int krem = k;                            // rank (1-based) still to locate inside the current prefix bucket
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+                const unsigned pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+                for (int v = tid; v < nvec; v += 1024) {
+                    const uint4 q = cv[v];
+                    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (((w4[e >> 2] >> (8 * (e & 3))) & 255u) == want) {
+                            const unsigned key = sample_key(sdc, (unsigned long long)(v * 16 + e));
+                            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+                        }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int acc = 0, bkt = 0;
+                    for (; bkt < 256; ++bkt) {
+                        if (acc + hist[bkt] >= krem) break;
+                        acc += hist[bkt];
+                    }
+                    sel[0] = bkt; sel[1] = krem - acc;
+                }
+                __syncthreads();
+                prefix |= (unsigned)sel[0] << shift;
+                krem = sel[1];
+                __syncthreads();
+            }
+            T = prefix;
+            k_eq = krem;
+        }
+        // ---- ordered compaction: candidates with key < T plus the first k_eq with key == T (mode 0 / k == cnt: the first k)
+        int base_lt = 0, base_eq = 0;                // running counts (block-uniform)
+        for (int v0 = 0; v0 < nvec; v0 += 1024) {    // 16384 boxes per round, 16 consecutive ones per thread
+            const int v = v0 + tid;
+            unsigned mlt = 0u, meq = 0u;             // bit e: element e of this thread is below / at the threshold
+            if (v < nvec) {
+                const uint4 q = cv[v];
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (((w4[e >> 2] >> (8 * (e & 3))) & 255u) == want) {
+                        if (thresh) {
+                            const unsigned key = sample_key(sdc, (unsigned long long)(v * 16 + e));
+                            mlt |= (key < T) ? (1u << e) : 0u;
+                            meq |= (key == T) ? (1u << e) : 0u;
+                        } else {
+                            mlt |= 1u << e;          // first k in index order (everything when k == cnt)
+                        }
+                    }
+            }
+            const int val = __popc(mlt) | (__popc(meq) << 16);   // two 16-bit counters per scan word (<= 16384 per round)
+            int incl = val;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += u;
+            }
+            __syncthreads();
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+            const int excl = incl - val + woff;
+            int r_lt = base_lt + (excl & 0xffff), r_eq = base_eq + (excl >> 16);
+            unsigned m = mlt | meq;
+            while (m) {
+                const int e = __builtin_ctz(m);
+                m &= m - 1u;
+                if ((mlt >> e) & 1u) {
+                    const int pos = r_lt + min(r_eq, k_eq);
+                    if (pos < k) { oidx[pos] = (int64_t)v * 16 + e; oval[pos] = 1; }
+                    ++r_lt;
+                } else {
+                    if (r_eq < k_eq) {
+                        const int pos = r_lt + r_eq;
+                        if (pos < k) { oidx[pos] = (int64_t)v * 16 + e; oval[pos] = 1; }
+                    }
+                    ++r_eq;
+                }
+            }
+            base_lt += tot & 0xffff; base_eq += tot >> 16;
+            if (base_lt + min(base_eq, k_eq) >= k) break;          // block-uniform early exit
+        }
+        for (int j = k + tid; j < cap; j += 1024) { oidx[j] = N - 1; oval[j] = 0; }
+        if (cls == 0) taken_pos = k;
+        __syncthreads();
+    }
+}
+LOFT_EXPORT int64_t loft_random_sample_workspace_bytes(int B, int N) { return (int64_t)B * ((N + 15) / 16 * 16); }
+
+LOFT_EXPORT int loft_random_sample(const int64_t* gt_inds, int B, int N, int num, int max_pos, int mode, uint64_t seed,
+                                   int64_t* pos_idx, uint8_t* pos_valid, int64_t* neg_idx, uint8_t* neg_valid, void* workspace,
+                                   void* stream) {
+    if (B <= 0) return 0;
+    if (N <= 0 || num < 0 || max_pos < 0 || (mode != 0 && mode != 1) || !workspace) return (int)hipErrorInvalidValue;
+    const int P = max_pos < N ? max_pos : N, Q = num < N ? num : N;
+    const int Np = (N + 15) / 16 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sample_codes_kernel, dim3(loft_cdiv(Np, 256), B), dim3(256), 0, s, gt_inds, N, Np, (uint8_t*)workspace);
+    LOFT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(random_sample_kernel, dim3(B), dim3(1024), 0, s, (const uint8_t*)workspace, N, Np, num, max_pos, mode,
+                       (unsigned long long)seed, P, Q, pos_idx, pos_valid, neg_idx, neg_valid);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -1020,6 +1020,35 @@ class PrepackRegistry:
 
 
 
+_SAMPLE_CALLS = [0]
+
+
+def random_sample(gt_inds, num, max_pos, mode='random'):
+    """RandomSampler.sample for a batch on the device (loft_random_sample).  gt_inds int64 [B,N] ->
+    (pos_idx int64 [B,P], pos_valid bool [B,P], neg_idx int64 [B,Q], neg_valid bool [B,Q]), ascending indices per image.
+    mode 'random': uniformly random subsets, deterministic in torch.initial_seed() and the call count; 'first': index order."""
+    lib = L.load()
+    L.dev_check(gt_inds)
+    gt_inds = gt_inds.contiguous()
+    if gt_inds.dtype != torch.int64:
+        raise L.LoftHipError(f'gt_inds must be int64, got {gt_inds.dtype}')
+    B, N = gt_inds.shape
+    P, Q = min(int(max_pos), N), min(int(num), N)
+    dev = gt_inds.device
+    pidx = torch.empty(B, P, dtype=torch.int64, device=dev)
+    nidx = torch.empty(B, Q, dtype=torch.int64, device=dev)
+    pval = torch.empty(B, P, dtype=torch.uint8, device=dev)
+    nval = torch.empty(B, Q, dtype=torch.uint8, device=dev)
+    _SAMPLE_CALLS[0] += 1
+    seed = (torch.initial_seed() * 6364136223846793005 + _SAMPLE_CALLS[0] * 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    if B > 0 and N > 0:
+        ws = torch.empty(B * ((N + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+        L.check(lib.loft_random_sample(L.ptr(gt_inds), B, N, int(num), int(max_pos), 0 if mode == 'first' else 1,
+                                       ctypes.c_uint64(seed), L.ptr(pidx), L.ptr(pval), L.ptr(nidx), L.ptr(nval), L.ptr(ws),
+                                       L.stream()), 'loft_random_sample')
+    return pidx, pval.bool(), nidx, nval.bool()
+
+
 def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=True):
     """Backward of a 1x1 head with Cout <= 8 outputs in one pass over x (loft_narrow_head_bwd).
     g fp32 [N,c4,H,W] channels_last (c4 >= Cout), x bf16 NHWC [N,Cin,H,W], w fp32 [Cout,Cin]

@@ -125,6 +125,17 @@ class RandomSampler:
         dev = gt_inds.device
         P = min(int(self.num * self.pos_fraction), N)
         Q = min(self.num, N)
+        if gt_inds.is_cuda and N > 0:       # the product path: one launch (radix select on hashed keys + ordered compaction)
+            pidx, pvalid, nidx, nvalid = K.random_sample(gt_inds, self.num, int(self.num * self.pos_fraction), self.choice_mode)
+            return dict(pos_idx=pidx, pos_valid=pvalid, neg_idx=nidx, neg_valid=nvalid)
+        return self.sample_batched_host(gt_inds)
+
+    def sample_batched_host(self, gt_inds):
+        """The same contract with torch ops: host tensors in the CPU-side logic tests, and the checker of the kernel."""
+        B, N = gt_inds.shape
+        dev = gt_inds.device
+        P = min(int(self.num * self.pos_fraction), N)
+        Q = min(self.num, N)
         if self.choice_mode == 'first':
             key = torch.arange(N, dtype=torch.float32, device=dev).expand(B, N)
         else:

@@ -312,6 +312,16 @@ int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, cons
 int loft_narrow_head_bwd(const float* g, int g_stride, const void* x, const float* w, int64_t M, int Cin, int Cout,
                          int relu_in, void* gx, float* dw, float* db, void* stream);
 
+/* loft_random_sample: RandomSampler.sample for a batch (mmdet/core/bbox/samplers/random_sampler.py:31-75,
+ * base_sampler.py:34-101).  gt_inds int64 [B,N] (>0 positive, 0 negative, <0 ignored).  Per image: min(#pos, max_pos) positives,
+ * then min(#neg, num - sampled_pos) negatives; mode 1 = uniformly random subsets (hashed keys, deterministic in `seed`), mode 0 =
+ * the first ones in index order.  Outputs in ascending index order: pos_idx int64 [B,P] / pos_valid u8 [B,P] with
+ * P = min(max_pos, N), neg_idx / neg_valid [B,Q] with Q = min(num, N); unused slots hold index N-1 and valid 0.
+ * workspace: loft_random_sample_workspace_bytes(B, N) bytes (16-byte aligned) for the per-box class codes. */
+int64_t loft_random_sample_workspace_bytes(int B, int N);
+int loft_random_sample(const int64_t* gt_inds, int B, int N, int num, int max_pos, int mode, uint64_t seed,
+                       int64_t* pos_idx, uint8_t* pos_valid, int64_t* neg_idx, uint8_t* neg_valid, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

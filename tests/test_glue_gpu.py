@@ -246,3 +246,55 @@ def test_fold_pack_multi_flat_linear_packing():
     want = 1.0 + dwp.view(O, H * W, C).permute(0, 2, 1).reshape(O, -1)
     assert torch.equal(slot_w, want)
     assert torch.equal(slot_b, 1.0 + db)
+
+
+@pytest.mark.parametrize('N,num,frac,npos', [(261888, 256, 0.5, 300), (261888, 256, 0.5, 40), (3080, 1024, 0.25, 600),
+                                               (3080, 1024, 0.25, 10), (100, 256, 0.5, 30), (1500, 512, 0.25, 0)])
+def test_random_sampler_kernel(N, num, frac, npos):
+    """loft_random_sample: 'first' mode equals the torch implementation exactly; 'random' mode draws valid, ascending, unique
+    subsets of the right sizes, reproducibly for a seed and differently for another, and roughly uniformly."""
+    from bonai_amd.loft.core import RandomSampler
+    rng = np.random.RandomState(N + npos)
+    B = 4
+    gi = np.zeros((B, N), np.int64)
+    for b in range(B):
+        pos = rng.choice(N, size=min(N, npos + b), replace=False)
+        gi[b, pos] = rng.randint(1, 80, size=pos.shape[0])
+        ign = rng.choice(N, size=N // 50, replace=False)
+        gi[b, ign] = np.where(gi[b, ign] > 0, gi[b, ign], -1)
+    gt_inds = torch.from_numpy(gi).cuda()
+    smp = RandomSampler(num, frac)
+    smp.choice_mode = 'first'
+    got, want = smp.sample_batched(gt_inds), smp.sample_batched_host(gt_inds)
+    for k in ('pos_valid', 'neg_valid'):
+        assert torch.equal(got[k], want[k]), k
+    for k, v in (('pos_idx', 'pos_valid'), ('neg_idx', 'neg_valid')):
+        assert torch.equal(got[k][got[v]], want[k][want[v]]), k
+        assert int(got[k].max()) <= N - 1
+    smp.choice_mode = 'random'
+    torch.manual_seed(3)
+    from bonai_amd import kernels as K
+    K._SAMPLE_CALLS[0] = 0
+    a = smp.sample_batched(gt_inds)
+    K._SAMPLE_CALLS[0] = 0
+    a2 = smp.sample_batched(gt_inds)
+    c = smp.sample_batched(gt_inds)            # next call: another draw
+    P = min(int(num * frac), N)
+    for b in range(B):
+        np_all = int((gt_inds[b] > 0).sum())
+        nn_all = int((gt_inds[b] == 0).sum())
+        kp = min(np_all, P)
+        kn = min(nn_all, num - kp)
+        pv, nv = a['pos_valid'][b], a['neg_valid'][b]
+        assert int(pv.sum()) == kp and int(nv.sum()) == kn
+        assert bool(pv[:kp].all()) and bool(nv[:kn].all())           # valid slots first
+        pi, ni = a['pos_idx'][b][pv], a['neg_idx'][b][nv]
+        assert bool((gt_inds[b][pi] > 0).all()) and bool((gt_inds[b][ni] == 0).all())
+        assert bool((pi[1:] > pi[:-1]).all()) and bool((ni[1:] > ni[:-1]).all())   # ascending and unique
+    for k in a:
+        assert torch.equal(a[k], a2[k])
+    if N > 3000 and npos >= 40:
+        assert not torch.equal(a['neg_idx'], c['neg_idx'])
+        # uniformity: mean of the drawn negative indices ~ N/2 (std of the mean of 256 uniform draws = N / sqrt(12 * 256))
+        m = a['neg_idx'][a['neg_valid']].float().mean().item()
+        assert abs(m - N / 2) < 6 * N / (12 * a['neg_valid'].sum().item()) ** 0.5

@@ -754,50 +754,83 @@ LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const fl
 //     dw[n][c] += sum_m g[m][n] * x[m][c],   db[n] += sum_m g[m][n]         (fp32 registers -> LDS -> one atomic per entry and block)
 // HBM-bound: reads x once (it is also the ReLU mask of the producer), writes gx once.  g fp32 [M][gs] (gs = Cout rounded up
 // to 4), x bf16 [M][Cin], w fp32 [Cout][Cin]; Cin % 4 == 0, Cin <= 1024.
-template <int NOUT>
+template <int V> struct NhbIO;
+template <> struct NhbIO<4> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) { ld4(p, v); }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) { st4(p, v); }
+};
+template <> struct NhbIO<8> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) { ld8(p, v); }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) { st8(p, v); }
+};
+
+// V channels per lane: 8 (16-byte accesses; the mask-logits launch ran at 2.4 TB/s with 8-byte ones) while the weight and
+// accumulator registers allow it (NOUT <= 4), else 4.
+template <int NOUT, int V>
 __global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __restrict__ g, int gs, const bf16_t* __restrict__ x,
                                                               const float* __restrict__ w, long M, int Cin, int relu_in,
                                                               bf16_t* __restrict__ gx, float* __restrict__ dw,
                                                               float* __restrict__ db) {
-    const int cg = Cin >> 2;                       // column groups of 4 channels
-    const int ppi = 256 / cg > 0 ? 256 / cg : 1;   // pixels per block iteration (Cin = 256 -> 4, Cin = 1024 -> 1)
+    const int cg = Cin / V;                        // column groups of V channels
+    const int ppi = 256 / cg > 0 ? 256 / cg : 1;   // pixels per block round (Cin = 256, V = 8 -> 8)
     const int tid = threadIdx.x;
     const int col = tid % cg, sub = tid / cg;
     const bool act = sub < ppi;
-    const int c0 = col << 2;
-    float wr[NOUT][4], acc[NOUT][4], bacc[NOUT];
+    const int c0 = col * V;
+    float wr[NOUT][V], acc[NOUT][V], bacc[NOUT];
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
-        const float4 t = *reinterpret_cast<const float4*>(w + (long)n * Cin + c0);
-        wr[n][0] = t.x; wr[n][1] = t.y; wr[n][2] = t.z; wr[n][3] = t.w;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[n][q] = 0.f;
+        for (int q = 0; q < V; ++q) { wr[n][q] = w[(long)n * Cin + c0 + q]; acc[n][q] = 0.f; }
         bacc[n] = 0.f;
     }
-    if (act)
-        for (long m = (long)blockIdx.x * ppi + sub; m < M; m += (long)gridDim.x * ppi) {
-            float xv[4], gv[NOUT];
-            ld4(x + m * Cin + c0, xv);
+    if (act) {
+        constexpr int UN = 4;                          // pixels in flight per lane: the loop is latency-, not bandwidth-bound
+        // each block streams ONE contiguous pixel range (UN * ppi consecutive pixels per round)
+        const long step = ppi;
+        const long per_blk = ((M + gridDim.x - 1) / gridDim.x + (long)ppi * UN - 1) / ((long)ppi * UN) * ((long)ppi * UN);
+        const long m_beg = (long)blockIdx.x * per_blk, m_end = m_beg + per_blk < M ? m_beg + per_blk : M;
+        for (long m0 = m_beg + sub; m0 < m_end; m0 += step * UN) {
+            float xv[UN][V], gv[UN][NOUT];
 #pragma unroll
-            for (int n = 0; n < NOUT; ++n) gv[n] = g[m * gs + n];
-            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < UN; ++u) {
+                const long m = m0 + u * step;
+                if (m < m_end) {
+                    NhbIO<V>::ld(x + m * Cin + c0, xv[u]);
 #pragma unroll
-            for (int n = 0; n < NOUT; ++n) {
+                    for (int n = 0; n < NOUT; ++n) gv[u][n] = g[m * gs + n];
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    o[q] += gv[n] * wr[n][q];
-                    acc[n][q] += gv[n] * xv[q];
+                    for (int q = 0; q < V; ++q) xv[u][q] = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NOUT; ++n) gv[u][n] = 0.f;
                 }
-                bacc[n] += gv[n];
             }
-            if (gx) {
-                if (relu_in) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = xv[q] > 0.f ? o[q] : 0.f;
+            for (int u = 0; u < UN; ++u) {
+                const long m = m0 + u * step;
+                float o[V];
+#pragma unroll
+                for (int q = 0; q < V; ++q) o[q] = 0.f;
+#pragma unroll
+                for (int n = 0; n < NOUT; ++n) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) {
+                        o[q] += gv[u][n] * wr[n][q];
+                        acc[n][q] += gv[u][n] * xv[u][q];
+                    }
+                    bacc[n] += gv[u][n];
                 }
-                st4(gx + m * Cin + c0, o);
+                if (gx && m < m_end) {
+                    if (relu_in) {
+#pragma unroll
+                        for (int q = 0; q < V; ++q) o[q] = xv[u][q] > 0.f ? o[q] : 0.f;
+                    }
+                    NhbIO<V>::st(gx + m * Cin + c0, o);
+                }
             }
         }
+    }
     // block reduction over the ppi pixel sub-streams, then one atomic per (n, c) and block
     __shared__ float red[NOUT][1024];
     for (int s2 = 0; s2 < ppi; ++s2) {
@@ -805,7 +838,7 @@ __global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __res
 #pragma unroll
             for (int n = 0; n < NOUT; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < V; ++q) {
                     if (s2 == 0) red[n][c0 + q] = acc[n][q];
                     else red[n][c0 + q] += acc[n][q];
                 }
@@ -823,15 +856,23 @@ LOFT_EXPORT int loft_narrow_head_bwd(const float* g, int g_stride, const void* x
                                      int relu_in, void* gx, float* dw, float* db, void* stream) {
     if (M <= 0) return 0;
     if (Cout < 1 || Cout > 8 || (Cin & 3) || Cin > 1024 || g_stride < Cout) return (int)hipErrorInvalidValue;
-    const int cg = Cin >> 2, ppi = 256 / cg > 0 ? 256 / cg : 1;
-    long blocks = (M + ppi - 1) / ppi;
-    if (blocks > 2048) blocks = 2048;
+    const int V = (Cout <= 4 && (Cin & 7) == 0) ? 8 : 4;
+    const int cg = Cin / V, ppi = 256 / cg > 0 ? 256 / cg : 1;
+    // >= 16 pixel rounds per block (each block ends with an LDS reduction and Cout * Cin atomics), at most 2048 blocks
+    // (measured: 8192 blocks +0.7 ms per step, 512..2048 equal)
+    long blocks = (M + (long)ppi * 16 - 1) / ((long)ppi * 16);
+    static const long cap = getenv("LOFT_NHB_BLOCKS") ? atol(getenv("LOFT_NHB_BLOCKS")) : 2048;
+    if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
-#define NHB(N) hipLaunchKernelGGL(narrow_head_bwd_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, s, g, g_stride, (const bf16_t*)x, w, \
-                                  (long)M, Cin, relu_in, (bf16_t*)gx, dw, db)
-    switch (Cout) {
-        case 1: NHB(1); break; case 2: NHB(2); break; case 3: NHB(3); break; case 4: NHB(4); break;
-        case 5: NHB(5); break; case 6: NHB(6); break; case 7: NHB(7); break; default: NHB(8); break;
+#define NHB(N, VV) hipLaunchKernelGGL((narrow_head_bwd_kernel<N, VV>), dim3((unsigned)blocks), dim3(256), 0, s, g, g_stride, \
+                                      (const bf16_t*)x, w, (long)M, Cin, relu_in, (bf16_t*)gx, dw, db)
+    if (V == 8) {
+        switch (Cout) { case 1: NHB(1, 8); break; case 2: NHB(2, 8); break; case 3: NHB(3, 8); break; default: NHB(4, 8); break; }
+    } else {
+        switch (Cout) {
+            case 1: NHB(1, 4); break; case 2: NHB(2, 4); break; case 3: NHB(3, 4); break; case 4: NHB(4, 4); break;
+            case 5: NHB(5, 4); break; case 6: NHB(6, 4); break; case 7: NHB(7, 4); break; default: NHB(8, 4); break;
+        }
     }
 #undef NHB
     LOFT_LAUNCH_CHECK();

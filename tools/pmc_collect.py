@@ -16,7 +16,9 @@ import sys
 
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'gpurun_out', 'pmc')
-FAMILIES = ['conv_tap_kernel', 'conv_wgrad_kernel', 'conv_wgrad64_kernel', 'roi_align_fwd_kernel', 'roi_align_bwd_tile_kernel',
+FAMILIES = ['conv_tap_kernel', 'conv_wgrad_kernel', 'conv_wgrad64_kernel', 'roi_align_fwd_kernel', 'roi_align_fwd_sep_kernel',
+            'roi_align_bwd_tile_kernel', 'roi_align_bwd_mfma_kernel', 'narrow_head_bwd_kernel', 'random_sample_kernel',
+            'fold_pack_multi_kernel', 'fold_unpack_bwd_multi_kernel',
             'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
             'fuse_sum_relu_kernel', 'stem_mfma_kernel']
 PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE'])]

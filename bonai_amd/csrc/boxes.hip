@@ -728,3 +728,81 @@ LOFT_EXPORT int loft_random_sample(const int64_t* gt_inds, int B, int N, int num
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------- RPN: everything between the sampler and the losses
+// For each sampled anchor (b, s) -- positives first, then negatives (anchor_head.py:187-237 `_get_targets_single`, :429-497
+// `loss`): the anchor's pyramid level / pixel / slot, its objectness logit and 4 deltas gathered STRAIGHT from the fused head
+// outputs (no [B, 261888, 5] flatten + concat), the classification label and weight, and for positives the regression target
+// bbox2delta(anchor, assigned gt) (delta_xywh_bbox_coder.py:74-120).  One launch instead of ~45 small tensor ops.
+struct RpnLevels {
+    const float* head[8];
+    int H[8], W[8];
+    long off[9];
+    int L;
+};
+
+__global__ void rpn_sample_gather_kernel(RpnLevels lv, int B, int Cp, int A, const float* __restrict__ anchors,
+                                         const float* __restrict__ gts, int Kmax, const int64_t* __restrict__ gt_inds, long N,
+                                         const int64_t* __restrict__ pidx, const uint8_t* __restrict__ pval, int P,
+                                         const int64_t* __restrict__ nidx, const uint8_t* __restrict__ nval, int Q, Coder4 c,
+                                         float* __restrict__ vals, int* __restrict__ rows, int64_t* __restrict__ slot_out,
+                                         float* __restrict__ tgt, int64_t* __restrict__ label, float* __restrict__ weight) {
+    const int S = P + Q;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * S) return;
+    const int b = (int)(i / S), s = (int)(i - (long)b * S);
+    const bool is_pos = s < P;
+    const long idx = is_pos ? pidx[(long)b * P + s] : nidx[(long)b * Q + (s - P)];
+    const bool valid = is_pos ? pval[(long)b * P + s] != 0 : nval[(long)b * Q + (s - P)] != 0;
+    int l = 0;
+    for (int k = 1; k < lv.L; ++k) l = (idx >= lv.off[k]) ? k : l;
+    const long local = idx - lv.off[l];
+    const int pix = (int)(local / A), a = (int)(local - (long)pix * A);
+    const int y = pix / lv.W[l], x = pix - y * lv.W[l];
+    const float* hp = lv.head[l] + (((long)b * lv.H[l] + y) * lv.W[l] + x) * Cp;
+    float* vo = vals + i * 5;
+    vo[0] = hp[a];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vo[1 + j] = hp[A + 4 * a + j];
+    reinterpret_cast<int4*>(rows)[i] = make_int4(b, valid ? l : -1, y, x);
+    slot_out[i] = a;
+    label[i] = (is_pos && valid) ? 1 : 0;
+    weight[i] = valid ? 1.f : 0.f;
+    if (is_pos) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            long gi = gt_inds[(long)b * N + idx] - 1;
+            gi = gi < 0 ? 0 : gi;
+            const float4 p = reinterpret_cast<const float4*>(anchors)[idx];
+            const float4 g = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + gi];
+            const float px = (p.x + p.z) * 0.5f, py = (p.y + p.w) * 0.5f, pw = p.z - p.x, ph = p.w - p.y;
+            const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+            o.x = ((gx - px) / pw - c.means[0]) / c.stds[0];
+            o.y = ((gy - py) / ph - c.means[1]) / c.stds[1];
+            o.z = (logf(gw / pw) - c.means[2]) / c.stds[2];
+            o.w = (logf(gh / ph) - c.means[3]) / c.stds[3];
+        }
+        reinterpret_cast<float4*>(tgt)[(long)b * P + s] = o;
+    }
+}
+LOFT_EXPORT int loft_rpn_sample_gather(const void* const* heads, const int* H, const int* W, const int64_t* lvl_off, int num_levels,
+                                       int B, int Cp, int A, const float* anchors, const float* gts, int Kmax,
+                                       const int64_t* gt_inds, int64_t N, const int64_t* pos_idx, const uint8_t* pos_valid, int P,
+                                       const int64_t* neg_idx, const uint8_t* neg_valid, int Q, const float* means_host,
+                                       const float* stds_host, float* vals, int32_t* rows, int64_t* slot, float* tgt,
+                                       int64_t* label, float* weight, void* stream) {
+    if (B <= 0 || P + Q <= 0) return 0;
+    if (num_levels < 1 || num_levels > 8 || Kmax < 1) return (int)hipErrorInvalidValue;
+    RpnLevels lv;
+    for (int i = 0; i < num_levels; ++i) { lv.head[i] = (const float*)heads[i]; lv.H[i] = H[i]; lv.W[i] = W[i]; lv.off[i] = lvl_off[i]; }
+    lv.off[num_levels] = lvl_off[num_levels];
+    lv.L = num_levels;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    const long n = (long)B * (P + Q);
+    hipLaunchKernelGGL(rpn_sample_gather_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, lv, B, Cp, A, anchors,
+                       gts, Kmax, gt_inds, (long)N, pos_idx, pos_valid, P, neg_idx, neg_valid, Q, c, vals, rows, slot, tgt, label,
+                       weight);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

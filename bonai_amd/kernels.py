@@ -1020,6 +1020,35 @@ class PrepackRegistry:
 
 
 
+def rpn_sample_gather(heads, lvl_off, A, anchors, gts, gt_inds, pidx, pval, nidx, nval, means, stds):
+    """Everything between the RPN's sampler and its losses in one launch (loft_rpn_sample_gather).
+    heads: per level fp32 NHWC [B,Cp,H,W]; -> (vals [B,S,5], rows int32 [B*S,4], slot int64 [B*S], tgt [B,P,4],
+    label int64 [B,S], weight fp32 [B,S])."""
+    lib = L.load()
+    L.dev_check(anchors, gts, gt_inds, pidx, nidx, *heads)
+    heads = [_nhwc(h) for h in heads]
+    B, Cp = heads[0].shape[0], heads[0].shape[1]
+    P, Q = pidx.shape[1], nidx.shape[1]
+    S = P + Q
+    dev = gt_inds.device
+    vals = torch.empty(B, S, 5, dtype=torch.float32, device=dev)
+    rows = torch.empty(B * S, 4, dtype=torch.int32, device=dev)
+    slot = torch.empty(B * S, dtype=torch.int64, device=dev)
+    tgt = torch.empty(B, P, 4, dtype=torch.float32, device=dev)
+    label = torch.empty(B, S, dtype=torch.int64, device=dev)
+    weight = torch.empty(B, S, dtype=torch.float32, device=dev)
+    pv, nv = pval.contiguous().view(torch.uint8), nval.contiguous().view(torch.uint8)
+    Lv = len(heads)
+    L.check(lib.loft_rpn_sample_gather(L.arr(c_void_p, [h.data_ptr() for h in heads]), L.arr(c_int, [h.shape[2] for h in heads]),
+                                       L.arr(c_int, [h.shape[3] for h in heads]), L.arr(c_int64, list(lvl_off)), Lv, B, Cp, int(A),
+                                       L.ptr(anchors.float().contiguous()), L.ptr(gts.float().contiguous()), int(gts.shape[1]),
+                                       L.ptr(gt_inds.contiguous()), c_int64(gt_inds.shape[1]), L.ptr(pidx.contiguous()), L.ptr(pv), P,
+                                       L.ptr(nidx.contiguous()), L.ptr(nv), Q, L.arr(c_float, list(means)), L.arr(c_float, list(stds)),
+                                       L.ptr(vals), L.ptr(rows), L.ptr(slot), L.ptr(tgt), L.ptr(label), L.ptr(weight), L.stream()),
+            'loft_rpn_sample_gather')
+    return vals, rows, slot, tgt, label, weight
+
+
 _SAMPLE_CALLS = [0]
 
 

@@ -116,6 +116,25 @@ class RPNHead(nn.Module):
             num_pos = pval.sum(1).clamp(min=1).sum()
             num_neg = nval.sum(1).clamp(min=1).sum()
             avg = (num_pos + num_neg).float()
+        if sparse is not None and fused[0].is_cuda and not os.environ.get('LOFT_RPN_TORCH_GATHER'):
+            # one launch: level / pixel / slot of every sampled anchor, its logit + deltas straight from the fused head outputs,
+            # labels, weights and the positives' regression targets
+            xs, hs = sparse
+            A = self.num_anchors
+            with torch.no_grad():
+                vals, rows, slot, tgt, label, w = K.rpn_sample_gather(list(fused), geo['lvl_off'], A, geo['anchors'], gts, gt_inds,
+                                                                      pidx, pval, nidx, nval, self.bbox_coder.means,
+                                                                      self.bbox_coder.stds)
+            S = vals.shape[1]
+            vals = F2.rpn_sparse_outputs(vals.reshape(-1, 5), rows, slot, A, list(xs), list(hs), self.rpn_conv.weight,
+                                         self.rpn_conv.bias, self.rpn_cls.weight, self.rpn_cls.bias, self.rpn_reg.weight,
+                                         self.rpn_reg.bias).view(B, S, 5)
+            logit = vals[..., 0]
+            pred = vals[:, :pidx.shape[1], 1:5]
+            loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
+            loss_bbox = self.loss_bbox(pred, tgt, w[:, :pidx.shape[1], None].expand_as(pred), avg_factor=avg)
+            return dict(loss_rpn_cls=loss_cls, loss_rpn_bbox=loss_bbox)
+        with torch.no_grad():
             pos_anchor = geo['anchors'][pidx.reshape(-1)]
             pos_gt_i = (torch.gather(gt_inds, 1, pidx) - 1).clamp(min=0)
             pos_gt = torch.gather(gts, 1, pos_gt_i[..., None].expand(-1, -1, 4)).reshape(-1, 4)

@@ -322,6 +322,20 @@ int64_t loft_random_sample_workspace_bytes(int B, int N);
 int loft_random_sample(const int64_t* gt_inds, int B, int N, int num, int max_pos, int mode, uint64_t seed,
                        int64_t* pos_idx, uint8_t* pos_valid, int64_t* neg_idx, uint8_t* neg_valid, void* workspace, void* stream);
 
+/* loft_rpn_sample_gather: the RPN's target / prediction gathering for the sampled anchors of a batch
+ * (anchor_head.py:187-237 targets, :429-497 loss inputs; rpn_head.py:38-54 outputs).  heads[l]: fused head output of level l,
+ * fp32 [B,H_l,W_l,Cp] with channel a < A = objectness logit of anchor slot a, channel A + 4a + j = delta j; lvl_off[L+1]: first
+ * flat anchor index of each level (flat index = lvl_off[l] + (y*W_l + x)*A + a).  For s < P the sample is pos_idx[b,s], else
+ * neg_idx[b,s-P] (loft_random_sample outputs).  Writes vals [B,S,5] (logit, 4 deltas), rows int32 [B*S,4] = (b, level or -1 if
+ * the slot is unused, y, x), slot int64 [B*S], tgt [B,P,4] = bbox2delta(anchor, gts[b, gt_inds-1]) (0 for unused slots), label
+ * int64 [B,S] (1 = positive), weight [B,S] (1 = used).  S = P + Q. */
+int loft_rpn_sample_gather(const void* const* heads, const int* H, const int* W, const int64_t* lvl_off, int num_levels,
+                           int B, int Cp, int A, const float* anchors, const float* gts, int Kmax,
+                           const int64_t* gt_inds, int64_t N, const int64_t* pos_idx, const uint8_t* pos_valid, int P,
+                           const int64_t* neg_idx, const uint8_t* neg_valid, int Q, const float* means_host,
+                           const float* stds_host, float* vals, int32_t* rows, int64_t* slot, float* tgt,
+                           int64_t* label, float* weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

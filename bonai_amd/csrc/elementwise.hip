@@ -475,6 +475,16 @@ LOFT_EXPORT int loft_fold_pack(const float* w, const float* conv_bias, const flo
     return 0;
 }
 
+// Record lookup of the batched kernels: largest j with desc[j][15] <= key (first_chunk / first_block are ascending).  A binary
+// search is a chain of ~7 dependent global loads (~8 us before a short block does any work); here every lane tests its own
+// entries with independent loads and the wave counts the hits.
+__device__ __forceinline__ int find_record(const long* __restrict__ desc, int n, long key) {
+    int cnt = 0;
+    for (int j = threadIdx.x & 63; j < n; j += 64) cnt += desc[(long)j * 16 + 15] <= key ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    return cnt - 1;
+}
+
 // Batched form: ONE launch packs every registered conv of the model (the trainer knows the full list after the first step;
 // weights only change in the SGD kernel, so all packings of a step can be produced up front).  desc: n records of 16 int64
 // {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_chunk};
@@ -489,11 +499,7 @@ constexpr int FOLD_TILE_FLOATS = 16 * (64 * FOLD_TILE_MAX_RS + 1);      // >= 64
 __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __restrict__ desc, int n, long nchunks) {
     __shared__ float tile[FOLD_TILE_FLOATS];
     for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        int lo = 0, hi = n - 1;                                  // binary search once per chunk (block-uniform)
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (desc[(long)mid * 16 + 15] <= c) lo = mid; else hi = mid - 1;
-        }
+        const int lo = find_record(desc, n, c);                  // (block-uniform)
         const long* d = desc + (long)lo * 16;
         const float* w = reinterpret_cast<const float*>(d[0]);
         const float* cbias = reinterpret_cast<const float*>(d[1]);
@@ -665,12 +671,8 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_kernel(const float* __res
 // dbeta_or_dbias, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_block}; block b serves output channel
 // b - first_block of the record with the largest first_block <= b and ACCUMULATES into dw / dgamma / dbeta (slots of the
 // flat gradient arena).  Without BN (gamma == 0) the last slot is the conv's bias gradient: dbias[n] += db[n].
-__global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* __restrict__ desc, int njobs) {
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (desc[(long)mid * 16 + 15] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+__global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* __restrict__ desc, int njobs, int lds_floats) {
+    const int lo = find_record(desc, njobs, (long)blockIdx.x);
     const long* d = desc + (long)lo * 16;
     const float* dwp = reinterpret_cast<const float*>(d[0]);
     const float* db = reinterpret_cast<const float*>(d[1]);
@@ -705,6 +707,58 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         if (threadIdx.x == 0 && dbeta && db) dbeta[n] += db[n];
         return;
     }
+    if (RS > 1 && per <= lds_floats) {
+        // taps > 1: the RS planes dwp[t][n][:] are read contiguously and interleaved to the parameter's (c, t) order through LDS
+        // (the direct form below reads 4 bytes from RS different planes per lane group: uncoalesced)
+        extern __shared__ float urow[];
+        if ((Cin & 3) == 0 && (CinP & 3) == 0) {          // 16-byte accesses on both sides
+            for (int j = threadIdx.x * 4; j < per; j += blockDim.x * 4) {
+                const int t = j / Cin, c = j - t * Cin;
+                const float4 v = *reinterpret_cast<const float4*>(dwp + ((long)t * CoutP + n) * CinP + c);
+                urow[c * RS + t] = v.x; urow[(c + 1) * RS + t] = v.y; urow[(c + 2) * RS + t] = v.z; urow[(c + 3) * RS + t] = v.w;
+            }
+            __syncthreads();
+            for (int j = threadIdx.x * 4; j < per; j += blockDim.x * 4) {
+                const float4 g = *reinterpret_cast<const float4*>(urow + j);
+                const long wi = (long)n * per + j;
+                if (dw) {
+                    float4 o = *reinterpret_cast<float4*>(dw + wi);
+                    o.x += g.x * scale; o.y += g.y * scale; o.z += g.z * scale; o.w += g.w * scale;
+                    *reinterpret_cast<float4*>(dw + wi) = o;
+                }
+                if (gamma) {
+                    const float4 ww = *reinterpret_cast<const float4*>(w + wi);
+                    acc += g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w;
+                }
+            }
+        } else {
+            for (int j = threadIdx.x; j < per; j += blockDim.x) {
+                const int t = j / Cin, c = j - t * Cin;
+                urow[c * RS + t] = dwp[((long)t * CoutP + n) * CinP + c];
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < per; j += blockDim.x) {
+                const float g = urow[j];
+                const long wi = (long)n * per + j;
+                if (dw) dw[wi] += g * scale;
+                if (gamma) acc += g * w[wi];
+            }
+        }
+    } else if (RS == 1 && (Cin & 3) == 0 && (CinP & 3) == 0) {
+        for (int j = threadIdx.x * 4; j < per; j += blockDim.x * 4) {     // 1x1 / Linear: same order on both sides
+            const float4 g = *reinterpret_cast<const float4*>(dwp + (long)n * CinP + j);
+            const long wi = (long)n * per + j;
+            if (dw) {
+                float4 o = *reinterpret_cast<float4*>(dw + wi);
+                o.x += g.x * scale; o.y += g.y * scale; o.z += g.z * scale; o.w += g.w * scale;
+                *reinterpret_cast<float4*>(dw + wi) = o;
+            }
+            if (gamma) {
+                const float4 ww = *reinterpret_cast<const float4*>(w + wi);
+                acc += g.x * ww.x + g.y * ww.y + g.z * ww.z + g.w * ww.w;
+            }
+        }
+    } else
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
         const float g = dwp[((long)t * CoutP + n) * CinP + c];
@@ -731,7 +785,7 @@ LOFT_EXPORT int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64
     if (njobs <= 0 || nblocks <= 0) return 0;
     if (lds_floats < 0 || lds_floats > 16384) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_unpack_bwd_multi_kernel, dim3((unsigned)nblocks), dim3(256), (size_t)lds_floats * 4, (hipStream_t)stream,
-                       (const long*)desc, njobs);
+                       (const long*)desc, njobs, lds_floats);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

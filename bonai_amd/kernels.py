@@ -1132,7 +1132,9 @@ class UnpackQueue:
                              struct.unpack('<i', struct.pack('<f', eps))[0], Cout, Cin, RS, coutp, cinp, blk])
                 blk += Cout
             desc = h2d(rows, torch.int64, self.jobs[0][2].device)
-            lds = max([r[11] * -r[12] for r in rows if r[12] < 0], default=0)
+            # dynamic LDS row: records that interleave taps through LDS (n-major Linear records must fit; conv records with
+            # more than one tap use it when they fit, else the direct form)
+            lds = max([r[11] * abs(r[12]) for r in rows if (r[12] < 0 or r[12] > 1) and r[11] * abs(r[12]) <= 16384], default=0)
             L.check(L.load().loft_fold_unpack_bwd_multi(L.ptr(desc), len(rows), c_int64(blk), int(lds), L.stream()),
                     'loft_fold_unpack_bwd_multi')
             self.jobs = []

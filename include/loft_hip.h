@@ -294,8 +294,8 @@ int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stre
 /* loft_fold_unpack_bwd_multi: loft_fold_unpack_bwd for MANY convs in one launch, accumulate-only (the trainer's direct gradient
  * sink).  desc (device): njobs records of 16 int64 {dwp, db, w, gamma, mean, var, dw, dgamma, dbeta_or_dbias (device addresses,
  * 0 = absent), eps as float bits, Cout, Cin, RS, CoutP, CinP, first_block}; record i owns blocks [first_block_i, first_block_i +
- * Cout_i); nblocks = their total.  lds_floats: dynamic LDS in floats = max Cin * |RS| over the RS < 0 records (0 if none;
- * <= 16384). */
+ * Cout_i); nblocks = their total.  lds_floats: dynamic LDS in floats (<= 16384): >= Cin * |RS| of every RS < 0 record
+ * (required); records with RS > 1 and Cin * RS <= lds_floats interleave their taps through it (coalesced reads). */
 int loft_fold_unpack_bwd_multi(const int64_t* desc, int njobs, int64_t nblocks, int lds_floats, void* stream);
 /* loft_transpose_bf16: dst[Cc][R] = src[R][Cc]^T (row-major bf16, R and Cc even): the [K][O] data-gradient operand of an
  * n-major record from its [O][K] forward packing. */

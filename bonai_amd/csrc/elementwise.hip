@@ -564,9 +564,12 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
         const int n0 = (local_chunk / tc) * NT, c0 = (local_chunk % tc) * 64;
         const int span = 64 * RS, ldw = span + 1;
         __syncthreads();                                         // the previous chunk's readers are done with the tile
+        // (index math without per-element integer division by run-time values -- reciprocal multiplies and shifts)
+        const unsigned rs_mul = RS == 1 ? 0u : 0xFFFFFFFFu / (unsigned)RS + 1u;      // x / RS == umulhi(x, rs_mul) for x < 2^16
+        const unsigned sp_mul = 0xFFFFFFFFu / (unsigned)span + 1u;                   // x / span likewise
         for (int i = threadIdx.x; i < NT * span; i += 256) {
-            const int row = i / span, off = i - row * span;
-            const int nn = n0 + row, cc = c0 + off / RS;
+            const int row = (int)__umulhi((unsigned)i, sp_mul), off = i - row * span;
+            const int nn = n0 + row, cc = c0 + (RS == 1 ? off : (int)__umulhi((unsigned)off, rs_mul));
             float v = 0.f;
             if (nn < Cout && cc < Cin) {
                 v = w[((long)nn * Cin + c0) * RS + off];
@@ -575,9 +578,10 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
             tile[row * ldw + off] = v;
         }
         __syncthreads();
+        const int ntsh = RS == 1 ? 6 : 4;                           // log2(NT)
         if (wp)                                                  // [t][nn][cc pair]: 32 lanes = one 128-byte run
             for (int i = threadIdx.x; i < RS * NT * 32; i += 256) {
-                const int cp = i & 31, row = (i >> 5) % NT, t = (i >> 5) / NT;
+                const int cp = i & 31, r2 = i >> 5, row = r2 & (NT - 1), t = r2 >> ntsh;
                 const int nn = n0 + row, cc = c0 + 2 * cp;
                 if (nn < CoutP && cc < CinP) {
                     const float* tp = tile + row * ldw + 2 * cp * RS + t;
@@ -586,9 +590,9 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
                 }
             }
         if (wpt) {                                               // [t][cc][nn pair]: NT/2 lanes = one 2*NT-byte run
-            const int hp = NT >> 1;
+            const int hsh = ntsh - 1, hp = 1 << hsh;
             for (int i = threadIdx.x; i < RS * 64 * hp; i += 256) {
-                const int np = i % hp, ccl = (i / hp) & 63, t = i / (hp * 64);
+                const int np = i & (hp - 1), r2 = i >> hsh, ccl = r2 & 63, t = r2 >> 6;
                 const int nn = n0 + 2 * np, cc = c0 + ccl;
                 if (nn < CoutP && cc < CinP) {
                     const float* tp = tile + 2 * np * ldw + ccl * RS + t;

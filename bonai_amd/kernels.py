@@ -1104,17 +1104,32 @@ class UnpackQueue:
     def __init__(self, limit=48):
         self.limit = limit
         self.jobs, self.done = [], []
+        # jobs may be produced on a side stream (the mask branch runs beside the FOA branch); the batched launch always goes to
+        # the stream the queue was created on and waits for an event per foreign job
+        self.home = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        self.home_raw = L.stream().value if self.home is not None else None
+        self.events = []
 
     def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None):
         """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
         launch that served this job has been enqueued (the reducer's gradient-ready notifications).
         flat_chw = (C, H, W): w is a Linear weight [O, C*H*W] and dwp [O, H*W*C] its gradient in NHWC-flattened K order."""
         self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw))
+        if self.home is not None and L.stream().value != self.home_raw:
+            ev = torch.cuda.Event()
+            ev.record()                       # (on the producing side stream)
+            self.events.append(ev)
         self.done.extend(on_done)
         if len(self.jobs) >= self.limit:
             self.flush()
 
     def flush(self):
+        if self.home is not None and L.stream().value != self.home_raw:
+            with torch.cuda.stream(self.home):
+                return self.flush()
+        for ev in self.events:
+            self.home.wait_event(ev)
+        self.events = []
         if self.jobs:
             import struct
             rows, blk = [], 0

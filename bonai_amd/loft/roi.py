@@ -10,6 +10,8 @@ Mirrors (constructor arguments, parameter names, loss keys, output ordering):
   attribute_heads/offset_head.py:23-265                 -> plain LOFT head (no FOA)
   loft_roi_head.py:22-227 (+ standard_roi_head.py, test_mixins.py:211-241)
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -396,18 +398,36 @@ class LoftRoIHead(nn.Module):
         cls_score, bbox_pred = self.bbox_head(bbox_feats)
         losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights))
 
+        side = None
         if self.with_mask:
             mask_feats = self.mask_roi_extractor(xm[:self.mask_roi_extractor.num_inputs], pos_rois)
-            mask_pred = self.mask_head(mask_feats)
-            with torch.no_grad():
-                masks, moffs = _masks_to_device(gt_masks, dev)
-                H, W = masks[0].shape[1], masks[0].shape[2]
-                pb = pos_rois[:, 1:].clone()
-                pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
-                pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
-                gidx = pos_gt_i + K.h2d(moffs[:-1], torch.int64, dev)[pos_b]
-                mask_targets = K.mask_target(masks, pb, gidx, int(self.train_cfg.mask_size))
-            losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel]))
+            # The mask branch (4 convs + deconv + logits at 14x14 / 28x28) and the FOA branch (40 convs at 7x7) are independent
+            # chains of launches that each fill 2.6 rounds of the 256 CUs: on two HIP streams their tails fill each other's
+            # idle CUs, forward and (autograd replays each node on its forward stream) backward.  RoIAlign stays on the main
+            # stream -- its backward accumulates into the shared per-level gradient maps.
+            if dev.type == 'cuda' and torch.is_grad_enabled() and K.PROFILE is None and not os.environ.get('LOFT_NO_SIDE_STREAM'):
+                if getattr(self, '_side_stream', None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side = self._side_stream
+                side.wait_stream(torch.cuda.current_stream())
+                mask_feats.record_stream(side)
+
+            def mask_branch():
+                mask_pred = self.mask_head(mask_feats)
+                with torch.no_grad():
+                    masks, moffs = _masks_to_device(gt_masks, dev)
+                    H, W = masks[0].shape[1], masks[0].shape[2]
+                    pb = pos_rois[:, 1:].clone()
+                    pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
+                    pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
+                    gidx = pos_gt_i + K.h2d(moffs[:-1], torch.int64, dev)[pos_b]
+                    mask_targets = K.mask_target(masks, pb, gidx, int(self.train_cfg.mask_size))
+                return self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel])
+            if side is not None:
+                with torch.cuda.stream(side):
+                    mask_losses = mask_branch()
+            else:
+                losses.update(mask_branch())
 
         with torch.no_grad():
             off_pad = torch.zeros(B, Kmax, 2, device=dev)
@@ -426,6 +446,12 @@ class LoftRoIHead(nn.Module):
             losses.update(loss_offset=offset_pred.sum() * 0)
         else:
             losses.update(self.offset_head.loss(offset_pred, offset_targets))
+        if side is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            for v in mask_losses.values():
+                v.record_stream(main)
+            losses.update(mask_losses)
         return losses
 
     # ---------------------------------------------------------------- inference

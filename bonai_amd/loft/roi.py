@@ -395,8 +395,13 @@ class LoftRoIHead(nn.Module):
             xb, xm, xo = x.branches[1], x.branches[2], x.branches[3]
         feats = xb[:self.bbox_roi_extractor.num_inputs]
         bbox_feats = self.bbox_roi_extractor(feats, rois)
-        cls_score, bbox_pred = self.bbox_head(bbox_feats)
-        losses.update(self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights))
+
+        def bbox_branch():
+            cls_score, bbox_pred = self.bbox_head(bbox_feats)
+            return self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights)
+        bbox_on_side = self.with_mask and not os.environ.get('LOFT_NO_BBOX_SIDE_STREAM')   # the bbox head's 512-workgroup GEMMs ride along
+        if not bbox_on_side:
+            losses.update(bbox_branch())
 
         side = None
         if self.with_mask:
@@ -411,6 +416,8 @@ class LoftRoIHead(nn.Module):
                 side = self._side_stream
                 side.wait_stream(torch.cuda.current_stream())
                 mask_feats.record_stream(side)
+                if bbox_on_side:
+                    bbox_feats.record_stream(side)
 
             def mask_branch():
                 mask_pred = self.mask_head(mask_feats)
@@ -425,8 +432,11 @@ class LoftRoIHead(nn.Module):
                 return self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel])
             if side is not None:
                 with torch.cuda.stream(side):
-                    mask_losses = mask_branch()
+                    mask_losses = dict(bbox_branch()) if bbox_on_side else dict()
+                    mask_losses.update(mask_branch())
             else:
+                if bbox_on_side:
+                    losses.update(bbox_branch())
                 losses.update(mask_branch())
 
         with torch.no_grad():

@@ -211,6 +211,10 @@ def main():
         roofline = dict(bound='mfma', kernel=kname,
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
+                        measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
+                                 'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
+                                 'rocprofv3 summary of that mode: profiles/round1_bench_kernel_stats_serial.csv '
+                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round1_bench_kernel_stats.csv',
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     if rank == 0:

@@ -1020,6 +1020,46 @@ class PrepackRegistry:
 
 
 
+_LOSS_SCRATCH = {}
+
+
+def fused_loss(mode, pred, target, weight=None, avg_factor=None, count=None, scale=1.0, beta=1.0):
+    """loft_fused_loss: -> (loss fp32 [1], grad fp32 like pred).  mode: 'l1' | 'smooth_l1' | 'bce' | 'ce'.
+    avg_factor: device scalar tensor, python number or None (then `count`, default = number of elements / rows)."""
+    lib = L.load()
+    L.dev_check(pred, target, weight)
+    m = {'l1': 0, 'smooth_l1': 1, 'bce': 2, 'ce': 3}[mode]
+    pred = pred.float().contiguous()
+    dev = pred.device
+    if m == 3:
+        n, C = pred.shape[0], pred.shape[1]
+        target = target.contiguous()
+        if target.dtype != torch.int64:
+            target = target.long()
+    else:
+        n, C = pred.numel(), 1
+        target = target.float().contiguous()
+    if weight is not None:
+        weight = weight.float().expand(pred.shape if m != 3 else (n,)).contiguous()
+    af = None
+    cnt = float(n if count is None else count)
+    if torch.is_tensor(avg_factor):
+        af = avg_factor.float().reshape(1).contiguous()
+    elif avg_factor is not None:
+        cnt = float(avg_factor)
+    key = (dev.index, L.stream().value)
+    if key not in _LOSS_SCRATCH:             # per stream: the ticket counter must not be shared by concurrent launches
+        _LOSS_SCRATCH[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    counter = _LOSS_SCRATCH[key]
+    partial = torch.empty(256, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(pred)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    L.check(lib.loft_fused_loss(m, L.ptr(pred), L.ptr(target), L.ptr(weight), c_int64(n), int(C), L.ptr(af), c_float(max(cnt, 1e-30)),
+                                c_float(scale), c_float(beta), L.ptr(grad), L.ptr(partial), L.ptr(counter), L.ptr(out), L.stream()),
+            'loft_fused_loss')
+    return out, grad
+
+
 def rpn_sample_gather(heads, lvl_off, A, anchors, gts, gt_inds, pidx, pval, nidx, nval, means, stds):
     """Everything between the RPN's sampler and its losses in one launch (loft_rpn_sample_gather).
     heads: per level fp32 NHWC [B,Cp,H,W]; -> (vals [B,S,5], rows int32 [B*S,4], slot int64 [B*S], tgt [B,P,4],

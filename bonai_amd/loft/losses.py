@@ -9,6 +9,36 @@ from torch import nn
 from .builder import LOSSES
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """Loss value + gradient in ONE launch (loft_fused_loss); backward is the stored gradient times the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, mode, target, weight, avg_factor, count, scale, beta, out_shape):
+        from .. import kernels as K
+        loss, grad = K.fused_loss(mode, pred, target, weight, avg_factor, count, scale, beta)
+        ctx.save_for_backward(grad)
+        ctx.meta = (tuple(pred.shape), pred.dtype)
+        return loss.reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        shape, dt = ctx.meta
+        gp = (grad * g.reshape(())).reshape(shape)
+        return (gp if dt == torch.float32 else gp.to(dt)), None, None, None, None, None, None, None, None
+
+
+def _fusable(pred, reduction):
+    """The product path: device tensors, the configs' 'mean' reduction.  Host tensors (CPU-side tests) and the other reductions
+    keep the elementwise formulation below."""
+    import os
+    return pred.is_cuda and reduction == 'mean' and pred.numel() > 0 and not os.environ.get('LOFT_TORCH_LOSSES')
+
+
+def _fused(mode, pred, target, weight, avg_factor, scale, beta=1.0, count=None, out_shape=()):
+    return _FusedLossFn.apply(pred, mode, target, weight, avg_factor, count, float(scale), float(beta), out_shape)
+
+
 def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
     if weight is not None:
         loss = loss * weight
@@ -54,6 +84,21 @@ class CrossEntropyLoss(nn.Module):
 
     def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
         reduction = reduction_override if reduction_override else self.reduction
+        if self.class_weight is None and not kwargs and _fusable(cls_score, reduction):
+            if self.use_sigmoid:
+                if cls_score.dim() != label.dim():          # RPN: labels in {0,1} -> one channel
+                    if cls_score.numel() == label.numel():
+                        return _fused('bce', cls_score.reshape(-1), (label >= 1).reshape(-1), None if weight is None else
+                                      weight.reshape(-1), avg_factor, self.loss_weight)
+                else:
+                    return _fused('bce', cls_score, label, weight, avg_factor, self.loss_weight)
+            elif self.use_mask:
+                # (here the third positional argument carries the RoIs' class labels, fcn_mask_head.py:143-149; with one mask
+                #  channel they select nothing)
+                if cls_score.shape[1] == 1 and avg_factor is None:
+                    return _fused('bce', cls_score.reshape(-1), label.reshape(-1), None, None, self.loss_weight, out_shape=(1,))
+            elif cls_score.dim() == 2:
+                return _fused('ce', cls_score, label, weight, avg_factor, self.loss_weight)
         cw = None if self.class_weight is None else cls_score.new_tensor(self.class_weight)
         return self.loss_weight * self.cls_criterion(cls_score, label, weight, class_weight=cw, reduction=reduction,
                                                      avg_factor=avg_factor, **kwargs)
@@ -67,6 +112,8 @@ class L1Loss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         reduction = reduction_override if reduction_override else self.reduction
+        if _fusable(pred, reduction):
+            return _fused('l1', pred, target, weight, avg_factor, self.loss_weight)
         return self.loss_weight * weight_reduce_loss((pred - target).abs(), weight, reduction, avg_factor)
 
 
@@ -78,6 +125,8 @@ class SmoothL1Loss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
         reduction = reduction_override if reduction_override else self.reduction
+        if not kwargs and _fusable(pred, reduction):
+            return _fused('smooth_l1', pred, target, weight, avg_factor, self.loss_weight, beta=self.beta)
         d = (pred - target).abs()
         loss = torch.where(d < self.beta, 0.5 * d * d / self.beta, d - 0.5 * self.beta)
         return self.loss_weight * weight_reduce_loss(loss, weight, reduction, avg_factor)

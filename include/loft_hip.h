@@ -336,6 +336,16 @@ int loft_rpn_sample_gather(const void* const* heads, const int* H, const int* W,
                            const float* stds_host, float* vals, int32_t* rows, int64_t* slot, float* tgt,
                            int64_t* label, float* weight, void* stream);
 
+/* loft_fused_loss: a weighted, normalised loss and its gradient in one launch (mmdet/models/losses/utils.py:26-52 around
+ * smooth_l1_loss.py:8-50 and cross_entropy_loss.py:9-125).  mode 0 L1, 1 SmoothL1(beta), 2 sigmoid cross-entropy on logits (target
+ * fp32 in [0,1]), 3 softmax cross-entropy (pred [n,C], target int64 [n], weight per row).  n = number of elements (rows for mode 3);
+ * weight fp32 per element / row or NULL.  loss_out[0] = scale / denom * sum_i w_i l_i, grad (same shape as pred) = d loss / d pred;
+ * denom = *avg_factor (device scalar) if not NULL else `count`.  partial: >= 256 floats of scratch; counter: one uint32 that is 0
+ * before the first launch (the kernel leaves it 0).  Deterministic summation order. */
+int loft_fused_loss(int mode, const float* pred, const void* target, const float* weight, int64_t n, int C,
+                    const float* avg_factor, float count, float scale, float beta, float* grad, float* partial,
+                    uint32_t* counter, float* loss_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

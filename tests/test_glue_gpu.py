@@ -298,3 +298,47 @@ def test_random_sampler_kernel(N, num, frac, npos):
         # uniformity: mean of the drawn negative indices ~ N/2 (std of the mean of 256 uniform draws = N / sqrt(12 * 256))
         m = a['neg_idx'][a['neg_valid']].float().mean().item()
         assert abs(m - N / 2) < 6 * N / (12 * a['neg_valid'].sum().item()) ** 0.5
+
+
+def test_fused_losses_match_elementwise_formulation():
+    """loft_fused_loss (value + gradient in one launch) against the torch formulation of the same modules: L1, SmoothL1,
+    sigmoid / softmax / mask cross-entropy with weights, device and python avg_factor, plain mean."""
+    import os
+    from bonai_amd.loft.losses import CrossEntropyLoss, L1Loss, SmoothL1Loss
+    torch.manual_seed(0)
+    dev = 'cuda'
+    cases = []
+    p = torch.randn(8, 128, 4, device=dev)
+    cases.append((L1Loss(loss_weight=1.0), (p, torch.randn_like(p), (torch.rand(8, 128, 1, device=dev) > 0.5).float().expand_as(p)),
+                  dict(avg_factor=torch.tensor(1900.0, device=dev))))
+    p = torch.randn(4000, 4, device=dev) * 2
+    cases.append((SmoothL1Loss(beta=1.0, loss_weight=1.0), (p, torch.randn_like(p), (torch.rand(4000, 4, device=dev) > 0.7).float()),
+                  dict(avg_factor=4000.0)))
+    p = torch.randn(3000, 2, device=dev)
+    cases.append((SmoothL1Loss(beta=1.0, loss_weight=16.0), (p, torch.randn_like(p)), dict()))
+    p = torch.randn(3072, 1, device=dev) * 3
+    cases.append((CrossEntropyLoss(use_sigmoid=True, loss_weight=1.0), (p, torch.randint(0, 2, (3072,), device=dev),
+                                                                         (torch.rand(3072, device=dev) > 0.2).float()),
+                  dict(avg_factor=torch.tensor(2450.0, device=dev))))
+    p = torch.randn(8192, 2, device=dev) * 2
+    cases.append((CrossEntropyLoss(loss_weight=1.0), (p, torch.randint(0, 2, (8192,), device=dev), torch.ones(8192, device=dev)),
+                  dict(avg_factor=torch.tensor(8192.0, device=dev))))
+    p = torch.randn(300, 1, 28, 28, device=dev) * 2
+    cases.append((CrossEntropyLoss(use_mask=True, loss_weight=1.0), (p, (torch.rand(300, 28, 28, device=dev) > 0.5).float(),
+                                                                      torch.zeros(300, dtype=torch.long, device=dev)), dict()))
+    for mod, args, kw in cases:
+        res = []
+        for env in ('', '1'):
+            if env:
+                os.environ['LOFT_TORCH_LOSSES'] = '1'
+            else:
+                os.environ.pop('LOFT_TORCH_LOSSES', None)
+            pred = args[0].clone().requires_grad_(True)
+            loss = mod(pred, *args[1:], **kw)
+            (loss.sum() * 1.7).backward()
+            res.append((loss.detach().reshape(-1), pred.grad.clone()))
+        os.environ.pop('LOFT_TORCH_LOSSES', None)
+        (l0, g0), (l1, g1) = res
+        assert l0.shape == l1.shape
+        assert (l0 - l1).abs().max().item() <= 2e-5 * max(1.0, l1.abs().max().item()), type(mod).__name__
+        assert (g0 - g1).abs().max().item() <= 2e-5 * max(1e-6, g1.abs().max().item()), type(mod).__name__

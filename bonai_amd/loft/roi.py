@@ -114,8 +114,11 @@ class Shared2FCBBoxHead(nn.Module):
         pos = (labels >= 0) & (labels < self.num_classes)
         n = bbox_pred.shape[0]
         pred = bbox_pred.view(n, -1, 4)
-        idx = labels.clamp(max=pred.shape[1] - 1)
-        pred = pred[torch.arange(n, device=pred.device), idx]
+        if pred.shape[1] == 1:          # one class (BONAI): nothing to select -- no gather / scatter-back launches
+            pred = pred[:, 0]
+        else:
+            idx = labels.clamp(max=pred.shape[1] - 1)
+            pred = pred[torch.arange(n, device=pred.device), idx]
         w = bbox_weights * pos[:, None].float()
         losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, w, avg_factor=float(max(n, 1)))
         return losses

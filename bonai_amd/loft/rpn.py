@@ -62,9 +62,10 @@ class RPNHead(nn.Module):
         w = torch.cat([self.rpn_cls.weight.view(A, -1), self.rpn_reg.weight.view(4 * A, -1)], 0)
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
         outs, hs = [], []
+        pre = F2.narrow_head_prepack(w, b, feats[0].dtype)        # one packing for the five levels
         for x in feats:
             h = F2.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, pad=1, relu=True)
-            outs.append(F2.narrow_head(h, w, b))
+            outs.append(F2.narrow_head(h, w, b, prepacked=pre))
             hs.append(h)
         return (outs, hs) if keep_hidden else outs
 

@@ -322,17 +322,13 @@ class _NarrowHeadFn(torch.autograd.Function):
     PADW = 128
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, input_relu=False):
+    def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None):
         Cout, Cin, R, S = w.shape
         ctx.input_relu = input_relu
         c4 = (Cout + 3) // 4 * 4
-        wpad = torch.zeros(c4, Cin, R, S, dtype=w.dtype, device=w.device)
-        wpad[:Cout] = w
-        bpad = torch.zeros(c4, dtype=torch.float32, device=w.device)
-        if b is not None:
-            bpad[:Cout] = b
+        wp, bpad = prepacked if prepacked is not None else narrow_head_prepack(w, b, x.dtype)
         K.ALGO_SCALE = Cout / c4
-        y = K.conv2d_fwd(x, K.pack_w_fwd(wpad, x.dtype)[None], bpad, R, S, stride, pad, out_dtype=torch.float32)
+        y = K.conv2d_fwd(x, wp, bpad, R, S, stride, pad, out_dtype=torch.float32)
         K.ALGO_SCALE = 1.0
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -354,7 +350,7 @@ class _NarrowHeadFn(torch.autograd.Function):
                                            need_dw=ctx.needs_input_grad[1], need_db=want_b)
             if gx is not None and ctx.input_relu:
                 gx._loft_premasked = x.data_ptr()
-            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None
+            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
         gp = torch.zeros(N, P, H, W, dtype=torch.bfloat16, device=g.device).contiguous(memory_format=torch.channels_last)
@@ -377,15 +373,27 @@ class _NarrowHeadFn(torch.autograd.Function):
         K.ALGO_SCALE = 1.0
         if want_b:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False):
+def narrow_head_prepack(w, b, dtype):
+    """(packed weight [1,T,c4,Cin], bias [c4]) of a narrow head: Cout zero-padded to a multiple of 4 by the packing kernel itself
+    (one launch; callers that apply the same head to several maps -- the RPN's five levels -- pack once)."""
+    if w.dim() == 2:
+        w = w.view(w.shape[0], w.shape[1], 1, 1)
+    c4 = (w.shape[0] + 3) // 4 * 4
+    pdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
+    with torch.no_grad():
+        wp, _, bias = K.fold_pack(w, b, None, 1e-5, want_dgrad=False, dtype=pdt, cout_pad=c4)
+    return wp[None], bias
+
+
+def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False, prepacked=None):
     """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW].
     input_relu: x is the output of a ReLU -- the backward folds that ReLU's mask into the data gradient it produces."""
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
-    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu)
+    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu, prepacked)
 
 
 class _MdcnSampleFn(torch.autograd.Function):

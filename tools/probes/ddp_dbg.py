@@ -1,6 +1,9 @@
+"""Two ranks on one GPU (RANK=0 / RANK=1 in two shells or backgrounded): traces the reducer's bucket launches against the pending
+gradient deposits of the unpack queue and checks the all-reduced arena against the sum of both ranks' local autograd gradients."""
 import os, sys, torch
 import torch.distributed as dist
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 os.environ['MASTER_ADDR']='127.0.0.1'; os.environ['MASTER_PORT']='29533'
 rank=int(os.environ['RANK']); dist.init_process_group('gloo', rank=rank, world_size=2)
 from bonai_amd.config import Config
@@ -9,7 +12,6 @@ from bonai_amd.loft import build_detector
 from bonai_amd.loft.core import RandomSampler
 from bonai_amd.synth import make_batch
 RandomSampler.choice_mode = 'first'
-ROOT='/root/repo'
 cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
 def build():
     torch.manual_seed(0)

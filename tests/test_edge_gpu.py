@@ -106,18 +106,26 @@ def test_trainer_direct_grad_sink_matches_autograd_accumulation():
         m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
         return m.cuda().train()
     ref = build()
-    ref.train_step(data)['loss'].backward()
+    os.environ['LOFT_NO_SIDE_STREAM'] = '1'          # reference: one stream, plain autograd accumulation
+    try:
+        ref.train_step(data)['loss'].backward()
+    finally:
+        os.environ.pop('LOFT_NO_SIDE_STREAM', None)
     want = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
     m = build()
     tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
-    tr.train_step(data, lr=0.0)
-    got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
-    assert set(want) <= set(got)
-    for n, w in want.items():
-        assert (got[n] - w).norm().item() <= 1e-2 * w.norm().item() + 1e-7, (n, (got[n] - w).norm().item(), w.norm().item())
-    for n, g in got.items():
-        if n not in want:
-            assert g.abs().max().item() == 0, n
+    # the trainer path also runs the bbox / mask branches on the side stream (forward and backward) and deposits through the
+    # unpack queue; lr = 0 keeps the weights, so every repetition must reproduce the same gradients (a stream race would not)
+    for rep in range(3):
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+        got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+        assert set(want) <= set(got)
+        for n, w in want.items():
+            assert (got[n] - w).norm().item() <= 1e-2 * w.norm().item() + 1e-7, (rep, n, (got[n] - w).norm().item(), w.norm().item())
+        for n, g in got.items():
+            if n not in want:
+                assert g.abs().max().item() == 0, n
 
 
 def test_static_loss_scale_is_transparent():

@@ -59,6 +59,7 @@ struct ConvArgs {
     int relu, out_f32, accumulate;
     long src_gs, wgt_gs, out_gs, bias_gs;
     int M;
+    int pixmajor;            // FAST kernels on small RoI maps: tile rows enumerate (pixel, RoI) instead of (RoI, pixel) -- see below
     int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
     int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
 };
@@ -82,7 +83,7 @@ __device__ __forceinline__ int xcd_remap(int L, int N) {
 template <int NT, int MT, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], int g, int m0, int n0, int wm, int wn,
                                               int frow, int fq, int ohw, const char* res_t = nullptr,
-                                              const char* mask_t = nullptr, char* out_t = nullptr) {
+                                              const char* mask_t = nullptr, char* out_t = nullptr, bool pixmajor = false) {
     // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
     // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
     //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
@@ -93,7 +94,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * WM + j * 32 + frow;
         if (m >= a.M) continue;
-        const int b = m / ohw, rem = m - b * ohw;
+        int b, rem;
+        if (pixmajor) { rem = m / a.B; b = m - rem * a.B; } else { b = m / ohw; rem = m - b * ohw; }
         const int oy = rem / a.OW, ox = rem - oy * a.OW;
         const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
 #pragma unroll
@@ -234,7 +236,8 @@ void conv_tap_kernel(const ConvArgs a) {
         a_base[i] = 0; a_y[i] = -100000; a_x[i] = -100000;
         a_ptr[i] = src; a_mask[i] = 0u;
         if (m < a.M) {
-            const int b = m / ohw, rem = m - b * ohw;
+            int b, rem;
+            if (FAST && a.pixmajor) { rem = m / a.B; b = m - rem * a.B; } else { b = m / ohw; rem = m - b * ohw; }
             const int oy = rem / a.OW, ox = rem - oy * a.OW;
             a_base[i] = b * a.IH * a.IW;
             a_y[i] = oy * a.ss;
@@ -250,10 +253,32 @@ void conv_tap_kernel(const ConvArgs a) {
             }
         }
     }
+    // pixmajor (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs): the 256 rows of a tile are ONE pixel position (at most two)
+    // of 256 different RoIs, so a tap that leaves the map does so for the whole tile and its K-steps are skipped outright --
+    // 18 % of the 3x3 taps of a 7x7 map, 9 % of a 14x14 one, are zero padding.  Memory layout and addresses are unchanged:
+    // only the enumeration of the rows differs (every row is gathered / stored through its own pointer anyway).
+    unsigned tmask = 0xffffffffu;
+    int nk_eff = nk;
+    if constexpr (FAST) {
+        if (a.pixmajor) {
+            __shared__ unsigned wor[NW];
+            unsigned mm = 0u;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) mm |= a_mask[i];
+            for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
+            if (lane == 0) wor[wave] = mm;
+            __syncthreads();
+            tmask = 0u;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) tmask |= wor[w2];
+            nk_eff = __popc(tmask) * kchunks;
+        }
+    }
     // FAST: running (wave-uniform) position of the NEXT K-step to stage
     int st_t = 0, st_c = 0;
-    long st_aoff = ((long)a.dy[0] * a.IW + a.dx[0]) * a.Cin;       // element offset of tap st_t relative to the base pixel
-    const bf16_t* st_w = wgt + (long)a.wt[0] * a.Cout * a.Cin;
+    if constexpr (FAST) { while (st_t < a.T - 1 && !((tmask >> st_t) & 1u)) ++st_t; }
+    long st_aoff = ((long)a.dy[st_t] * a.IW + a.dx[st_t]) * a.Cin;   // element offset of tap st_t relative to the base pixel
+    const bf16_t* st_w = wgt + (long)a.wt[st_t] * a.Cout * a.Cin;
 
     auto stage = [&](int kk, int buf) {
         char* abuf = lds + buf * (A_BYTES + B_BYTES);
@@ -271,6 +296,7 @@ void conv_tap_kernel(const ConvArgs a) {
             if (st_c == a.Cin) {
                 st_c = 0;
                 ++st_t;
+                while (st_t < a.T && !((tmask >> st_t) & 1u)) ++st_t;      // (pixmajor: taps outside the map for the whole tile)
                 if (st_t < a.T) {
                     st_aoff = ((long)a.dy[st_t] * a.IW + a.dx[st_t]) * a.Cin;
                     st_w = wgt + (long)a.wt[st_t] * a.Cout * a.Cin;
@@ -344,24 +370,24 @@ void conv_tap_kernel(const ConvArgs a) {
 
     stage(0, 0);
     if constexpr (STAGES == 2) {
-        for (int kk = 0; kk < nk; kk += 2) {
+        for (int kk = 0; kk < nk_eff; kk += 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kk + 1 < nk) stage(kk + 1, 1);
+            if (kk + 1 < nk_eff) stage(kk + 1, 1);
             compute(buf0_t{});
-            if (kk + 1 < nk) {
+            if (kk + 1 < nk_eff) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (kk + 2 < nk) stage(kk + 2, 0);
+                if (kk + 2 < nk_eff) stage(kk + 2, 0);
                 compute(buf1_t{});
             }
         }
     } else {
-        for (int kk = 0; kk < nk; ++kk) {
+        for (int kk = 0; kk < nk_eff; ++kk) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             compute(buf0_t{});
-            if (kk + 1 < nk) {
+            if (kk + 1 < nk_eff) {
                 __syncthreads();          // everyone is done reading the single buffer
                 stage(kk + 1, 0);
             }
@@ -396,7 +422,7 @@ void conv_tap_kernel(const ConvArgs a) {
             return;
         }
     }
-    conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw);
+    conv_epilogue<NT, MT, WM, WN>(a, acc, g, m0, n0, wm, wn, frow, fq, ohw, nullptr, nullptr, nullptr, FAST && a.pixmajor);
 }
 
 
@@ -427,6 +453,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     // instead of once per channel tile.
     static const int staged_out_mode = getenv("LOFT_CONV_STAGED_OUT") ? atoi(getenv("LOFT_CONV_STAGED_OUT")) : 1;
     a.staged_out = staged_out_mode && !accumulate;
+    a.pixmajor = 0;
     static const int nfast_mode = getenv("LOFT_CONV_NFAST") ? atoi(getenv("LOFT_CONV_NFAST")) : 1;
     a.nfast = nfast_mode == 2 ? ((long)T * Cin * Cout * 2 <= (3L << 20)) : nfast_mode;
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
@@ -452,6 +479,9 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
         //  CU and cover each other's barriers), single- and double-buffered: 560 vs 780 TFLOP/s on the P2 / mask / FOA 3x3.
         //  Reference point: hipBLASLt on the equivalent explicit GEMM (M=524288, N=256, K=2304) reaches 955 TFLOP/s.)
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
+        static const int pixmajor_mode = getenv("LOFT_CONV_PIXMAJOR") ? atoi(getenv("LOFT_CONV_PIXMAJOR")) : 1;
+        a.pixmajor = pixmajor_mode && deepk && T > 1 && T <= 32 && B >= 256 && OH * OW <= 1024 && os == 1 && ss == 1 &&
+                     OHf == OH && OWf == OW;
         if (deepk) hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
     } else if (Cout % 128 == 0) {

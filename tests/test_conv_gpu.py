@@ -191,3 +191,29 @@ def test_narrow_head_bwd_one_pass(N, Cin, Cout, hw, relu_in):
     want_dw = g2.t() @ x2
     assert (dw - want_dw).abs().max().item() <= 1e-4 * max(1.0, want_dw.abs().max().item())
     assert (db - g2.sum(0)).abs().max().item() <= 1e-4 * max(1.0, g2.sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize('G,B,hw', [(4, 260, 7), (1, 300, 14), (2, 513, 7)])
+def test_conv_pixel_major_tiles_on_roi_maps(G, B, hw):
+    """Hundreds of small RoI maps (the FOA and mask heads): the 256x256 FAST kernel enumerates tile rows pixel-major and skips
+    the taps that leave the map for a whole tile -- forward (bias + ReLU, fp32 and bf16 out) and data gradient (with a ReLU mask)
+    against torch, per group, on inputs whose border behaviour matters (no zero padding in the data itself)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(G * 1000 + B)
+    C = 256
+    x = _r(torch.randn(G * B, C, hw, hw) + 0.5)
+    w = _r(torch.randn(G, C, C, 3, 3) / (C * 9) ** 0.5)
+    b = torch.randn(G, C)
+    wp = torch.stack([K.pack_w_fwd(w[i].cuda()) for i in range(G)])
+    out = K.conv2d_fwd(_cl(x), wp, b.cuda().contiguous(), 3, 3, 1, 1, relu=True, out_dtype=torch.float32, groups=G)
+    outb = K.conv2d_fwd(_cl(x), wp, b.cuda().contiguous(), 3, 3, 1, 1, relu=True, groups=G)
+    g = _r(torch.randn(G * B, C, hw, hw))
+    wpt = torch.stack([K.pack_w_dgrad(w[i].cuda()) for i in range(G)])
+    gx = K.conv2d_dgrad(_cl(g), wpt, (hw, hw), 3, 3, 1, 1, groups=G, mask=_cl(x))
+    for i in range(G):
+        sl = slice(i * B, (i + 1) * B)
+        ref = F.relu(F.conv2d(x[sl], w[i], b[i], padding=1))
+        assert (out[sl].cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+        assert (outb[sl].float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+        refg = F.conv_transpose2d(g[sl], w[i], padding=1) * (x[sl] > 0)
+        assert (gx[sl].float().cpu() - refg).abs().max().item() < 1e-2 * max(1.0, refg.abs().max().item())

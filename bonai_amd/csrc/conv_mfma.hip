@@ -779,6 +779,187 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
     }
 }
 
+// All-taps form for the narrow stride-1 same-size convs at high resolution (HRNet's 32/64-channel 3x3 branches at 256^2 / 128^2):
+// the tap-parallel kernels above give every (tap, pixel range) its own workgroup, so with a 64 x 64 output tile a K-step is
+// 16 KB of copies for 4 MFMAs per wave -- the loop runs at one global->LDS round trip per 64 pixels (228 us for 8 x 256^2 pixels,
+// 0.6 TB/s).  Here a workgroup walks 8x8-PIXEL PATCHES: it stages the patch of G (64 rows) and the 10x10 halo of X (100 rows)
+// once and feeds ALL taps from them -- the MFMA k index runs over the patch's pixels, tap (dy, dx) just reads X rows shifted
+// inside the halo (the transposing reader takes one address per lane, so any row map is free): 21 KB of copies for 36 MFMAs.
+// 128-byte LDS rows, 16-byte chunk q of row r stored at q ^ (((r >> 1) & 1) << 2) (rows r and r+2 would share banks).
+__device__ __forceinline__ int psw(int row) { return ((row >> 1) & 1) << 2; }
+
+__device__ __forceinline__ bf16x8 patch_frag(const char* tile, int r0, int r1, int col) {
+    // lane's 4 columns col..col+3 (8 bytes) of LDS rows r0 / r1 -> "8 consecutive k for my column" after the transpose
+    const char* p0 = tile + r0 * 128 + (((col >> 3) ^ psw(r0)) << 4) + (col & 7) * 2;
+    const char* p1 = tile + r1 * 128 + (((col >> 3) ^ psw(r1)) << 4) + (col & 7) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))      // 160 accumulator registers + <= 96 others: two workgroups per CU
+void conv_wgrad64_patch_kernel(const WgradArgs a, int ptx, int pty, int npatch,
+                                                                 float* __restrict__ partial) {
+    constexpr int GB = 64 * 128, XB = 104 * 128, STG = GB + XB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.y;
+    const bf16_t* G = a.g + (long)grp * a.g_gs;
+    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const int H = a.OH, W = a.OW;
+    const int lrow = lane >> 3, pc = lane & 7;
+    auto stage = [&](int p, int buf) {
+        char* gb = lds + buf * STG;
+        char* xb = gb + GB;
+        const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
+        const int y0 = (rem / ptx) * 8, x0 = (rem % ptx) * 8;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                       // G: 64 patch pixels, 8 rows per wave-level copy
+            const int row = it * 32 + wave * 8 + lrow;
+            const int q = pc ^ psw(row);
+            const int y = y0 + (row >> 3), x = x0 + (row & 7);
+            const bf16_t* ptr = a.zero_page;
+            if (y < H && x < W && q * 8 < a.Cout) ptr = G + ((long)(b * H + y) * W + x) * a.Cout + q * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lds_ptr_t)(gb + (it * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                       // X: 10 x 10 halo (13 copies of 8 rows; rows >= 100 unused)
+            const int slot = it * 4 + wave;
+            if (slot < 13) {
+                const int row = slot * 8 + lrow;
+                const int q = pc ^ psw(row);
+                const int hy = row / 10, hx = row - hy * 10;
+                const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+                const bf16_t* ptr = a.zero_page;
+                if (row < 100 && y >= 0 && y < H && x >= 0 && x < W && q * 8 < a.Cin) ptr = X + ((long)(b * H + y) * W + x) * a.Cin + q * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lds_ptr_t)(xb + slot * 8 * 128), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc[9], accb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const int wn = wave >> 1, wc = wave & 1;
+    const bool do_db = a.db != nullptr && wc == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    // this lane's fragment rows inside a 16-pixel k block: patch row 2*ks + (gl >> 1), patch columns (il >> 2) and (il >> 2) + 4
+    const int il = lane & 15, gl = lane >> 4;
+    const int fcol = 16 * (gl & 1) + (il & 3) * 4;
+    const int fpy = gl >> 1, fpx = il >> 2;
+    int p = blockIdx.x;
+    if (p < npatch) stage(p, 0);
+    for (int s = 0; p < npatch; p += gridDim.x, ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p + (int)gridDim.x < npatch) stage(p + gridDim.x, (s + 1) & 1);
+        const char* gb = lds + (s & 1) * STG;
+        const char* xb = gb + GB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int py = 2 * ks + fpy;                       // k = py * 8 + px
+            const int gr0 = py * 8 + fpx;
+            const bf16x8 gf = patch_frag(gb, gr0, gr0 + 4, wn * 32 + fcol);
+            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ones, accb, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (t < a.T) {
+                    const int hr0 = (py + 1 + a.dy[t]) * 10 + fpx + 1 + a.dx[t];
+                    const bf16x8 xf = patch_frag(xb, hr0, hr0 + 4, wc * 32 + fcol);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[t], 0, 0, 0);
+                }
+        }
+    }
+    // per-workgroup partial sums [group][block][T * Cout * Cin + Cout] (plain stores; 36 864 atomics per workgroup cost more than
+    // the kernel itself: 1024 workgroups +24 ms per HRNet step), summed by conv_wgrad_patch_reduce_kernel
+    const long pstride = (long)a.T * a.Cout * a.Cin + a.Cout;
+    float* pp = partial + ((long)grp * gridDim.x + blockIdx.x) * pstride;
+    if (do_db && (lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < a.Cout) pp[(long)a.T * a.Cout * a.Cin + n] = accb[r];
+        }
+    }
+    const int c = wc * 32 + (lane & 31);
+    if (c < a.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (t < a.T) {
+                float* dw = pp + (long)a.wt[t] * a.Cout * a.Cin;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (n < a.Cout) dw[(long)n * a.Cin + c] = acc[t][r];
+                }
+            }
+    }
+}
+
+// dw[g][i] += sum_b partial[g][b][i], db[g][n] += sum_b partial[g][b][T*Cout*Cin + n]
+__global__ void conv_wgrad_patch_reduce_kernel(const float* __restrict__ partial, int nb, long pstride, long nw, int Cout,
+                                               float* __restrict__ dw, long dw_gs, float* __restrict__ db) {
+    // grid.z slices of 16 partials each: 16 loads per thread, then one atomic (a single-pass sum over 512 partials per thread is
+    // a 512-deep chain of dependent-latency loads)
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= pstride) return;
+    const int b0 = blockIdx.z * 16, b1 = min(nb, b0 + 16);
+    const float* p = partial + (long)g * nb * pstride + i;
+    float sacc = 0.f;
+    for (int b = b0; b < b1; ++b) sacc += p[(long)b * pstride];
+    if (i < nw) unsafeAtomicAdd(dw + (long)g * dw_gs + i, sacc);
+    else if (db) unsafeAtomicAdd(db + (long)g * Cout + (i - nw), sacc);
+}
+
+LOFT_EXPORT int64_t loft_conv_wgrad_patch_workspace_bytes(int B, int H, int W, int Cout, int Cin, int T, int groups) {
+    const long np = (long)B * ((W + 7) / 8) * ((H + 7) / 8);
+    const long nb = np < 512 ? np : 512;
+    return (int64_t)groups * nb * ((long)T * Cout * Cin + Cout) * 4;
+}
+
+// Weight (+ bias) gradient of a stride-1, same-size conv with <= 64 input and output channels and taps within +-1 pixel
+// (see conv_wgrad64_patch_kernel).  dw [groups][T][Cout][Cin] / db [groups][Cout] are ACCUMULATED into.
+LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int H, int W,
+                                           int Cout, int Cin, int T, const int* dy_host, const int* dx_host, const int* wt_host,
+                                           int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, float* db, void* workspace,
+                                           void* stream) {
+    if (T < 1 || T > 9 || Cout > 64 || Cin > 64 || (Cin % 8) || (Cout % 8) || groups < 1 || !workspace) return (int)hipErrorInvalidValue;
+    WgradArgs a;
+    a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
+    a.B = B; a.GH = H; a.GW = W; a.Cout = Cout; a.XH = H; a.XW = W; a.Cin = Cin; a.OH = H; a.OW = W;
+    a.gos = 1; a.ss = 1; a.T = T;
+    for (int t = 0; t < T; ++t) {
+        if (dy_host[t] < -1 || dy_host[t] > 1 || dx_host[t] < -1 || dx_host[t] > 1) return (int)hipErrorInvalidValue;
+        a.goy[t] = 0; a.gox[t] = 0; a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t];
+    }
+    a.g_gs = g_gs; a.x_gs = x_gs; a.dw_gs = dw_gs;
+    a.M = B * H * W; a.pix_per_split = 0; a.ctiles = 1;
+    a.ohw_mul = a.ohw_sh = a.ow_mul = a.ow_sh = 0;
+    a.db = db; a.db_tap = -2;
+    const int ptx = (W + 7) / 8, pty = (H + 7) / 8;
+    const long np = (long)B * ptx * pty;
+    const long nb = np < 512 ? np : 512;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad64_patch_kernel, dim3((unsigned)nb, groups), dim3(256), 0, s, a, ptx, pty, (int)np, (float*)workspace);
+    LOFT_LAUNCH_CHECK();
+    const long nw = (long)T * Cout * Cin, pstride = nw + Cout;
+    hipLaunchKernelGGL(conv_wgrad_patch_reduce_kernel, dim3(loft_cdiv(pstride, 256), groups, loft_cdiv(nb, 16)), dim3(256), 0, s, (const float*)workspace,
+                       (int)nb, pstride, nw, Cout, dw, (long)dw_gs, db);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+
 LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
                                      int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                                      const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,

@@ -378,6 +378,10 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
     return out
 
 
+import os as _os
+_WGRAD_NO_PATCH = bool(_os.environ.get('LOFT_WGRAD_NO_PATCH'))     # A/B switch
+
+
 def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,
                splits=0, dw=None, db=None, db_tap=-1):
     """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index).
@@ -389,6 +393,18 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
         dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
     A = lambda i: L.arr(c_int, [t[i] for t in taps])
     _ev = _prof_begin()
+    if (Cout <= 64 and Cin <= 64 and len(taps) <= 9 and gos == 1 and ss == 1 and (GH, GW) == (OH, OW) == (XH, XW)
+            and B * OH * OW >= 65536 and all(t[0] == 0 and t[1] == 0 and abs(t[2]) <= 1 and abs(t[3]) <= 1 for t in taps)
+            and (db is None or db_tap != -1) and not _WGRAD_NO_PATCH):
+        # narrow stride-1 convs at high resolution: all taps from one staged pixel patch (loft_conv_wgrad_patch_bf16)
+        ws = torch.empty(lib.loft_conv_wgrad_patch_workspace_bytes(B, OH, OW, Cout, Cin, len(taps), groups), dtype=torch.uint8,
+                         device=g.device)
+        L.check(lib.loft_conv_wgrad_patch_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, OH, OW, Cout, Cin,
+                                               len(taps), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
+                                               c_int64(n_wtaps * Cout * Cin), L.ptr(db), L.ptr(ws), L.stream()),
+                'loft_conv_wgrad_patch_bf16')
+        _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
+        return dw
     L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                      XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
                                      c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),

@@ -35,6 +35,7 @@ def load():
         lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64]
         lib.loft_soft_nms_workspace_bytes.restype = c_int64
         lib.loft_random_sample_workspace_bytes.restype = c_int64
+        lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64
         lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
         lib.loft_mdcn_bwd_workspace_bytes.restype = c_int64
         _lib = lib

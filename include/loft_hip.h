@@ -117,6 +117,16 @@ int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* ze
                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                          const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
                          float* db, int db_tap, void* stream);
+/* loft_conv_wgrad_patch_bf16: the same weight (+ bias) gradient for stride-1, same-size convs with <= 64 input and output
+ * channels and taps within +-1 pixel (HRNet's high-resolution 3x3 branches, hrnet.py:12-60 via resnet.py:13-92 BasicBlock): every
+ * workgroup walks 8x8-pixel patches and feeds ALL taps from one staged patch of g and its 10x10 halo of x.  g [groups*B,H,W,Cout],
+ * x [groups*B,H,W,Cin] bf16 NHWC; dw [groups][T][Cout][Cin] and db [groups][Cout] (may be NULL) fp32 are accumulated into;
+ * workspace: loft_conv_wgrad_patch_workspace_bytes(...) bytes for the per-workgroup partial sums. */
+int64_t loft_conv_wgrad_patch_workspace_bytes(int B, int H, int W, int Cout, int Cin, int T, int groups);
+int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int H, int W,
+                               int Cout, int Cin, int T, const int* dy_host, const int* dx_host, const int* wt_host,
+                               int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, float* db, void* workspace, void* stream);
+
 
 /* ---- HBM-bound glue (bf16 NHWC unless noted; n = element counts, multiples of 8) ------------
  * relu_bwd: out = g * (y > 0)  -- autograd of the ReLUs fused into the conv epilogues

@@ -217,3 +217,23 @@ def test_conv_pixel_major_tiles_on_roi_maps(G, B, hw):
         assert (outb[sl].float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
         refg = F.conv_transpose2d(g[sl], w[i], padding=1) * (x[sl] > 0)
         assert (gx[sl].float().cpu() - refg).abs().max().item() < 1e-2 * max(1.0, refg.abs().max().item())
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k', [(2, 64, 64, 192, 176, 3), (1, 32, 64, 260, 256, 3), (4, 64, 48, 128, 130, 3),
+                                               (2, 64, 64, 200, 168, 1)])
+def test_wgrad_patch_form_narrow_channels(B, cin, cout, H, W, k):
+    """conv_wgrad64_patch_kernel (all taps of a narrow stride-1 conv from one staged 8x8 patch + halo): weight and bias gradient
+    against torch, sizes that are not multiples of the patch, partial channel tiles, 3x3 and 1x1."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(B * H + cout)
+    pad = k // 2
+    x = _r(torch.randn(B, cin, H, W))
+    g = _r(torch.randn(B, cout, H, W))
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(x, w, padding=pad).backward(g)
+    dwp, db = K.conv2d_wgrad(_cl(g), _cl(x), k, k, 1, pad, with_bias=True)
+    got = K.unpack_dw(dwp[0], w.shape).cpu()
+    ref = w.grad
+    assert (got - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
+    want_b = g.sum(dim=(0, 2, 3))
+    assert (db[0, :cout].cpu() - want_b).abs().max().item() < 1e-3 * max(1.0, want_b.abs().max().item())

@@ -426,6 +426,120 @@ void conv_tap_kernel(const ConvArgs a) {
 }
 
 
+// =====================================================================================
+// 64 -> 64 channel stride-1 convs at high resolution (HRNet's first two branches, hrnet.py via resnet.py:13-92 BasicBlock; the
+// 32-channel branch is carried zero-padded at 64).  The generic tap kernel gives such a layer a K-step of 8 MFMAs per wave per
+// global->LDS round trip (9 round trips per 128-pixel tile: 110 us for 8 x 256^2 pixels, 1.8 TB/s).  Here the packed weights of
+// ALL taps (T x 64 x 64 bf16 = 72 KiB) stay in LDS for the lifetime of a persistent workgroup, which walks 16 x 16-PIXEL PATCHES:
+// the 18 x 18 halo of a 16 x 16 patch (41 KiB, double-buffered: 154 KiB of LDS in all, one workgroup per CU) is staged once and
+// every tap reads its shifted rows from it -- one round trip per 72 MFMAs per wave, hidden behind the previous patch.
+// 8 waves: wave w -> patch rows 2w, 2w+1 (32 pixels) x all 64 output channels.  128-byte LDS rows, 16-byte chunk q of row r at q ^ (r & 7) (32 lanes read 32 consecutive rows).
+// Epilogue as the tap kernels: bias, residual, ReLU, ReLU-backward mask, bf16 store (8 bytes per lane).
+// =====================================================================================
+struct Conv64Args {
+    const bf16_t* src; const bf16_t* wgt; const float* bias; const bf16_t* residual; const bf16_t* mask; bf16_t* out;
+    const bf16_t* zero_page;
+    int B, H, W, T, relu;
+    int dy[9], dx[9], wt[9];
+};
+
+__global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, int ptx, int pty, int npatch) {
+    constexpr int HW_ = 18, HR = 18 * 18;              // halo of a 16 x 16 patch
+    constexpr int SLOTS = 41, HB = SLOTS * 8 * 128;    // 41 wave-copies of 8 rows (328 >= 324)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* wl = lds;                                    // [T * 64 rows][128 B]
+    char* hl = lds + a.T * 64 * 128;                   // 2 x halo
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 3, pc = lane & 7;
+    // ---- all taps' weights, once
+    for (int r8 = wave; r8 < a.T * 8; r8 += 8) {       // 8 rows per wave-level copy
+        const int row = r8 * 8 + lrow;
+        const int q = pc ^ (row & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.wgt + (long)row * 64 + q * 8), (lds_ptr_t)(wl + r8 * 8 * 128), 16, 0, 0);
+    }
+    auto stage = [&](int p, int buf) {
+        char* hb = hl + buf * HB;
+        const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
+        const int y0 = (rem / ptx) * 16, x0 = (rem % ptx) * 16;
+        for (int slot = wave; slot < SLOTS; slot += 8) {
+            const int row = slot * 8 + lrow;
+            const int q = pc ^ (row & 7);
+            const int hy = row / HW_, hx = row - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bf16_t* ptr = a.zero_page;
+            if (row < HR && y >= 0 && y < a.H && x >= 0 && x < a.W) ptr = a.src + ((long)(b * a.H + y) * a.W + x) * 64 + q * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lds_ptr_t)(hb + slot * 8 * 128), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 31, fq = lane >> 5;
+    const int ppy = 2 * wave + (frow >> 4), ppx = frow & 15;    // this lane's pixel inside the patch (wave w: patch rows 2w, 2w+1)
+    int p = blockIdx.x;
+    if (p < npatch) stage(p, 0);
+    for (int s2 = 0; p < npatch; p += gridDim.x, ++s2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p + (int)gridDim.x < npatch) stage(p + gridDim.x, (s2 + 1) & 1);
+        const char* hb = hl + (s2 & 1) * HB;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            if (t < a.T) {
+                const int hr = (ppy + 1 + a.dy[t]) * HW_ + ppx + 1 + a.dx[t];
+                const int wr = a.wt[t] * 64 + frow;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int q = ks * 2 + fq;
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ (hr & 7)) << 4));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int wri = wr + i * 32;
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        // ---- epilogue: lane holds pixel (ppy, ppx) and 2 x 4 x 4 consecutive channels
+        const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
+        const int y = (rem / ptx) * 16 + ppy, x = (rem % ptx) * 16 + ppx;
+        if (y < a.H && x < a.W) {
+            const long o0 = ((long)(b * a.H + y) * a.W + x) * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = i * 32 + 8 * gq + 4 * fq;
+                    float v[4] = {acc[i][gq * 4 + 0], acc[i][gq * 4 + 1], acc[i][gq * 4 + 2], acc[i][gq * 4 + 3]};
+                    if (a.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if (a.residual) {
+                        float rv[4];
+                        ld4(a.residual + o0 + n, rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.mask) {
+                        float mv[4];
+                        ld4(a.mask + o0 + n, mv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                    }
+                    st4(a.out + o0 + n, v);
+                }
+        }
+    }
+}
+
 LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
                                    const void* relu_mask, void* out,
                                    const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
@@ -448,6 +562,31 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
+    {
+        static const bool p64_off = getenv("LOFT_CONV_NO_PATCH64") != nullptr;
+        bool p64 = !p64_off && Cin == 64 && Cout == 64 && T >= 4 && T <= 9 && groups == 1 && ss == 1 && os == 1 && OH == IH && OW == IW &&
+                   OHf == OH && OWf == OW && oo_y == 0 && oo_x == 0 && !out_f32 && !accumulate && M >= 65536;
+        for (int t = 0; t < T && p64; ++t) p64 = dy_host[t] >= -1 && dy_host[t] <= 1 && dx_host[t] >= -1 && dx_host[t] <= 1;
+        if (p64) {
+            Conv64Args c;
+            c.src = a.src; c.wgt = a.wgt; c.bias = bias; c.residual = a.residual; c.mask = a.mask; c.out = (bf16_t*)out;
+            c.zero_page = a.zero_page; c.B = B; c.H = OH; c.W = OW; c.T = T; c.relu = relu;
+            for (int t = 0; t < T; ++t) { c.dy[t] = dy_host[t]; c.dx[t] = dx_host[t]; c.wt[t] = wt_host[t]; }
+            const int ptx = (OW + 15) / 16, pty = (OH + 15) / 16;
+            const long np = (long)B * ptx * pty;
+            static const int cus = [] { int v = 256; hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v; }();
+            const long nb = np < cus ? np : cus;
+            const size_t lds_bytes = (size_t)T * 64 * 128 + 2 * 41 * 8 * 128;
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute((const void*)conv64_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(conv64_patch_kernel, dim3((unsigned)nb), dim3(512), lds_bytes, s, c, ptx, pty, (int)np);
+            LOFT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // Channel-tile-fastest order when the activation is the big operand (it does not fit the 4 MiB L2 of an XCD but the packed
     // weights do): every channel tile of a pixel tile then runs back to back on one XCD and the pixel tile comes from HBM once
     // instead of once per channel tile.

@@ -237,3 +237,32 @@ def test_wgrad_patch_form_narrow_channels(B, cin, cout, H, W, k):
     assert (got - ref).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
     want_b = g.sum(dim=(0, 2, 3))
     assert (db[0, :cout].cpu() - want_b).abs().max().item() < 1e-3 * max(1.0, want_b.abs().max().item())
+
+
+@pytest.mark.parametrize('B,H,W,k', [(2, 200, 168, 3), (1, 264, 250, 3), (5, 128, 128, 3), (2, 192, 176, 2)])
+def test_conv64_patch_kernel(B, H, W, k):
+    """conv64_patch_kernel (64 -> 64 channels, weights resident in LDS, taps fed from a staged patch halo): forward with bias +
+    residual + ReLU and data gradient with a ReLU mask against torch; sizes that are not multiples of the 8 x 16 patch; k = 2
+    exercises an asymmetric tap set (taps (0,0),(0,1),(1,0),(1,1))."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(B * H + W)
+    C = 64
+    x = _r(torch.randn(B, C, H, W))
+    res = _r(torch.randn(B, C, H, W))
+    w = _r(torch.randn(C, C, k, k) / (C * k * k) ** 0.5)
+    b = torch.randn(C)
+    if k == 3:
+        out = K.conv2d_fwd(_cl(x), K.pack_w_fwd(w.cuda())[None], b.cuda(), 3, 3, 1, 1, relu=True, residual=_cl(res))
+        ref = F.relu(F.conv2d(x, w, b, padding=1) + res)
+        assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+        g = _r(torch.randn(B, C, H, W))
+        gx = K.conv2d_dgrad(_cl(g), K.pack_w_dgrad(w.cuda())[None], (H, W), 3, 3, 1, 1, mask=_cl(x))
+        refg = F.conv_transpose2d(g, w, padding=1) * (x > 0)
+        assert (gx.float().cpu() - refg).abs().max().item() < 1e-2 * max(1.0, refg.abs().max().item())
+    else:
+        taps = [(dy, dx, dy * 2 + dx) for dy in range(2) for dx in range(2)]
+        wp = K.pack_w_fwd(w.cuda())
+        out = K.empty_nhwc(B, C, H, W, torch.bfloat16, 'cuda')
+        K.conv_tap(_cl(x), wp, out, B, H, W, C, C, H, W, H, W, taps, bias=b.cuda(), relu=False)
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b)
+        assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())

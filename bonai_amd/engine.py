@@ -185,7 +185,8 @@ class Trainer:
         if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
         if F2.GRAD_SINK is not None and not os.environ.get('LOFT_NO_UNPACK_QUEUE'):
-            F2.UNPACK_Q = K.UnpackQueue()
+            # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
+            F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48)
         try:
             (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
             if F2.UNPACK_Q is not None:

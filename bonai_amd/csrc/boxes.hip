@@ -806,3 +806,70 @@ LOFT_EXPORT int loft_rpn_sample_gather(const void* const* heads, const int* H, c
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------- RoI head: sampled RoIs, labels and regression targets
+// SamplingResult + bbox2roi + BBoxHead.get_targets (sampling_result.py:25-53, transforms.py:54-73, bbox_head.py:84-138) for a
+// batch in one launch.  The sampler writes its valid slots first, so entry (b, s) lands at off[b] + s (positives) or
+// off[b] + npos[b] + (s - P) (negatives): per image [pos..., neg...] without a compaction scan; the counts come from one host
+// read.  Positives also fill the mask / offset branches' lists (pos_rois, image index, assigned gt, row in the RoI list).
+__global__ void roi_sample_targets_kernel(const float* __restrict__ cand, int Ncand, const int64_t* __restrict__ gt_inds,
+                                          const float* __restrict__ gts, const int64_t* __restrict__ gt_labels, int Kmax,
+                                          const int64_t* __restrict__ pidx, const int64_t* __restrict__ nidx, int P, int Q, int B,
+                                          const int* __restrict__ npos, const int* __restrict__ nneg, const int* __restrict__ roff,
+                                          const int* __restrict__ poff, int num_classes, Coder4 c, float* __restrict__ rois,
+                                          int64_t* __restrict__ labels, float* __restrict__ label_w, float* __restrict__ tgt,
+                                          float* __restrict__ tgt_w, float* __restrict__ pos_rois, int64_t* __restrict__ pos_b,
+                                          int64_t* __restrict__ pos_gt, int64_t* __restrict__ pos_row) {
+    const int S = P + Q;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)B * S) return;
+    const int b = (int)(i / S), s = (int)(i - (long)b * S);
+    const bool is_pos = s < P;
+    const int r = is_pos ? s : s - P;
+    if (r >= (is_pos ? npos[b] : nneg[b])) return;
+    const long idx = is_pos ? pidx[(long)b * P + r] : nidx[(long)b * Q + r];
+    const int o = roff[b] + (is_pos ? r : npos[b] + r);
+    const float4 box = reinterpret_cast<const float4*>(cand)[(long)b * Ncand + idx];
+    float* ro = rois + (long)o * 5;
+    ro[0] = (float)b; ro[1] = box.x; ro[2] = box.y; ro[3] = box.z; ro[4] = box.w;
+    label_w[o] = 1.f;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tw = 0.f;
+    if (is_pos) {
+        long gi = gt_inds[(long)b * Ncand + idx] - 1;
+        gi = gi < 0 ? 0 : gi;
+        labels[o] = gt_labels[(long)b * Kmax + gi];
+        const float4 g = reinterpret_cast<const float4*>(gts)[(long)b * Kmax + gi];
+        const float px = (box.x + box.z) * 0.5f, py = (box.y + box.w) * 0.5f, pw = box.z - box.x, ph = box.w - box.y;
+        const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+        t.x = ((gx - px) / pw - c.means[0]) / c.stds[0];
+        t.y = ((gy - py) / ph - c.means[1]) / c.stds[1];
+        t.z = (logf(gw / pw) - c.means[2]) / c.stds[2];
+        t.w = (logf(gh / ph) - c.means[3]) / c.stds[3];
+        tw = 1.f;
+        const int po = poff[b] + r;
+        float* pr = pos_rois + (long)po * 5;
+        pr[0] = (float)b; pr[1] = box.x; pr[2] = box.y; pr[3] = box.z; pr[4] = box.w;
+        pos_b[po] = b; pos_gt[po] = gi; pos_row[po] = o;
+    } else {
+        labels[o] = num_classes;
+    }
+    reinterpret_cast<float4*>(tgt)[o] = t;
+    reinterpret_cast<float4*>(tgt_w)[o] = make_float4(tw, tw, tw, tw);
+}
+LOFT_EXPORT int loft_roi_sample_targets(const float* cand, int Ncand, const int64_t* gt_inds, const float* gts,
+                                        const int64_t* gt_labels, int Kmax, const int64_t* pos_idx, const int64_t* neg_idx, int P,
+                                        int Q, int B, const int32_t* npos_dev, const int32_t* nneg_dev, const int32_t* roi_off_dev,
+                                        const int32_t* pos_off_dev, int num_classes, const float* means_host, const float* stds_host,
+                                        float* rois, int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
+                                        float* pos_rois, int64_t* pos_img, int64_t* pos_gt, int64_t* pos_row, void* stream) {
+    if (B <= 0 || P + Q <= 0) return 0;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    const long n = (long)B * (P + Q);
+    hipLaunchKernelGGL(roi_sample_targets_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, cand, Ncand, gt_inds, gts,
+                       gt_labels, Kmax, pos_idx, neg_idx, P, Q, B, npos_dev, nneg_dev, roi_off_dev, pos_off_dev, num_classes, c, rois,
+                       labels, label_weights, bbox_targets, bbox_weights, pos_rois, pos_img, pos_gt, pos_row);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

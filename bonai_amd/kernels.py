@@ -1105,6 +1105,39 @@ def rpn_sample_gather(heads, lvl_off, A, anchors, gts, gt_inds, pidx, pval, nidx
     return vals, rows, slot, tgt, label, weight
 
 
+def roi_sample_targets(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, num_classes, means, stds):
+    """Sampled RoIs, labels and regression targets of a batch in one launch (loft_roi_sample_targets) after ONE host read of the
+    per-image counts.  -> dict(rois [M,5], labels, label_weights, bbox_targets, bbox_weights, pos_rois [Np,5], pos_b, pos_gt_i,
+    pos_sel)."""
+    lib = L.load()
+    L.dev_check(cand, gt_inds, gts, gt_labels, pidx, nidx)
+    B, Ncand = gt_inds.shape
+    P, Q = pidx.shape[1], nidx.shape[1]
+    dev = gt_inds.device
+    counts = torch.stack([pval.sum(1), nval.sum(1)], 1).tolist()          # the step's one host sync of the RoI head
+    npos, nneg = [int(c[0]) for c in counts], [int(c[1]) for c in counts]
+    roff, poff, M, Np = [], [], 0, 0
+    for b in range(B):
+        roff.append(M); poff.append(Np)
+        M += npos[b] + nneg[b]; Np += npos[b]
+    tab = h2d([npos, nneg, roff, poff], torch.int32, dev)
+    out = dict(rois=torch.empty(M, 5, device=dev), labels=torch.empty(M, dtype=torch.int64, device=dev),
+               label_weights=torch.empty(M, device=dev), bbox_targets=torch.empty(M, 4, device=dev),
+               bbox_weights=torch.empty(M, 4, device=dev), pos_rois=torch.empty(Np, 5, device=dev),
+               pos_b=torch.empty(Np, dtype=torch.int64, device=dev), pos_gt_i=torch.empty(Np, dtype=torch.int64, device=dev),
+               pos_sel=torch.empty(Np, dtype=torch.int64, device=dev))
+    if M > 0:
+        L.check(lib.loft_roi_sample_targets(L.ptr(cand.float().contiguous()), Ncand, L.ptr(gt_inds.contiguous()),
+                                            L.ptr(gts.float().contiguous()), L.ptr(gt_labels.contiguous()), int(gts.shape[1]),
+                                            L.ptr(pidx.contiguous()), L.ptr(nidx.contiguous()), P, Q, B, L.ptr(tab[0]), L.ptr(tab[1]),
+                                            L.ptr(tab[2]), L.ptr(tab[3]), int(num_classes), L.arr(c_float, list(means)),
+                                            L.arr(c_float, list(stds)), L.ptr(out['rois']), L.ptr(out['labels']),
+                                            L.ptr(out['label_weights']), L.ptr(out['bbox_targets']), L.ptr(out['bbox_weights']),
+                                            L.ptr(out['pos_rois']), L.ptr(out['pos_b']), L.ptr(out['pos_gt_i']), L.ptr(out['pos_sel']),
+                                            L.stream()), 'loft_roi_sample_targets')
+    return out
+
+
 _SAMPLE_CALLS = [0]
 
 

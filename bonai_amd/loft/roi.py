@@ -365,31 +365,43 @@ class LoftRoIHead(nn.Module):
                 gt_inds, cand = gi_p, props[..., :4]
             smp = self.bbox_sampler.sample_batched(gt_inds)
             pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
-            # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53); one host sync for the counts
-            idx = torch.cat([pidx, nidx], 1)
-            val = torch.cat([pval, nval], 1)
-            is_pos = torch.cat([pval, torch.zeros_like(nval)], 1)
-            bidx = torch.arange(B, device=dev)[:, None].expand_as(idx)
-            sel = val.reshape(-1).nonzero(as_tuple=False).flatten()
-            b_s, i_s, pos_s = bidx.reshape(-1)[sel], idx.reshape(-1)[sel], is_pos.reshape(-1)[sel]
-            boxes_s = cand[b_s, i_s]
-            rois = torch.cat([b_s[:, None].float(), boxes_s], 1)
-            assigned = (gt_inds[b_s, i_s] - 1).clamp(min=0)
-            pos_sel = pos_s.nonzero(as_tuple=False).flatten()
-            pos_rois, pos_b, pos_gt_i = rois[pos_sel], b_s[pos_sel], assigned[pos_sel]
-            pos_gt_boxes = gts[pos_b, pos_gt_i]
             lab_pad = torch.zeros(B, Kmax, dtype=torch.long, device=dev)
             for i, l in enumerate(gt_labels):
                 lab_pad[i, :l.shape[0]] = l.to(dev)
+        fused_targets = dev.type == 'cuda' and not os.environ.get('LOFT_ROI_TORCH_TARGETS')
+        if fused_targets:
+            # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53), labels and bbox targets: one launch
+            with torch.no_grad():
+                tg = K.roi_sample_targets(cand, gt_inds, gts, lab_pad, pidx, pval, nidx, nval, self.bbox_head.num_classes,
+                                          self.bbox_head.bbox_coder.means, self.bbox_head.bbox_coder.stds)
+            rois, labels, label_weights = tg['rois'], tg['labels'], tg['label_weights']
+            bbox_targets, bbox_weights = tg['bbox_targets'], tg['bbox_weights']
+            pos_rois, pos_b, pos_gt_i, pos_sel = tg['pos_rois'], tg['pos_b'], tg['pos_gt_i'], tg['pos_sel']
             M = rois.shape[0]
-            labels = torch.full((M,), self.bbox_head.num_classes, dtype=torch.long, device=dev)
-            labels[pos_sel] = lab_pad[pos_b, pos_gt_i]
-            bbox_targets = torch.zeros(M, 4, device=dev)
-            bbox_weights = torch.zeros(M, 4, device=dev)
-            if pos_sel.numel():
-                bbox_targets[pos_sel] = self.bbox_head.bbox_coder.encode(pos_rois[:, 1:].contiguous(), pos_gt_boxes)
-                bbox_weights[pos_sel] = 1.0
-            label_weights = torch.ones(M, device=dev)
+        with torch.no_grad():
+          if not fused_targets:
+              # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53); two host syncs (nonzero)
+              idx = torch.cat([pidx, nidx], 1)
+              val = torch.cat([pval, nval], 1)
+              is_pos = torch.cat([pval, torch.zeros_like(nval)], 1)
+              bidx = torch.arange(B, device=dev)[:, None].expand_as(idx)
+              sel = val.reshape(-1).nonzero(as_tuple=False).flatten()
+              b_s, i_s, pos_s = bidx.reshape(-1)[sel], idx.reshape(-1)[sel], is_pos.reshape(-1)[sel]
+              boxes_s = cand[b_s, i_s]
+              rois = torch.cat([b_s[:, None].float(), boxes_s], 1)
+              assigned = (gt_inds[b_s, i_s] - 1).clamp(min=0)
+              pos_sel = pos_s.nonzero(as_tuple=False).flatten()
+              pos_rois, pos_b, pos_gt_i = rois[pos_sel], b_s[pos_sel], assigned[pos_sel]
+              pos_gt_boxes = gts[pos_b, pos_gt_i]
+              M = rois.shape[0]
+              labels = torch.full((M,), self.bbox_head.num_classes, dtype=torch.long, device=dev)
+              labels[pos_sel] = lab_pad[pos_b, pos_gt_i]
+              bbox_targets = torch.zeros(M, 4, device=dev)
+              bbox_weights = torch.zeros(M, 4, device=dev)
+              if pos_sel.numel():
+                  bbox_targets[pos_sel] = self.bbox_head.bbox_coder.encode(pos_rois[:, 1:].contiguous(), pos_gt_boxes)
+                  bbox_weights[pos_sel] = 1.0
+              label_weights = torch.ones(M, device=dev)
         self.last_stats = dict(num_rois=int(M), num_pos=int(pos_sel.numel()))
 
         losses = dict()

@@ -356,6 +356,20 @@ int loft_fused_loss(int mode, const float* pred, const void* target, const float
                     const float* avg_factor, float count, float scale, float beta, float* grad, float* partial,
                     uint32_t* counter, float* loss_out, void* stream);
 
+/* loft_roi_sample_targets: SamplingResult + bbox2roi + BBoxHead.get_targets for a batch (sampling_result.py:25-53,
+ * transforms.py:54-73, bbox_head.py:84-138).  cand [B,Ncand,4] candidate boxes (gts first when add_gt_as_proposals), gt_inds int64
+ * [B,Ncand], gts [B,Kmax,4], gt_labels int64 [B,Kmax]; pos_idx [B,P] / neg_idx [B,Q] from loft_random_sample (valid slots first);
+ * npos / nneg int32 [B] = numbers of valid slots, roi_off / pos_off int32 [B] = exclusive prefix sums of npos+nneg / npos (device
+ * arrays built from ONE host read of the counts).  Writes, per image [pos..., neg...]: rois [M,5] (b, x1, y1, x2, y2), labels int64
+ * [M] (num_classes for negatives), label_weights [M] = 1, bbox_targets / bbox_weights [M,4] (bbox2delta for positives, weight 1),
+ * and the positives' lists pos_rois [Np,5], pos_img / pos_gt / pos_row int64 [Np] (image, assigned gt, row in rois). */
+int loft_roi_sample_targets(const float* cand, int Ncand, const int64_t* gt_inds, const float* gts,
+                            const int64_t* gt_labels, int Kmax, const int64_t* pos_idx, const int64_t* neg_idx, int P,
+                            int Q, int B, const int32_t* npos_dev, const int32_t* nneg_dev, const int32_t* roi_off_dev,
+                            const int32_t* pos_off_dev, int num_classes, const float* means_host, const float* stds_host,
+                            float* rois, int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
+                            float* pos_rois, int64_t* pos_img, int64_t* pos_gt, int64_t* pos_row, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

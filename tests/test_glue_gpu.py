@@ -342,3 +342,47 @@ def test_fused_losses_match_elementwise_formulation():
         assert l0.shape == l1.shape
         assert (l0 - l1).abs().max().item() <= 2e-5 * max(1.0, l1.abs().max().item()), type(mod).__name__
         assert (g0 - g1).abs().max().item() <= 2e-5 * max(1e-6, g1.abs().max().item()), type(mod).__name__
+
+
+def test_roi_sample_targets_matches_tensor_formulation():
+    """loft_roi_sample_targets (sampled RoIs per image [pos..., neg...], labels, bbox2delta targets, positives' lists) against the
+    gather / nonzero formulation it replaces, incl. an image without positives and one without negatives."""
+    from bonai_amd import kernels as K
+    from bonai_amd.loft.core import RandomSampler
+    rng = np.random.RandomState(2)
+    B, N, Kmax, num = 4, 700, 9, 128
+    x1, y1 = rng.uniform(0, 400, (B, N)), rng.uniform(0, 400, (B, N))
+    cand = torch.tensor(np.stack([x1, y1, x1 + rng.uniform(8, 100, (B, N)), y1 + rng.uniform(8, 100, (B, N))], -1), dtype=torch.float32).cuda()
+    gx, gy = rng.uniform(0, 400, (B, Kmax)), rng.uniform(0, 400, (B, Kmax))
+    gts = torch.tensor(np.stack([gx, gy, gx + rng.uniform(8, 100, (B, Kmax)), gy + rng.uniform(8, 100, (B, Kmax))], -1), dtype=torch.float32).cuda()
+    gt_inds = torch.tensor(rng.choice([-1, 0, 0, 0, 1, 2, 5, 9], size=(B, N)), dtype=torch.int64)
+    gt_inds[1] = gt_inds[1].clamp(max=0)          # image without positives
+    gt_inds[2] = gt_inds[2].clamp(min=1)          # image without negatives
+    gt_inds = gt_inds.cuda()
+    lab = torch.tensor(rng.randint(0, 3, (B, Kmax)), dtype=torch.int64).cuda()
+    smp = RandomSampler(num, 0.25)
+    smp.choice_mode = 'first'
+    r = smp.sample_batched(gt_inds)
+    pidx, pval, nidx, nval = r['pos_idx'], r['pos_valid'], r['neg_idx'], r['neg_valid']
+    means, stds = (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)
+    got = K.roi_sample_targets(cand, gt_inds, gts, lab, pidx, pval, nidx, nval, 3, means, stds)
+    # the tensor formulation
+    idx, val = torch.cat([pidx, nidx], 1), torch.cat([pval, nval], 1)
+    is_pos = torch.cat([pval, torch.zeros_like(nval)], 1)
+    bidx = torch.arange(B, device='cuda')[:, None].expand_as(idx)
+    sel = val.reshape(-1).nonzero().flatten()
+    b_s, i_s, pos_s = bidx.reshape(-1)[sel], idx.reshape(-1)[sel], is_pos.reshape(-1)[sel]
+    rois = torch.cat([b_s[:, None].float(), cand[b_s, i_s]], 1)
+    assigned = (gt_inds[b_s, i_s] - 1).clamp(min=0)
+    pos_sel = pos_s.nonzero().flatten()
+    labels = torch.full((rois.shape[0],), 3, dtype=torch.long, device='cuda')
+    labels[pos_sel] = lab[b_s[pos_sel], assigned[pos_sel]]
+    tgt = torch.zeros(rois.shape[0], 4, device='cuda')
+    tgt[pos_sel] = K.bbox2delta(rois[pos_sel][:, 1:].contiguous(), gts[b_s[pos_sel], assigned[pos_sel]], means, stds)
+    assert torch.equal(got['rois'], rois) and torch.equal(got['labels'], labels)
+    assert torch.equal(got['pos_sel'], pos_sel) and torch.equal(got['pos_b'], b_s[pos_sel]) and torch.equal(got['pos_gt_i'], assigned[pos_sel])
+    assert torch.equal(got['pos_rois'], rois[pos_sel])
+    assert torch.equal(got['bbox_targets'], tgt)
+    w = torch.zeros(rois.shape[0], 4, device='cuda')
+    w[pos_sel] = 1.0
+    assert torch.equal(got['bbox_weights'], w) and bool((got['label_weights'] == 1).all())

@@ -31,6 +31,7 @@
 // 2-stage / 2-blocks-per-CU form (fpn P2 3x3: 538 vs 649 TFLOP/s) -- the second resident block hides more than the
 // deeper prefetch does; the next step is a 256-row, 8-wave tile with fragment double-buffering, not more stages.
 #include "loft_common.h"
+#include <algorithm>
 #include <type_traits>
 #include "../../include/loft_hip.h"
 #include <stdlib.h>
@@ -670,6 +671,13 @@ struct WgradArgs {
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW and OW via multiply-high (host-computed)
     float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
     int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
+    // PM form (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs; stride 1): the K dimension of tap t runs over
+    // (position inside the tap's valid rectangle, RoI) -- rows whose tap leaves the map (18 % of a 7x7 map's 3x3 taps, 9 % of a
+    // 14x14 one) are never staged, and every tap gets a number of K-splits proportional to its valid rows so that all
+    // workgroups run the same number of K-steps.  Workgroup j of a group serves tap t with pm_blk0[t] <= j < pm_blk0[t+1].
+    int pm_blk0[CONV_MAX_TAPS + 1], pm_pps[CONV_MAX_TAPS], pm_rows[CONV_MAX_TAPS];
+    int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
+    unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
 };
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
@@ -705,7 +713,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0,
 
 // TN = output tile edge (n and c), NW = waves.  <128,4>: 2x2 waves of 64x64; <256,8>: 2x4 waves of 128(n)x64(c) --
 // the 256 form halves the LDS-DMA bytes per FLOP and is used when Cout and Cin are multiples of 256.
-template <int TN, int NW>
+template <int TN, int NW, bool PM = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int RB = TN * 2;                 // bytes per pixel row of a tile
     constexpr int CPR = RB / 16;               // 16-byte chunks per row
@@ -722,15 +730,26 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
     const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
     const int nt = bx / a.ctiles, ct = bx - nt * a.ctiles;
-    const int t = by % a.T, grp = by / a.T;
+    int t, grp, mbeg, mend;
+    if constexpr (PM) {
+        grp = by;
+        t = 0;
+        while (t + 1 < a.T && bz >= a.pm_blk0[t + 1]) ++t;
+        mbeg = (bz - a.pm_blk0[t]) * a.pm_pps[t];
+        mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
+    } else {
+        t = by % a.T; grp = by / a.T;
+        mbeg = bz * a.pix_per_split;
+        mend = min(a.M, mbeg + a.pix_per_split);
+    }
     const int n0 = nt * TN, c0 = ct * TN;
-    const int mbeg = bz * a.pix_per_split;
-    const int mend = min(a.M, mbeg + a.pix_per_split);
     if (mbeg >= mend) return;
     const bf16_t* G = a.g + (long)grp * a.g_gs;
     const bf16_t* X = a.x + (long)grp * a.x_gs;
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
+    const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
+    const unsigned pm_mul = PM ? a.pm_rw_mul[t] : 0u, pm_sh = PM ? a.pm_rw_sh[t] : 0u;
 
     const int lrow = lane / CPR, lchunk = lane % CPR;
     auto stage = [&](int m_base, int buf) {
@@ -744,6 +763,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
             const bf16_t* pg = a.zero_page;
             const bf16_t* px = a.zero_page;
             if (m < mend) {
+                if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * B + RoI; stride 1, all in bounds
+                    const int p = fastdiv(m, a.b_mul, a.b_sh), b = m - p * a.B;
+                    const int ry = fastdiv(p, pm_mul, pm_sh), rx = p - ry * pm_rw;
+                    const int oy = pm_y0 + ry, ox = pm_x0 + rx;
+                    pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + q;
+                    px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + q;
+                } else {
                 const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
                 const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
                 const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
@@ -751,6 +777,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
                 if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
                     pg = G + ((long)(b * a.GH + gy) * a.GW + gx) * a.Cout + n0 + q;
                     px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + q;
+                }
                 }
             }
             __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(gbuf + (i * 16 + wave * RPW) * RB), 16, 0, 0);
@@ -1145,6 +1172,45 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     int pps = (int)((M + splits - 1) / splits);
     pps = ((pps + 63) / 64) * 64;
     a.pix_per_split = pps;
+    static const int pm_mode = getenv("LOFT_WGRAD_PIXMAJOR") ? atoi(getenv("LOFT_WGRAD_PIXMAJOR")) : 1;
+    if (pm_mode && !narrow && T > 1 && gos == 1 && ss == 1 && B >= 128 && OH * OW <= 1024) {
+        // valid rectangle of every tap; K-splits per tap proportional to its rows: the smallest common K length L (multiple of
+        // the 64-row K-step) with sum_t ceil(rows_t / L) <= the workgroup budget per group
+        const long budget = (long)splits * T;
+        long rows[CONV_MAX_TAPS], total = 0;
+        for (int t = 0; t < T; ++t) {
+            const int ylo = std::max(0, std::max(-a.goy[t], -a.dy[t])), yhi = std::min(OH, std::min(GH - a.goy[t], XH - a.dy[t]));
+            const int xlo = std::max(0, std::max(-a.gox[t], -a.dx[t])), xhi = std::min(OW, std::min(GW - a.gox[t], XW - a.dx[t]));
+            const int rh = std::max(0, yhi - ylo), rw = std::max(0, xhi - xlo);
+            a.pm_y0[t] = ylo; a.pm_x0[t] = xlo; a.pm_rw[t] = rw > 0 ? rw : 1;
+            fastdiv_setup((unsigned)a.pm_rw[t], &a.pm_rw_mul[t], &a.pm_rw_sh[t]);
+            rows[t] = (long)rh * rw * B;
+            a.pm_rows[t] = (int)rows[t];
+            total += rows[t];
+        }
+        if (total > 0) {
+            long L = ((total + budget - 1) / budget + 63) / 64 * 64;
+            for (;; L += 64) {
+                long nb = 0;
+                for (int t = 0; t < T; ++t) nb += (rows[t] + L - 1) / L;
+                if (nb <= budget) break;
+            }
+            int blk = 0;
+            for (int t = 0; t < T; ++t) {
+                const long ns = (rows[t] + L - 1) / L;
+                a.pm_blk0[t] = blk;
+                a.pm_pps[t] = ns ? (int)(((rows[t] + ns - 1) / ns + 63) / 64 * 64) : 64;
+                blk += (int)ns;
+            }
+            a.pm_blk0[T] = blk;
+            fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
+            dim3 grid(tiles, groups, blk);
+            if (big) hipLaunchKernelGGL((conv_wgrad_kernel<256, 8, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<128, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+            LOFT_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     splits = (int)((M + pps - 1) / pps);
     dim3 grid(tiles, T * groups, splits);
     if (narrow)

@@ -266,3 +266,29 @@ def test_conv64_patch_kernel(B, H, W, k):
         K.conv_tap(_cl(x), wp, out, B, H, W, C, C, H, W, H, W, taps, bias=b.cuda(), relu=False)
         ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b)
         assert (out.float().cpu() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,R,pad', [
+    (300, 256, 256, 7, 7, 3, 1),        # 128-tile form
+    (1300, 256, 256, 7, 7, 3, 1),       # 256-tile form (FOA head shape)
+    (260, 128, 256, 14, 14, 3, 1),      # mask-head map
+    (130, 128, 128, 5, 9, 3, 1),        # non-square map, 130 RoIs (K-steps straddle positions)
+])
+def test_wgrad_roi_maps_valid_rows_only(B, Cin, Cout, H, W, R, pad):
+    """RoI-map form of conv_wgrad_kernel (K runs over the valid rectangle of each tap only, K-splits proportional to the tap's
+    rows) vs torch-CPU autograd; LOFT_WGRAD_PIXMAJOR=0 is the plain enumeration."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(11)
+    x = _r(torch.randn(B, Cin, H, W))
+    w = torch.randn(Cout, Cin, R, R, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=1, padding=pad)
+    g = _r(torch.randn_like(y))
+    (ref,) = torch.autograd.grad(y, w, g)
+    tol = 1e-3 * max(1.0, ref.abs().max().item())
+    for splits in (0, 1, 5):
+        dwp = K.conv2d_wgrad(_cl(g), _cl(x), R, R, 1, pad, splits=splits)
+        assert (K.unpack_dw(dwp[0], w.shape).cpu() - ref).abs().max().item() < tol, splits
+    dwp, db = K.conv2d_wgrad(_cl(g), _cl(x), R, R, 1, pad, with_bias=True)
+    want_b = g.sum(dim=(0, 2, 3))
+    assert (db[0].cpu() - want_b).abs().max().item() < 2e-3 * max(1.0, want_b.abs().max().item())
+    assert (K.unpack_dw(dwp[0], w.shape).cpu() - ref).abs().max().item() < tol

@@ -375,11 +375,28 @@ LOFT_EXPORT int loft_add_bf16(const void* a, const void* b, void* out, int64_t n
 
 // ---- optimizer: sum of squares (for clip_grad_norm_) and fused SGD step on a flat fp32 arena ----
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
-    float acc = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = g[i];
-        acc += v * v;
+    // 16-byte loads, four independent chains per lane (a pure HBM stream: 4-byte loads reached 2.2 TB/s)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const long n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n >> 2 : 0;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {          // four loads in flight per lane
+        const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+        a0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+        a1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        a2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+        a3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
     }
+    for (; i < n4; i += stride) {
+        const float4 v = g4[i];
+        a0 += v.x * v.x; a1 += v.y * v.y; a2 += v.z * v.z; a3 += v.w * v.w;
+    }
+    for (long j = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float v = g[j];
+        a0 += v * v;
+    }
+    float acc = (a0 + a1) + (a2 + a3);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 LOFT_EXPORT int loft_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(sumsq_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, ew_grid(n / 16), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -406,7 +423,23 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
         if (norm > max_norm) clip = max_norm / (norm + 1e-6f);
     }
     const float s = clip * gscale;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    // 16-byte accesses on the aligned body (five HBM streams), scalar tail
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m)) & 15) == 0;
+    const long n4 = al ? n >> 2 : 0;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = t0; i < n4; i += stride) {
+        float4 pv = p4[i], mv = m4[i];
+        const float4 gv = g4[i];
+        mv.x = mu * mv.x + (gv.x * s + wd * pv.x); pv.x -= lr * mv.x;
+        mv.y = mu * mv.y + (gv.y * s + wd * pv.y); pv.y -= lr * mv.y;
+        mv.z = mu * mv.z + (gv.z * s + wd * pv.z); pv.z -= lr * mv.z;
+        mv.w = mu * mv.w + (gv.w * s + wd * pv.w); pv.w -= lr * mv.w;
+        m4[i] = mv; p4[i] = pv;
+    }
+    for (long i = n4 * 4 + t0; i < n; i += stride) {
         const float pv = p[i];
         const float d = g[i] * s + wd * pv;
         const float mv = mu * m[i] + d;
@@ -417,7 +450,7 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 LOFT_EXPORT int loft_sgd_momentum_f32(float* p, const float* g, float* m, int64_t n, const float* gnorm_sq, float max_norm,
                                       float lr, float momentum, float weight_decay, float grad_scale, void* stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(sgd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, p, g, m, (long)n, gnorm_sq, max_norm, lr,
+    hipLaunchKernelGGL(sgd_kernel, ew_grid(n / 4), dim3(256), 0, (hipStream_t)stream, p, g, m, (long)n, gnorm_sq, max_norm, lr,
                        momentum, weight_decay, grad_scale);
     LOFT_LAUNCH_CHECK();
     return 0;

@@ -86,6 +86,9 @@ class BucketedAllReduce:
         self._seen = set()
         self._next = 0
         self.works = []
+        self._streams = [dict() for _ in self.buckets]
+        if self.on_gpu:
+            self._dev = torch.cuda.current_device()
 
     def _autograd_hook(self, p):
         """autograd's post-accumulate callback.  It also runs for parameters whose Function returned None because a kernel
@@ -102,6 +105,12 @@ class BucketedAllReduce:
         self._seen.add(id(p))
         bi = self.param_bucket[id(p)]
         self._remaining[bi] -= 1
+        if self.on_gpu:
+            # the RoI head's mask / bbox branches replay their backward on a second stream: a bucket can hold gradients
+            # deposited on different streams, and its collective has to wait for the tail of every one of them
+            raw = torch._C._cuda_getCurrentRawStream(self._dev)
+            if raw not in self._streams[bi]:
+                self._streams[bi][raw] = torch.cuda.current_stream()
         # collectives must be issued in the SAME order on every rank even when a rank's graph lacks some branch
         # (e.g. no positive RoI -> no mask/FOA gradients there): buckets are launched strictly in index order
         while self._next < len(self.buckets) and self._remaining[self._next] == 0:
@@ -113,9 +122,13 @@ class BucketedAllReduce:
         if not self.on_gpu:   # gloo / CPU (tests): same bucket order, no stream juggling
             self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.stream.wait_event(ev)
+        cur = torch.cuda.current_stream()
+        producers = dict(self._streams[bi])
+        producers[torch._C._cuda_getCurrentRawStream(self._dev)] = cur
+        for st in producers.values():
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
             self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
 

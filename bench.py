@@ -218,11 +218,13 @@ def main():
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     if rank == 0:
+        arch = ('LOFT HRNetV2p-W32 + FOA' if 'hrnet' in args.config else
+                'LOFT R50-FPN (DCNv2 c3-c5) + FOA' if 'mdconv' in args.config else 'LOFT R50-FPN + FOA')
         f_img = f_train_gflop(mean_roi, mean_pos, sparse_rpn_backward=model.rpn_head.sparse_backward)
         res = dict(metric='training img/s at 1024x1024 LOFT R50-FPN', value=round(value, 3), unit='img/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload=f'LOFT R50-FPN + FOA, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
+                   config=dict(workload=f'{arch}, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
                                         f'({"BASELINE configs[1]" if headline else args.config}), {args.num_gt} gt/img, full train step '
                                         '(fwd+losses+bwd+allreduce+clip+SGD), random-init weights',
                                global_batch=args.batch * world, per_gpu_batch=args.batch, parallelism=f'dp{world}',

@@ -15,7 +15,9 @@ def _cl(t):
 
 @pytest.mark.parametrize('B,C,H,W,R,stride', [(8, 256, 256, 256, 3, 1),      # FPN P2 / RPN conv: M = 524 288
                                                (8, 256, 128, 128, 3, 2),      # stride-2 3x3 (layer3.0.conv2 shape)
-                                               (8, 512, 128, 128, 1, 1)])     # deep 1x1
+                                               (8, 512, 128, 128, 1, 1),      # deep 1x1
+                                               (3524, 256, 7, 7, 3, 1),       # FOA head maps (881 positives x 4 branches): pixel-major
+                                               (881, 256, 14, 14, 3, 1)])     # mask head maps    tiles, valid-rows-only weight gradient
 def test_conv_triple_adjoint_full_size(B, C, H, W, R, stride):
     from bonai_amd import kernels as K
     torch.manual_seed(0)

@@ -29,6 +29,28 @@ __device__ __forceinline__ float iou_pair(const float4 g, const float4 b) {
     return overlap / uni;
 }
 
+// Bounding box of the wavefront's 64 boxes (scalar registers).  Anchors are enumerated position-major, so a wavefront of the RPN
+// assignment covers a strip of ~21 grid positions and intersects 2-5 of an image's 80 gt boxes: a gt outside the strip has
+// IoU == 0 with every lane (w or h clamps to 0), cannot raise a maximum (all maxima start at 0 with strict '>' updates, the
+// first-index tie rule of torch.max is kept) and cannot equal a gt maximum >= min_pos_iou > 0, so it is skipped outright.
+struct WaveBox { float x1, y1, x2, y2; };
+__device__ __forceinline__ WaveBox wave_bbox(const float4 bx, bool live) {
+    float x1 = live ? bx.x : 3.4e38f, y1 = live ? bx.y : 3.4e38f, x2 = live ? bx.z : -3.4e38f, y2 = live ? bx.w : -3.4e38f;
+    for (int o = 32; o > 0; o >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, o, 64)); y1 = fminf(y1, __shfl_xor(y1, o, 64));
+        x2 = fmaxf(x2, __shfl_xor(x2, o, 64)); y2 = fmaxf(y2, __shfl_xor(y2, o, 64));
+    }
+    WaveBox w;
+    w.x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x1)));
+    w.y1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y1)));
+    w.x2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x2)));
+    w.y2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y2)));
+    return w;
+}
+__device__ __forceinline__ bool gt_outside(const float4 g, const WaveBox& w) {
+    return (g.z <= w.x1) | (g.x >= w.x2) | (g.w <= w.y1) | (g.y >= w.y2);
+}
+
 // pass 1: per box max/argmax over gts; per gt max over boxes.  The per-gt maximum is reduced inside the
 // wavefront (DPP/shuffle max), then across the block's 4 waves in LDS, and only then published with one
 // atomicMax per (block, gt) on the non-negative float's bit pattern -- not one per (box, gt).
@@ -49,17 +71,20 @@ __global__ __launch_bounds__(256) void iou_pass1_kernel(const float* __restrict_
     const bool live = n < N;
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
-    float best = -1.f;
+    const WaveBox wb = wave_bbox(bx, live);
+    float best = 0.f;
     int bi = 0;
     for (int i = 0; i < K; ++i) {
-        float v = live ? iou_pair(sg[i], bx) : 0.f;
-        if (live && v > best) { best = v; bi = i; }
+        const float4 g = sg[i];
+        if (gt_outside(g, wb)) continue;                  // wave-uniform (scalar) branch
+        float v = live ? iou_pair(g, bx) : 0.f;
+        if (v > best) { best = v; bi = i; }
         float m = v;
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(sgm + i, __float_as_uint(m));
     }
     if (live) {
-        max_ov[(long)b * Nmax + n] = K > 0 ? best : 0.f;
+        max_ov[(long)b * Nmax + n] = best;
         argmax[(long)b * Nmax + n] = bi;
     }
     __syncthreads();
@@ -82,21 +107,32 @@ __global__ __launch_bounds__(256) void iou_pass2_kernel(const float* __restrict_
     }
     __syncthreads();
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Nmax) return;
-    if (n >= N) { gt_inds[(long)b * Nmax + n] = -1; return; }
-    if (K == 0) { gt_inds[(long)b * Nmax + n] = 0; return; }
-    const float mo = max_ov[(long)b * Nmax + n];
+    const bool live = n < N;
     long a = -1;
-    if (mo >= 0.f && mo < neg_thr) a = 0;
-    if (mo >= pos_thr) a = argmax[(long)b * Nmax + n] + 1;
-    if (low_quality) {
-        const float4 bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && K > 0) {
+        const float mo = max_ov[(long)b * Nmax + n];
+        if (mo >= 0.f && mo < neg_thr) a = 0;
+        if (mo >= pos_thr) a = argmax[(long)b * Nmax + n] + 1;
+        bx = reinterpret_cast<const float4*>(boxes)[(long)b * Nmax + n];
+    } else if (live) {
+        a = 0;
+    }
+    if (low_quality && K > 0 && min_pos > 0.f) {
+        const WaveBox wb = wave_bbox(bx, live);
         for (int i = 0; i < K; ++i) {
             const float gm = sgm[i];
-            if (gm >= min_pos && iou_pair(sg[i], bx) == gm) a = i + 1;
+            const float4 g = sg[i];
+            if (!(gm >= min_pos) || gt_outside(g, wb)) continue;      // wave-uniform
+            if (live && iou_pair(g, bx) == gm) a = i + 1;
+        }
+    } else if (low_quality && K > 0) {
+        for (int i = 0; i < K; ++i) {
+            const float gm = sgm[i];
+            if (live && gm >= min_pos && iou_pair(sg[i], bx) == gm) a = i + 1;
         }
     }
-    gt_inds[(long)b * Nmax + n] = a;
+    if (n < Nmax) gt_inds[(long)b * Nmax + n] = a;
 }
 
 LOFT_EXPORT int loft_iou_assign(const float* boxes, const int* nbox, int Nmax, const float* gts, const int* ngt, int Kmax,

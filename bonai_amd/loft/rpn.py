@@ -242,6 +242,9 @@ class RPNHead(nn.Module):
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
         if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == torch.bfloat16 and x[0].shape[1] % 128 == 0:
+            if (proposal_cfg is not None and x[0].is_cuda and K.PROFILE is None and not os.environ.get('LOFT_NO_SIDE_STREAM')
+                    and not os.environ.get('LOFT_NO_RPN_SIDE_STREAM')):
+                return self._forward_train_two_streams(x, img_metas, gt_bboxes, gt_bboxes_ignore, proposal_cfg)
             with torch.no_grad():
                 fused, hs = self.forward_fused(x, keep_hidden=True)
             losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore, sparse=(x, hs))
@@ -251,6 +254,25 @@ class RPNHead(nn.Module):
         if proposal_cfg is None:
             return losses
         return losses, self.get_bboxes_fused([f.detach() for f in fused], img_metas, proposal_cfg)
+
+    def _forward_train_two_streams(self, x, img_metas, gt_bboxes, gt_bboxes_ignore, proposal_cfg):
+        """Target assignment + sampling + losses on the calling stream, proposal generation (score sort, decode, NMS, re-sort) on
+        a second HIP stream: two chains of small launches that each keep only a few CUs busy (8 workgroups in the NMS scan and
+        the sampler) and share nothing but the head's outputs.  Proposals carry no gradient, so autograd never sees the stream."""
+        main = torch.cuda.current_stream()
+        if getattr(self, '_prop_stream', None) is None:
+            self._prop_stream = torch.cuda.Stream()
+        side = self._prop_stream
+        with torch.no_grad():
+            fused, hs = self.forward_fused(x, keep_hidden=True)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            props, counts = self.get_bboxes_fused([f.detach() for f in fused], img_metas, proposal_cfg)
+        losses = self.loss_fused(fused, gt_bboxes, img_metas, gt_bboxes_ignore, sparse=(x, hs))
+        main.wait_stream(side)
+        props.record_stream(main)
+        counts.record_stream(main)
+        return losses, (props, counts)
 
     def simple_test_rpn(self, x, img_metas):
         fused = self.forward_fused(x)

@@ -348,6 +348,57 @@ LOFT_EXPORT int loft_foa_fuse_decode(const float* pred, const float* boxes, int6
     return 0;
 }
 
+// ---- plain LOFT OffsetHead (no FOA): targets and inference decode ------------------------------
+// (attribute_heads/offset_head.py:118-188 get_targets / _offset_target_single, :190-243 get_offsets;
+//  delta_xy_offset_coder.py:46-88).  reg_num = 2: out[i] = ((gx/pw, gy/ph) - mean)/std.  reg_num = 3 ("polar" heads):
+//  the two encoded values are read as (length, angle) and the target is (length, cos(angle), sin(angle)) (:176-183).
+__global__ void offset_targets_kernel(const float* __restrict__ pos_boxes, const float* __restrict__ gt_off, long n, float mean_x,
+                                      float mean_y, float std_x, float std_y, int reg_num, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = reinterpret_cast<const float4*>(pos_boxes)[i];
+    const float pw = p.z - p.x, ph = p.w - p.y;
+    const float dx = (gt_off[2 * i] / pw - mean_x) / std_x;
+    const float dy = (gt_off[2 * i + 1] / ph - mean_y) / std_y;
+    if (reg_num == 2) { out[2 * i] = dx; out[2 * i + 1] = dy; }
+    else { out[3 * i] = dx; out[3 * i + 1] = cosf(dy); out[3 * i + 2] = sinf(dy); }
+}
+LOFT_EXPORT int loft_offset_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_t n, float mean_x, float mean_y,
+                                    float std_x, float std_y, int reg_num, float* out, void* stream) {
+    if (reg_num != 2 && reg_num != 3) return (int)hipErrorInvalidValue;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(offset_targets_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pos_boxes, pos_gt_offsets,
+                       (long)n, mean_x, mean_y, std_x, std_y, reg_num, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+// pred [n, reg_num] -> offsets [n,2]: reg_num = 3 first folds (length, cos, sin) to (length, atan2(sin, cos)); decode
+// (d*std + mean) * (pw, ph) clamped to +-(max_w, max_h); polar != 0 then maps (length, angle) -> length*(cos, sin) (:232-236).
+__global__ void offset_decode_kernel(const float* __restrict__ pred, const float* __restrict__ boxes, long n, float mean_x,
+                                     float mean_y, float std_x, float std_y, float max_h, float max_w, int reg_num, int polar,
+                                     float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d0, d1;
+    if (reg_num == 2) { d0 = pred[2 * i]; d1 = pred[2 * i + 1]; }
+    else { d0 = pred[3 * i]; d1 = atan2f(pred[3 * i + 2], pred[3 * i + 1]); }
+    const float4 r = reinterpret_cast<const float4*>(boxes)[i];
+    float gx = (r.z - r.x) * (d0 * std_x + mean_x), gy = (r.w - r.y) * (d1 * std_y + mean_y);
+    gx = fminf(fmaxf(gx, -max_w), max_w);
+    gy = fminf(fmaxf(gy, -max_h), max_h);
+    if (polar) { const float l = gx, a = gy; gx = l * cosf(a); gy = l * sinf(a); }
+    out[2 * i] = gx; out[2 * i + 1] = gy;
+}
+LOFT_EXPORT int loft_offset_decode(const float* pred, const float* boxes, int64_t n, float mean_x, float mean_y, float std_x,
+                                   float std_y, float max_h, float max_w, int reg_num, int polar, float* out, void* stream) {
+    if (reg_num != 2 && reg_num != 3) return (int)hipErrorInvalidValue;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(offset_decode_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, boxes, (long)n,
+                       mean_x, mean_y, std_x, std_y, max_h, max_w, reg_num, polar, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- mask targets -------------------------------------------------------------------------------
 // masks u8 [Ktot,H,W]; for RoI i: mask index gt_idx[i], box (already clipped to the image) boxes[i];
 // out[i][S][S] = (RoIAlign_avg_aligned(mask, box, S, scale 1, adaptive grid) >= 0.5) as fp32 0/1.

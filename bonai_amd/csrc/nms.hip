@@ -26,6 +26,11 @@
 
 #define NMS_MAX_WORDS_PER_LANE 8  // segments up to 64*64*8 = 32768 boxes
 
+// PRED = LOFT_NMS_PRED_DEVICE (0): the division-free predicate of mmcv-1.0.5's CUDA kernel, inter > thr * union -- the form
+// the reference's GPU training / tools/test.py runs execute, and the library default.  PRED = LOFT_NMS_PRED_CPU (1): the
+// predicate of mmcv-1.0.5's host nms (nms_cpu), inter / union >= thr.  The two differ exactly AT the threshold (IoU == thr is
+// kept by the device form, suppressed by the host form) and, rarely, by one rounding of the division next to it.
+template <int PRED>
 __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr) {
     float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
     float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
@@ -34,7 +39,8 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
     float sa = (a.z - a.x) * (a.w - a.y);
     float sb = (b.z - b.x) * (b.w - b.y);
     float uni = sa + sb - inter;
-    return inter > thr * uni;
+    if constexpr (PRED == 0) return inter > thr * uni;
+    else return inter / uni >= thr;
 }
 
 __device__ __forceinline__ float4 load_box(const float* boxes, long i, float shift) {
@@ -44,6 +50,7 @@ __device__ __forceinline__ float4 load_box(const float* boxes, long i, float shi
 }
 
 // grid: (col_tile, row_tile, segment); block: 64 threads (one wave).
+template <int PRED>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ seg_off,
                                                       const float* __restrict__ seg_shift, float thr, int max_words,
                                                       unsigned long long* __restrict__ mask) {
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     unsigned long long m = 0ull;
     const int start = (rt == ct) ? t + 1 : 0;
     for (int j = start; j < ncol; ++j)
-        if (iou_gt(a, cb[j], thr)) m |= (1ull << j);
+        if (iou_gt<PRED>(a, cb[j], thr)) m |= (1ull << j);
     mask[(size_t)(o + ri) * max_words + ct] = m;
 }
 
@@ -199,21 +206,33 @@ LOFT_EXPORT int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_se
     return total_boxes * words * 8;
 }
 
-LOFT_EXPORT int loft_nms_segmented(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
-                                   int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr,
-                                   void* workspace, uint8_t* keep, void* stream) {
+LOFT_EXPORT int loft_nms_segmented_pred(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
+                                        int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr,
+                                        int predicate, void* workspace, uint8_t* keep, void* stream) {
+    if (predicate != LOFT_NMS_PRED_DEVICE && predicate != LOFT_NMS_PRED_CPU) return (int)hipErrorInvalidValue;
     if (num_segments <= 0 || total_boxes <= 0) return 0;
     const int max_words = (int)((max_segment + 63) / 64);
     if (max_words > 64 * NMS_MAX_WORDS_PER_LANE) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(max_words, max_words, num_segments);
-    hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, s, boxes, seg_offsets_dev, seg_shift_dev, iou_thr, max_words,
-                       (unsigned long long*)workspace);
+    if (predicate == LOFT_NMS_PRED_DEVICE)
+        hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(64), 0, s, boxes, seg_offsets_dev, seg_shift_dev, iou_thr, max_words,
+                           (unsigned long long*)workspace);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(64), 0, s, boxes, seg_offsets_dev, seg_shift_dev, iou_thr, max_words,
+                           (unsigned long long*)workspace);
     LOFT_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(num_segments), dim3(64), 0, s, (const unsigned long long*)workspace,
                        seg_offsets_dev, max_words, keep);
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_nms_segmented(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
+                                   int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr,
+                                   void* workspace, uint8_t* keep, void* stream) {
+    return loft_nms_segmented_pred(boxes, seg_offsets_dev, seg_shift_dev, num_segments, total_boxes, max_segment, iou_thr,
+                                   LOFT_NMS_PRED_DEVICE, workspace, keep, stream);
 }
 
 // ---------------------------------------------------------------- segmented stable sort, descending

@@ -167,9 +167,14 @@ def map_roi_levels(rois, num_levels=4, finest_scale=56):
 
 # ------------------------------------------------------------------ NMS / sort
 
-def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segment=None):
+NMS_PREDICATES = {'device': 0, 'cpu': 1}   # include/loft_hip.h LOFT_NMS_PRED_*
+
+
+def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segment=None, predicate='device'):
     """boxes_sorted [T,4] fp32 sorted (score desc, index asc) inside each segment;
-    seg_offsets int64 [S+1] (device).  -> keep mask uint8 [T]."""
+    seg_offsets int64 [S+1] (device).  -> keep mask uint8 [T].
+    predicate: 'device' (default; mmcv-1.0.5's CUDA kernel, inter > thr*union -- what the reference's GPU runs execute) or
+    'cpu' (its host nms_cpu, inter/union >= thr); they differ exactly at IoU == thr."""
     lib = L.load()
     L.dev_check(boxes_sorted, seg_offsets, seg_shift)
     boxes_sorted = boxes_sorted.float().contiguous()
@@ -181,9 +186,9 @@ def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segmen
     if max_segment is None:
         max_segment = int((seg_offsets[1:] - seg_offsets[:-1]).max().item())
     ws = torch.empty(lib.loft_nms_workspace_bytes(T, max_segment), dtype=torch.uint8, device=boxes_sorted.device)
-    L.check(lib.loft_nms_segmented(L.ptr(boxes_sorted), L.ptr(seg_offsets), L.ptr(seg_shift), S, c_int64(T),
-                                   c_int64(max_segment), c_float(iou_thr), L.ptr(ws), L.ptr(keep), L.stream()),
-            'loft_nms_segmented')
+    L.check(lib.loft_nms_segmented_pred(L.ptr(boxes_sorted), L.ptr(seg_offsets), L.ptr(seg_shift), S, c_int64(T),
+                                        c_int64(max_segment), c_float(iou_thr), c_int(NMS_PREDICATES[predicate]), L.ptr(ws),
+                                        L.ptr(keep), L.stream()), 'loft_nms_segmented_pred')
     return keep
 
 
@@ -211,13 +216,13 @@ def segmented_sort_desc(keys, seg_offsets, values=None):
     return ko, vo
 
 
-def nms(boxes, scores, iou_thr):
+def nms(boxes, scores, iou_thr, predicate='device'):
     """mmcv.ops.nms contract: -> (dets [M,5], keep [M] int64 in score-descending order)."""
     n = boxes.shape[0]
     off = torch.tensor([0, n], dtype=torch.int64, device=boxes.device)
     _, order = segmented_sort_desc(scores, off)
     order = order.long()
-    keep_mask = nms_segmented(boxes[order], off, iou_thr, max_segment=n)
+    keep_mask = nms_segmented(boxes[order], off, iou_thr, max_segment=n, predicate=predicate)
     keep = order[keep_mask.bool()]
     return torch.cat([boxes[keep], scores[keep, None]], dim=1), keep
 
@@ -656,6 +661,32 @@ def foa_fuse_decode(pred, boxes, stds=(0.5, 0.5), max_shape=(1024, 1024)):
     return out
 
 
+def offset_targets(pos_boxes, pos_gt_offsets, means=(0., 0.), stds=(0.5, 0.5), reg_num=2):
+    """OffsetHead.get_targets (attribute_heads/offset_head.py:118-188): [n,4] boxes, [n,2] gt offsets -> [n,reg_num]."""
+    lib = L.load()
+    L.dev_check(pos_boxes, pos_gt_offsets)
+    pos_boxes, pos_gt_offsets = pos_boxes.float().contiguous(), pos_gt_offsets.float().contiguous()
+    n = pos_boxes.shape[0]
+    out = torch.empty(n, reg_num, dtype=torch.float32, device=pos_boxes.device)
+    L.check(lib.loft_offset_targets(L.ptr(pos_boxes), L.ptr(pos_gt_offsets), c_int64(n), c_float(means[0]), c_float(means[1]),
+                                    c_float(stds[0]), c_float(stds[1]), c_int(reg_num), L.ptr(out), L.stream()),
+            'loft_offset_targets')
+    return out
+
+
+def offset_decode(pred, boxes, means=(0., 0.), stds=(0.5, 0.5), max_shape=(1024, 1024), polar=False):
+    """OffsetHead.get_offsets (attribute_heads/offset_head.py:190-243): pred [n,2|3], boxes [n,>=4] -> [n,2] pixels."""
+    lib = L.load()
+    L.dev_check(pred, boxes)
+    pred, boxes = pred.float().contiguous(), boxes[:, :4].float().contiguous()
+    n, reg_num = boxes.shape[0], int(pred.shape[1])
+    out = torch.empty(n, 2, dtype=torch.float32, device=pred.device)
+    L.check(lib.loft_offset_decode(L.ptr(pred), L.ptr(boxes), c_int64(n), c_float(means[0]), c_float(means[1]),
+                                   c_float(stds[0]), c_float(stds[1]), c_float(max_shape[0]), c_float(max_shape[1]),
+                                   c_int(reg_num), c_int(1 if polar else 0), L.ptr(out), L.stream()), 'loft_offset_decode')
+    return out
+
+
 def mask_target(masks_u8, boxes, gt_idx, S=28):
     """masks: uint8 [K,H,W] (device), or a LIST of per-image uint8 [K_b,H,W] tensors (gt_idx then indexes their
     concatenation; no copy is made: the kernel gets a table of instance addresses); boxes [n,4] already clipped to the
@@ -716,7 +747,7 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         shifted = boxes + (idxs.to(boxes) * (boxes.max() + 1))[:, None]
     typ = cfg.pop('type', 'nms')
     if typ == 'nms':
-        dets, keep = nms(shifted, scores, cfg['iou_threshold'])
+        dets, keep = nms(shifted, scores, cfg['iou_threshold'], predicate=cfg.get('predicate', 'device'))
     elif typ == 'soft_nms':
         dets, keep = soft_nms(shifted, scores, **cfg)
     else:

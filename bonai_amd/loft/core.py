@@ -82,8 +82,14 @@ class DeltaXYWHBBoxCoder(_Coder):
 class DeltaXYOffsetCoder(_Coder):
     def __init__(self, target_means=(0., 0.), target_stds=(0.5, 0.5)):
         super().__init__(target_means, target_stds)
-        if self.means != (0., 0.):
-            raise NotImplementedError('non-zero offset means')
+
+    def encode(self, bboxes, gt_offsets):
+        """delta_xy_offset_coder.py:28-32 -> offset2delta :46-65."""
+        return K.offset_targets(bboxes, gt_offsets, self.means, self.stds, 2)
+
+    def decode(self, bboxes, pred_offsets, max_shape=None, wh_ratio_clip=16 / 1000):
+        """delta_xy_offset_coder.py:34-43 -> delta2offset :67-88 (no clamp when max_shape is None)."""
+        return K.offset_decode(pred_offsets, bboxes, self.means, self.stds, max_shape if max_shape is not None else (3.0e38, 3.0e38))
 
 
 @IOU_CALCULATORS.register_module()

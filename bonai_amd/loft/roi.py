@@ -178,8 +178,11 @@ class FCNMaskHead(nn.Module):
 class _OffsetBase(nn.Module):
     def _common(self, roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
                 loss_offset, offset_coordinate, reg_decoded_offset):
-        if reg_num != 2 or offset_coordinate != 'rectangle' or reg_decoded_offset or num_fcs < 1:
+        if reg_num not in (2, 3) or offset_coordinate not in ('rectangle', 'polar') or num_fcs < 1:
             raise NotImplementedError('offset head variant not used by configs/loft_foa')
+        if getattr(self, 'expand_feature_num', 1) != 1 and (reg_num != 2 or offset_coordinate != 'rectangle' or reg_decoded_offset):
+            raise NotImplementedError('FOA is built for reg_num=2 rectangular encoded offsets (configs/loft_foa)')
+        self.offset_coordinate, self.reg_decoded_offset = offset_coordinate, reg_decoded_offset
         self.roi_feat_size, self.in_channels, self.conv_out_channels = roi_feat_size, in_channels, conv_out_channels
         self.fc_out_channels, self.reg_num = fc_out_channels, reg_num
         self.offset_coder = build_bbox_coder(offset_coder)
@@ -226,6 +229,8 @@ class OffsetHeadExpandFeature(_OffsetBase):
             raise NotImplementedError('FOA is built natively for 4 rotations (0/90/180/270) with shared FCs')
         self.expand_feature_num, self.rotations, self.share_expand_fc = expand_feature_num, list(rotations), True
         self.num_convs = num_convs
+        if tuple(float(v) for v in offset_coder.get('target_means', (0., 0.))) != (0., 0.):
+            raise NotImplementedError('FOA target / fusion kernels take zero offset means (configs/loft_foa)')
         self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
                      loss_offset, offset_coordinate, reg_decoded_offset)
         self.expand_convs = nn.ModuleList([nn.ModuleList([ConvW(conv_out_channels, conv_out_channels, 3, bias=True)
@@ -283,11 +288,26 @@ class OffsetHead(_OffsetBase):
         self._init_fcs()
 
     def forward(self, x):
+        """bf16 NHWC RoI features [N,C,7,7] -> fp32 [N,reg_num] (offset_head.py:90-106; empty input -> (0, 2))."""
         if x.shape[0] == 0:
             return x.new_zeros(0, 2, dtype=torch.float32)
-        for c in self.convs:
-            x = F2.conv2d(x, c.weight, c.bias, pad=1, relu=True)
+        for i, c in enumerate(self.convs):
+            x = F2.conv2d(x, c.weight, c.bias, pad=1, relu=True, input_relu=i > 0)
         return self._fc_tail(x)
+
+    def get_targets(self, pos_bboxes, pos_gt_offsets):
+        """offset_head.py:118-188 on the concatenated positives: [n,4] boxes + their assigned gt offsets [n,2] (what
+        `_offset_target_single`'s per-RoI python loop gathers) -> [n,reg_num]; one launch."""
+        if self.reg_decoded_offset:
+            t = pos_gt_offsets.float()
+            return t if self.reg_num == 2 else torch.stack([t[:, 0], torch.cos(t[:, 1]), torch.sin(t[:, 1])], -1)
+        return K.offset_targets(pos_bboxes, pos_gt_offsets, self.offset_coder.means, self.offset_coder.stds, self.reg_num)
+
+    def get_offsets(self, offset_pred, det_bboxes, scale_factor=None, rescale=False, img_shape=(1024, 1024)):
+        """offset_head.py:190-243 -> np.float32 [n,2] (pixels of the network input; scale_factor is ignored there too)."""
+        o = K.offset_decode(offset_pred, det_bboxes, self.offset_coder.means, self.offset_coder.stds, img_shape,
+                            polar=self.offset_coordinate == 'polar')
+        return o.cpu().numpy().astype(np.float32)
 
 
 def _masks_to_device(gt_masks, device):
@@ -460,13 +480,8 @@ class LoftRoIHead(nn.Module):
                 off_pad[i, :o.shape[0]] = o.to(dev)
             pos_gt_off = off_pad[pos_b, pos_gt_i]
         offset_pred = self._offset_forward(xo, pos_rois)
-        if hasattr(self.offset_head, 'get_targets') and isinstance(self.offset_head, OffsetHeadExpandFeature):
+        with torch.no_grad():
             offset_targets = self.offset_head.get_targets(pos_rois[:, 1:].contiguous(), pos_gt_off)
-        else:
-            from .core import DeltaXYOffsetCoder  # noqa
-            s = self.offset_head.offset_coder.stds
-            wh = pos_rois[:, 3:5] - pos_rois[:, 1:3]
-            offset_targets = pos_gt_off / wh / pos_gt_off.new_tensor(s)
         if offset_pred.shape[0] == 0:
             losses.update(loss_offset=offset_pred.sum() * 0)
         else:
@@ -556,12 +571,7 @@ class LoftRoIHead(nn.Module):
                 for i in range(im.shape[0]):
                     segm_results[int(dl[i])].append(im[i])
         offset_pred = self._offset_forward(x, det_rois)
-        if isinstance(self.offset_head, OffsetHeadExpandFeature):
-            offset_results = self.offset_head.get_offsets(offset_pred, _bboxes.contiguous(), scale_factor, rescale)
-        else:
-            s = self.offset_head.offset_coder.stds
-            wh = _bboxes[:, 2:4] - _bboxes[:, 0:2]
-            offset_results = (offset_pred * offset_pred.new_tensor(s) * wh).clamp(-1024, 1024).cpu().numpy().astype(np.float32)
+        offset_results = self.offset_head.get_offsets(offset_pred, _bboxes.contiguous(), scale_factor, rescale)
         return bbox_results, segm_results, offset_results
 
     def forward_dummy(self, x, proposals):

@@ -218,7 +218,8 @@ class RPNHead(nn.Module):
             self._static[key] = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64,
                                              device=dev)
             self._static[('img_seg', B, C)] = torch.arange(B + 1, dtype=torch.int64, device=dev) * C
-        keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk))
+        keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk),
+                               predicate=cfg.get('nms_predicate', 'device'))
         masked = torch.where(keep.view(B, C).bool(), cscore, torch.full_like(cscore, -1.0))
         fs, fi = K.segmented_sort_desc(masked.reshape(-1), self._static[('img_seg', B, C)])
         post = min(cfg.nms_post, cfg.max_num) if cfg.get('max_num', 0) > 0 else cfg.nms_post

@@ -63,6 +63,16 @@ int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_segment);
 int loft_nms_segmented(const float* boxes, const int64_t* seg_offsets, const float* seg_shift, int num_segments,
                        int64_t total_boxes, int64_t max_segment, float iou_thr, void* workspace, uint8_t* keep,
                        void* stream);
+/* The same with the suppression predicate chosen by the caller.  mmcv-1.0.5 (not in the reference tree) has two:
+ * LOFT_NMS_PRED_DEVICE  inter > thr * union    -- its CUDA kernel, i.e. what the reference's GPU training and
+ *                                                 tools/test.py runs execute; loft_nms_segmented's behaviour, the default;
+ * LOFT_NMS_PRED_CPU     inter / union >= thr   -- its host path (nms_cpu).
+ * They differ exactly at IoU == thr (kept by the device form, suppressed by the host form). */
+#define LOFT_NMS_PRED_DEVICE 0
+#define LOFT_NMS_PRED_CPU 1
+int loft_nms_segmented_pred(const float* boxes, const int64_t* seg_offsets, const float* seg_shift, int num_segments,
+                            int64_t total_boxes, int64_t max_segment, float iou_thr, int predicate, void* workspace,
+                            uint8_t* keep, void* stream);
 /* Stable segmented sort by key, descending (ties keep input order) -- the `scores.sort(
  * descending=True)` of rpn_head.py:129 with a defined tie order.  Call with workspace == NULL to
  * query *workspace_bytes. */
@@ -196,6 +206,14 @@ int loft_foa_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_
                      void* stream);
 int loft_foa_fuse_decode(const float* pred, const float* boxes, int64_t n, float std_x, float std_y, float max_h,
                          float max_w, float* out, void* stream);
+/* Plain LOFT OffsetHead without FOA (attribute_heads/offset_head.py:118-188 get_targets, :190-243 get_offsets;
+ * DeltaXYOffsetCoder delta_xy_offset_coder.py:46-88).  targets: out [n,reg_num]; reg_num 2 = encoded (dx,dy), reg_num 3 =
+ * (length, cos(angle), sin(angle)) of the encoded pair (:176-183).  decode: pred [n,reg_num] -> out [n,2] pixels, clamped to
+ * +-(max_w,max_h); polar != 0 = offset_coordinate 'polar' (length*(cos,sin) of the decoded pair, :232-236). */
+int loft_offset_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_t n, float mean_x, float mean_y,
+                        float std_x, float std_y, int reg_num, float* out, void* stream);
+int loft_offset_decode(const float* pred, const float* boxes, int64_t n, float mean_x, float mean_y, float std_x, float std_y,
+                       float max_h, float max_w, int reg_num, int polar, float* out, void* stream);
 /* Mask targets on device (mmdet/core/mask/mask_target.py:33-62 -> structures.py:261-291):
  * masks u8 [K,H,W]; RoI i crops mask gt_idx[i] with box boxes[i] (clipped to the image) to SxS,
  * RoIAlign(avg, aligned, adaptive grid) >= 0.5 -> out fp32 {0,1} [n,S,S].  mask_addr (optional, device int64 [#instances]): the address of every instance mask -- gt_idx then

@@ -16,6 +16,7 @@ def lib():
     if _lib is None:
         _lib = ctypes.CDLL(build_oracle.build())
         _lib.orc_nms.restype = ctypes.c_int64
+        _lib.orc_nms_pred.restype = ctypes.c_int64
         _lib.orc_soft_nms.restype = ctypes.c_int64
     return _lib
 
@@ -79,12 +80,14 @@ def argsort_desc(scores):
     return order
 
 
-def nms(boxes, scores, iou_threshold):
-    """-> (dets [M,5], keep [M] int64), keep in score-descending order (mmcv.ops.nms contract)."""
+def nms(boxes, scores, iou_threshold, predicate='device'):
+    """-> (dets [M,5], keep [M] int64), keep in score-descending order (mmcv.ops.nms contract).
+    predicate: 'device' = mmcv-1.0.5's CUDA kernel (inter > thr*union), 'cpu' = its host nms_cpu (inter/union >= thr)."""
     boxes, scores = _f32(boxes), _f32(scores)
     n = boxes.shape[0]
     keep = torch.empty(n, dtype=torch.int64)
-    nk = lib().orc_nms(_p(boxes), _p(scores), ctypes.c_int64(n), ctypes.c_float(iou_threshold), _p(keep)) if n else 0
+    pred = {'device': 0, 'cpu': 1}[predicate]
+    nk = lib().orc_nms_pred(_p(boxes), _p(scores), ctypes.c_int64(n), ctypes.c_float(iou_threshold), pred, _p(keep)) if n else 0
     keep = keep[:nk]
     dets = torch.cat([boxes[keep], scores[keep, None]], dim=1)
     return dets, keep

@@ -265,6 +265,18 @@ def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.'):
     return torch.cat(outs, 0)
 
 
+def offset_head(sd, x, num_convs=4, num_fcs=2, prefix='roi_head.offset_head.'):
+    """roi_heads/attribute_heads/offset_head.py:90-106: num_convs x (conv3x3 + ReLU), flatten, num_fcs x (FC + ReLU), FC -> reg_num."""
+    if x.shape[0] == 0:
+        return x.new_empty(0, 2)
+    for i in range(num_convs):
+        x = F.relu(F.conv2d(x, sd[f'{prefix}convs.{i}.weight'], sd[f'{prefix}convs.{i}.bias'], padding=1))
+    h = x.reshape(x.shape[0], -1)
+    for i in range(num_fcs):
+        h = F.relu(_fc(sd, f'{prefix}fcs.{i}', h))
+    return _fc(sd, prefix + 'fc_offset', h)
+
+
 def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.choose_first,
                       num_classes=1):
     B = len(proposals)

@@ -173,8 +173,26 @@ static int iou_gt(const float* a, const float* b, float thr) {
     return inter > thr * uni;
 }
 
+/* Suppression predicate of the mmcv-1.0.5 HOST kernel (nms_cpu, offset = 0): ovr = inter / (Sa + Sb - inter); ovr >= thr.
+ * [mmcv-1.0.5, not in tree: restated from the published source; parity unpinned] */
+static int iou_ge_div(const float* a, const float* b, float thr) {
+    float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+    float inter = w * h;
+    float sa = (a[2] - a[0]) * (a[3] - a[1]);
+    float sb = (b[2] - b[0]) * (b[3] - b[1]);
+    float uni = sa + sb - inter;
+    return inter / uni >= thr;
+}
+
+int64_t orc_nms_pred(const float* boxes, const float* scores, int64_t n, float thr, int pred, int64_t* keep);
 /* Greedy NMS.  keep[] receives original indices in score-descending order; returns count. */
 int64_t orc_nms(const float* boxes, const float* scores, int64_t n, float thr, int64_t* keep) {
+    return orc_nms_pred(boxes, scores, n, thr, 0, keep);
+}
+/* pred 0: device predicate (inter > thr*union); pred 1: host predicate (inter/union >= thr). */
+int64_t orc_nms_pred(const float* boxes, const float* scores, int64_t n, float thr, int pred, int64_t* keep) {
     int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
     unsigned char* dead = (unsigned char*)calloc((size_t)(n > 0 ? n : 1), 1);
     orc_argsort_desc(scores, n, order);
@@ -185,7 +203,7 @@ int64_t orc_nms(const float* boxes, const float* scores, int64_t n, float thr, i
         keep[nk++] = i;
         for (int64_t _j = _i + 1; _j < n; ++_j) {
             if (dead[_j]) continue;
-            if (iou_gt(boxes + 4 * i, boxes + 4 * order[_j], thr)) dead[_j] = 1;
+            if (pred ? iou_ge_div(boxes + 4 * i, boxes + 4 * order[_j], thr) : iou_gt(boxes + 4 * i, boxes + 4 * order[_j], thr)) dead[_j] = 1;
         }
     }
     free(order); free(dead);

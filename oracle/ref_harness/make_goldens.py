@@ -241,6 +241,59 @@ def hrnet(size=128):
     print(f'hrnet_{size}.npz', [tuple(y.shape) for y in ys], [float(out[f'neck_{i}_absmean']) for i in range(5)], float(loss))
 
 
+def offset_head():
+    """Reference OffsetHead (attribute_heads/offset_head.py:23-265, the basic LOFT head without FOA): forward + loss + backward,
+    get_targets and get_offsets for the rectangular reg_num=2 head (SmoothL1 x16 as configs/loft_foa use, and the default MSE)
+    and the polar reg_num=3 variant.  Inputs are regenerated from names (synth_tensor), only expected outputs are stored."""
+    from mmdet.models.roi_heads.attribute_heads.offset_head import OffsetHead
+    from oracle.synth_weights import synth_tensor
+    out = {}
+    rng = np.random.RandomState(7)
+
+    class _Res:
+        pass
+
+    def boxes(n, size=1024.):
+        cx, cy = rng.uniform(0, size, n), rng.uniform(0, size, n)
+        w, h = rng.uniform(8, 200, n), rng.uniform(8, 200, n)
+        return torch.tensor(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).clip(0, size), dtype=torch.float32)
+    res, gt_offs = [], []
+    for i, n in enumerate((5, 0, 3)):                       # the middle image has no positives (offset_head.py:142-143)
+        r = _Res()
+        r.pos_bboxes = boxes(n)
+        r.pos_assigned_gt_inds = torch.tensor(rng.randint(0, 4, n), dtype=torch.long)
+        res.append(r)
+        gt_offs.append(torch.tensor(rng.uniform(-40, 40, (4, 2)), dtype=torch.float32))
+        out[f'pos_{i}'], out[f'ind_{i}'], out[f'gtoff_{i}'] = T(r.pos_bboxes), T(r.pos_assigned_gt_inds), T(gt_offs[-1])
+    det = boxes(8)
+    det[0] = torch.tensor([0., 0., 1024., 1024.])           # decode clamp at +-1024
+    out['det'] = T(det)
+    for tag, kw, nconv in (('rect', dict(reg_num=2, loss_offset=dict(type='SmoothL1Loss', loss_weight=16.0)), 2),
+                           ('mse', dict(reg_num=2), 1),
+                           ('polar', dict(reg_num=3, offset_coordinate='polar',
+                                          loss_offset=dict(type='SmoothL1Loss', loss_weight=16.0)), 1)):
+        head = OffsetHead(num_convs=nconv, **kw)
+        sd = {k: synth_tensor('roi_head.offset_head.' + k, v.shape) for k, v in head.state_dict().items()}
+        sd['fc_offset.weight'] = sd['fc_offset.weight'] * 30.0   # O(1) predictions so the SmoothL1 knee and the clamp are hit
+        head.load_state_dict(sd)
+        x = (synth_tensor(f'offset_head.x.{tag}', (8, 256, 7, 7)) * 1.0).requires_grad_(True)
+        pred = head(x)
+        tg = head.get_targets(res, gt_offs, None)
+        loss = head.loss(pred, tg)['loss_offset']
+        loss.backward()
+        out[f'{tag}_pred'], out[f'{tag}_targets'], out[f'{tag}_loss'] = T(pred), T(tg), T(loss)
+        out[f'{tag}_offsets'] = head.get_offsets(pred.detach(), det, None, False)
+        out[f'{tag}_empty_shape'] = np.array(head(x[:0]).shape)
+        for n, p_ in head.named_parameters():
+            if n in ('convs.0.weight', 'convs.0.bias', 'fcs.0.weight', 'fcs.1.bias', 'fc_offset.weight', 'fc_offset.bias'):
+                out[f'{tag}_gradnorm_{n}'] = T(p_.grad.norm())
+                out[f'{tag}_gradhead_{n}'] = T(p_.grad.reshape(-1)[:16])
+        out[f'{tag}_gradx_crop'] = T(x.grad[:, :8, :3, :3])
+        out[f'{tag}_gradx_norm'] = T(x.grad.norm())
+    np.savez_compressed(os.path.join(GOLD, 'offset_head.npz'), **out)
+    print('offset_head.npz', len(out), 'arrays', {k: float(out[k]) for k in out if k.endswith('_loss')}, out['polar_offsets'][:2])
+
+
 def data_pipeline():
     """Reference BONAI._parse_ann_info (bonai.py:105-256) and RandomFlip.bbox_flip/offset_flip (transforms.py:379-466) on
     synthetic annotations; the expected outputs are stored, the inputs are regenerated by synth_bonai_anns()."""
@@ -285,8 +338,12 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'hrnet':
         hrnet()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'offset_head':
+        offset_head()
+        sys.exit(0)
     core_ops()
     e2e()
     e2e_test()
     hrnet()
+    offset_head()
     data_pipeline()

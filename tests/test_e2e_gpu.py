@@ -59,6 +59,13 @@ def test_e2e_losses_features_grads_vs_reference_fixture():
             want = float(gd[k])
             got = float(grads[n].norm()) if n in grads else 0.0
             assert abs(got - want) <= 0.08 * max(1e-2, want), (n, got, want)
+            # element level (first 16 gradient entries of the reference run): a sign / permutation error inside a composite
+            # autograd node cannot hide behind a matching norm.  bf16 chain: 12 % of the head's own norm + a floor of the
+            # tensor's RMS entry.
+            wh = torch.from_numpy(gd['gradhead_' + n])
+            gh = grads[n].float().reshape(-1)[:16].cpu()
+            rms = want / grads[n].numel() ** 0.5
+            assert (gh - wh).norm().item() <= 0.12 * wh.norm().item() + 0.5 * rms, (n, gh, wh)
 
 
 def test_e2e_vs_oracle_proposals_and_targets():

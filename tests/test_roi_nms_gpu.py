@@ -115,6 +115,42 @@ def test_nms_segmented_matches_batched():
     assert kk == keep_ref.tolist()
 
 
+def _tie_boxes(rng, n):
+    """Boxes on a small integer lattice: many pairs whose IoU equals 0.5 EXACTLY (e.g. [0,0,1,2] vs [0,0,1,1]: inter 1, union 2),
+    which is where the two mmcv-1.0.5 predicates differ (device: inter > thr*union keeps; host: inter/union >= thr suppresses)."""
+    x1, y1 = rng.randint(0, 6, n), rng.randint(0, 6, n)
+    w, h = rng.randint(1, 4, n), rng.randint(1, 4, n)
+    return torch.tensor(np.stack([x1, y1, x1 + w, y1 + h], 1), dtype=torch.float32)
+
+
+@pytest.mark.parametrize('predicate', ['device', 'cpu'])
+def test_nms_predicate_at_threshold_ties(predicate):
+    """DESIGN.md 'NMS predicate': both published mmcv-1.0.5 predicates, bit-exact against the oracle, on inputs where they
+    differ; plus the two-box known answer."""
+    from bonai_amd import kernels as K
+    two = torch.tensor([[0., 0., 1., 2.], [0., 0., 1., 1.]])
+    sc2 = torch.tensor([0.9, 0.8])
+    _, keep = K.nms(two.cuda(), sc2.cuda(), 0.5, predicate=predicate)
+    assert keep.cpu().tolist() == ([0, 1] if predicate == 'device' else [0])          # IoU == thr exactly
+    rng = np.random.RandomState(11)
+    differ = 0
+    for n in (64, 500, 3000):
+        boxes = _tie_boxes(rng, n)
+        scores = torch.tensor(rng.permutation(n).astype(np.float32) / n)
+        _, kref = cops.nms(boxes, scores, 0.5, predicate=predicate)
+        _, kother = cops.nms(boxes, scores, 0.5, predicate='cpu' if predicate == 'device' else 'device')
+        differ += int(kref.tolist() != kother.tolist())
+        _, keep = K.nms(boxes.cuda(), scores.cuda(), 0.5, predicate=predicate)
+        assert keep.cpu().tolist() == kref.tolist()
+    assert differ >= 2          # the inputs do exercise the difference
+    # random float boxes: the two forms agree except (rarely) within one rounding of the threshold; each is bit-exact to its oracle
+    boxes = _rand_boxes(rng, 4000)
+    scores = torch.tensor(rng.uniform(0, 1, 4000), dtype=torch.float32)
+    _, kref = cops.nms(boxes, scores, 0.7, predicate=predicate)
+    _, keep = K.nms(boxes.cuda(), scores.cuda(), 0.7, predicate=predicate)
+    assert keep.cpu().tolist() == kref.tolist()
+
+
 def test_sort_stability():
     from bonai_amd import kernels as K
     rng = np.random.RandomState(3)

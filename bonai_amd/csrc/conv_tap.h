@@ -1,0 +1,120 @@
+// conv_tap.h -- shared pieces of the NHWC "tap" convolution kernels (conv_mfma.hip, conv_pipe.hip): argument block, LDS swizzle,
+// XCD-aware workgroup order and the fused epilogue.  See conv_mfma.hip for the contract.
+#pragma once
+#include "loft_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+#define CONV_MAX_TAPS 16
+#define BK 64
+
+struct ConvArgs {
+    const bf16_t* src;
+    const bf16_t* wgt;
+    const float* bias;
+    const bf16_t* residual;
+    const bf16_t* mask;      // optional: zero the result where mask <= 0 (ReLU backward of the tensor this gradient is for)
+    void* out;
+    const bf16_t* zero_page;
+    int B, IH, IW, Cin, Cout;
+    int OH, OW, OHf, OWf;
+    int os, oo_y, oo_x, ss;
+    int T;
+    int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    int relu, out_f32, accumulate;
+    long src_gs, wgt_gs, out_gs, bias_gs;
+    int M;
+    int pixmajor;            // FAST kernels on small RoI maps: tile rows enumerate (pixel, RoI) instead of (RoI, pixel) -- see below
+    int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
+    int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
+};
+
+__device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
+
+// XCD-aware workgroup order (speed only, never correctness): hardware places linear workgroup L on XCD L % 8, each with
+// a private L2.  Re-label so that every XCD works on ONE contiguous range of the logical tile order -- neighbouring
+// tiles (3x3 halo rows of adjacent pixel tiles; all taps / channel tiles of one pixel range in wgrad) then share an L2
+// instead of being fetched eight times.  Bijective for any workgroup count.
+__device__ __forceinline__ int xcd_remap(int L, int N) {
+    const int xcd = L & 7, q = N >> 3, r = N & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (L >> 3);
+}
+
+// Shared epilogue of the tap-conv kernels: bias (= folded BN shift) + residual + ReLU + ReLU-backward mask + bf16/fp32 store.
+// res_t / mask_t (optional): the 128x128 bf16 tiles of a.residual / a.mask staged in LDS by conv_stage_tile() with coalesced
+// 16-byte global->LDS copies (row r, logical 16-byte chunk c at r*256 + ((c ^ (r & 15)) * 16)); the per-lane 8-byte reads then
+// hit LDS instead of scattering 8-byte loads over 32 different 64-byte sectors of HBM/L2 per instruction.
+template <int NT, int MT, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NT][MT], int g, int m0, int n0, int wm, int wn,
+                                              int frow, int fq, int ohw, const char* res_t = nullptr,
+                                              const char* mask_t = nullptr, char* out_t = nullptr, bool pixmajor = false) {
+    // ---- epilogue: lane holds, per (i,j) tile, pixel m = ..+(lane&31) and 4x4 consecutive channels.
+    // (Measured alternatives, both slower on MI355X: swapping the MFMA operands so lanes run along channels and storing
+    //  2-byte scalars -- 5x slower, sub-dword stores do not coalesce; the same with a DPP pair exchange and dword stores in
+    //  64-byte runs -- 8 % slower end to end: store width per lane matters more than run contiguity, L2 merges the lines.)
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+    const long out_g = (long)g * a.out_gs;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * WM + j * 32 + frow;
+        if (m >= a.M) continue;
+        int b, rem;
+        if (pixmajor) { rem = m / a.B; b = m - rem * a.B; } else { b = m / ohw; rem = m - b * ohw; }
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * WN + i * 32 + 8 * gq + 4 * fq;
+                if (n >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                const long o = out_g + opix * a.Cout + n;
+                const int trow = wm * WM + j * 32 + frow;                      // position inside a staged 128x128 tile
+                const int tcol = (((wn * WN + i * 32 + 8 * gq) >> 3) ^ (trow & 15)) * 16 + 8 * fq;
+                if (a.residual) {
+                    float rv[4];
+                    if (res_t) ld4(reinterpret_cast<const bf16_t*>(res_t + trow * 256 + tcol), rv);
+                    else ld4(a.residual + o, rv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (a.mask) {
+                    float mv[4];
+                    if (mask_t) ld4(reinterpret_cast<const bf16_t*>(mask_t + trow * 256 + tcol), mv);
+                    else ld4(a.mask + o, mv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                }
+                if (out_t) {              // bf16 tile collected in LDS (same swizzle), written out by conv_unstage_tile
+                    st4(reinterpret_cast<bf16_t*>(out_t + trow * 256 + tcol), v);
+                } else if (a.out_f32) {
+                    float* op = reinterpret_cast<float*>(a.out) + o;
+                    if (a.accumulate) {
+                        float ov[4];
+                        ld4(op, ov);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                    }
+                    st4(op, v);
+                } else {
+                    st4(reinterpret_cast<bf16_t*>(a.out) + o, v);
+                }
+            }
+        }
+    }
+}

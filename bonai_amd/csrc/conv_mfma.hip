@@ -433,15 +433,18 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
     }
 }
 
-LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
-                                   const void* relu_mask, void* out,
-                                   const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
-                                   int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
-                                   const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
-                                   int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
-                                   void* stream) {
+int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, hipStream_t s);     // conv_pipe.hip
+
+LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,
+                                     const void* relu_mask, void* out,
+                                     const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                                     int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                                     const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
+                                     int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                                     int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
-    static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;   // A/B switch for benchmarking
+    const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
+    if (kern > LOFT_CONV_STREAM256 || (variant & ~0xffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -450,91 +453,128 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
     for (int t = 0; t < T; ++t) { a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t]; }
     a.relu = relu; a.out_f32 = out_f32; a.accumulate = accumulate;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
+    a.trace = nullptr;
+    fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
+    fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
+    fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
     const long M = (long)B * OH * OW;
     if (M <= 0) return 0;
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     hipStream_t s = (hipStream_t)stream;
     {
-        static const bool p64_off = getenv("LOFT_CONV_NO_PATCH64") != nullptr;
-        bool p64 = !p64_off && Cin == 64 && Cout == 64 && T >= 4 && T <= 9 && groups == 1 && ss == 1 && os == 1 && OH == IH && OW == IW &&
-                   OHf == OH && OWf == OW && oo_y == 0 && oo_x == 0 && !out_f32 && !accumulate && M >= 65536;
+        bool p64 = Cin == 64 && Cout == 64 && T >= 4 && T <= 9 && groups == 1 && ss == 1 && os == 1 && OH == IH && OW == IW &&
+                   OHf == OH && OWf == OW && oo_y == 0 && oo_x == 0 && !out_f32 && !accumulate;
         for (int t = 0; t < T && p64; ++t) p64 = dy_host[t] >= -1 && dy_host[t] <= 1 && dx_host[t] >= -1 && dx_host[t] <= 1;
-        if (p64) {
+        if (kern == LOFT_CONV_PATCH64 && !p64) return (int)hipErrorInvalidValue;
+        if (kern == LOFT_CONV_PATCH64 || (kern == LOFT_CONV_AUTO && p64 && M >= 65536)) {
             Conv64Args c;
             c.src = a.src; c.wgt = a.wgt; c.bias = bias; c.residual = a.residual; c.mask = a.mask; c.out = (bf16_t*)out;
             c.zero_page = a.zero_page; c.B = B; c.H = OH; c.W = OW; c.T = T; c.relu = relu;
             for (int t = 0; t < T; ++t) { c.dy[t] = dy_host[t]; c.dx[t] = dx_host[t]; c.wt[t] = wt_host[t]; }
             const int ptx = (OW + 15) / 16, pty = (OH + 15) / 16;
             const long np = (long)B * ptx * pty;
-            static const int cus = [] { int v = 256; hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0); return v; }();
+            int cus = 256;
+            { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
             const long nb = np < cus ? np : cus;
             const size_t lds_bytes = (size_t)T * 64 * 128 + 2 * 41 * 8 * 128;
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipFuncSetAttribute((const void*)conv64_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_set = true;
-            }
+            hipFuncSetAttribute((const void*)conv64_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(conv64_patch_kernel, dim3((unsigned)nb), dim3(512), lds_bytes, s, c, ptx, pty, (int)np);
             LOFT_LAUNCH_CHECK();
             return 0;
         }
     }
+    // Thresholds below are measured on MI355X; `variant` overrides the kernel choice for tests and A/B timing.
+    // staged_out: the 128x128 kernels collect a dense bf16 output tile in LDS and store it row-contiguously.
+    a.staged_out = !(variant & LOFT_CONV_FLAG_NO_STAGED_OUT) && !accumulate;
+    a.pixmajor = 0;
     // Channel-tile-fastest order when the activation is the big operand (it does not fit the 4 MiB L2 of an XCD but the packed
     // weights do): every channel tile of a pixel tile then runs back to back on one XCD and the pixel tile comes from HBM once
     // instead of once per channel tile.
-    static const int staged_out_mode = getenv("LOFT_CONV_STAGED_OUT") ? atoi(getenv("LOFT_CONV_STAGED_OUT")) : 1;
-    a.staged_out = staged_out_mode && !accumulate;
-    a.pixmajor = 0;
-    static const int nfast_mode = getenv("LOFT_CONV_NFAST") ? atoi(getenv("LOFT_CONV_NFAST")) : 1;
-    a.nfast = nfast_mode == 2 ? ((long)T * Cin * Cout * 2 <= (3L << 20)) : nfast_mode;
+    a.nfast = !(variant & LOFT_CONV_FLAG_NO_NFAST);
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
-    static const long deepk_min = getenv("LOFT_CONV_DEEPK") ? atol(getenv("LOFT_CONV_DEEPK")) : 2048;
-    static const long single_max = getenv("LOFT_CONV_SINGLE") ? atol(getenv("LOFT_CONV_SINGLE")) : 256;
-    const bool deepk = (long)T * Cin >= deepk_min;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
-    static const long big_min = getenv("LOFT_CONV_BIG_MIN") ? atol(getenv("LOFT_CONV_BIG_MIN")) : 192;
-    static const long big_k = getenv("LOFT_CONV_BIG_K") ? atol(getenv("LOFT_CONV_BIG_K")) : 512;
-    if (Cout % 256 == 0 && big_blocks >= big_min && (long)T * Cin >= big_k && !force_small_tile) {
+    const long Kdim = (long)T * Cin;
+    const bool deepk = Kdim >= 2048;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
+    // pixel-major enumeration of RoI-map tiles (FAST / pipelined 256-row kernels): taps that leave the map are skipped per tile
+    const bool pix_ok = !(variant & LOFT_CONV_FLAG_NO_PIXMAJOR) && T > 1 && T <= 32 && B >= 256 && OH * OW <= 1024 && os == 1 &&
+                        ss == 1 && OHf == OH && OWf == OW;
+    int k = kern;
+    if (k == LOFT_CONV_AUTO) {
+        if (Cout % 256 == 0 && big_blocks >= 192 && Kdim >= 512) {
+            // bf16 output without a shortcut operand: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue
+            // (conv_pipe.hip; +26..43 % over the lockstep kernel on the 3x3 / FC shapes); everything else: lockstep kernels
+            if (!out_f32 && !accumulate && !residual) k = LOFT_CONV_STREAM256;
+            else k = deepk ? LOFT_CONV_T256_FAST : LOFT_CONV_T256;
+        }
+        else if (Cout % 128 == 0) {
+            const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
+            const bool two_tiles = residual && relu_mask && dense_out;        // needs both halves of the double buffer
+            if (!two_tiles && a.staged_out && Kdim <= 256) k = LOFT_CONV_T128_SINGLE;
+            else k = deepk ? LOFT_CONV_T128_FAST : LOFT_CONV_T128;
+        } else k = LOFT_CONV_T128x64;
+    }
+    switch (k) {
+    case LOFT_CONV_STREAM256:
+    case LOFT_CONV_PIPE256:
+        // software-pipelined 256x256 kernels (conv_pipe.hip)
+        // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
+        if (Cout % 256 || out_f32 || accumulate || residual) return (int)hipErrorInvalidValue;
+        a.pixmajor = pix_ok;
+        a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
+        if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
+        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_STREAM256 ? 1 : 0, (variant >> 12) & 0xf, s);
+    case LOFT_CONV_T256_FAST:
+    case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
         // fills the 256 CUs and K is deep enough (>= 8 K-steps) to amortise the one-block-per-CU prologue/epilogue.
-        // (Measured and rejected in round 1: staging the bf16 output tile through LDS for 16-byte coalesced stores --
-        //  neutral on the K-shallow 1x1 convs, which are latency- not store-pattern-bound, and -10..20 % on dgrads;
-        //  4 waves of 128x128 (16 accumulator tiles per wave, 0.5 instead of 0.75 fragment reads per MFMA, one wave per
-        //  SIMD) -- 12 % slower than the 8-wave form with or without explicit fragment double-buffering + sched_group_barrier
-        //  hints: with one wave per SIMD the per-K-step vmcnt(0)+barrier is fully exposed;
-        //  a 4-stage pipeline with 32-channel K-steps (same 128 KiB of LDS, three global->LDS copies in flight, counted vmcnt
-        //  waits) -- correct, 4 % slower: the copies' latency is not what parks the waves.  SQ counters of the 8-wave form on
-        //  the P2 3x3: MFMA pipe busy 40 % of the SIMD cycles, waves parked on waitcnt/barrier 37 %, issue-stalled 39 %, LDS
-        //  bank conflicts 0, LDS array active 8 %: the remaining loss is barrier skew between the two waves of a SIMD plus the
-        //  un-overlapped prologue/epilogue of a one-block-per-CU kernel -- a persistent, software-pipelined rewrite is the fix.
-        //  Also rejected: 256x128 tiles with 4 waves (same 128x64 wave tile, 48/96 KiB LDS so two independent blocks share a
-        //  CU and cover each other's barriers), single- and double-buffered: 560 vs 780 TFLOP/s on the P2 / mask / FOA 3x3.
-        //  Reference point: hipBLASLt on the equivalent explicit GEMM (M=524288, N=256, K=2304) reaches 955 TFLOP/s.)
+        // (Round-1 measurements of rejected forms -- 4 waves of 128x128, 256x128 tiles with 4 waves, LDS-staged output -- are in
+        //  DESIGN.md; note that round 1's pipelining experiments ran with a compiler-inserted vmcnt(0) in front of every
+        //  K-step's fragment reads, see conv_tap_kernel.)
+        if (Cout % 256) return (int)hipErrorInvalidValue;
         dim3 grid(loft_cdiv(M, 256), Cout / 256, groups);
-        static const int pixmajor_mode = getenv("LOFT_CONV_PIXMAJOR") ? atoi(getenv("LOFT_CONV_PIXMAJOR")) : 1;
-        a.pixmajor = pixmajor_mode && deepk && T > 1 && T <= 32 && B >= 256 && OH * OW <= 1024 && os == 1 && ss == 1 &&
-                     OHf == OH && OWf == OW;
-        if (deepk) hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
-    } else if (Cout % 128 == 0) {
+        if (k == LOFT_CONV_T256_FAST) {
+            a.pixmajor = pix_ok;
+            hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4, 2, true>), grid, dim3(512), 0, s, a);
+        } else hipLaunchKernelGGL((conv_tap_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, a);
+        break;
+    }
+    case LOFT_CONV_T128_SINGLE:
+    case LOFT_CONV_T128_FAST:
+    case LOFT_CONV_T128: {
+        if (Cout % 128) return (int)hipErrorInvalidValue;
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
-        const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
-        const bool two_tiles = residual && relu_mask && dense_out;        // needs both halves of the double buffer
-        const bool staged_epi = (residual || relu_mask) && dense_out;
-        static const long single_res_max = getenv("LOFT_CONV_SINGLE_RES") ? atol(getenv("LOFT_CONV_SINGLE_RES")) : 256;
-        if (!force_small_tile && !two_tiles && a.staged_out &&
-            (long)T * Cin <= (staged_epi ? single_res_max : single_max))
+        if (k == LOFT_CONV_T128_SINGLE) {
+            const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
+            if (residual && relu_mask && dense_out) return (int)hipErrorInvalidValue;   // one LDS tile only
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);
-        else if (deepk)
+        } else if (k == LOFT_CONV_T128_FAST)
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2, 2, true>), grid, dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((conv_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
-    } else {
+        break;
+    }
+    case LOFT_CONV_T128x64: {
         dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 64), groups);
         hipLaunchKernelGGL((conv_tap_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, a);
+        break;
+    }
+    default:
+        return (int)hipErrorInvalidValue;
     }
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
+                                   const void* relu_mask, void* out,
+                                   const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                                   int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                                   const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
+                                   int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                                   void* stream) {
+    return loft_conv_tap_bf16_v(src, wgt, bias, residual, relu_mask, out, zero_page, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os,
+                                oo_y, oo_x, ss, T, dy_host, dx_host, wt_host, relu, out_f32, accumulate, groups, src_gs, wgt_gs,
+                                out_gs, bias_gs, LOFT_CONV_AUTO, stream);
 }
 
 // =====================================================================================
@@ -573,17 +613,6 @@ struct WgradArgs {
 };
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
-
-// n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)
-__device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned sh) {
-    return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> sh);
-}
-static inline void fastdiv_setup(unsigned d, unsigned* mul, unsigned* sh) {
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    *sh = l;
-}
 
 template <int RB>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {

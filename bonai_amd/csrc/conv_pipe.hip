@@ -1,0 +1,667 @@
+// conv_pipe.hip -- the deep-K form of the NHWC tap convolution (contract and epilogue: conv_mfma.hip / conv_tap.h) as a
+// software-pipelined 256 x 256 x 64 kernel for gfx950.
+//
+// Reference call sites served: every 3x3 / FC contraction with K = T*Cin >= 512 and Cout % 256 == 0 -- FPN output convs
+// (necks/fpn.py:170-199), the RPN 3x3 (dense_heads/rpn_head.py:38-44), bottleneck 3x3s (backbones/resnet.py:266-298), the
+// mask head (mask_heads/fcn_mask_head.py:118-126), the FOA branches (attribute_heads/offset_head_expand_feature.py:134-161)
+// and the shared FCs, forward and data gradient.
+//
+// Why a second kernel.  conv_tap_kernel<256,256,...> runs all eight waves in lockstep: per K-tile every wave issues its eight
+// global->LDS copies, waits at the barrier, reads 24 fragments, issues 32 MFMAs.  While the copies are being issued (60-180
+// cycles each, plus the per-row address selects) and while the barrier drains, the matrix pipe of every SIMD idles: 33 % of the
+// bf16 MFMA peak on the best shape.  Here the eight waves form TWO GROUPS of four (one wave of each group per SIMD) that run
+// the same instruction stream ONE BARRIER APART: a K-tile is cut into four phases, each phase = a "load" half (fragment reads of
+// one accumulator quadrant + ONE half-tile of global->LDS copies for a later K-tile: 2 copies per thread) and an "MFMA" half
+// (the quadrant's 8 v_mfma_f32_32x32x16_bf16), separated by raw s_barriers.  Because of the one-barrier stagger, in every slot
+// one wave of a SIMD issues MFMAs while its partner reads fragments / issues copies.  Copies stay in flight across barriers and
+// are retired by COUNTED s_waitcnt vmcnt(N) (never 0 in the steady state), placed one slot before the first read of the data.
+//
+// LDS (128 KiB, ONE array -- a second __shared__ object makes hipcc fence every ds_read behind all LDS-DMA):
+//   [W buf0 32K][W buf1 32K][X buf0 32K][X buf1 32K]; a tile = 256 rows x 128 B (64 bf16 of one K-tile), 16-byte chunk q of
+//   row r at slot q ^ ((r>>1)&7) (applied on the copy's per-lane SOURCE address and on the ds_read_b128 address).
+//   Half-tile pieces (16 KiB = 512 threads x 2 copies): W0/W1 = weight rows 0-127 / 128-255, X0/X1 = pixel rows 0-127 / 128-255.
+//   Wave (wm, wn): pixels [128 wm, +128) = X piece wm only; couts [64 wn, +64) = W piece wn>>1 only.
+//
+// Schedule.  Slot s = the code between barrier s-1 and barrier s.  Group 0 (wm = 0) runs L(t,p) in slot 8t+2p and M(t,p) in
+// 8t+2p+1; group 1 (wm = 1) one slot later.  Per K-tile t (buffer t&1), quadrants (p0/p1 = first/second 64 pixels, c0/c1 =
+// first/second 32 couts of the wave tile):
+//   L0: read X p0 (8 x b128), W c0 (4)      + issue W1(t+1)      M0: acc[c0][p0] (8 MFMA)
+//   L1: read W c1 (4)                       + issue X0(t+1)      M1: acc[c1][p0]
+//   L2: read X p1 (8, same registers)       + issue X1(t+1)      M2: acc[c1][p1]
+//   L3: (no reads) advance the tap/channel state, issue W0(t+2), s_waitcnt vmcnt(4)   -> retires X0(t+1) and older
+//   M3: acc[c0][p1] (W c0 still in registers),                  s_waitcnt vmcnt(2)   -> retires X1(t+1)
+// RAW (a piece is read only after EVERY issuing thread's counted wait and one more barrier): W1(t+1) issued in slots 8t/8t+1,
+//   X0(t+1) in 8t+2/3 -- retired in slots 8t+6/7, first read in slot 8t+8; X1(t+1) issued 8t+4/5, retired 8t+7/8, first read (by
+//   group 1 only) in 8t+9; W0(t+2) issued 8t+6/7, retired 8t+14/15, first read 8t+16.
+// WAR (a piece is overwritten no earlier than two slots after the last ds_read of its previous contents was ISSUED -- the reads
+//   are complete after the lgkmcnt wait that opens the reader's next slot): W(t-1) last read in slot 8t-5, X0(t-1) 8t-4,
+//   X1(t-1) 8t-3, all before slot 8t; W0(t) last read in slot 8t+3 (group 1's L1), overwritten from slot 8t+6.
+// Roofline: MFMA (dense bf16 2.5 PFLOP/s); algorithmic work 2*M*Cout*Cin*T FLOP per launch.
+#include "conv_tap.h"
+#include <type_traits>
+#include "../../include/loft_hip.h"
+
+namespace {
+constexpr int PW_OFF = 0, PX_OFF = 65536, PBUF = 32768, PLDS = 131072;
+}
+
+#define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
+#define PIPE_BARRIER()                      \
+    do {                                    \
+        PIPE_SB();                          \
+        __builtin_amdgcn_s_barrier();       \
+        PIPE_SB();                          \
+    } while (0)
+
+
+// Epilogue of the 256 x 256 kernels for bf16 outputs: bias + residual + ReLU + ReLU-backward mask as conv_epilogue, but every
+// HBM access of the tile is a whole 512-byte output-pixel row (16 bytes per lane, 32 lanes per row): the result tile (128 KiB
+// of bf16 = the LDS the K loop just released) is collected in LDS and copied out row by row; residual / mask tiles come in
+// the same way.  The direct form stores 8 bytes per lane to 64 different rows per instruction, 32 instructions per wave --
+// measured 25-27k cycles per workgroup on the 8 x 256^2 P2 conv against 108k for its whole K loop; this form: see DESIGN.md.
+// LDS image: row r (tile pixel row) x 32 chunks of 16 B, logical chunk c at position c ^ (r & 31).
+__device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const bf16_t* base, long out_g, int m, int n0, int ohw) {
+    int b, rem;
+    if (a.pixmajor) { rem = fastdiv(m, a.b_mul, a.b_sh); b = m - rem * a.B; }
+    else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
+    const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+    const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+    return base + out_g + opix * a.Cout + n0;
+}
+
+// bias + ReLU -> bf16 -> LDS -> whole rows out; the ReLU-backward mask (data-gradient launches) is applied in the copy-out pass on
+// the packed bf16 values against 16-byte mask loads with the address pattern of the stores -- the accumulators are dead by then.
+// (No residual input: launches with a shortcut operand are K-shallow and keep the 128-wide kernels.)
+template <typename StampFn>
+__device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[2][4], char* lds, int g, int m0, int n0, int wave,
+                                                     int lane, int ohw, StampFn&& kstamp) {
+    const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
+    const long out_g = (long)g * a.out_gs;
+    // (no bias: read zeros -- a branch around the adds makes hipcc keep two copies of the 128 accumulator registers)
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs + n0 + wn * 64 + 4 * fq : reinterpret_cast<const float*>(a.zero_page) + 4 * fq;
+    // This lane's 8-byte piece (4 couts) of block (i, gq) in tile row r = wm*128 + j*32 + frow is piece p = wn*16 + i*8 + 2*gq + fq,
+    // i.e. 16-byte chunk wn*8 + k (k = i*4 + gq) at position chunk ^ (r & 31) = ((wn ^ (frow>>3)) << 3) | (k ^ (frow & 7)):
+    // eight per-lane offsets, the row block j is a ds immediate (j * 16 KiB).
+    char* rowb = lds + (wm * 128 + frow) * 512 + fq * 8 + (((wn ^ (frow >> 3)) << 3) << 4);
+    const int f7 = frow & 7;
+    const float lo = a.relu ? 0.f : -__builtin_inff();          // ReLU as a branch-free max
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every wave is done with the K loop's fragments
+    kstamp(44);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = k >> 2, gq = k & 3;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + i * 32 + 8 * gq);
+        char* q = rowb + ((k ^ f7) << 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+            v[0] = fmaxf(acc[i][j][gq * 4 + 0] + bv.x, lo); v[1] = fmaxf(acc[i][j][gq * 4 + 1] + bv.y, lo);
+            v[2] = fmaxf(acc[i][j][gq * 4 + 2] + bv.z, lo); v[3] = fmaxf(acc[i][j][gq * 4 + 3] + bv.w, lo);
+            st4(reinterpret_cast<bf16_t*>(q + j * 16384), v);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    kstamp(46);
+    __syncthreads();
+    kstamp(47);
+    // LDS -> HBM, whole rows
+    const bf16_t* mask = a.mask;
+#pragma unroll 2
+    for (int it = 0; it < 16; ++it) {
+        const int r = wave * 32 + it * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ (r & 31);
+        const int m = m0 + r;
+        if (m < a.M) {
+            uint4 v = *reinterpret_cast<const uint4*>(lds + r * 512 + (lane & 31) * 16);
+            const bf16_t* p = pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw) + c * 8;
+            if (mask) {
+                const uint4 mk = *reinterpret_cast<const uint4*>(mask + (p - reinterpret_cast<const bf16_t*>(a.out)));
+                // keep a bf16 lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
+                auto sel = [](unsigned vv, unsigned mm) {
+                    const unsigned lo16 = ((mm & 0x8000u) == 0u && (mm & 0x7fffu) != 0u) ? 0xffffu : 0u;
+                    const unsigned hi16 = ((mm & 0x80000000u) == 0u && (mm & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+                    return vv & (lo16 | hi16);
+                };
+                v.x = sel(v.x, mk.x); v.y = sel(v.y, mk.y); v.z = sel(v.z, mk.z); v.w = sel(v.w, mk.w);
+            }
+            *reinterpret_cast<uint4*>(const_cast<bf16_t*>(p)) = v;
+        }
+    }
+    kstamp(48);
+}
+
+// VAR bits (A/B experiments, selected through the C-ABI variant argument; 0 = the shipped schedule):
+//   1 TRACE      lane 0 of every wave stores s_memtime at every barrier exit of K-tiles 8..11 to a.trace ([wave][32] u64)
+//   2 NOPRIO     no s_setprio around the MFMA clusters
+//   4 OLDORDER   fragment reads 12 / 4 / 8 / 0 per phase (W c0 read in L0 instead of the previous tile's L3)
+// MODE 0: "phase" schedule above.  MODE 1: "stream" schedule (below, after the phase loop's description): every wave runs ONE
+// software-pipelined instruction stream with a single barrier per K-tile.
+template <int MODE, int VAR>
+__global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
+    constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
+    constexpr bool TRACE = VAR & 1, NOPRIO = !ABL && (VAR & 2), OLDORDER = !ABL && (VAR & 4);
+    constexpr bool NOGLDS = ABL && ((VAR >> 1) & 3) == 0, NOREADS = ABL && ((VAR >> 1) & 3) == 1, NOMFMA = ABL && ((VAR >> 1) & 3) == 2,
+                   NOSEL = ABL && ((VAR >> 1) & 3) == 3;
+    __shared__ __attribute__((aligned(16))) char lds[PLDS];
+    unsigned long long kst0 = 0ull, kst1 = 0ull, kst2 = 0ull;
+    const int trace_b0 = gridDim.x > 1100 ? 1024 : 0;        // TRACE: a workgroup of a later round (steady state) when there is one
+    auto kstamp = [&](int slot) {                             // TRACE, outside the K loop: time stamp straight to the buffer
+        if constexpr (TRACE && MODE == 1) {
+            if ((int)blockIdx.x >= trace_b0 && (int)blockIdx.x < trace_b0 + 2 && blockIdx.y == 0 && blockIdx.z == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63) == 0)
+                    (reinterpret_cast<unsigned long long*>(a.trace) + ((long)(blockIdx.x - trace_b0) * 8 + (threadIdx.x >> 6)) * 64)[slot] = now;
+            }
+        }
+    };
+    if constexpr (TRACE && MODE == 1) kst0 = __builtin_amdgcn_s_memtime();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bz = V / (gridDim.x * gridDim.y), Vg = V - bz * (gridDim.x * gridDim.y);
+    const int bx = a.nfast ? Vg / gridDim.y : Vg % gridDim.x, by = a.nfast ? Vg % gridDim.y : Vg / gridDim.x;
+    const int m0 = bx * 256, n0 = by * 256;
+    const int g = bz;
+    const bf16_t* src = a.src + (long)g * a.src_gs;
+    const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const int ohw = a.OH * a.OW;
+    const int kchunks = a.Cin / BK;
+
+    // ---- rows this thread stages: i = 0..3 -> tile row i*64 + wave*8 + lrow (rows 64 apart share their swizzle)
+    const int srow = wave * 8 + lrow;
+    const int b_off0 = (n0 + srow) * a.Cin + swz(srow, lchunk) * 8;      // weight row of piece-row i: + i*64*Cin
+    const int b_step = 64 * a.Cin;
+    // Per-tap tables live in LANES (lane t = tap t) and are fetched with v_readlane: a kernarg (SMEM) load indexed by a loop
+    // counter costs a ~200-cycle round trip each (the tap-mask loop of round 1's kernels: 36 of them, 7k cycles per workgroup),
+    // and inside the K loop it would make hipcc wait lgkmcnt(0), i.e. for every fragment read in flight.
+    int tab_dy = 0, tab_dx = 0, tab_a = 0, tab_w = 0;
+    if (lane < a.T) {
+        tab_dy = a.dy[lane]; tab_dx = a.dx[lane];
+        tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
+        tab_w = a.wt[lane] * a.Cout * a.Cin;
+    }
+    kstamp(40);
+    const bf16_t* a_ptr[4];
+    unsigned a_mask[4];
+    int a_iy[4], a_ix[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 64 + srow;
+        const int m = m0 + row;
+        a_ptr[i] = src;
+        a_mask[i] = 0u;
+        a_iy[i] = -(1 << 20); a_ix[i] = -(1 << 20);
+        if (m < a.M) {
+            int b, rem;
+            if (a.pixmajor) { rem = fastdiv(m, a.b_mul, a.b_sh); b = m - rem * a.B; }
+            else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
+            const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+            a_iy[i] = oy * a.ss; a_ix[i] = ox * a.ss;
+            a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + swz(row, lchunk) * 8);
+        }
+    }
+    kstamp(41);
+    for (int t = 0; t < a.T; ++t) {
+        const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
+        }
+    }
+    kstamp(42);
+    // pixel-major tiles (RoI maps): taps that leave the map for every row of the tile are skipped (see conv_mfma.hip)
+    unsigned tmask = 0xffffffffu;
+    int nk = a.T * kchunks;
+    if (a.pixmajor) {
+        unsigned* wor = reinterpret_cast<unsigned*>(lds + PLDS - 64);   // inside X buf1's last row: first overwritten in slot 4
+        unsigned mm = a_mask[0] | a_mask[1] | a_mask[2] | a_mask[3];
+        for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
+        if (lane == 0) wor[wave] = mm;
+        __syncthreads();
+        tmask = 0u;
+#pragma unroll
+        for (int w2 = 0; w2 < 8; ++w2) tmask |= wor[w2];
+        tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)tmask);
+        nk = __popc(tmask) * kchunks;
+    }
+    // ---- wave-uniform state of the K-tile being STAGED: tap, channel offset, the tap's source / weight offsets
+    int st_t = 0, st_c = 0;
+    while (st_t < a.T - 1 && !((tmask >> st_t) & 1u)) ++st_t;
+    long st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+    const bf16_t* st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
+    // (stream mode: the weight pieces are issued one K-tile ahead of the activation pieces -> their own tap / channel state)
+    int sw_t = st_t, sw_c = 0;
+    auto advance_w = [&]() {
+        sw_c += BK;
+        if (sw_c == a.Cin) {
+            sw_c = 0;
+            ++sw_t;
+            while (sw_t < a.T && !((tmask >> sw_t) & 1u)) ++sw_t;
+            if (sw_t < a.T) st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
+        }
+    };
+    auto advance_x = [&]() {
+        st_c += BK;
+        if (st_c == a.Cin) {
+            st_c = 0;
+            ++st_t;
+            while (st_t < a.T && !((tmask >> st_t) & 1u)) ++st_t;
+            if (st_t < a.T) st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+        }
+    };
+    auto advance = [&]() {
+        st_c += BK;
+        if (st_c == a.Cin) {
+            st_c = 0;
+            ++st_t;
+            while (st_t < a.T && !((tmask >> st_t) & 1u)) ++st_t;
+            if (st_t < a.T) {
+                st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+                st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
+            }
+        }
+    };
+    bool in_loop = false;
+    auto issue_w = [&](auto halfc, auto bufc) {
+        constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
+        if constexpr (NOGLDS) { if (in_loop) return; }
+        const bf16_t* wt = st_w + (MODE == 1 ? sw_c : st_c) + b_off0;
+#pragma unroll
+        for (int i = 2 * H; i < 2 * H + 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + (long)i * b_step),
+                                             (lds_ptr_t)(lds + PW_OFF + B * PBUF + (i * 64 + wave * 8) * 128), 16, 0, 0);
+    };
+    auto issue_x = [&](auto halfc, auto bufc) {
+        constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
+        if constexpr (NOGLDS) { if (in_loop) return; }
+        const long aoff = st_aoff + st_c;
+#pragma unroll
+        for (int i = 2 * H; i < 2 * H + 2; ++i) {
+            const bf16_t* p = (NOSEL || ((a_mask[i] >> st_t) & 1u)) ? a_ptr[i] + aoff : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PX_OFF + B * PBUF + (i * 64 + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+    using c0_t = std::integral_constant<int, 0>;
+    using c1_t = std::integral_constant<int, 1>;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 31, fq = lane >> 5;
+    // fragment bases per 16-channel sub-step ks (the swizzle depends on ks); buffer / 32-row block offsets are ds_read immediates
+    const char* wb[4];
+    const char* xb[4];
+    {
+        const int rw = wn * 64 + frow, rx = wm * 128 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks * 2 + fq;
+            wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
+            xb[ks] = lds + PX_OFF + rx * 128 + swz(rx, q) * 16;
+        }
+    }
+
+    if constexpr (MODE == 1) {
+        // ================= stream schedule =================
+        // Per K-tile t (buffer B = t&1), 16-channel sub-steps ks = 0..3; fragment set F(t,ks) = 2 weight + 4 activation
+        // ds_read_b128.  Two register sets alternate (ks even -> fa, odd -> fb); the reads of a sub-step are issued ONE SUB-STEP
+        // AHEAD of its MFMAs, also across the tile boundary, so the matrix pipe never waits for LDS latency:
+        //   ks0: read F(t,1) -> fb | issue X(t+1) -> buffer 1-B (4 copies) | MFMA fa
+        //   ks1: read F(t,2) -> fa |                                       | MFMA fb
+        //   ks2: read F(t,3) -> fb |                                       | MFMA fa
+        //   SYNC: s_waitcnt vmcnt(0) (W(t+1), X(t+1) landed: issued >= 2.5 sub-steps ago), lgkmcnt(0) (this wave's reads of
+        //         buffer B are complete), s_barrier                            -- the ONLY barrier of the K-tile
+        //   ks3: read F(t+1,0) -> fa (buffer 1-B) | issue W(t+2) -> buffer B (4 copies) | MFMA fb
+        // RAW: every piece of K-tile t+1 is covered by the issuing thread's vmcnt(0) and the barrier of SYNC(t) before its first
+        // read in ks3(t).  WAR: buffer B is rewritten (W(t+2) in ks3(t), X(t+2) in ks0(t+1)) only behind SYNC(t), by which every
+        // wave has completed its last reads of buffer B (F(t,3), issued in ks2(t)).
+        bf16x8 fa[6], fb[6];
+        auto rd1 = [&](bf16x8 (&f)[6], auto bufc, auto ksc, auto idxc) {      // fragment idx of set F(., KS): 0,1 = W c0,c1; 2..5 = X
+            constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
+            if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
+            else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBUF + I * 4096);
+            else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBUF + (I - 2) * 4096);
+        };
+        auto mm2 = [&](bf16x8 (&f)[6], auto jc) {                               // the two MFMAs of pixel block j
+            constexpr int J = decltype(jc)::value;
+            if constexpr (NOMFMA) { asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2 + J])); }
+            else {
+                acc[0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[2 + J], acc[0][J], 0, 0, 0);
+                acc[1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[2 + J], acc[1][J], 0, 0, 0);
+            }
+        };
+        using k0_t = std::integral_constant<int, 0>;
+        using k1_t = std::integral_constant<int, 1>;
+        using k2_t = std::integral_constant<int, 2>;
+        using k3_t = std::integral_constant<int, 3>;
+        using i4_t = std::integral_constant<int, 4>;
+        using i5_t = std::integral_constant<int, 5>;
+        // one sub-step: 8 MFMAs on `cur` with the 6 reads of `nxt` (and up to four copies) pinned between MFMA pairs -- every
+        // other instruction issues in the shadow of an MFMA of this wave instead of in front of the whole cluster
+        unsigned long long stp[24];
+        int stn = 0, cur_t = 0;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) stp[i] = 0ull;
+        // TRACE: s_memtime into SGPRs with NO wait (a compiler-visible use would force lgkmcnt(0) and distort the time line);
+        // the values are stored after the traced tiles behind one explicit wait
+#define STREAM_STAMP(slot)                                                                                     \
+        do {                                                                                                   \
+            if constexpr (TRACE) {                                                                             \
+                if (cur_t == 8 || cur_t == 9) asm volatile("s_memtime %0" : "=s"(stp[(slot)]));              \
+            }                                                                                                  \
+        } while (0)
+        auto substep = [&](bf16x8 (&cur)[6], bf16x8 (&nxt)[6], auto bufc, auto ksc, bool do_read, auto&& copy0, auto&& copy1, auto slotc) {
+            constexpr int SL = decltype(slotc)::value;
+            STREAM_STAMP(SL);
+            PIPE_SB();
+            mm2(cur, k0_t{});
+            PIPE_SB();
+            STREAM_STAMP(SL + 1);
+            if (do_read) { rd1(nxt, bufc, ksc, k0_t{}); rd1(nxt, bufc, ksc, k1_t{}); }
+            PIPE_SB();
+            mm2(cur, k1_t{});
+            if (do_read) { rd1(nxt, bufc, ksc, k2_t{}); rd1(nxt, bufc, ksc, k3_t{}); }
+            copy0();
+            PIPE_SB();
+            mm2(cur, k2_t{});
+            if (do_read) { rd1(nxt, bufc, ksc, i4_t{}); rd1(nxt, bufc, ksc, i5_t{}); }
+            PIPE_SB();
+            mm2(cur, k3_t{});
+            copy1();
+            PIPE_SB();
+        };
+        auto nop = [] {};
+        // prologue: W(0), X(0), W(1)
+        unsigned long long kst_setup = 0ull;
+        if constexpr (TRACE) kst_setup = __builtin_amdgcn_s_memtime();
+        issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
+        issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
+        if (nk > 1) {
+            advance_w(); advance_x();
+            issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
+            advance_w();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PIPE_BARRIER();
+        in_loop = true;
+#pragma unroll
+        for (int ks = 0; ks < 1; ++ks) {
+            rd1(fa, c0_t{}, k0_t{}, k0_t{}); rd1(fa, c0_t{}, k0_t{}, k1_t{}); rd1(fa, c0_t{}, k0_t{}, k2_t{});
+            rd1(fa, c0_t{}, k0_t{}, k3_t{}); rd1(fa, c0_t{}, k0_t{}, i4_t{}); rd1(fa, c0_t{}, k0_t{}, i5_t{});
+        }
+        auto stile = [&](auto bufc, bool has1, bool has2) {
+            constexpr int B = decltype(bufc)::value;
+            using other_t = std::integral_constant<int, 1 - B>;
+            // ---- ks0: MFMA fa, read F(t,1) -> fb, issue X(t+1) -> buffer 1-B
+            using s0_t = std::integral_constant<int, 12 * B + 0>;
+            using s1_t = std::integral_constant<int, 12 * B + 2>;
+            using s2_t = std::integral_constant<int, 12 * B + 4>;
+            using s3_t = std::integral_constant<int, 12 * B + 8>;
+            substep(fa, fb, bufc, k1_t{}, true,
+                    [&] { if (has1) issue_x(c0_t{}, other_t{}); },
+                    [&] { if (has1) { issue_x(c1_t{}, other_t{}); advance_x(); } }, s0_t{});
+            // ---- ks1, ks2
+            substep(fb, fa, bufc, k2_t{}, true, nop, nop, s1_t{});
+            substep(fa, fb, bufc, k3_t{}, true, nop, nop, s2_t{});
+            // ---- SYNC
+            if (has1) {
+                STREAM_STAMP(12 * B + 6);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                STREAM_STAMP(12 * B + 7);
+                PIPE_BARRIER();
+            }
+            // ---- ks3: MFMA fb, read F(t+1,0) -> fa from buffer 1-B, issue W(t+2) -> buffer B
+            substep(fb, fa, other_t{}, k0_t{}, has1,
+                    [&] { if (has2) issue_w(c0_t{}, bufc); },
+                    [&] { if (has2) { issue_w(c1_t{}, bufc); advance_w(); } }, s3_t{});
+            STREAM_STAMP(12 * B + 10);
+            ++cur_t;
+            if constexpr (TRACE) {
+                if (cur_t == 10 && (int)blockIdx.x >= trace_b0 && (int)blockIdx.x < trace_b0 + 2 && blockIdx.y == 0 && blockIdx.z == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    PIPE_SB();
+                    unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.trace) + ((long)(blockIdx.x - trace_b0) * 8 + wave) * 64;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 24; ++i) tr[i] = stp[i];
+                        unsigned hwid;
+                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                        tr[63] = hwid;
+                    }
+                }
+            }
+        };
+        if constexpr (TRACE) kst1 = __builtin_amdgcn_s_memtime();
+        for (int t = 0; t < nk; t += 2) {
+            stile(c0_t{}, t + 1 < nk, t + 2 < nk);
+            if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+        }
+        if constexpr (TRACE) kst2 = __builtin_amdgcn_s_memtime();
+        if constexpr (VAR & 2)
+            conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
+                                         a.pixmajor != 0);
+        else pipe_epilogue_staged(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        if constexpr (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long kst3 = __builtin_amdgcn_s_memtime();
+            if ((int)blockIdx.x >= trace_b0 && (int)blockIdx.x < trace_b0 + 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+                unsigned long long* tr = reinterpret_cast<unsigned long long*>(a.trace) + ((long)(blockIdx.x - trace_b0) * 8 + wave) * 64;
+                tr[32] = kst0; tr[33] = kst1; tr[34] = kst2; tr[35] = kst3; tr[36] = kst_setup;
+            }
+        }
+        return;
+    }
+    // ---- prologue: all of K-tile 0 and W0 of K-tile 1
+    issue_w(c0_t{}, c0_t{});
+    issue_w(c1_t{}, c0_t{});
+    issue_x(c0_t{}, c0_t{});
+    issue_x(c1_t{}, c0_t{});
+    if (nk > 1) {
+        advance();
+        issue_w(c0_t{}, c1_t{});
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PIPE_BARRIER();
+    if (wm == 1) PIPE_BARRIER();          // the stagger: group 1 runs one slot behind group 0
+
+    bf16x8 wf0[4];                       // W c0 of the CURRENT K-tile: read one phase early (previous tile's L3)
+    unsigned long long* trace = nullptr;
+    int trace_n = 0;
+    if constexpr (TRACE) {
+        trace = reinterpret_cast<unsigned long long*>(a.trace) + ((long)(blockIdx.x == 0 ? 0 : 1) * 8 + wave) * 64;
+        if (blockIdx.x < 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            trace[63] = hwid;
+        }
+    }
+    auto stamp = [&](int t) {
+        if constexpr (TRACE) {
+            if (t >= 8 && t < 11 && blockIdx.x < 2 && blockIdx.y == 0 && blockIdx.z == 0 && trace_n < 63) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if (lane == 0) trace[trace_n] = now;
+                ++trace_n;
+            }
+        }
+    };
+#define PIPE_PRIO(p) do { if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(p); } while (0)
+    if constexpr (!OLDORDER) {
+        // W c0 of K-tile 0 (retired by the prologue wait + barrier above)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf0[ks] = *reinterpret_cast<const bf16x8*>(wb[ks]);
+    }
+
+    in_loop = true;
+    auto rd = [&](const char* p) {
+        if constexpr (NOREADS) { bf16x8 v; asm volatile("" : "=v"(v)); return v; }
+        else return *reinterpret_cast<const bf16x8*>(p);
+    };
+    auto mm = [&](bf16x8 w_, bf16x8 x_, f32x16 c_) {
+        if constexpr (NOMFMA) { asm volatile("" :: "v"(w_), "v"(x_)); return c_; }
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, c_, 0, 0, 0);
+    };
+    auto tile = [&](auto bufc, int t, bool has1, bool has2) {
+        constexpr int B = decltype(bufc)::value;
+        using other_t = std::integral_constant<int, 1 - B>;
+        bf16x8 xf[2][4], wf1[4], wfn[4];
+        // ---------------- L0: X p0 (+ W c0 in the old order); issue W1(t+1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (OLDORDER) wf0[ks] = rd(wb[ks] + B * PBUF);
+            xf[0][ks] = rd(xb[ks] + B * PBUF);
+            xf[1][ks] = rd(xb[ks] + B * PBUF + 4096);
+        }
+        if (has1) issue_w(c1_t{}, other_t{});
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- M0
+        if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PIPE_SB(); stamp(t); }
+        PIPE_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = mm(wf0[ks], xf[0][ks], acc[0][0]);
+            acc[0][1] = mm(wf0[ks], xf[1][ks], acc[0][1]);
+        }
+        PIPE_PRIO(0);
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- L1: W c1; issue X0(t+1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf1[ks] = rd(wb[ks] + B * PBUF + 4096);
+        if (has1) issue_x(c0_t{}, other_t{});
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- M1
+        if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PIPE_SB(); stamp(t); }
+        PIPE_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[1][0] = mm(wf1[ks], xf[0][ks], acc[1][0]);
+            acc[1][1] = mm(wf1[ks], xf[1][ks], acc[1][1]);
+        }
+        PIPE_PRIO(0);
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- L2: X p1 (same registers); issue X1(t+1); retire W1(t+1) (new order: it is read in L3)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            xf[0][ks] = rd(xb[ks] + B * PBUF + 8192);
+            xf[1][ks] = rd(xb[ks] + B * PBUF + 12288);
+        }
+        if (has1) issue_x(c1_t{}, other_t{});
+        if constexpr (!OLDORDER) {
+            if (has1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // in flight: X0(t+1), X1(t+1)
+        }
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- M2
+        if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PIPE_SB(); stamp(t); }
+        PIPE_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[1][2] = mm(wf1[ks], xf[0][ks], acc[1][2]);
+            acc[1][3] = mm(wf1[ks], xf[1][ks], acc[1][3]);
+        }
+        PIPE_PRIO(0);
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- L3: (new order) W c0 of K-tile t+1; advance the staging state, issue W0(t+2); retire X0(t+1)
+        if constexpr (!OLDORDER) {
+            if (has1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wfn[ks] = rd(wb[ks] + (1 - B) * PBUF);
+            }
+        }
+        if (has2) {
+            advance();
+            issue_w(c0_t{}, bufc);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+        // ---------------- M3
+        if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PIPE_SB(); stamp(t); }
+        PIPE_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][2] = mm(wf0[ks], xf[0][ks], acc[0][2]);
+            acc[0][3] = mm(wf0[ks], xf[1][ks], acc[0][3]);
+        }
+        PIPE_PRIO(0);
+        if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!OLDORDER) {
+            if (has1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wf0[ks] = wfn[ks];
+            }
+        }
+        stamp(t);
+        PIPE_BARRIER();
+        stamp(t);
+    };
+
+    for (int t = 0; t < nk; t += 2) {
+        tile(c0_t{}, t, t + 1 < nk, t + 2 < nk);
+        if (t + 1 < nk) tile(c1_t{}, t + 1, t + 2 < nk, t + 3 < nk);
+    }
+    if (wm == 0) PIPE_BARRIER();          // barrier counts of the two groups match again
+
+    pipe_epilogue_staged(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+}
+
+// host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
+int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, hipStream_t s) {
+    dim3 grid(loft_cdiv(a.M, 256), a.Cout / 256, groups);
+#define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
+    if (mode == 1) {
+        switch (var) {
+        case 0: PIPE_LAUNCH(1, 0); break;
+        case 1: PIPE_LAUNCH(1, 1); break;
+        case 2: PIPE_LAUNCH(1, 2); break;      // direct (unstaged) epilogue
+        case 3: PIPE_LAUNCH(1, 3); break;
+        case 8: PIPE_LAUNCH(1, 8); break;
+        case 10: PIPE_LAUNCH(1, 10); break;
+        case 12: PIPE_LAUNCH(1, 12); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+    } else {
+        switch (var) {
+        case 0: PIPE_LAUNCH(0, 0); break;
+        case 1: PIPE_LAUNCH(0, 1); break;
+        case 4: PIPE_LAUNCH(0, 4); break;
+        case 5: PIPE_LAUNCH(0, 5); break;
+        case 8: PIPE_LAUNCH(0, 8); break;
+        case 10: PIPE_LAUNCH(0, 10); break;
+        case 12: PIPE_LAUNCH(0, 12); break;
+        default: return (int)hipErrorInvalidValue;
+        }
+    }
+#undef PIPE_LAUNCH
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -30,7 +30,20 @@ struct ConvArgs {
     int pixmajor;            // FAST kernels on small RoI maps: tile rows enumerate (pixel, RoI) instead of (RoI, pixel) -- see below
     int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
     int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
+    void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
+    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
 };
+
+// n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned sh) {
+    return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> sh);
+}
+static inline void fastdiv_setup(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    *sh = l;
+}
 
 __device__ __forceinline__ int swz(int row, int q) { return q ^ ((row >> 1) & 7); }
 

@@ -51,10 +51,20 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
 __device__ __forceinline__ void st4(float* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// two fp32 -> packed bf16 pair with the hardware conversion (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN) -- the
+// software form above costs a compare + divergent branch per element, which in the conv epilogues meant thousands of tiny basic
+// blocks (and register spills) per workgroup
+typedef __attribute__((ext_vector_type(2))) float loft_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 loft_bf16x2;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const loft_f32x2 v = {lo, hi};
+    const loft_bf16x2 r = __builtin_convertvector(v, loft_bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ void st4(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.x = pack2_bf16(v[0], v[1]);
+    t.y = pack2_bf16(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = t;
 }
 

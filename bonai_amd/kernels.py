@@ -284,6 +284,14 @@ def _bf16(t):
     return t
 
 
+# include/loft_hip.h LOFT_CONV_*: kernel selector of loft_conv_tap_bf16_v.  0 = the library's shape heuristics (the shipped path).
+# tests / tools set CONV_VARIANT to a code, or to a callable (groups, B, OH, OW, Cin, Cout, T, ss, os) -> code, to pin a template.
+CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_FAST, CONV_T128, CONV_T128x64, CONV_PATCH64, \
+    CONV_STREAM256 = range(10)
+CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT = 0x100, 0x200, 0x400
+CONV_VARIANT = CONV_AUTO
+
+
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
              residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None):
     """Raw launch of loft_conv_tap_bf16 (or loft_conv_tap_f32 when every operand is fp32: the forward-only parity mode).
@@ -313,11 +321,12 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
     if not out_f32:
         _bf16(out)
     _ev = _prof_begin()
-    L.check(lib.loft_conv_tap_bf16(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
-                                   L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
-                                   oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
-                                   c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
-            'loft_conv_tap_bf16')
+    variant = CONV_VARIANT(groups, B, OH, OW, Cin, Cout, T, ss, os) if callable(CONV_VARIANT) else CONV_VARIANT
+    L.check(lib.loft_conv_tap_bf16_v(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
+                                     L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
+                                     oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
+                                     c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), int(variant),
+                                     L.stream()), 'loft_conv_tap_bf16_v')
     _prof_end(_ev, 'conv_tap', 2.0 * groups * B * OH * OW * Cout * Cin * T, (groups, B, OH, OW, Cin, Cout, T, ss, os))
     return out
 

@@ -105,6 +105,28 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
                        int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                        const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
                        int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream);
+/* The same with the kernel chosen by the caller instead of the shape heuristics (tests pin every template the bench
+ * dispatches; A/B timing).  variant = one LOFT_CONV_* kernel code, optionally OR-ed with LOFT_CONV_FLAG_*; LOFT_CONV_AUTO is
+ * loft_conv_tap_bf16.  A kernel that cannot serve the shape returns hipErrorInvalidValue (1). */
+#define LOFT_CONV_AUTO 0
+#define LOFT_CONV_PIPE256 1      /* 256x256x64, two wave groups one barrier apart, counted vmcnt (Cout % 256 == 0) */
+#define LOFT_CONV_T256_FAST 2    /* 256x256x64, lockstep double buffer, hoisted addressing (Cout % 256 == 0) */
+#define LOFT_CONV_T256 3
+#define LOFT_CONV_T128_SINGLE 4  /* 128x128x64, one LDS stage, 4 waves per SIMD (K-shallow launches; Cout % 128 == 0) */
+#define LOFT_CONV_T128_FAST 5
+#define LOFT_CONV_T128 6
+#define LOFT_CONV_T128x64 7      /* any Cout % 4 == 0 */
+#define LOFT_CONV_PATCH64 8      /* 64 -> 64 channels, stride 1, <= 3x3: halo patch kernel */
+#define LOFT_CONV_STREAM256 9    /* 256x256x64, one software-pipelined stream per wave, one barrier per K-tile (Cout % 256 == 0) */
+#define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
+#define LOFT_CONV_FLAG_NO_NFAST 0x200
+#define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400
+int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual, const void* relu_mask,
+                         void* out,
+                         const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
+                         int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
+                         const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
+                         int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int variant, void* stream);
 /* loft_conv_tap_f32: the fp32 parity mode of the same contract (all operands and the output fp32, contraction on
  * v_mfma_f32_32x32x2_f32 = exact fp32 products and sums).  Forward / data-gradient only; it exists so inference results can
  * be checked against the reference's fp32 outputs at the north-star tolerance (1e-3), not for speed.  Cin % 32 == 0. */

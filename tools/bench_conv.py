@@ -18,8 +18,9 @@ SHAPES = [
     ('layer4.1x1.512-2048', 8, 512, 2048, 32, 32, 1, 1, 0, 1),
     ('fpn.P2.3x3', 8, 256, 256, 256, 256, 3, 1, 1, 1),
     ('fpn.P3.3x3', 8, 256, 256, 128, 128, 3, 1, 1, 1),
-    ('mask.3x3(1000roi)', 1000, 256, 256, 14, 14, 3, 1, 1, 1),
-    ('foa.3x3(4x1000roi)', 4000, 256, 256, 7, 7, 3, 1, 1, 4),
+    ('mask.3x3(872roi)', 872, 256, 256, 14, 14, 3, 1, 1, 1),
+    ('foa.3x3(4x872roi)', 3488, 256, 256, 7, 7, 3, 1, 1, 4),
+    ('rpn.P2.3x3+fpn', 8, 256, 256, 256, 256, 3, 1, 1, 1),
     ('fc1(8192x12544x1024)', 8192, 12544, 1024, 1, 1, 1, 1, 0, 1),
 ]
 
@@ -51,7 +52,21 @@ def main():
         g = torch.randn_like(y)
         row = f'{name:28s} {gflop:8.1f} '
         for wh in which:
-            if wh == 'fwd':
+            if wh == 'pipe':
+                if Cout % 256:
+                    row += f'{"-":>10s} {"-":>8s} '
+                    continue
+                K.CONV_VARIANT = K.CONV_PIPE256
+                ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
+                K.CONV_VARIANT = K.CONV_AUTO
+            elif wh == 'pipe_dgrad':
+                if Cin % 256 or st != 1:
+                    row += f'{"-":>10s} {"-":>8s} '
+                    continue
+                K.CONV_VARIANT = K.CONV_PIPE256
+                ms = timeit(lambda: K.conv2d_dgrad(g, wpt, (H, W), R, R, st, pad, groups=G))
+                K.CONV_VARIANT = K.CONV_AUTO
+            elif wh == 'fwd':
                 ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
             elif wh == 'dgrad':
                 ms = timeit(lambda: K.conv2d_dgrad(g, wpt, (H, W), R, R, st, pad, groups=G))

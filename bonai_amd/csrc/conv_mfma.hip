@@ -588,32 +588,6 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
 // Split-K over pixel ranges (grid.z) with fp32 atomic accumulation into dW (caller zeroes it).
 // Rows are 256 B = one full bank row, so 16-byte chunk q of pixel row r is stored at q ^ ((r&3)<<2).
 // =====================================================================================
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-struct WgradArgs {
-    const bf16_t* g;
-    const bf16_t* x;
-    float* dw;
-    const bf16_t* zero_page;
-    int B, GH, GW, Cout, XH, XW, Cin, OH, OW;
-    int gos, ss, T;
-    int goy[CONV_MAX_TAPS], gox[CONV_MAX_TAPS], dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
-    long g_gs, x_gs, dw_gs;
-    int M, pix_per_split, ctiles;
-    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW and OW via multiply-high (host-computed)
-    float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
-    int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
-    // PM form (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs; stride 1): the K dimension of tap t runs over
-    // (position inside the tap's valid rectangle, RoI) -- rows whose tap leaves the map (18 % of a 7x7 map's 3x3 taps, 9 % of a
-    // 14x14 one) are never staged, and every tap gets a number of K-splits proportional to its valid rows so that all
-    // workgroups run the same number of K-steps.  Workgroup j of a group serves tap t with pm_blk0[t] <= j < pm_blk0[t+1].
-    int pm_blk0[CONV_MAX_TAPS + 1], pm_pps[CONV_MAX_TAPS], pm_rows[CONV_MAX_TAPS];
-    int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
-    unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
-};
-
-__device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
-
 template <int RB>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
     // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][RB/2] bf16 tile (RB bytes per pixel row):
@@ -1047,12 +1021,15 @@ LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* 
 }
 
 
-LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
-                                     int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
-                                     const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
-                                     const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
-                                     int splits, float* db, int db_tap, void* stream) {
+int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStream_t s);     // conv_wgrad_pipe.hip
+
+LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                                       int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                       const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                                       int splits, float* db, int db_tap, int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 8) || (Cout % 8) || groups < 1) return (int)hipErrorInvalidValue;
+    if (variant < LOFT_WGRAD_AUTO || variant > LOFT_WGRAD_T128) return (int)hipErrorInvalidValue;
     const bool narrow = (Cin % 128) || (Cout % 128);
     WgradArgs a;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
@@ -1069,19 +1046,21 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     a.M = (int)M;
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
     fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
-    static const bool force_small_tile = getenv("LOFT_CONV_SMALL_TILE") != nullptr;
     // 256x256 tiles only when >= 256 workgroups can each run >= ~32 K-steps (else the 65k-atomic epilogue dominates)
-    const bool big = (Cout % 256 == 0) && (Cin % 256 == 0) && !force_small_tile &&
-                     M * (long)(Cout / 256) * (Cin / 256) * T * groups >=
-                         (getenv("LOFT_WGRAD_BIG_MIN") ? atol(getenv("LOFT_WGRAD_BIG_MIN")) : 524288L);
+    const bool big_ok = (Cout % 256 == 0) && (Cin % 256 == 0);
+    if ((variant == LOFT_WGRAD_STREAM256 || variant == LOFT_WGRAD_T256) && !big_ok) return (int)hipErrorInvalidValue;
+    if (variant == LOFT_WGRAD_T128 && narrow) return (int)hipErrorInvalidValue;
+    const bool big = variant == LOFT_WGRAD_AUTO ? (big_ok && M * (long)(Cout / 256) * (Cin / 256) * T * groups >= 524288L)
+                                                : (variant != LOFT_WGRAD_T128);
+    const bool piped = big && variant != LOFT_WGRAD_T256;       // the software-pipelined form (conv_wgrad_pipe.hip)
     const int TNv = narrow ? 64 : (big ? 256 : 128);
     a.ctiles = (Cin + TNv - 1) / TNv;
     const int tiles = ((Cout + TNv - 1) / TNv) * a.ctiles;
     if (splits <= 0) {
         // split-K factor: ~512 workgroups (two resident 128-tile workgroups per CU).  More splits only add fp32 atomic
         // traffic to dW -- measured on the 1x1 shapes: 1024 workgroups 202-222 TFLOP/s, 512: 279-305, 256: 261-274.
-        static const long tgt_small = getenv("LOFT_WGRAD_TARGET") ? atol(getenv("LOFT_WGRAD_TARGET")) : 512;
-        static const long tgt_big = getenv("LOFT_WGRAD_TARGET_BIG") ? atol(getenv("LOFT_WGRAD_TARGET_BIG")) : 256;   // 256-tile: one workgroup per CU
+        const long tgt_small = 512;
+        const long tgt_big = 256;   // 256-tile: one workgroup per CU
         // (big tile, measured: 256 workgroups 708-791 TFLOP/s on the FOA / mask / P2-P3 3x3 shapes, 512: 606-754, 1024: 474-719)
         // (also measured: a single-stage 128-tile form at four workgroups per CU -- what helped the K-shallow forward convs --
         //  changes nothing here, with 512 or 1024 workgroups: these launches are bound by the fp32-atomic epilogue and the
@@ -1093,8 +1072,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     int pps = (int)((M + splits - 1) / splits);
     pps = ((pps + 63) / 64) * 64;
     a.pix_per_split = pps;
-    static const int pm_mode = getenv("LOFT_WGRAD_PIXMAJOR") ? atoi(getenv("LOFT_WGRAD_PIXMAJOR")) : 1;
-    if (pm_mode && !narrow && T > 1 && gos == 1 && ss == 1 && B >= 128 && OH * OW <= 1024) {
+    if (!narrow && T > 1 && gos == 1 && ss == 1 && B >= 128 && OH * OW <= 1024) {
         // valid rectangle of every tap; K-splits per tap proportional to its rows: the smallest common K length L (multiple of
         // the 64-row K-step) with sum_t ceil(rows_t / L) <= the workgroup budget per group
         const long budget = (long)splits * T;
@@ -1126,6 +1104,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
             a.pm_blk0[T] = blk;
             fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
             dim3 grid(tiles, groups, blk);
+            if (piped) return loft_launch_conv_wgrad_stream(a, grid, true, (hipStream_t)stream);
             if (big) hipLaunchKernelGGL((conv_wgrad_kernel<256, 8, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((conv_wgrad_kernel<128, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
             LOFT_LAUNCH_CHECK();
@@ -1134,6 +1113,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
     }
     splits = (int)((M + pps - 1) / pps);
     dim3 grid(tiles, T * groups, splits);
+    if (piped) return loft_launch_conv_wgrad_stream(a, grid, false, (hipStream_t)stream);
     if (narrow)
         hipLaunchKernelGGL(conv_wgrad64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (big)
@@ -1142,6 +1122,15 @@ LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, co
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                                     int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                     const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                     const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                                     int splits, float* db, int db_tap, void* stream) {
+    return loft_conv_wgrad_bf16_v(g, x, dw, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host,
+                                  dx_host, wt_host, groups, g_gs, x_gs, dw_gs, splits, db, db_tap, LOFT_WGRAD_AUTO, stream);
 }
 
 // =====================================================================================

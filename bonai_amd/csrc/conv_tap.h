@@ -131,3 +131,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         }
     }
 }
+
+// ---- weight gradient (conv_mfma.hip conv_wgrad_kernel, conv_wgrad_pipe.hip): argument block and LDS swizzle
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradArgs {
+    const bf16_t* g;
+    const bf16_t* x;
+    float* dw;
+    const bf16_t* zero_page;
+    int B, GH, GW, Cout, XH, XW, Cin, OH, OW;
+    int gos, ss, T;
+    int goy[CONV_MAX_TAPS], gox[CONV_MAX_TAPS], dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    long g_gs, x_gs, dw_gs;
+    int M, pix_per_split, ctiles;
+    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW and OW via multiply-high (host-computed)
+    float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
+    int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
+    // PM form (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs; stride 1): the K dimension of tap t runs over
+    // (position inside the tap's valid rectangle, RoI) -- rows whose tap leaves the map (18 % of a 7x7 map's 3x3 taps, 9 % of a
+    // 14x14 one) are never staged, and every tap gets a number of K-splits proportional to its valid rows so that all
+    // workgroups run the same number of K-steps.  Workgroup j of a group serves tap t with pm_blk0[t] <= j < pm_blk0[t+1].
+    int pm_blk0[CONV_MAX_TAPS + 1], pm_pps[CONV_MAX_TAPS], pm_rows[CONV_MAX_TAPS];
+    int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
+    unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
+};
+
+__device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
+

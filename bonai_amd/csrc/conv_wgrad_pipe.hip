@@ -1,0 +1,278 @@
+// conv_wgrad_pipe.hip -- weight gradient of the tap convolution (contract: conv_mfma.hip "Weight gradient") for 256 x 256 tiles as
+// ONE software-pipelined instruction stream per wave -- the weight-gradient twin of conv_pipe.hip's stream schedule.
+//
+//   dW[wt[t]][n][c] += sum_m  G[b, oy*gos+goy[t], ox*gos+gox[t], n] * X[b, oy*ss+dy[t], ox*ss+dx[t], c]
+//
+// Reference call sites: the autograd of every nn.Conv2d / nn.Linear with Cout, Cin multiples of 256 on the LOFT path (FOA branches
+// offset_head_expand_feature.py:134-161, mask head fcn_mask_head.py:118-126, FPN / RPN 3x3 fpn.py:170-199, rpn_head.py:38-44, FCs).
+//
+// What was wrong with conv_wgrad_kernel<256,8> (ISA of round 1's build): (1) its fragments come from
+// __builtin_amdgcn_ds_read_tr16_b64, and hipcc fences that builtin behind EVERY outstanding global->LDS copy: an
+// `s_waitcnt vmcnt(0)` sat between stage() and the first fragment read, so the "prefetch" of K-step s+1 was waited for before
+// K-step s was computed; (2) all eight waves issued their eight copies, each with a full pixel decode, in lockstep in front of
+// the MFMAs.  Here: the transposing reads are inline asm (ds_read_b64_tr_b16 with compile-time offsets from six per-lane base
+// registers, waited for by hand), fragments are double-buffered one 16-pixel sub-step ahead also across K-steps, one barrier
+// per K-step, copies are spread over two sub-steps, each pixel is decoded once per K-step for both operands.
+//
+// LDS (128 KiB, one array): [G buf0][G buf1][X buf0][X buf1], 32 KiB each = 64 pixel rows x 512 B (256 channels); 16-byte chunk
+// q of pixel row r at q ^ ((r & 3) << 2).  Waves: 2 (n) x 4 (c); wave tile 128 (n) x 64 (c): 4 G fragments + 2 X fragments and
+// 8 MFMAs per sub-step.  Schedule per K-step s (buffer B = s & 1):
+//   ks0: MFMA fa | read F(s,1) -> fb | issue X(s+2)... see kernel body for the exact windows
+// Roofline: MFMA; algorithmic work 2*M*Cout*Cin*T FLOP per launch.
+#include "conv_tap.h"
+#include <type_traits>
+#include "../../include/loft_hip.h"
+
+namespace {
+constexpr int WG_OFF = 0, WX_OFF = 65536, WBUF = 32768, WLDS = 131072;
+}
+#define WSB() __builtin_amdgcn_sched_barrier(0)
+
+// one transposing read: 4 consecutive pixels (k) of one channel for each lane of a 16-lane group -- half of an MFMA operand
+#define TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+
+template <bool PM>
+__global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[WLDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int nt = bx / a.ctiles, ct = bx - nt * a.ctiles;
+    int t, grp, mbeg, mend;
+    if constexpr (PM) {
+        grp = by;
+        t = 0;
+        while (t + 1 < a.T && bz >= a.pm_blk0[t + 1]) ++t;
+        mbeg = (bz - a.pm_blk0[t]) * a.pm_pps[t];
+        mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
+    } else {
+        t = by % a.T; grp = by / a.T;
+        mbeg = bz * a.pix_per_split;
+        mend = min(a.M, mbeg + a.pix_per_split);
+    }
+    const int n0 = nt * 256, c0 = ct * 256;
+    if (mbeg >= mend) return;
+    const bf16_t* G = a.g + (long)grp * a.g_gs;
+    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const int ohw = a.OH * a.OW;
+    const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
+    const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
+    const unsigned pm_mul = PM ? a.pm_rw_mul[t] : 0u, pm_sh = PM ? a.pm_rw_sh[t] : 0u;
+
+    // ---- staging: thread -> pixel rows i*16 + wave*2 + (lane>>5), i = 0..3, 16-byte chunk lane & 31 (swizzled on the source)
+    const int srow = wave * 2 + (lane >> 5);
+    const int schunk = (lane & 31) ^ ((srow & 3) << 2);           // rows 16 apart share (row & 3)
+    const bf16_t* px_next[4];                                      // X pointers of the K-step whose G rows were issued last
+    // decode pixel m of the reduction range once: G pointer (or the zero page), X pointer (or the zero page)
+    auto decode = [&](int m, const bf16_t*& pg, const bf16_t*& px) {
+        pg = a.zero_page; px = a.zero_page;
+        if (m < mend) {
+            if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * B + RoI; stride 1, all in bounds
+                const int p = fastdiv(m, a.b_mul, a.b_sh), b = m - p * a.B;
+                const int ry = fastdiv(p, pm_mul, pm_sh), rx = p - ry * pm_rw;
+                const int oy = pm_y0 + ry, ox = pm_x0 + rx;
+                pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + schunk * 8;
+                px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + schunk * 8;
+            } else {
+                const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
+                const int iy = oy * a.ss + dy, ix = ox * a.ss + dx;
+                // a product with a zero operand contributes nothing: either side may carry the zero
+                if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                    pg = G + ((long)(b * a.GH + gy) * a.GW + gx) * a.Cout + n0 + schunk * 8;
+                    px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + schunk * 8;
+                }
+            }
+        }
+    };
+    // issue the G rows i0, i0+1 of K-step `step` into buffer B and remember their X pointers
+    auto issue_g = [&](int step, auto bufc, auto i0c) {
+        constexpr int B = decltype(bufc)::value, I0 = decltype(i0c)::value;
+#pragma unroll
+        for (int i = I0; i < I0 + 2; ++i) {
+            const bf16_t* pg;
+            decode(mbeg + step * 64 + i * 16 + srow, pg, px_next[i]);
+            __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(lds + WG_OFF + B * WBUF + (i * 16 + wave * 2) * 512), 16, 0, 0);
+        }
+    };
+    auto issue_x = [&](auto bufc, auto i0c) {
+        constexpr int B = decltype(bufc)::value, I0 = decltype(i0c)::value;
+#pragma unroll
+        for (int i = I0; i < I0 + 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)px_next[i], (lds_ptr_t)(lds + WX_OFF + B * WBUF + (i * 16 + wave * 2) * 512), 16, 0, 0);
+    };
+    using c0_t = std::integral_constant<int, 0>;
+    using c1_t = std::integral_constant<int, 1>;
+    using c2_t = std::integral_constant<int, 2>;
+    using c3_t = std::integral_constant<int, 3>;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wn = wave >> 2, wc = wave & 3;
+    // bias gradient rides along on the blocks of the first channel tile (see conv_wgrad_kernel): one extra MFMA per sub-step
+    // against an all-ones operand; wave (wn, wc) takes n-block wn*4 + wc
+    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+
+    // ---- fragment addressing (tr_frag of conv_mfma.hip with everything lane-constant folded): lane l -> channel
+    // col0 + 16*((l>>4)&1) + 4*(l&3) + [0,4) of pixel rows ks*16 + 8*(l>>5) + ((l&15)>>2) (+4 for the second half); the swizzle
+    // term of a row is ((row & 3) << 2) = (((l&15)>>2) & 3) << 2 for both halves and every ks.
+    const int il = lane & 15, gl = lane >> 4;
+    const int frow0 = 8 * (gl >> 1) + (il >> 2);
+    const int xq = (il >> 2) & 3;
+    int gaddr[4], xaddr[2];                             // LDS byte addresses for ks = 0, first half, buffer 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = wn * 128 + i * 32 + 16 * (gl & 1) + (il & 3) * 4;
+        gaddr[i] = (int)(size_t)(lds + WG_OFF) + frow0 * 512 + (((col >> 3) ^ (xq << 2)) << 4) + (col & 7) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wc * 64 + j * 32 + 16 * (gl & 1) + (il & 3) * 4;
+        xaddr[j] = (int)(size_t)(lds + WX_OFF) + frow0 * 512 + (((col >> 3) ^ (xq << 2)) << 4) + (col & 7) * 2;
+    }
+    // fragment sets: 6 fragments x 2 halves of 4 bf16
+    s16x4 fa[12], fb[12];
+    // reads of fragment F of set (B, KS): 2 transposing reads
+#define WG_READ(f, F, B_, KS_)                                                                         \
+    do {                                                                                               \
+        if ((F) < 4) {                                                                                 \
+            TR_READ((f)[2 * (F)], gaddr[(F) < 4 ? (F) : 0], (B_) * WBUF + (KS_) * 8192);               \
+            TR_READ((f)[2 * (F) + 1], gaddr[(F) < 4 ? (F) : 0], (B_) * WBUF + (KS_) * 8192 + 2048);    \
+        } else {                                                                                       \
+            TR_READ((f)[2 * (F)], xaddr[(F) >= 4 ? (F) - 4 : 0], (B_) * WBUF + (KS_) * 8192);          \
+            TR_READ((f)[2 * (F) + 1], xaddr[(F) >= 4 ? (F) - 4 : 0], (B_) * WBUF + (KS_) * 8192 + 2048); \
+        }                                                                                              \
+    } while (0)
+    // wait for every transposing read in flight; naming the registers keeps hipcc from touching them before the data has landed
+#define WG_WAIT(f)                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                      \
+                 : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]), "+v"((f)[4]), "+v"((f)[5]), "+v"((f)[6]), "+v"((f)[7]), \
+                   "+v"((f)[8]), "+v"((f)[9]), "+v"((f)[10]), "+v"((f)[11]))
+    auto frag = [&](s16x4 (&f)[12], int F) {
+        bf16x8 v;
+        v[0] = f[2 * F][0]; v[1] = f[2 * F][1]; v[2] = f[2 * F][2]; v[3] = f[2 * F][3];
+        v[4] = f[2 * F + 1][0]; v[5] = f[2 * F + 1][1]; v[6] = f[2 * F + 1][2]; v[7] = f[2 * F + 1][3];
+        return v;
+    };
+    // the two MFMAs of G block I (against both X blocks)
+    auto mm2 = [&](s16x4 (&f)[12], auto ic) {
+        constexpr int I = decltype(ic)::value;
+        const bf16x8 gv = frag(f, I);
+        acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv, frag(f, 4), acc[I][0], 0, 0, 0);
+        acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv, frag(f, 5), acc[I][1], 0, 0, 0);
+    };
+    auto mmb = [&](s16x4 (&f)[12]) {
+        if (do_db) {   // static register selects (a runtime-indexed fragment array would be demoted to scratch)
+            bf16x8 gsel = frag(f, 0);
+            gsel = (wc == 1) ? frag(f, 1) : gsel;
+            gsel = (wc == 2) ? frag(f, 2) : gsel;
+            gsel = (wc == 3) ? frag(f, 3) : gsel;
+            accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gsel, ones, accb, 0, 0, 0);
+        }
+    };
+
+    const int nsteps = (mend - mbeg + 63) / 64;
+    // ---- prologue: G(0), X(0), G(1) (+ its X pointers)
+    issue_g(0, c0_t{}, c0_t{}); issue_g(0, c0_t{}, c2_t{});
+    issue_x(c0_t{}, c0_t{}); issue_x(c0_t{}, c2_t{});
+    if (nsteps > 1) {
+        issue_g(1, c1_t{}, c0_t{}); issue_g(1, c1_t{}, c2_t{});
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    WSB();
+    __builtin_amdgcn_s_barrier();
+    WSB();
+    WG_READ(fa, 0, 0, 0); WG_READ(fa, 1, 0, 0); WG_READ(fa, 2, 0, 0); WG_READ(fa, 3, 0, 0); WG_READ(fa, 4, 0, 0); WG_READ(fa, 5, 0, 0);
+
+    // one sub-step: 8 (+1) MFMAs on `cur`, the 12 transposing reads of `nxt` and up to two pairs of copies pinned between MFMA pairs
+#define WG_SUBSTEP(cur, nxt, B_, KS_, do_read, copy0, copy1)                                  \
+    do {                                                                                      \
+        WG_WAIT(cur);                                                                         \
+        WSB();                                                                                \
+        mm2(cur, c0_t{});                                                                     \
+        if (do_read) { WG_READ(nxt, 0, B_, KS_); WG_READ(nxt, 1, B_, KS_); }                  \
+        WSB();                                                                                \
+        mm2(cur, c1_t{});                                                                     \
+        if (do_read) { WG_READ(nxt, 2, B_, KS_); WG_READ(nxt, 3, B_, KS_); }                  \
+        copy0;                                                                                \
+        WSB();                                                                                \
+        mm2(cur, c2_t{});                                                                     \
+        if (do_read) { WG_READ(nxt, 4, B_, KS_); WG_READ(nxt, 5, B_, KS_); }                  \
+        WSB();                                                                                \
+        mm2(cur, c3_t{});                                                                     \
+        mmb(cur);                                                                             \
+        copy1;                                                                                \
+        WSB();                                                                                \
+    } while (0)
+
+    // K-step s in buffer B:
+    //   ks0: MFMA fa | read F(s,1) -> fb | issue X(s+1) -> buffer 1-B  (its G rows went out in ks3(s-1); buffer 1-B is free since
+    //        SYNC(s-1))
+    //   ks1: MFMA fb | read F(s,2) -> fa        ks2: MFMA fa | read F(s,3) -> fb
+    //   SYNC(s): vmcnt(0) (G(s+1), X(s+1) landed), lgkmcnt(0) (this wave's reads of buffer B are complete), barrier
+    //   ks3: MFMA fb | read F(s+1,0) -> fa from buffer 1-B | decode + issue G(s+2) -> buffer B (free behind SYNC(s))
+    auto step = [&](auto bufc, int s, bool has1, bool has2) {
+        constexpr int B = decltype(bufc)::value;
+        using other_t = std::integral_constant<int, 1 - B>;
+        WG_SUBSTEP(fa, fb, B, 1, true, if (has1) issue_x(other_t{}, c0_t{}), if (has1) issue_x(other_t{}, c2_t{}));
+        WG_SUBSTEP(fb, fa, B, 2, true, (void)0, (void)0);
+        WG_SUBSTEP(fa, fb, B, 3, true, (void)0, (void)0);
+        if (has1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            WSB();
+            __builtin_amdgcn_s_barrier();
+            WSB();
+        }
+        WG_SUBSTEP(fb, fa, 1 - B, 0, has1, if (has2) issue_g(s + 2, bufc, c0_t{}), if (has2) issue_g(s + 2, bufc, c2_t{}));
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(c0_t{}, s, s + 1 < nsteps, s + 2 < nsteps);
+        if (s + 1 < nsteps) step(c1_t{}, s + 1, s + 2 < nsteps, s + 3 < nsteps);
+    }
+
+    if (do_db && (lane & 31) == 0) {
+        float* db = a.db + (long)grp * a.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 128 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            unsafeAtomicAdd(db + n, accb[r]);
+        }
+    }
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[i][j][r]);
+            }
+        }
+}
+
+// host side: launched from loft_conv_wgrad_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0 and Cin % 256 == 0.
+int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStream_t s) {
+    if (pm) hipLaunchKernelGGL(conv_wgrad_stream_kernel<true>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_stream_kernel<false>, grid, dim3(512), 0, s, a);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

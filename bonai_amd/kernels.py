@@ -290,6 +290,8 @@ CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_
     CONV_STREAM256 = range(10)
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT = 0x100, 0x200, 0x400
 CONV_VARIANT = CONV_AUTO
+WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128 = range(4)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
+WGRAD_VARIANT = WGRAD_AUTO
 
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
@@ -419,11 +421,11 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                 'loft_conv_wgrad_patch_bf16')
         _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
         return dw
-    L.check(lib.loft_conv_wgrad_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
-                                     XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
-                                     c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
-                                     int(db_tap), L.stream()),
-            'loft_conv_wgrad_bf16')
+    L.check(lib.loft_conv_wgrad_bf16_v(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
+                                       XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
+                                       c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
+                                       int(db_tap), int(WGRAD_VARIANT), L.stream()),
+            'loft_conv_wgrad_bf16_v')
     _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
     return dw
 

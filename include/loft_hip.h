@@ -149,6 +149,16 @@ int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* ze
                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                          const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
                          float* db, int db_tap, void* stream);
+/* The same with the kernel chosen by the caller (tests / A-B timing): LOFT_WGRAD_AUTO = loft_conv_wgrad_bf16's heuristics. */
+#define LOFT_WGRAD_AUTO 0
+#define LOFT_WGRAD_STREAM256 1   /* 256x256 tile, software-pipelined stream (Cout, Cin multiples of 256) */
+#define LOFT_WGRAD_T256 2        /* 256x256 tile, lockstep double buffer */
+#define LOFT_WGRAD_T128 3        /* 128x128 tile (Cout, Cin multiples of 128) */
+int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW,
+                         int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                         const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                         const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
+                         float* db, int db_tap, int variant, void* stream);
 /* loft_conv_wgrad_patch_bf16: the same weight (+ bias) gradient for stride-1, same-size convs with <= 64 input and output
  * channels and taps within +-1 pixel (HRNet's high-resolution 3x3 branches, hrnet.py:12-60 via resnet.py:13-92 BasicBlock): every
  * workgroup walks 8x8-pixel patches and feeds ALL taps from one staged patch of g and its 10x10 halo of x.  g [groups*B,H,W,Cout],

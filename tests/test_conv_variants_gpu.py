@@ -171,7 +171,19 @@ def test_wgrad_bench_size_sampled_values(name, shape):
     x = _cl(torch.randn(G * B, Cin, H, W, device='cuda', generator=gsd).bfloat16())
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     g = _cl(torch.randn(G * B, Cout, OH, OW, device='cuda', generator=gsd).bfloat16())
-    dwp, db = K.conv2d_wgrad(g, x, R, R, stride, pad, groups=G, with_bias=True)
+    variants = [K.WGRAD_AUTO] + ([K.WGRAD_STREAM256, K.WGRAD_T256] if Cin % 256 == 0 and Cout % 256 == 0 else [])
+    outs = []
+    for v in variants:
+        K.WGRAD_VARIANT = v
+        try:
+            outs.append(K.conv2d_wgrad(g, x, R, R, stride, pad, groups=G, with_bias=True))
+        finally:
+            K.WGRAD_VARIANT = K.WGRAD_AUTO
+    for dwp_v, db_v in outs[1:]:            # same tiles, same K order per split: only the split-K atomics' order differs
+        assert (dwp_v - outs[0][0]).abs().max().item() < 1e-3 * (B * OH * OW) ** 0.5
+        assert (db_v - outs[0][1]).abs().max().item() < 1e-3 * (B * OH * OW) ** 0.5
+    dwp, db = outs[-1] if len(outs) > 1 else outs[0]        # sampled value check on the lockstep kernel when there is one ...
+    dwp_s, db_s = outs[1] if len(outs) > 1 else outs[0]     # ... and on the streamed kernel
     rng = np.random.RandomState(6)
     xf = torch.nn.functional.pad(x.float(), (pad, pad, pad, pad))
     gf = g.float()
@@ -182,8 +194,8 @@ def test_wgrad_bench_size_sampled_values(name, shape):
         gs = gf[gi * B:(gi + 1) * B, n]
         xs = xf[gi * B:(gi + 1) * B, c, r:r + (OH - 1) * stride + 1:stride, s:s + (OW - 1) * stride + 1:stride]
         want = float((gs.double() * xs.double()).sum())
-        got = float(dwp[gi, r * R + s, n, c])
-        worst = max(worst, abs(got - want))
+        worst = max(worst, abs(float(dwp[gi, r * R + s, n, c]) - want), abs(float(dwp_s[gi, r * R + s, n, c]) - want))
     assert worst < 5e-4 * scale, (worst, scale)
     want_b = gf.view(G, B, Cout, -1).double().sum(dim=(1, 3)).float()
     assert (db[:, :Cout] - want_b).abs().max().item() < 1e-3 * scale
+    assert (db_s[:, :Cout] - want_b).abs().max().item() < 1e-3 * scale

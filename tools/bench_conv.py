@@ -70,6 +70,13 @@ def main():
                 ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
             elif wh == 'dgrad':
                 ms = timeit(lambda: K.conv2d_dgrad(g, wpt, (H, W), R, R, st, pad, groups=G))
+            elif wh in ('wgrad_stream', 'wgrad_t256'):
+                if Cin % 256 or Cout % 256:
+                    row += f'{"-":>10s} {"-":>8s} '
+                    continue
+                K.WGRAD_VARIANT = K.WGRAD_STREAM256 if wh == 'wgrad_stream' else K.WGRAD_T256
+                ms = timeit(lambda: K.conv2d_wgrad(g, x, R, R, st, pad, groups=G))
+                K.WGRAD_VARIANT = K.WGRAD_AUTO
             elif wh == 'wgrad':
                 if Cin % 128 or Cout % 128:
                     row += f'{"-":>10s} {"-":>8s} '

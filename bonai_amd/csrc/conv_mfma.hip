@@ -588,23 +588,32 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
 // Split-K over pixel ranges (grid.z) with fp32 atomic accumulation into dW (caller zeroes it).
 // Rows are 256 B = one full bank row, so 16-byte chunk q of pixel row r is stored at q ^ ((r&3)<<2).
 // =====================================================================================
+// Operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][RB/2] bf16 tile (RB bytes per pixel row): lane l ->
+// channel col0 + (l&31), pixels kbase + 8*(l>>5) + 0..7, as two transposing reads (4 pixels each).  The reads are INLINE ASM:
+// hipcc fences __builtin_amdgcn_ds_read_tr16_b64 behind every outstanding global->LDS copy (`s_waitcnt vmcnt(0)` in front of the
+// first fragment read of a K-step, i.e. the prefetch of the next K-step was waited for before computing the current one).  The
+// caller waits with TR_WAIT*, naming the registers, before assembling the fragments (cdna_hip_programming.md 5.7).
 template <int RB>
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int kbase, int col0, int lane) {
-    // operand fragment for v_mfma_f32_32x32x16_bf16 from a pixel-major [64][RB/2] bf16 tile (RB bytes per pixel row):
-    // lane l -> channel col0 + (l&31), pixels kbase + 8*(l>>5) + 0..7
+__device__ __forceinline__ void tr_frag_issue(const char* tile, int kbase, int col0, int lane, s16x4& lo, s16x4& hi) {
     const int il = lane & 15, gl = lane >> 4;
     const int col = col0 + 16 * (gl & 1) + (il & 3) * 4;
     const int r0 = kbase + 8 * (gl >> 1) + (il >> 2);
     const int r1 = r0 + 4;
-    const char* p0 = tile + r0 * RB + wswz(r0, col >> 3) * 16 + (col & 7) * 2;
-    const char* p1 = tile + r1 * RB + wswz(r1, col >> 3) * 16 + (col & 7) * 2;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    const unsigned p0 = (unsigned)(size_t)(tile + r0 * RB + wswz(r0, col >> 3) * 16 + (col & 7) * 2);
+    const unsigned p1 = (unsigned)(size_t)(tile + r1 * RB + wswz(r1, col >> 3) * 16 + (col & 7) * 2);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(p0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(p1));
+}
+__device__ __forceinline__ bf16x8 tr_join(const s16x4 lo, const s16x4 hi) {
     bf16x8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
+#define TR_WAIT4(l, h) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((l)[0]), "+v"((l)[1]), "+v"((l)[2]), "+v"((l)[3]), \
+                                    "+v"((h)[0]), "+v"((h)[1]), "+v"((h)[2]), "+v"((h)[3]))
+#define TR_WAIT6(l, h) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((l)[0]), "+v"((l)[1]), "+v"((l)[2]), "+v"((l)[3]), "+v"((l)[4]), \
+                                    "+v"((l)[5]), "+v"((h)[0]), "+v"((h)[1]), "+v"((h)[2]), "+v"((h)[3]), "+v"((h)[4]), "+v"((h)[5]))
 
 // TN = output tile edge (n and c), NW = waves.  <128,4>: 2x2 waves of 64x64; <256,8>: 2x4 waves of 128(n)x64(c) --
 // the 256 form halves the LDS-DMA bytes per FLOP and is used when Cout and Cin are multiples of 256.
@@ -709,10 +718,16 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 gf[NI], xf[NJ];
+            s16x4 flo[NI + NJ], fhi[NI + NJ];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) gf[i] = tr_frag<RB>(gbuf, ks * 16, wn * (TN / 2) + i * 32, lane);
+            for (int i = 0; i < NI; ++i) tr_frag_issue<RB>(gbuf, ks * 16, wn * (TN / 2) + i * 32, lane, flo[i], fhi[i]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xf[j] = tr_frag<RB>(xbuf, ks * 16, wc * (TN / WAVES_C) + j * 32, lane);
+            for (int j = 0; j < NJ; ++j) tr_frag_issue<RB>(xbuf, ks * 16, wc * (TN / WAVES_C) + j * 32, lane, flo[NI + j], fhi[NI + j]);
+            if constexpr (NI + NJ == 4) TR_WAIT4(flo, fhi); else TR_WAIT6(flo, fhi);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) gf[i] = tr_join(flo[i], fhi[i]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xf[j] = tr_join(flo[NI + j], fhi[NI + j]);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -815,8 +830,12 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
         const char* tb = lds + (s & 1) * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 gf = tr_frag<RB>(tb, ks * 16, wn * 32, lane);
-            const bf16x8 xf = tr_frag<RB>(tb, ks * 16, 64 + wc * 32, lane);
+            s16x4 flo[2], fhi[2];
+            tr_frag_issue<RB>(tb, ks * 16, wn * 32, lane, flo[0], fhi[0]);
+            tr_frag_issue<RB>(tb, ks * 16, 64 + wc * 32, lane, flo[1], fhi[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flo[0]), "+v"(flo[1]), "+v"(fhi[0]), "+v"(fhi[1]));
+            const bf16x8 gf = tr_join(flo[0], fhi[0]);
+            const bf16x8 xf = tr_join(flo[1], fhi[1]);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc, 0, 0, 0);
             if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ones, accb, 0, 0, 0);
         }

@@ -145,8 +145,10 @@ class BucketedAllReduce:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
-def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16, 22), gamma=0.1):
-    """mmcv StepLrUpdaterHook + linear warm-up as configured in schedule_2x_bonai.py:5-10."""
+def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16, 22), gamma=0.1, step=None):
+    """mmcv StepLrUpdaterHook + linear warm-up as configured in schedule_2x_bonai.py:5-10 (``step``: the config's key name)."""
+    if step is not None:
+        steps = step
     lr = base_lr * gamma ** sum(epoch >= s for s in steps)
     if it < warmup_iters:
         k = (1 - it / warmup_iters) * (1 - warmup_ratio)
@@ -173,6 +175,33 @@ class Trainer:
         # kernels accumulate weight / BN gradients straight into the arena slots (bonai_amd.nn.GRAD_SINK); the callback
         # replaces the post-accumulate-grad hook for those parameters
         self._sink = self.reducer._hook if self.reducer.enabled else (lambda p: None)
+
+    def optimizer_state_dict(self):
+        """The arena's SGD state in torch.optim.SGD.state_dict() layout (what mmcv's CheckpointHook stores under 'optimizer',
+        apis/train.py:139-140 resumes from): parameters indexed in ``model.parameters()`` order (frozen ones included, as the
+        reference builds its optimizer over all of them), one ``momentum_buffer`` per parameter that has been stepped."""
+        a = self.arena
+        state, idx = {}, {}
+        for i, p in enumerate(self.model.parameters()):
+            idx[id(p)] = i
+        if self.iter > 0:
+            for p in a.params:
+                o = a.offsets[id(p)]
+                state[idx[id(p)]] = dict(momentum_buffer=a.momentum[o:o + p.numel()].view(p.shape).detach().cpu().clone())
+        group = dict(lr=self.lr, momentum=self.mu, dampening=0, weight_decay=self.wd, nesterov=False,
+                     params=list(range(len(idx))))
+        return dict(state=state, param_groups=[group], iter=self.iter)
+
+    def load_optimizer_state(self, sd):
+        """Inverse of optimizer_state_dict (also accepts a reference checkpoint's torch SGD state)."""
+        a = self.arena
+        params = list(self.model.parameters())
+        for i, st in sd.get('state', {}).items():
+            p = params[int(i)]
+            if id(p) in a.offsets and st.get('momentum_buffer') is not None:
+                o = a.offsets[id(p)]
+                a.momentum[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1).to(a.momentum.device))
+        self.iter = int(sd.get('iter', self.iter))
 
     def train_step(self, data, lr=None):
         """One full optimisation step: forward, losses, backward, gradient all-reduce, clip, SGD."""

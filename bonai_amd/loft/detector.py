@@ -17,6 +17,36 @@ from .. import nn as F2
 from .builder import DETECTORS, build_backbone, build_head, build_neck
 
 
+def resolve_pretrained(pretrained):
+    """``pretrained`` of a detector config -> a local checkpoint path, or None.
+
+    The reference hands ``torchvision://resnet50`` / ``open-mmlab://...`` to mmcv's load_checkpoint, which downloads it
+    (resnet.py:591-600).  There is no network in this deployment: the URI's model name is looked up as
+    ``$LOFT_PRETRAINED_DIR/<name>.pth`` (or ``.pt`` / the bare name; torchvision's ``resnet50-19c8e357.pth`` style names match by
+    prefix).  When nothing is found the run continues from random initialisation -- with ``frozen_stages=1`` that means a frozen
+    RANDOM stem and layer1, so it is reported with a RuntimeWarning (and an error when LOFT_PRETRAINED_STRICT=1), never silently."""
+    import os
+    import warnings
+    if not isinstance(pretrained, str) or '://' not in pretrained:
+        return pretrained
+    name = pretrained.split('://', 1)[1].strip('/')
+    root = os.environ.get('LOFT_PRETRAINED_DIR')
+    if root and os.path.isdir(root):
+        for cand in (name, name + '.pth', name + '.pt'):
+            if os.path.isfile(os.path.join(root, cand)):
+                return os.path.join(root, cand)
+        for f in sorted(os.listdir(root)):
+            if f.startswith(os.path.basename(name) + '-') and f.endswith(('.pth', '.pt')):
+                return os.path.join(root, f)
+    msg = (f'pretrained={pretrained!r} cannot be downloaded (no network) and no local copy was found under LOFT_PRETRAINED_DIR='
+           f'{root!r}: the backbone keeps its RANDOM initialisation (frozen_stages then freezes random features). '
+           'Pass a local checkpoint path as `pretrained`, set LOFT_PRETRAINED_DIR, or use tools/train.py --pretrained.')
+    if os.environ.get('LOFT_PRETRAINED_STRICT') == '1':
+        raise FileNotFoundError(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return None
+
+
 @DETECTORS.register_module()
 class LOFT(nn.Module):
     def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None, pretrained=None):
@@ -40,9 +70,9 @@ class LOFT(nn.Module):
     with_roi_head = property(lambda self: hasattr(self, 'roi_head'))
 
     def init_weights(self, pretrained=None):
-        """two_stage.py:60-78.  ``torchvision://`` checkpoints cannot be fetched here (no network): a path loads by key."""
-        if isinstance(pretrained, str) and '://' in pretrained:
-            pretrained = None
+        """two_stage.py:60-78.  Model-zoo URIs (``torchvision://resnet50``, bonai_loft_foa_r50_fpn_basic.py:4) resolve to a local
+        file (no network here) or warn loudly: see ``resolve_pretrained``."""
+        pretrained = resolve_pretrained(pretrained)
         self.backbone.init_weights(pretrained=pretrained)
         if self.with_neck:
             self.neck.init_weights()

@@ -147,3 +147,48 @@ def test_sparse_rpn_backward_matches_dense_autograd():
         a, b = grads[0][n], grads[1][n]
         tol = 0.03 if n.startswith('rpn_head') else 0.05     # (backbone/neck: plus the bf16 atomics of the scattered dx)
         assert (a - b).norm().item() <= tol * max(b.norm().item(), 1e-6), (n, (a - b).norm().item(), b.norm().item())
+
+
+def test_reference_format_checkpoints_through_the_hip_model(tmp_path):
+    """(i) a checkpoint in the layout mmcv's CheckpointHook writes ({'meta', 'state_dict', 'optimizer'}, keys with the
+    'module.' prefix of MMDistributedDataParallel; apis/train.py:139-142, tools/publish_model.py:16-30) and (ii) a torchvision-keyed
+    backbone file handed over as ``pretrained`` (bonai_loft_foa_r50_fpn_basic.py:4, resnet.py:591-600) are loaded through
+    bonai_amd.checkpoint.load_checkpoint into the HIP model, which must then reproduce the reference-generated fixture."""
+    from collections import OrderedDict
+    from bonai_amd.checkpoint import load_checkpoint
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    from bonai_amd.loft.core import RandomSampler
+    from bonai_amd.synth import make_batch
+    from oracle.synth_weights import synth_tensor
+    gd = np.load(os.path.join(GOLD, 'e2e_256.npz'))
+    size, batch, num_gt = [int(v) for v in gd['meta']]
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    # (ii) torchvision layout: backbone keys without prefix, plus the classifier the detector does not have
+    probe = build_detector(dict(cfg.model, pretrained=None), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    names = {k: tuple(v.shape) for k, v in probe.state_dict().items()}
+    tv = OrderedDict((k[len('backbone.'):], synth_tensor(k, s)) for k, s in names.items() if k.startswith('backbone.'))
+    tv['fc.weight'], tv['fc.bias'] = torch.zeros(1000, 2048), torch.zeros(1000)
+    tv_path = str(tmp_path / 'resnet50-synth.pth')
+    torch.save(tv, tv_path)
+    torch.manual_seed(123)                                      # everything else starts from some OTHER random init
+    RandomSampler.choice_mode = 'first'
+    m = build_detector(dict(cfg.model, pretrained=tv_path), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    for k, v in m.backbone.state_dict().items():
+        assert torch.equal(v.cpu(), tv[k]), k
+    # (i) reference training checkpoint of the whole detector, DDP-prefixed, with optimizer state and meta
+    ck = dict(meta=dict(mmdet_version='2.3.0', config='(text)', CLASSES=('building',), epoch=3, iter=1234),
+              state_dict=OrderedDict(('module.' + k, synth_tensor(k, s)) for k, s in names.items()),
+              optimizer=dict(state={}, param_groups=[dict(lr=0.005, momentum=0.9, weight_decay=1e-4, params=list(range(len(names))))]))
+    ck_path = str(tmp_path / 'epoch_3.pth')
+    torch.save(ck, ck_path)
+    out = load_checkpoint(m, ck_path, strict=True)
+    assert out['meta']['iter'] == 1234
+    m = m.cuda().train()
+    data = make_batch(batch, size, num_gt, device='cuda')
+    lv = dict(m.train_step(data)['log_vars'].items())
+    tol = dict(loss_rpn_cls=0.02, loss_rpn_bbox=0.05, loss_cls=0.03, loss_bbox=0.05, loss_mask=0.03, loss_offset=0.05, loss=0.05)
+    for k, t in tol.items():
+        want = float(gd['log_' + k])
+        assert abs(lv[k] - want) <= t * max(1.0, abs(want)), (k, lv[k], want)
+    RandomSampler.choice_mode = 'random'

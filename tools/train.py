@@ -22,7 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('config')
     ap.add_argument('--work-dir')
-    ap.add_argument('--resume-from')
+    ap.add_argument('--resume-from', help='checkpoint written by this tool / the reference: weights, SGD momentum, iter, epoch')
+    ap.add_argument('--load-from', help='weights only (apis/train.py:141-142)')
+    ap.add_argument('--pretrained', help='local backbone checkpoint (torchvision / model-zoo keys) replacing cfg.model.pretrained')
+    ap.add_argument('--iters-per-epoch', type=int, default=0, help='synthetic stream: iterations that count as one epoch (0: one epoch)')
     ap.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     ap.add_argument('--options', nargs='+', default=[])
     ap.add_argument('--seed', type=int, default=0)
@@ -44,27 +47,37 @@ def main():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', args.local_rank)))
         dist.init_process_group(cfg.dist_params.get('backend', 'nccl'))
     torch.manual_seed(args.seed)
+    from bonai_amd.checkpoint import load_checkpoint, save_checkpoint
+    if args.pretrained:
+        cfg.model['pretrained'] = args.pretrained
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-    if args.resume_from:
-        from bonai_amd.checkpoint import load_checkpoint
-        load_checkpoint(model, args.resume_from, strict=True)
+    if args.load_from:
+        load_checkpoint(model, args.load_from, strict=False)
     tr = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
                  max_norm=cfg.optimizer_config.grad_clip.max_norm,
                  loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0))
+    start_iter = 0
+    if args.resume_from:                                   # mmcv runner.resume: weights + optimizer state + iter / epoch
+        ckpt = load_checkpoint(model, args.resume_from, strict=True)
+        if ckpt.get('optimizer') is not None:
+            tr.load_optimizer_state(ckpt['optimizer'])
+        start_iter = int(ckpt.get('meta', {}).get('iter', 0))
     bs = cfg.data.get('samples_per_gpu', 8)
     interval = cfg.log_config.get('interval', 10)
+    ipe = args.iters_per_epoch or max(args.iters, 1)
+    sched = {k: cfg.lr_config[k] for k in ('warmup_iters', 'warmup_ratio', 'step') if k in cfg.lr_config}
     t0 = time.time()
-    for it in range(args.iters):
+    for it in range(start_iter, args.iters):
         data = make_batch(bs, 1024, 80, rank=rank, step=it, device='cuda')
-        out = tr.train_step(data, lr=step_lr(cfg.optimizer.lr, it, 0, **{k: cfg.lr_config[k] for k in ('warmup_iters', 'warmup_ratio')}))
+        out = tr.train_step(data, lr=step_lr(cfg.optimizer.lr, it, it // ipe, **sched))
         if rank == 0 and (it + 1) % interval == 0:
             torch.cuda.synchronize()
             lv = ', '.join(f'{k}: {v:.4f}' for k, v in out['log_vars'].items())
-            print(f'Iter [{it + 1}/{args.iters}] time: {(time.time() - t0) / (it + 1):.3f}, {lv}', flush=True)
+            print(f'Epoch [{it // ipe + 1}][{it % ipe + 1}/{ipe}] time: {(time.time() - t0) / (it - start_iter + 1):.3f}, {lv}', flush=True)
     if args.work_dir and rank == 0:
         os.makedirs(args.work_dir, exist_ok=True)
-        from bonai_amd.checkpoint import save_checkpoint
-        save_checkpoint(model, os.path.join(args.work_dir, 'latest.pth'), meta=dict(config=cfg.filename, iter=args.iters))
+        save_checkpoint(model, os.path.join(args.work_dir, 'latest.pth'), optimizer_state=tr.optimizer_state_dict(),
+                        meta=dict(config=cfg.filename, iter=args.iters, epoch=args.iters // ipe))
     if world > 1:
         dist.destroy_process_group()
 

@@ -399,6 +399,134 @@ LOFT_EXPORT int loft_offset_decode(const float* pred, const float* boxes, int64_
     return 0;
 }
 
+// ---- polygon -> instance bitmap on the device ------------------------------------------------------------------------------
+// Replaces LoadAnnotations._poly2mask (mmdet/datasets/pipelines/loading.py:301-326: pycocotools frPyObjects + merge + decode) so
+// that the K x H x W uint8 masks of a tile are never built on the host nor uploaded: the polygons' vertices go up
+// (a few KB) and each instance's bitmap is rasterised where mask_target reads it.  Algorithm = pycocotools' rleFrPoly restated
+// ([pycocotools, not in tree]; oracle/ops_ref.py::poly2mask): vertices to a 5x grid, every edge walked along its major axis,
+// one crossing (x, y) wherever the walk enters a new 5x column that is a pixel centre, the column-major run-length code
+// toggles at x*H + y; decode = running parity.  One workgroup per INSTANCE (its polygons are OR-merged, = maskUtils.merge):
+// the H*W+1 toggle bits live in LDS (128 KiB + 4 B for a 1024 x 1024 tile), crossings are XOR-ed in with LDS atomics, each
+// thread then owns columns: parity carried word by word down the column, bytes written row-major (coalesced across the
+// column-threads).  fp64 throughout like the C original; this file is built with -ffp-contract=off.
+struct PolyPt { int u, v; };
+__device__ __forceinline__ PolyPt poly_edge_point(const double* xy, int k, int e, int d) {
+    const double scale = 5.0;
+    const int e1 = (e + 1 == k) ? 0 : e + 1;
+    int xs = (int)(scale * xy[2 * e] + .5), ys = (int)(scale * xy[2 * e + 1] + .5);
+    int xe = (int)(scale * xy[2 * e1] + .5), ye = (int)(scale * xy[2 * e1 + 1] + .5);
+    const int dx = abs(xe - xs), dy = abs(ys - ye);
+    const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) { int t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+    PolyPt p;
+    if (dx >= dy) {
+        const double s = dx > 0 ? (double)(ye - ys) / dx : 0.0;
+        const int t = flip ? dx - d : d;
+        p.u = t + xs; p.v = (int)(ys + s * t + .5);
+    } else {
+        const double s = (double)(xe - xs) / dy;
+        const int t = flip ? dy - d : d;
+        p.v = t + ys; p.u = (int)(xs + s * t + .5);
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(1024) void poly2mask_kernel(const double* __restrict__ xy, const int64_t* __restrict__ poly_off,
+                                                         const int64_t* __restrict__ inst_poly_off, int H, int W,
+                                                         uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned pm_bits[];      // (H*W + 1) toggle bits, then the edge prefix table
+    const int inst = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const long nbits = (long)H * W + 1;
+    const int nwords = (int)((nbits + 31) / 32);
+    int* eoff = reinterpret_cast<int*>(pm_bits + nwords);                   // [k+1] prefix of points per edge (k <= 1023)
+    uint8_t* o = out + (long)inst * H * W;
+    const int p0 = (int)inst_poly_off[inst], p1 = (int)inst_poly_off[inst + 1];
+    for (int q = p0; q < p1; ++q) {
+        const double* pts = xy + 2 * poly_off[q];
+        const int k = (int)(poly_off[q + 1] - poly_off[q]);
+        for (int i = tid; i < nwords; i += nt) pm_bits[i] = 0u;
+        if (tid == 0) {                                                     // points per edge: max(|dx|, |dy|) + 1
+            int acc = 0;
+            for (int e = 0; e < k; ++e) {
+                const int e1 = (e + 1 == k) ? 0 : e + 1;
+                const int xs = (int)(5.0 * pts[2 * e] + .5), ys = (int)(5.0 * pts[2 * e + 1] + .5);
+                const int xe = (int)(5.0 * pts[2 * e1] + .5), ye = (int)(5.0 * pts[2 * e1 + 1] + .5);
+                eoff[e] = acc;
+                acc += max(abs(xe - xs), abs(ye - ys)) + 1;
+            }
+            eoff[k] = acc;
+        }
+        __syncthreads();
+        const int M = k > 0 ? eoff[k] : 0;
+        for (int j = tid + 1; j < M; j += nt) {                             // crossing test between walk points j-1 and j
+            int lo = 0, hi = k;                                             // edge of point j: eoff[e] <= j < eoff[e+1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (eoff[mid] <= j) lo = mid; else hi = mid; }
+            const PolyPt a = poly_edge_point(pts, k, lo, j - eoff[lo]);
+            const int ep = (j - 1 >= eoff[lo]) ? lo : lo - 1;
+            const PolyPt b = poly_edge_point(pts, k, ep, j - 1 - eoff[ep]);
+            if (a.u == b.u) continue;
+            double xd = (double)(a.u < b.u ? a.u : a.u - 1);
+            xd = (xd + .5) / 5.0 - .5;
+            if (floor(xd) != xd || xd < 0 || xd > W - 1) continue;
+            double yd = (double)(a.v < b.v ? a.v : b.v);
+            yd = (yd + .5) / 5.0 - .5;
+            if (yd < 0) yd = 0; else if (yd > H) yd = H;
+            yd = ceil(yd);
+            const long pos = (long)(int)xd * H + (int)yd;
+            atomicXor(&pm_bits[pos >> 5], 1u << (pos & 31));
+        }
+        __syncthreads();
+        // running parity in column-major order.  carry into column x = parity of all toggles before x*H: per-column parities
+        // first (the toggle words of a column are contiguous bits [x*H, (x+1)*H)), then an exclusive scan over the columns.
+        int* cpar = eoff + 1024 + 1;                                        // [W] (W <= blockDim handled by the loops)
+        for (int x = tid; x < W; x += nt) {
+            unsigned par = 0u;
+            const long b0 = (long)x * H, b1 = b0 + H;
+            for (long wd = b0 >> 5; wd <= (b1 - 1) >> 5; ++wd) {
+                unsigned w32 = pm_bits[wd];
+                const long lo_b = wd << 5;
+                if (lo_b < b0) w32 &= ~0u << (b0 - lo_b);
+                if (lo_b + 32 > b1) w32 &= ~0u >> (lo_b + 32 - b1);
+                par ^= (unsigned)__popc(w32);
+            }
+            cpar[x] = (int)(par & 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int x = 0; x < W; ++x) { const int c = cpar[x]; cpar[x] = run; run ^= c; }
+        }
+        __syncthreads();
+        for (int x = tid; x < W; x += nt) {
+            unsigned par = (unsigned)cpar[x];
+            const long b0 = (long)x * H;
+            for (int y = 0; y < H; ++y) {
+                const long pos = b0 + y;
+                par ^= (pm_bits[pos >> 5] >> (pos & 31)) & 1u;
+                const uint8_t bit = (uint8_t)par;
+                uint8_t* dst = o + (long)y * W + x;
+                *dst = (q == p0) ? bit : (uint8_t)(*dst | bit);            // maskUtils.merge of an instance's polygons: union
+            }
+        }
+        __syncthreads();
+    }
+    if (p1 == p0)
+        for (long i = tid; i < (long)H * W; i += nt) o[i] = 0;
+}
+
+LOFT_EXPORT int loft_poly2mask(const double* xy, const int64_t* poly_offsets, const int64_t* inst_poly_offsets, int num_inst, int H,
+                               int W, int max_vertices, uint8_t* out, void* stream) {
+    if (num_inst <= 0) return 0;
+    const long nbits = (long)H * W + 1;
+    const size_t lds = (size_t)((nbits + 31) / 32) * 4 + (1024 + 1 + (size_t)W) * 4;
+    if (max_vertices > 1023 || lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    hipFuncSetAttribute((const void*)poly2mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(poly2mask_kernel, dim3(num_inst), dim3(1024), lds, (hipStream_t)stream, xy, poly_offsets, inst_poly_offsets, H, W,
+                       out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- mask targets -------------------------------------------------------------------------------
 // masks u8 [Ktot,H,W]; for RoI i: mask index gt_idx[i], box (already clipped to the image) boxes[i];
 // out[i][S][S] = (RoIAlign_avg_aligned(mask, box, S, scale 1, adaptive grid) >= 0.5) as fp32 0/1.

@@ -6,8 +6,8 @@ define the *values* in that dict -- the BONAI annotation parser (mmdet/datasets/
 boxes and offsets (mmdet/datasets/pipelines/transforms.py:379-404, 458-466), Normalize and DefaultFormatBundle / Collect
 (pipelines/formating.py) -- and ends in ``to_device_batch``, which uploads once: images normalised on the GPU, instance
 masks as uint8 device tensors (the device-side mask_target kernel crops them; no per-step CPU round trip as in
-mmdet/core/mask/structures.py:261-291).  Image decoding / polygon rasterisation (cv2, pycocotools) stay outside: they are
-not in this image and not on the path.
+mmdet/core/mask/structures.py:261-291).  Polygon rasterisation (pycocotools in the reference) runs on the device
+(kernels.poly2mask); image decoding (cv2) stays outside: it is not in this image and not on the path.
 """
 import math
 
@@ -129,10 +129,20 @@ def flip_sample(sample, direction='horizontal'):
     return out
 
 
+def _masks_of(s, dev):
+    if 'gt_polygons' in s and s.get('gt_masks') is None:
+        from . import kernels as K
+        h, w = s['img'].shape[:2]
+        return K.poly2mask(s['gt_polygons'], h, w, device=dev)
+    return torch.from_numpy(np.ascontiguousarray(s['gt_masks'], dtype=np.uint8)).to(dev)
+
+
 def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True):
     """Collate + DefaultFormatBundle + Normalize, on the device: list of samples (img uint8/float HxWx3 BGR, gt_* numpy) ->
     the batch dict of forward_train.  Images are stacked (same size: BONAI tiles are 1024x1024), normalised on the GPU;
-    masks go up once as uint8 [K,H,W] tensors."""
+    masks go up once as uint8 [K,H,W] tensors -- or, when a sample carries ``gt_polygons`` (per instance a list of flat polygons: the
+    annotation's ``masks`` entry, bonai.py:186-199) instead of ``gt_masks``, only the vertices go up and the bitmaps are rasterised on the
+    device (kernels.poly2mask = LoadAnnotations._poly2mask, loading.py:301-326): no K x 1024^2 host bitmaps, no upload."""
     dev = torch.device(device)
     imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(s['img'])) for s in samples]).to(dev)
     x = imgs.float()
@@ -150,5 +160,5 @@ def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=
     return dict(img=img, img_metas=metas,
                 gt_bboxes=[torch.from_numpy(np.asarray(s['gt_bboxes'], np.float32)).to(dev) for s in samples],
                 gt_labels=[torch.from_numpy(np.asarray(s['gt_labels'], np.int64)).to(dev) for s in samples],
-                gt_masks=[torch.from_numpy(np.ascontiguousarray(s['gt_masks'], dtype=np.uint8)).to(dev) for s in samples],
+                gt_masks=[_masks_of(s, dev) for s in samples],
                 gt_offsets=[torch.from_numpy(np.asarray(s['gt_offsets'], np.float32).reshape(-1, 2)).to(dev) for s in samples])

@@ -698,6 +698,31 @@ def offset_decode(pred, boxes, means=(0., 0.), stds=(0.5, 0.5), max_shape=(1024,
     return out
 
 
+def poly2mask(instances, H, W, device='cuda'):
+    """instances: list (one per instance) of lists of polygons, each polygon a flat [x0, y0, x1, y1, ...] sequence (the BONAI
+    ``segmentation`` / ``[footprint_mask]`` fields) -> uint8 [K, H, W] device tensor.  LoadAnnotations._poly2mask
+    (datasets/pipelines/loading.py:301-326) for every instance of a tile in ONE launch; only the vertices cross PCIe."""
+    import numpy as np
+    lib = L.load()
+    K_ = len(instances)
+    out = torch.empty(K_, H, W, dtype=torch.uint8, device=device)
+    if K_ == 0:
+        return out
+    pts, poff, ioff = [], [0], [0]
+    for inst in instances:
+        for poly in inst:
+            a = np.asarray(poly, dtype=np.float64).reshape(-1, 2)
+            pts.append(a)
+            poff.append(poff[-1] + a.shape[0])
+        ioff.append(len(poff) - 1)
+    maxv = max((b - a for a, b in zip(poff[:-1], poff[1:])), default=0)
+    xy = torch.from_numpy(np.concatenate(pts, 0) if pts else np.zeros((0, 2))).to(device)
+    poff_t = torch.tensor(poff, dtype=torch.int64, device=device)
+    ioff_t = torch.tensor(ioff, dtype=torch.int64, device=device)
+    L.check(lib.loft_poly2mask(L.ptr(xy), L.ptr(poff_t), L.ptr(ioff_t), K_, H, W, int(maxv), L.ptr(out), L.stream()), 'loft_poly2mask')
+    return out
+
+
 def mask_target(masks_u8, boxes, gt_idx, S=28):
     """masks: uint8 [K,H,W] (device), or a LIST of per-image uint8 [K_b,H,W] tensors (gt_idx then indexes their
     concatenation; no copy is made: the kernel gets a table of instance addresses); boxes [n,4] already clipped to the

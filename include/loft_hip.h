@@ -246,6 +246,13 @@ int loft_offset_targets(const float* pos_boxes, const float* pos_gt_offsets, int
                         float std_x, float std_y, int reg_num, float* out, void* stream);
 int loft_offset_decode(const float* pred, const float* boxes, int64_t n, float mean_x, float mean_y, float std_x, float std_y,
                        float max_h, float max_w, int reg_num, int polar, float* out, void* stream);
+/* Polygon -> instance bitmaps on the device: LoadAnnotations._poly2mask (mmdet/datasets/pipelines/loading.py:301-326,
+ * pycocotools frPyObjects + merge + decode; the rleFrPoly algorithm restated, [pycocotools not in tree]).  xy: fp64 vertices
+ * [total_vertices, 2] of all polygons; poly_offsets int64 [P+1] (vertex ranges); inst_poly_offsets int64 [K+1] (polygon ranges of
+ * the K instances: an instance's polygons are OR-merged); out uint8 [K, H, W] (every byte written).  All DEVICE pointers.
+ * Limits: H*W <= 1024*1024 + slack (the toggle bitmap lives in LDS), max_vertices (largest polygon) <= 1023. */
+int loft_poly2mask(const double* xy, const int64_t* poly_offsets, const int64_t* inst_poly_offsets, int num_inst, int H, int W,
+                   int max_vertices, uint8_t* out, void* stream);
 /* Mask targets on device (mmdet/core/mask/mask_target.py:33-62 -> structures.py:261-291):
  * masks u8 [K,H,W]; RoI i crops mask gt_idx[i] with box boxes[i] (clipped to the image) to SxS,
  * RoIAlign(avg, aligned, adaptive grid) >= 0.5 -> out fp32 {0,1} [n,S,S].  mask_addr (optional, device int64 [#instances]): the address of every instance mask -- gt_idx then

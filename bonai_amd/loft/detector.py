@@ -151,6 +151,8 @@ class LOFT(nn.Module):
         return loss, log_vars, vec
 
     def train_step(self, data, optimizer=None):
+        from .. import nn as F2
+        F2._USES.clear()                                    # consumer counts of this step's ReLU outputs (nn._note_use)
         losses = self(**data)
         loss, log_vars, vec = self._parse_losses(losses)
         return dict(loss=loss, log_vars=_LazyLogVars(list(log_vars.keys()), vec), num_samples=len(data['img_metas']))

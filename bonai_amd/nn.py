@@ -51,6 +51,37 @@ def _sink_done(p):
         GRAD_SINK(p)
 
 
+# ---- ReLU-backward masks folded into a consumer's data-gradient epilogue ("pre-masked" gradients) -------------------------
+# A consumer whose input x is a ReLU output can apply that ReLU's backward mask in its own dgrad epilogue and tag the gradient
+# it returns; the producer of x then skips its relu_bwd pass.  That is only valid when the tagged gradient is the WHOLE gradient
+# of x: with a second consumer autograd sums the contributions (in place into whichever arrives first), and an un-masked
+# contribution would ride along under the tag.  So every Function that consumes activations registers its use of them in
+# forward (_note_use), producers start the count of their output (_begin_uses), and a tag is honoured only when exactly ONE use
+# was registered (_premasked).  The mask is idempotent, so the fallback -- the producer masks the accumulated gradient itself --
+# is always correct.  Counts are keyed by storage address: a producer's output is alive (saved for backward) until the
+# producer's own backward has consulted its count; the trainer clears the table every step.
+_USES = {}
+
+
+def _note_use(*tensors):
+    if len(_USES) > 65536:          # forward-only loops without a trainer: stale addresses only make the rule more conservative
+        _USES.clear()
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            k = t.data_ptr()
+            _USES[k] = _USES.get(k, 0) + 1
+
+
+def _begin_uses(y):
+    _USES[y.data_ptr()] = 0
+    return y
+
+
+def _premasked(g, y):
+    """Has the (accumulated) gradient g of the ReLU output y already been masked by y's ONLY consumer?"""
+    return getattr(g, '_loft_premasked', None) == y.data_ptr() and _USES.get(y.data_ptr(), 2) == 1
+
+
 UNPACK_Q = None    # the running Trainer's kernels.UnpackQueue: weight-gradient unpacking of many convs in one launch
 PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
 _PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
@@ -66,6 +97,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, meta, *tensors):
+        _note_use(x, residual)
         stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu, cout_pad = meta
         ws = tensors[0:2 * G:2]
         bs = tensors[1:2 * G:2]
@@ -112,7 +144,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.in_hw = tuple(x.shape[2:])
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y if relu else None, wpt, *tensors)
-        return y
+        return _begin_uses(y) if relu else y
 
     @staticmethod
     def backward(ctx, g):
@@ -126,7 +158,7 @@ class _ConvFn(torch.autograd.Function):
         g = to_nhwc(g)
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
-        if relu and getattr(g, '_loft_premasked', None) != y.data_ptr():
+        if relu and not _premasked(g, y):
             g = K.relu_bwd(g, y)        # (skipped when the consumer's dgrad epilogue already applied this mask)
         gx = None
         if ctx.needs_input_grad[0]:
@@ -233,6 +265,7 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, relu, input_relu, flat_chw):
+        _note_use(x)
         O = w.shape[0]
         N = x.shape[0]
         Kd = w.shape[1]
@@ -252,6 +285,8 @@ class _LinearFn(torch.autograd.Function):
             if t is not None and ctx.needs_input_grad[1 + k] and isinstance(t, torch.nn.Parameter):
                 t._loft_pending = getattr(t, '_loft_pending', 0) + 1
         ctx.save_for_backward(x4, y if relu else None, wpt, w)
+        if relu:
+            _begin_uses(y)
         return y.reshape(N, O)
 
     @staticmethod
@@ -264,7 +299,7 @@ class _LinearFn(torch.autograd.Function):
         g4 = g.reshape(N, O, 1, 1).contiguous(memory_format=torch.channels_last)
         if g4.dtype != torch.bfloat16:
             g4 = g4.to(torch.bfloat16)
-        if relu and getattr(g, '_loft_premasked', None) != y.data_ptr():
+        if relu and not _premasked(g, y):
             g4 = K.relu_bwd(g4, y)
         gx = None
         if ctx.needs_input_grad[0]:
@@ -323,6 +358,7 @@ class _NarrowHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None):
+        _note_use(x)
         Cout, Cin, R, S = w.shape
         ctx.input_relu = input_relu
         c4 = (Cout + 3) // 4 * 4
@@ -402,6 +438,7 @@ class _MdcnSampleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, om, meta):
+        _note_use(x, om)
         kh, kw, stride, pad, dil, dg = meta
         ctx.meta = meta
         ctx.save_for_backward(x, om)
@@ -441,6 +478,7 @@ class _DeconvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, input_relu=False):
+        _note_use(x)
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
         ctx.input_relu = input_relu
@@ -452,7 +490,7 @@ class _DeconvFn(torch.autograd.Function):
                 K.conv_tap(x, wp, y, N, H, W, Cin, Cout, H, W, 2 * H, 2 * W, [(0, 0, py * 2 + px)], ss=1, os=2,
                            oo=(py, px), bias=bias, relu=True)
         ctx.save_for_backward(x, w, y)
-        return y
+        return _begin_uses(y)
 
     @staticmethod
     def backward(ctx, g):
@@ -462,7 +500,7 @@ class _DeconvFn(torch.autograd.Function):
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
         g = to_nhwc(g)
-        if getattr(g, '_loft_premasked', None) != y.data_ptr():   # (the 1x1 logits head already applied this ReLU's mask)
+        if not _premasked(g, y):   # (else the 1x1 logits head already applied this ReLU's mask)
             g = K.relu_bwd(g, y)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -508,6 +546,7 @@ class FeatFork(tuple):
 class _FeatHubFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n, *feats):
+        _note_use(*feats)
         ctx.n, ctx.nf = n, len(feats)
         ctx.set_materialize_grads(False)      # consumers that accumulated into the shared map return None: keep it None
         return tuple(f.view_as(f) for _ in range(n) for f in feats)
@@ -548,6 +587,7 @@ def _hub_slots(tensors):
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, P, strides, finest_scale, n_rot, *feats):
+        _note_use(*feats)
         ctx.save_for_backward(rois)
         ctx.meta = (P, tuple(strides), finest_scale, n_rot, [tuple(f.shape) for f in feats], feats[0].dtype)
         ctx.hub_keys = _hub_slots(feats)
@@ -590,6 +630,7 @@ class _FpnTopDownFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *lats):
+        _note_use(*lats)
         lats = list(lats)
         for i in range(len(lats) - 1, 0, -1):
             K.upsample2x_add_(lats[i - 1], lats[i])
@@ -612,6 +653,7 @@ def fpn_top_down(lats):
 class _Subsample2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        _note_use(x)
         ctx.shape = tuple(x.shape)
         return K.subsample2(x)
 
@@ -633,6 +675,7 @@ class _FuseSumReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, shifts, *terms):
+        _note_use(*terms)
         y = K.fuse_sum_relu(list(terms), shifts, relu=True)
         ctx.shifts = shifts
         ctx.save_for_backward(y)
@@ -666,6 +709,7 @@ class _HRFPNConcatFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *xs):
+        _note_use(*xs)
         B, _, H, W = xs[0].shape
         ctot = sum(x.shape[1] for x in xs)
         out = K.empty_nhwc(B, ctot, H, W, xs[0].dtype, xs[0].device)
@@ -693,6 +737,7 @@ def hrfpn_concat(xs):
 class _AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, shift):
+        _note_use(x)
         ctx.shift = shift
         return K.avgpool(x, shift)
 
@@ -754,6 +799,7 @@ class _SparseRPNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vals, rows, slot, A, nlev, w_conv, b_conv, w_cls, b_cls, w_reg, b_reg, *maps):
+        _note_use(*maps)
         xs, hs = maps[:nlev], maps[nlev:]
         h_sel = K.rpn_gather_rows(list(hs), rows, 1)
         ctx.save_for_backward(rows, slot, w_conv, w_cls, w_reg, h_sel, *xs)
@@ -866,6 +912,7 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, specs, bns, x_is_relu_out, *tensors):
+        _note_use(x)
         main_specs, sc_spec = specs
         n = len(main_specs)
         pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
@@ -894,7 +941,7 @@ class _ResBlockFn(torch.autograd.Function):
         ctx.n_saved = (len(acts), len(packs))
         ctx.save_for_backward(h, *acts, *[p for p in packs if p is not None])
         ctx.pack_none = [p is None for p in packs]
-        return h
+        return _begin_uses(h)
 
     @staticmethod
     def backward(ctx, g):
@@ -914,7 +961,7 @@ class _ResBlockFn(torch.autograd.Function):
         g = to_nhwc(g)
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
-        if getattr(g, '_loft_premasked', None) != out.data_ptr():
+        if not _premasked(g, out):
             g = K.relu_bwd(g, out)
         grads = [None] * len(P)
         need_dx = needs[0]

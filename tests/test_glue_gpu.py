@@ -386,3 +386,49 @@ def test_roi_sample_targets_matches_tensor_formulation():
     w = torch.zeros(rois.shape[0], 4, device='cuda')
     w[pos_sel] = 1.0
     assert torch.equal(got['bbox_weights'], w) and bool((got['label_weights'] == 1).all())
+
+
+def test_premasked_gradient_with_two_consumers_any_order():
+    """ADVICE r1 (nn.py pre-masked gradients): y = relu(conv(x)) feeds a consumer that folds y's ReLU mask into its own dgrad
+    epilogue (input_relu=True) AND a consumer that does not.  Autograd sums the two contributions in place into whichever arrives
+    first; the producer may skip its relu_bwd only when the tagged gradient is the whole gradient.  Both creation orders, against
+    the same graph without any epilogue folding and against torch-CPU autograd."""
+    from bonai_amd import nn as F2
+    torch.manual_seed(0)
+    B, C, H, W = 2, 128, 12, 12
+    x0 = torch.randn(B, C, H, W).bfloat16()
+    ws = [torch.nn.Parameter((torch.randn(C, C, 3, 3) * (1.0 / (C * 9)) ** 0.5).cuda()) for _ in range(3)]
+
+    def run(order, fold):
+        for w in ws:
+            w.grad = None
+        x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = F2.conv2d(x, ws[0], None, pad=1, relu=True)
+        if order == 'plain_first':
+            b = F2.conv2d(y, ws[2], None, pad=1, relu=False)                       # consumer without mask folding
+            a = F2.conv2d(y, ws[1], None, pad=1, relu=True, input_relu=fold)       # consumer that folds y's mask
+        else:
+            a = F2.conv2d(y, ws[1], None, pad=1, relu=True, input_relu=fold)
+            b = F2.conv2d(y, ws[2], None, pad=1, relu=False)
+        (a.float().sum() * 0.5 + (b.float() * b.float()).sum() * 0.1).backward()
+        return x.grad.float().cpu(), [w.grad.float().cpu().clone() for w in ws]
+
+    ref_x, ref_w = run('plain_first', fold=False)
+    for order in ('plain_first', 'folding_first'):
+        gx, gw = run(order, fold=True)
+        assert (gx - ref_x).abs().max().item() <= 2e-2 * ref_x.abs().max().item(), order
+        for g, r in zip(gw, ref_w):
+            assert (g - r).abs().max().item() <= 2e-2 * r.abs().max().item(), order
+    # and the graph itself against torch-CPU fp32 autograd on the same bf16-rounded operands
+    xc = x0.float().requires_grad_(True)
+    wc = [w.detach().float().cpu().bfloat16().float().requires_grad_(True) for w in ws]
+    yc = torch.relu(torch.nn.functional.conv2d(xc, wc[0], padding=1))
+    ac = torch.relu(torch.nn.functional.conv2d(yc, wc[1], padding=1))
+    bc = torch.nn.functional.conv2d(yc, wc[2], padding=1)
+    (ac.sum() * 0.5 + (bc * bc).sum() * 0.1).backward()
+    assert (ref_x - xc.grad).abs().max().item() <= 5e-2 * xc.grad.abs().max().item()
+    # a single folding consumer still lets the producer skip its pass (the tag is honoured: exactly one registered use)
+    x = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = F2.conv2d(x, ws[0], None, pad=1, relu=True)
+    a = F2.conv2d(y, ws[1], None, pad=1, relu=True, input_relu=True)
+    assert F2._USES.get(y.data_ptr()) == 1

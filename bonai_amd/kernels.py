@@ -404,10 +404,20 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     db: optional zeroed fp32 [groups, Cout] -> bias gradient accumulated in the same pass."""
     lib = L.load()
     L.dev_check(g, x)
+    A = lambda i: L.arr(c_int, [t[i] for t in taps])
+    if g.dtype == torch.float32 and x.dtype == torch.float32:
+        # fp32 parity mode: exact-fp32 contraction (parity_f32.hip); the bias gradient is the plain column sum of g
+        if dw is None:
+            dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
+        L.check(lib.loft_conv_wgrad_f32(L.ptr(g), L.ptr(x), L.ptr(dw), B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps),
+                                        A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
+                                        c_int64(n_wtaps * Cout * Cin), L.stream()), 'loft_conv_wgrad_f32')
+        if db is not None:
+            db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
+        return dw
     _bf16(g), _bf16(x)
     if dw is None:
         dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
-    A = lambda i: L.arr(c_int, [t[i] for t in taps])
     _ev = _prof_begin()
     if (Cout <= 64 and Cin <= 64 and len(taps) <= 9 and gos == 1 and ss == 1 and (GH, GW) == (OH, OW) == (XH, XW)
             and B * OH * OW >= 65536 and all(t[0] == 0 and t[1] == 0 and abs(t[2]) <= 1 and abs(t[3]) <= 1 for t in taps)
@@ -454,6 +464,9 @@ def relu_bwd(g, y):
     lib = L.load()
     L.dev_check(g, y)
     out = torch.empty_like(g)
+    if g.dtype == torch.float32 and y.dtype == torch.float32:          # fp32 parity mode
+        L.check(lib.loft_relu_bwd_f32(L.ptr(g), L.ptr(y), L.ptr(out), c_int64(g.numel()), L.stream()), 'loft_relu_bwd_f32')
+        return out
     L.check(lib.loft_relu_bwd_bf16(L.ptr(_bf16(g)), L.ptr(_bf16(y)), L.ptr(out), c_int64(g.numel()), L.stream()),
             'loft_relu_bwd_bf16')
     return out
@@ -485,6 +498,10 @@ def downsum2x_add_(coarse, fine):
     lib = L.load()
     fine, coarse = _nhwc(fine), _nhwc(coarse)
     B, C, Hc, Wc = coarse.shape
+    if fine.dtype == torch.float32 and coarse.dtype == torch.float32:  # fp32 parity mode
+        L.check(lib.loft_downsum2x_add_f32(L.ptr(coarse), L.ptr(fine), B, Hc, Wc, fine.shape[2], fine.shape[3], C, L.stream()),
+                'loft_downsum2x_add_f32')
+        return coarse
     L.check(lib.loft_downsum2x_add_bf16(L.ptr(_bf16(coarse)), L.ptr(_bf16(fine)), B, Hc, Wc, C, L.stream()),
             'loft_downsum2x_add_bf16')
     return coarse
@@ -508,6 +525,10 @@ def subsample2_adjoint_add_(big, small):
     lib = L.load()
     big, small = _nhwc(big), _nhwc(small)
     B, C, H, W = big.shape
+    if big.dtype == torch.float32 and small.dtype == torch.float32:    # fp32 parity mode
+        L.check(lib.loft_subsample2_add_f32(L.ptr(big), L.ptr(small), B, small.shape[2], small.shape[3], H, W, C, L.stream()),
+                'loft_subsample2_add_f32')
+        return big
     L.check(lib.loft_subsample2_bf16(L.ptr(_bf16(small)), L.ptr(_bf16(big)), B, small.shape[2], small.shape[3], H, W, C,
                                      1, L.stream()), 'loft_subsample2_bf16(adjoint)')
     return big

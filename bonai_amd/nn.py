@@ -150,20 +150,18 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu, cout_pad = ctx.meta
         x, y, wpt = ctx.saved_tensors[:3]
-        if x.dtype != torch.bfloat16:
-            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         tensors = ctx.saved_tensors[3:]
         ws = tensors[0:2 * G:2]
         Cout, Cin, R, S = ws[0].shape
         g = to_nhwc(g)
-        if g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
+        if g.dtype != x.dtype:          # bf16 training path; fp32 parity mode keeps everything fp32 (parity_f32.hip kernels)
+            g = g.to(x.dtype)
         if relu and not _premasked(g, y):
             g = K.relu_bwd(g, y)        # (skipped when the consumer's dgrad epilogue already applied this mask)
         gx = None
         if ctx.needs_input_grad[0]:
             # input_relu: x is a ReLU output, so d/d(pre-activation) = gx * (x > 0): folded into the dgrad epilogue
-            gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G, mask=x if input_relu else None)
+            gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G, mask=x if input_relu else None, out_dtype=x.dtype)
             if input_relu and stride == 1:
                 gx._loft_premasked = x.data_ptr()
         ngrads = [None] * len(tensors)
@@ -374,12 +372,10 @@ class _NarrowHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        if x.dtype != torch.bfloat16:
-            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         stride, pad = ctx.sp
         Cout, Cin, R, S = w.shape
         if R == 1 and S == 1 and stride == 1 and pad == 0 and Cout <= 8 and Cin % 4 == 0 and Cin <= 1024 and \
-                not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
+                x.dtype == torch.bfloat16 and not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
             # one pass over x: gx (with the producer's ReLU mask when x is a ReLU output), dW and db together
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=ctx.input_relu, need_gx=ctx.needs_input_grad[0],
@@ -389,14 +385,14 @@ class _NarrowHeadFn(torch.autograd.Function):
             return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
-        gp = torch.zeros(N, P, H, W, dtype=torch.bfloat16, device=g.device).contiguous(memory_format=torch.channels_last)
+        gp = torch.zeros(N, P, H, W, dtype=x.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
         gp[:, :Cout] = g[:, :Cout]
         gx = gw = gb = None
         K.ALGO_SCALE = Cout / P
         if ctx.needs_input_grad[0]:
-            wt = torch.zeros(R * S, Cin, P, dtype=torch.bfloat16, device=w.device)
+            wt = torch.zeros(R * S, Cin, P, dtype=x.dtype, device=w.device)
             wt[:, :, :Cout] = w.permute(2, 3, 1, 0).reshape(R * S, Cin, Cout)
-            gx = K.conv2d_dgrad(gp, wt[None], tuple(x.shape[2:]), R, S, stride, pad)
+            gx = K.conv2d_dgrad(gp, wt[None], tuple(x.shape[2:]), R, S, stride, pad, out_dtype=x.dtype)
         want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_b:   # bias gradient from the same pass (ones-operand MFMA)
@@ -495,17 +491,17 @@ class _DeconvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        if x.dtype != torch.bfloat16:
-            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
         g = to_nhwc(g)
+        if g.dtype != x.dtype:
+            g = g.to(x.dtype)
         if not _premasked(g, y):   # (else the 1x1 logits head already applied this ReLU's mask)
             g = K.relu_bwd(g, y)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt = w.permute(2, 3, 0, 1).reshape(4, Cin, Cout).to(torch.bfloat16).contiguous()
-            gx = K.empty_nhwc(N, Cin, H, W, torch.bfloat16, x.device)
+            wt = w.permute(2, 3, 0, 1).reshape(4, Cin, Cout).to(x.dtype).contiguous()
+            gx = K.empty_nhwc(N, Cin, H, W, x.dtype, x.device)
             taps = [(py, px, py * 2 + px) for py in range(2) for px in range(2)]
             # x is the ReLU output of the last mask conv (fcn_mask_head.py:117-124): its mask rides in this epilogue
             K.conv_tap(g, wt, gx, N, 2 * H, 2 * W, Cout, Cin, H, W, H, W, taps, ss=2, mask=x if ctx.input_relu else None)
@@ -618,7 +614,7 @@ class _RoIAlignFn(torch.autograd.Function):
             return (None, None, None, None, None) + tuple(ret)
         grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True,       # (rois in bbox2roi order)
                                 out_dtype=torch.bfloat16 if direct else torch.float32)
-        return (None, None, None, None, None) + tuple(x if x.dtype == dt else K.cast_bf16(x) for x in grads)
+        return (None, None, None, None, None) + tuple(x if x.dtype == dt else K.cast_bf16(x) for x in grads)   # (fp32 maps: as is)
 
 
 def roi_align(feats, rois, P, strides, finest_scale=56, n_rot=1):
@@ -660,7 +656,7 @@ class _Subsample2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         n, c, h, w = ctx.shape
-        big = K.zeros_nhwc(n, c, h, w, torch.bfloat16, g.device)
+        big = K.zeros_nhwc(n, c, h, w, g.dtype, g.device)
         return K.subsample2_adjoint_add_(big, to_nhwc(g))
 
 
@@ -954,13 +950,11 @@ class _ResBlockFn(torch.autograd.Function):
         it = iter(saved[1 + na:])
         packs = [None if isnone else next(it) for isnone in ctx.pack_none]
         x = acts[0]
-        if x.dtype != torch.bfloat16:
-            raise K.L.LoftHipError('fp32 parity mode is forward-only (training runs bf16 activations)')
         P, bns = ctx.params, ctx.bns
         needs = ctx.needs_input_grad
         g = to_nhwc(g)
-        if g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
+        if g.dtype != x.dtype:          # bf16 training path; the fp32 parity mode stays fp32 throughout
+            g = g.to(x.dtype)
         if not _premasked(g, out):
             g = K.relu_bwd(g, out)
         grads = [None] * len(P)
@@ -972,20 +966,20 @@ class _ResBlockFn(torch.autograd.Function):
             xin = acts[i]
             grads[3 * i:3 * i + 3] = _rb_param_grads(gk, xin, P[3 * i], bns[i], k, s, p, needs[4 + 3 * i:7 + 3 * i])
             if i > 0:       # input of conv i is the ReLU output of conv i-1: its mask rides in this dgrad's epilogue
-                gk = K.conv2d_dgrad(gk, packs[i], tuple(xin.shape[2:]), k, k, s, p, mask=xin)
+                gk = K.conv2d_dgrad(gk, packs[i], tuple(xin.shape[2:]), k, k, s, p, mask=xin, out_dtype=x.dtype)
         gx = None
         if need_dx:
             k, s, p, cp = main_specs[0]
             mask = x if ctx.x_is_relu_out else None
             if sc_spec is None:
                 # shortcut = identity: its gradient (g) is the residual of the first conv's data gradient
-                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, residual=g, mask=mask)
+                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, residual=g, mask=mask, out_dtype=x.dtype)
             else:
                 # (mask on both launches: a strided shortcut conv only covers one output parity class, the other positions
                 #  are copies of the residual and must already be masked; the mask is idempotent)
-                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, mask=mask)
+                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, mask=mask, out_dtype=x.dtype)
                 ks, ss, ps, cps = sc_spec
-                gx = K.conv2d_dgrad(g, packs[n], tuple(x.shape[2:]), ks, ks, ss, ps, residual=gx, mask=mask)
+                gx = K.conv2d_dgrad(g, packs[n], tuple(x.shape[2:]), ks, ks, ss, ps, residual=gx, mask=mask, out_dtype=x.dtype)
             if mask is not None:
                 gx._loft_premasked = x.data_ptr()
         if sc_spec is not None:

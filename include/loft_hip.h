@@ -127,6 +127,16 @@ int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, co
                          int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                          const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
                          int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int variant, void* stream);
+/* fp32 parity mode, backward (parity_f32.hip): weight gradient of the same tap contract on v_mfma_f32_32x32x2_f32 (dw is
+ * accumulated into: the caller zeroes it), and the fp32 forms of the glue adjoints.  Checker path (1e-3 vs the reference's fp32
+ * autograd), not a performance path. */
+int loft_conv_wgrad_f32(const float* g, const float* x, float* dw, int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH,
+                        int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host, const int* dy_host,
+                        const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                        void* stream);
+int loft_relu_bwd_f32(const float* g, const float* y, float* out, int64_t n, void* stream);
+int loft_downsum2x_add_f32(float* coarse, const float* fine, int B, int Hc, int Wc, int Hf, int Wf, int C, void* stream);
+int loft_subsample2_add_f32(float* big, const float* small, int B, int Hs, int Ws, int Hb, int Wb, int C, void* stream);
 /* loft_conv_tap_f32: the fp32 parity mode of the same contract (all operands and the output fp32, contraction on
  * v_mfma_f32_32x32x2_f32 = exact fp32 products and sums).  Forward / data-gradient only; it exists so inference results can
  * be checked against the reference's fp32 outputs at the north-star tolerance (1e-3), not for speed.  Cin % 32 == 0. */

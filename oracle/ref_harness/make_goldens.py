@@ -168,6 +168,10 @@ def e2e(size=256, batch=2, num_gt=10):
         g = gr[n]
         out['gradnorm_' + n] = np.float32(g.norm().item())
         out['gradhead_' + n] = T(g.reshape(-1)[:16])
+    # every parameter: gradient norm + first 8 entries (the fp32 parity mode's backward is checked against ALL of them)
+    for n, g in gr.items():
+        out['allnorm_' + n] = np.float32(g.norm().item())
+        out['allhead_' + n] = T(g.reshape(-1)[:8])
     out['meta'] = np.array([size, batch, num_gt])
     np.savez_compressed(os.path.join(GOLD, f'e2e_{size}.npz'), **out)
     print(f'e2e_{size}.npz', {k: float(v) for k, v in log_vars.items()})
@@ -337,6 +341,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'hrnet':
         hrnet()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'e2e':
+        e2e()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'offset_head':
         offset_head()

@@ -97,8 +97,8 @@ def test_e2e_vs_oracle_proposals_and_targets():
 
 
 def test_e2e_fp32_parity_mode_vs_reference_fixture():
-    """North-star tolerance (1e-3) on the forward quantities: the same fixture as above with the fp32 parity mode
-    (fp32 MFMA contraction, fp32 activations, forward only) -- features and all seven losses at 1e-3."""
+    """North-star tolerance (1e-3), forward AND backward: the same fixture as above with the fp32 parity mode (fp32 MFMA
+    contraction, fp32 activations) -- features, all seven losses and the gradient of every parameter at 1e-3."""
     from bonai_amd.synth import make_batch
     gd = np.load(os.path.join(GOLD, 'e2e_256.npz'))
     size, batch, num_gt = [int(v) for v in gd['meta']]
@@ -113,18 +113,36 @@ def test_e2e_fp32_parity_mode_vs_reference_fixture():
             got = f[:, :8, :6, :6].cpu()
             scale = float(gd[f'feat_{i}_absmean'])
             assert (got - want).abs().max().item() < 1e-3 * scale, (i, (got - want).abs().max().item(), scale)
-        out = m.train_step(data)
+    out = m.train_step(data)
     lv = dict(out['log_vars'].items())
     for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'loss_mask', 'loss_offset', 'loss'):
         want = float(gd['log_' + k])
         assert abs(lv[k] - want) <= 1e-3 * max(1.0, abs(want)), (k, lv[k], want)
     assert abs(lv['acc'] - float(gd['log_acc'])) <= 0.2     # one of 1024 sampled RoIs flipping is 0.1
-    # the parity mode refuses to train
-    m2 = _build()
-    m2.backbone.compute_dtype = torch.float32
-    from bonai_amd.lib import LoftHipError
-    with pytest.raises(LoftHipError):
-        m2.train_step(data)['loss'].backward()
+    # BACKWARD in the parity mode (fp32 dgrad on loft_conv_tap_f32, fp32 weight gradient / glue adjoints of parity_f32.hip): the
+    # gradient of EVERY trainable parameter against the reference's own autograd -- norm at 1e-3, leading entries at 1e-2 of the
+    # gradient's scale.  This pins the composition of the autograd nodes (residual-block node, RoIAlign / FPN adjoints, narrow
+    # heads, grouped FOA launches), not just the kernels one by one.
+    out['loss'].backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    names = [k[len('allnorm_'):] for k in gd.files if k.startswith('allnorm_')]
+    assert sorted(names) == sorted(n for n, g in grads.items() if g is not None) and len(names) > 200
+    worst = (0.0, None)
+    for n in names:
+        g = grads[n].float()
+        wn = float(gd['allnorm_' + n])
+        gn = float(g.norm())
+        rms = wn / max(g.numel(), 1) ** 0.5
+        wh = torch.from_numpy(gd['allhead_' + n])
+        gh = g.reshape(-1)[:wh.numel()].cpu()
+        e1 = abs(gn - wn) / max(wn, 1e-12)
+        e2 = float((gh - wh).abs().max()) / max(float(wh.abs().max()), rms, 1e-12)
+        worst = max(worst, (e1, n), (e2, n))
+        assert e1 <= 1e-3, ('norm', n, gn, wn)
+        # single entries: 1e-2 of max(largest listed entry, rms) -- the entries are sums of ~1e5 signed fp32 products whose order
+        # differs from the reference's CPU kernels, on top of the few mask-target pixels that sit on the 0.5 edge
+        assert e2 <= 1e-2, ('head', n, gh, wh)
+    print('fp32 parity backward: worst relative error', worst)
 
 
 def test_sparse_rpn_backward_matches_dense_autograd():

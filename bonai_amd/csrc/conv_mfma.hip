@@ -500,11 +500,12 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                         ss == 1 && OHf == OH && OWf == OW;
     int k = kern;
     if (k == LOFT_CONV_AUTO) {
-        if (Cout % 256 == 0 && big_blocks >= 192 && Kdim >= 512) {
-            // bf16 output without a shortcut operand: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue
-            // (conv_pipe.hip; +26..43 % over the lockstep kernel on the 3x3 / FC shapes); everything else: lockstep kernels
-            if (!out_f32 && !accumulate && !residual) k = LOFT_CONV_STREAM256;
-            else k = deepk ? LOFT_CONV_T256_FAST : LOFT_CONV_T256;
+        if (Cout % 256 == 0 && big_blocks >= 192 && !out_f32 && !accumulate) {
+            // bf16 output: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue (conv_pipe.hip; +26..43 %
+            // over the lockstep 256-tile kernel on the 3x3 / FC shapes, +15..35 % over the 128-tile kernels on the K-shallow 1x1s)
+            k = LOFT_CONV_STREAM256;
+        } else if (Cout % 256 == 0 && big_blocks >= 192 && Kdim >= 512) {
+            k = deepk ? LOFT_CONV_T256_FAST : LOFT_CONV_T256;
         }
         else if (Cout % 128 == 0) {
             const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
@@ -518,7 +519,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     case LOFT_CONV_PIPE256:
         // software-pipelined 256x256 kernels (conv_pipe.hip)
         // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
-        if (Cout % 256 || out_f32 || accumulate || residual) return (int)hipErrorInvalidValue;
+        if (Cout % 256 || out_f32 || accumulate) return (int)hipErrorInvalidValue;
         a.pixmajor = pix_ok;
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer

@@ -69,10 +69,25 @@ __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const b
     return base + out_g + opix * a.Cout + n0;
 }
 
-// bias + ReLU -> bf16 -> LDS -> whole rows out; the ReLU-backward mask (data-gradient launches) is applied in the copy-out pass on
-// the packed bf16 values against 16-byte mask loads with the address pattern of the stores -- the accumulators are dead by then.
-// (No residual input: launches with a shortcut operand are K-shallow and keep the 128-wide kernels.)
-template <typename StampFn>
+// bias (+ residual) + ReLU -> bf16 -> LDS -> whole rows out; the ReLU-backward mask (data-gradient launches) is applied in the
+// copy-out pass on the packed bf16 values against 16-byte mask loads with the address pattern of the stores -- the accumulators
+// are dead by then.  RES: the residual tile (bottleneck shortcut, resnet.py:294-296; shortcut gradient of a fused block) comes in
+// through LDS with whole-row copies first; every lane reads its 8-byte pieces from there, adds in fp32 and overwrites them with
+// the result in place.
+__device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int ohw, int wave, int lane,
+                                              char* lds) {
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const int r = wave * 32 + it * 2 + (lane >> 5);
+        const int c = (lane & 31) ^ (r & 31);                 // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
+        const int m = m0 + r;
+        const bf16_t* p = a.zero_page;
+        if (m < a.M) p = pipe_row_ptr(a, t, out_g, m, n0, ohw) + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * 32 + it * 2) * 512), 16, 0, 0);
+    }
+}
+
+template <bool RES, typename StampFn>
 __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[2][4], char* lds, int g, int m0, int n0, int wave,
                                                      int lane, int ohw, StampFn&& kstamp) {
     const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
@@ -88,6 +103,11 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // every wave is done with the K loop's fragments
     kstamp(44);
+    if constexpr (RES) {
+        pipe_stage_in(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int i = k >> 2, gq = k & 3;
@@ -96,25 +116,41 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[4];
-            v[0] = fmaxf(acc[i][j][gq * 4 + 0] + bv.x, lo); v[1] = fmaxf(acc[i][j][gq * 4 + 1] + bv.y, lo);
-            v[2] = fmaxf(acc[i][j][gq * 4 + 2] + bv.z, lo); v[3] = fmaxf(acc[i][j][gq * 4 + 3] + bv.w, lo);
+            v[0] = acc[i][j][gq * 4 + 0] + bv.x; v[1] = acc[i][j][gq * 4 + 1] + bv.y;
+            v[2] = acc[i][j][gq * 4 + 2] + bv.z; v[3] = acc[i][j][gq * 4 + 3] + bv.w;
+            if constexpr (RES) {
+                float rv[4];
+                ld4(reinterpret_cast<const bf16_t*>(q + j * 16384), rv);
+                v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+            }
+            v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
             st4(reinterpret_cast<bf16_t*>(q + j * 16384), v);
+            if constexpr (RES) PIPE_SB();
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     kstamp(46);
     __syncthreads();
     kstamp(47);
-    // LDS -> HBM, whole rows
+    // LDS -> HBM, whole rows.  All 16 row reads first (the accumulators are dead: 64 free registers), then the stores: one
+    // lgkmcnt wait for the whole tile instead of a read -> wait -> store chain per row pair.
     const bf16_t* mask = a.mask;
-#pragma unroll 2
+    const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m: no decode
+    uint4 rowv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int r = wave * 32 + it * 2 + (lane >> 5);
+        rowv[it] = *reinterpret_cast<const uint4*>(lds + r * 512 + (lane & 31) * 16);
+    }
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int r = wave * 32 + it * 2 + (lane >> 5);
         const int c = (lane & 31) ^ (r & 31);
         const int m = m0 + r;
         if (m < a.M) {
-            uint4 v = *reinterpret_cast<const uint4*>(lds + r * 512 + (lane & 31) * 16);
-            const bf16_t* p = pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw) + c * 8;
+            uint4 v = rowv[it];
+            const bf16_t* p = (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
+                                     : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw)) + c * 8;
             if (mask) {
                 const uint4 mk = *reinterpret_cast<const uint4*>(mask + (p - reinterpret_cast<const bf16_t*>(a.out)));
                 // keep a bf16 lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
@@ -205,12 +241,34 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         }
     }
     kstamp(41);
-    for (int t = 0; t < a.T; ++t) {
-        const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+    if (a.pixmajor) {
+        // pixel-major rows: m = position * B + RoI with B >= 256, so the 256 rows of a tile sit on at most TWO pixel positions
+        // and the tap masks are functions of the position only: two wave-uniform (scalar) passes over the taps instead of a
+        // per-lane loop of T x 4 rows (3-4k cycles per workgroup on the 7x7 / 14x14 RoI maps)
+        const int rem0 = fastdiv(m0, a.b_mul, a.b_sh);
+        unsigned mk0 = 0u, mk1 = 0u;
+        const int oy0 = fastdiv(rem0, a.ow_mul, a.ow_sh), ox0 = rem0 - oy0 * a.OW;
+        const int rem1 = rem0 + 1;
+        const int oy1 = fastdiv(rem1, a.ow_mul, a.ow_sh), ox1 = rem1 - oy1 * a.OW;
+        for (int t = 0; t < a.T; ++t) {
+            const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+            const int iy0_ = oy0 * a.ss + dy, ix0_ = ox0 * a.ss + dx, iy1_ = oy1 * a.ss + dy, ix1_ = ox1 * a.ss + dx;
+            mk0 |= ((iy0_ >= 0) & (iy0_ < a.IH) & (ix0_ >= 0) & (ix0_ < a.IW)) ? (1u << t) : 0u;
+            mk1 |= ((iy1_ >= 0) & (iy1_ < a.IH) & (ix1_ >= 0) & (ix1_ < a.IW)) ? (1u << t) : 0u;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
+            const int m = m0 + i * 64 + srow;
+            if (m < a.M) a_mask[i] = (fastdiv(m, a.b_mul, a.b_sh) == rem0) ? mk0 : mk1;
+        }
+    } else {
+        for (int t = 0; t < a.T; ++t) {
+            const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
+            }
         }
     }
     kstamp(42);
@@ -453,7 +511,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         if constexpr (VAR & 2)
             conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
                                          a.pixmajor != 0);
-        else pipe_epilogue_staged(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else if (a.residual) pipe_epilogue_staged<true>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else pipe_epilogue_staged<false>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long kst3 = __builtin_amdgcn_s_memtime();
@@ -631,7 +690,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
     if (wm == 0) PIPE_BARRIER();          // barrier counts of the two groups match again
 
-    pipe_epilogue_staged(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    if (a.residual) pipe_epilogue_staged<true>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    else pipe_epilogue_staged<false>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.

@@ -138,14 +138,16 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256, K.CONV_T256, K.CONV_STREAM256):
             K.CONV_VARIANT = v
             try:
-                # (the pipelined kernels serve bf16 outputs without a shortcut operand; everything else stays on the lockstep ones)
+                # (the pipelined kernels serve bf16 outputs; fp32 / accumulating launches stay on the lockstep ones)
                 o16 = K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True)
+                o16r = K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, residual=res)
+                grm = K.conv2d_dgrad(res, wpt, (H, W), R, R, 1, pad, mask=x, residual=x) if Cin % 256 == 0 else None
                 # data-gradient form with the ReLU-backward mask epilogue (bf16 out); plain bf16 out without bias
                 gm = K.conv2d_dgrad(res, wpt, (H, W), R, R, 1, pad, mask=x) if Cin % 256 == 0 else None
                 o16p = K.conv2d_fwd(x, wp, None, R, R, 1, pad)
             finally:
                 K.CONV_VARIANT = K.CONV_AUTO
-            outs.append((o16, gm, o16p))
+            outs.append((o16, gm, o16p, o16r, grm))
         for o in outs[1:]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)

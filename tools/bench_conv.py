@@ -14,6 +14,10 @@ SHAPES = [
     ('layer2.1x1.512-128', 8, 512, 128, 128, 128, 1, 1, 0, 1),
     ('layer3.3x3', 8, 256, 256, 64, 64, 3, 1, 1, 1),
     ('layer3.1x1.1024-256', 8, 1024, 256, 64, 64, 1, 1, 0, 1),
+    ('layer3.1x1.256-1024', 8, 256, 1024, 64, 64, 1, 1, 0, 1),
+    ('layer2.1x1.128-512', 8, 128, 512, 128, 128, 1, 1, 0, 1),
+    ('fpn.lat.512-256', 8, 512, 256, 128, 128, 1, 1, 0, 1),
+    ('fpn.lat.256-256', 8, 256, 256, 256, 256, 1, 1, 0, 1),
     ('layer4.3x3', 8, 512, 512, 32, 32, 3, 1, 1, 1),
     ('layer4.1x1.512-2048', 8, 512, 2048, 32, 32, 1, 1, 0, 1),
     ('fpn.P2.3x3', 8, 256, 256, 256, 256, 3, 1, 1, 1),
@@ -52,18 +56,18 @@ def main():
         g = torch.randn_like(y)
         row = f'{name:28s} {gflop:8.1f} '
         for wh in which:
-            if wh == 'pipe':
+            if wh in ('pipe', 'stream'):
                 if Cout % 256:
                     row += f'{"-":>10s} {"-":>8s} '
                     continue
-                K.CONV_VARIANT = K.CONV_PIPE256
+                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe' else K.CONV_STREAM256
                 ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
                 K.CONV_VARIANT = K.CONV_AUTO
-            elif wh == 'pipe_dgrad':
+            elif wh in ('pipe_dgrad', 'stream_dgrad'):
                 if Cin % 256 or st != 1:
                     row += f'{"-":>10s} {"-":>8s} '
                     continue
-                K.CONV_VARIANT = K.CONV_PIPE256
+                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe_dgrad' else K.CONV_STREAM256
                 ms = timeit(lambda: K.conv2d_dgrad(g, wpt, (H, W), R, R, st, pad, groups=G))
                 K.CONV_VARIANT = K.CONV_AUTO
             elif wh == 'fwd':

@@ -262,14 +262,15 @@ def main():
         K.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
         ach = fam[dom][0] / fam[dom][1] / 1e12
-        kname = 'conv_tap_kernel' if dom == 'conv_tap' else 'conv_wgrad_kernel'
+        kname = dom     # family = one C-ABI entry point (loft_conv_tap_bf16_v / loft_conv_wgrad_bf16_v) and the kernel templates it dispatches
         traffic = mfma_util = None   # from separate rocprofv3 --pmc passes of this command (tools/pmc_collect.py -> profiles/)
         pmc = os.path.join(ROOT, 'profiles', 'round2_pmc_traffic.json')
         if os.path.exists(pmc) and args.batch == 8 and args.size == 1024 and headline:
             ent = json.load(open(pmc)).get(kname, {})
             traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
             mfma_util = round(ent['mfma_util'], 4) if 'mfma_util' in ent else None
-        roofline = dict(bound='mfma', kernel=kname,
+        roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates (loft_conv_tap_bf16_v)',
+                                              'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '

@@ -229,12 +229,17 @@ class Trainer:
         if F2.GRAD_SINK is not None and not os.environ.get('LOFT_NO_UNPACK_QUEUE'):
             # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
             F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48)
+            if not os.environ.get('LOFT_NO_SIDE_STREAM') and not os.environ.get('LOFT_NO_WGRAD_STREAM'):
+                if getattr(self, '_wgrad_stream', None) is None:
+                    self._wgrad_stream = torch.cuda.Stream()
+                F2.WGRAD_STREAM = self._wgrad_stream
         try:
             (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
             if F2.UNPACK_Q is not None:
                 F2.UNPACK_Q.flush()
         finally:
             F2.UNPACK_Q = None
+            F2.WGRAD_STREAM = None
             F2.GRAD_SINK = prev
             F2.HUB = None
             K.zero_pool_end()

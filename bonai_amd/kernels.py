@@ -1296,6 +1296,9 @@ class UnpackQueue:
             ev = torch.cuda.Event()
             ev.record()                       # (on the producing side stream)
             self.events.append(ev)
+            for t in (dwp, db):               # allocated on the side stream, read by the batched launch on the home stream
+                if t is not None:
+                    t.record_stream(self.home)
         self.done.extend(on_done)
         if len(self.jobs) >= self.limit:
             self.flush()

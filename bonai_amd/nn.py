@@ -82,6 +82,7 @@ def _premasked(g, y):
     return getattr(g, '_loft_premasked', None) == y.data_ptr() and _USES.get(y.data_ptr(), 2) == 1
 
 
+WGRAD_STREAM = None   # the running Trainer's second stream for backbone weight-gradient launches (None = same stream)
 UNPACK_Q = None    # the running Trainer's kernels.UnpackQueue: weight-gradient unpacking of many convs in one launch
 PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
 _PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
@@ -878,10 +879,24 @@ def _rb_param_grads(g, x, w, bn, k, stride, pad, needs):
     need_w, need_g, need_b = needs
     if not (need_w or need_g or need_b):
         return None, None, None
-    dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True)
     bnt = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
     slots = (_direct_slot(w) if need_w else None, _direct_slot(bn.weight) if need_g else None, _direct_slot(bn.bias) if need_b else None)
-    if need_w and need_g and need_b and all(s is not None for s in slots):
+    sunk = need_w and need_g and need_b and all(s is not None for s in slots)
+    if sunk and UNPACK_Q is not None and WGRAD_STREAM is not None and g.is_cuda and K.PROFILE is None:
+        # Nothing on the data-gradient chain reads a weight gradient, so the launch goes to a second stream and runs beside
+        # the next blocks' dgrad kernels (its split-K atomics tail and its < 256-workgroup grids leave CUs idle otherwise);
+        # the unpack queue waits for it with an event (UnpackQueue.add / flush).
+        cur = torch.cuda.current_stream()
+        WGRAD_STREAM.wait_stream(cur)
+        g.record_stream(WGRAD_STREAM)
+        x.record_stream(WGRAD_STREAM)
+        _mark_sunk(w, bn.weight, bn.bias)
+        with torch.cuda.stream(WGRAD_STREAM):
+            dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True)
+            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)])
+        return None, None, None
+    dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True)
+    if sunk:
         _mark_sunk(w, bn.weight, bn.bias)
         if UNPACK_Q is not None:
             UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)])

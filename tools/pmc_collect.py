@@ -16,11 +16,16 @@ import sys
 
 ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, 'gpurun_out', 'pmc')
-FAMILIES = ['conv_tap_kernel', 'conv_wgrad_kernel', 'conv_wgrad64_kernel', 'roi_align_fwd_kernel', 'roi_align_fwd_sep_kernel',
-            'roi_align_bwd_tile_kernel', 'roi_align_bwd_mfma_kernel', 'narrow_head_bwd_kernel', 'random_sample_kernel',
-            'fold_pack_multi_kernel', 'fold_unpack_bwd_multi_kernel',
-            'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
-            'fuse_sum_relu_kernel', 'stem_mfma_kernel']
+# family -> kernel-name substrings.  'conv_tap' / 'conv_wgrad' are the two C-ABI entry points (loft_conv_tap_bf16_v /
+# loft_conv_wgrad_bf16_v); each dispatches to several templates of a lock-step and a software-pipelined kernel.
+FAMILIES = {'conv_tap': ['conv_tap_kernel', 'conv_tap_pipe_kernel'],
+            'conv_wgrad': ['conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad64_kernel']}
+FAMILIES.update({k: [k] for k in [
+    'conv_tap_pipe_kernel', 'conv_wgrad_stream_kernel', 'conv64_patch_kernel',
+    'roi_align_fwd_kernel', 'roi_align_fwd_sep_kernel', 'roi_align_bwd_tile_kernel', 'roi_align_bwd_mfma_kernel',
+    'narrow_head_bwd_kernel', 'random_sample_kernel', 'fold_pack_multi_kernel', 'fold_unpack_bwd_multi_kernel',
+    'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
+    'fuse_sum_relu_kernel', 'stem_mfma_kernel']})
 PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE'])]
 
 
@@ -28,7 +33,7 @@ def run_pass(tag, counters, extra):
     d = os.path.join(OUT, tag)
     cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
                                                os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
-                                               '--no-roofline'] + extra
+                                               '--no-roofline', '--no-saturate'] + extra
     subprocess.run(cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     rows = []
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
@@ -46,14 +51,12 @@ def main():
     for tag, counters in PASSES:
         for r in run_pass(tag, counters, extra):
             name = r.get('Kernel_Name', '')
-            fam = next((f for f in FAMILIES if f in name), None)
-            if fam is None:
-                continue
-            a = agg.setdefault(fam, {})
-            c = r.get('Counter_Name')
-            a.setdefault(c, [0.0, set()])
-            a[c][0] += float(r.get('Counter_Value', 0.0))
-            a[c][1].add(r.get('Dispatch_Id'))
+            for fam in (f for f, subs in FAMILIES.items() if any(sub + '<' in name or sub + '(' in name or name.endswith(sub) for sub in subs)):
+                a = agg.setdefault(fam, {})
+                c = r.get('Counter_Name')
+                a.setdefault(c, [0.0, set()])
+                a[c][0] += float(r.get('Counter_Value', 0.0))
+                a[c][1].add(r.get('Dispatch_Id'))
     out = {'_how': __doc__.strip().split('\n\n')[0], '_args': extra}
     for fam, a in agg.items():
         n = max((len(v[1]) for v in a.values()), default=0)

@@ -166,6 +166,13 @@ def main():
                       max_norm=cfg.optimizer_config.grad_clip.max_norm)
     data = make_batch(args.batch, args.size, args.num_gt, rank=rank, device='cuda')
     n_pos, n_roi = [], []
+    comm = None
+    if world > 1:
+        seen = torch.ones(1, device='cuda')
+        dist.all_reduce(seen)                                  # one collective through the data-parallel backend before timing
+        comm = dict(backend='gloo (shared-GPU test)' if shared else 'rccl', rccl_ranks_seen=int(seen.item()),
+                    buckets=len(trainer.reducer.buckets), bucket_mib=round(max(b['end'] - b['start'] for b in trainer.reducer.buckets) * 4 / 2 ** 20, 1),
+                    grad_mib_per_step=round(trainer.arena.numel * 4 / 2 ** 20, 1))
 
     def one_step(it):
         trainer.train_step(data, lr=step_lr(cfg.optimizer.lr, it, 0))
@@ -296,6 +303,8 @@ def main():
                                algorithmic_gflop_per_img=round(f_img, 1),
                                conv_roofline_frac=round(f_img * 1e9 * value / (world * 2.5e15), 4)),
                    roofline=roofline)
+        if comm is not None:
+            res['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.size, args.num_gt, args.cpu_threads)
             if headline:

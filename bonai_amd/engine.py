@@ -9,9 +9,10 @@ Replaces, for the LOFT path, what the reference gets from mmcv/torch:
     (configs/_base_/schedules/schedule_2x_bonai.py:2-3): two kernels over the flat arena
     (loft_sumsq_f32, loft_sgd_momentum_f32) instead of ~300 per-tensor launches;
   * the step/warm-up LR schedule (schedule_2x_bonai.py:5-10).
-MI355X sizing: 81.2 M trainable parameters = 325 MB fp32; xGMI gives 7 links x ~153 GB/s per GPU, so the
-default 64 MiB buckets keep each collective bandwidth- rather than latency-bound while leaving 5-6 buckets
-to overlap with backward.
+MI355X sizing: 81.2 M trainable parameters = 325 MB fp32 = 13 buckets of the default 25 MiB (torch DDP's
+bucket_cap_mb, what the reference's wrapper runs with).  xGMI gives 7 links x ~153 GB/s per GPU: a 25 MiB ring
+all-reduce over 8 GPUs moves 2 * 7/8 * 25 MiB per link, ~0.3 ms -- bandwidth- rather than latency-bound, and the
+first bucket (FOA + part of the mask head) is on the wire while the mask / bbox branches are still in backward.
 """
 import os
 
@@ -54,7 +55,7 @@ class FlatArena:
 class BucketedAllReduce:
     """Gradient averaging for data parallelism: contiguous buckets, side-stream RCCL all-reduce, event-ordered."""
 
-    def __init__(self, arena, bucket_bytes=64 << 20):
+    def __init__(self, arena, bucket_bytes=25 << 20):
         self.arena = arena
         # LOFT_FORCE_REDUCER=1 keeps the whole hook / side-stream / RCCL path active in a 1-rank group (GPU test)
         self.enabled = dist.is_available() and dist.is_initialized() and (
@@ -63,8 +64,11 @@ class BucketedAllReduce:
         start, pending = 0, []
         for p in arena.order:
             o = arena.offsets[id(p)]
-            pending.append(p)
             end = o + (p.numel() + 7) // 8 * 8
+            if pending and (end - start) * 4 > bucket_bytes:     # a bucket exceeds the cap only for one oversized tensor (fc1)
+                self.buckets.append(dict(start=start, end=o, params=pending))
+                start, pending = o, []
+            pending.append(p)
             if (end - start) * 4 >= bucket_bytes:
                 self.buckets.append(dict(start=start, end=end, params=pending))
                 start, pending = end, []
@@ -157,7 +161,7 @@ def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16,
 
 
 class Trainer:
-    def __init__(self, model, lr=0.005, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_bytes=64 << 20,
+    def __init__(self, model, lr=0.005, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_bytes=25 << 20,
                  loss_scale=1.0):
         """loss_scale: the static scale of the reference's Fp16OptimizerHook (``fp16 = dict(loss_scale=512.)``,
         mmdet/core/fp16/hooks.py:64-96): the loss is multiplied before backward and the gradients are divided again inside

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode='balanced'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -44,6 +44,13 @@ def _worker(rank, world, port, q):
             torch.manual_seed(0)
             return build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
         data = make_batch(1, 256, 6, rank=rank, device='cuda')
+        if mode == 'imbalanced':
+            # rank 0: an image with no gt at all (no positive RoI -> its graph has no mask / FOA branch, those parameters get
+            # no gradient there); rank 1: a crowded image.  The collectives must still pair up bucket by bucket.
+            data = make_batch(1, 256, 40 if rank else 6, rank=rank, device='cuda')
+            if rank == 0:
+                for k in ('gt_bboxes', 'gt_labels', 'gt_masks', 'gt_offsets'):
+                    data[k] = [t[:0] for t in data[k]]
         # local gradient of this rank, no reducer (plain autograd)
         ref = build()
         ref.train_step(data)['loss'].backward()
@@ -51,10 +58,16 @@ def _worker(rank, world, port, q):
         del ref
         m = build()
         before = {n: p.detach().clone() for n, p in m.named_parameters()}
-        tr = Trainer(m, lr=0.01, momentum=0.0, weight_decay=0.0, max_norm=0.0, bucket_bytes=16 << 20)
+        tr = Trainer(m, lr=0.01, momentum=0.0, weight_decay=0.0, max_norm=0.0, **({} if mode == 'imbalanced' else dict(bucket_bytes=16 << 20)))
         assert tr.reducer.enabled and tr.reducer.on_gpu and len(tr.reducer.buckets) >= 4 and tr.world == 2
         out = tr.train_step(data)
         torch.cuda.synchronize()
+        if mode == 'imbalanced':
+            npos = [torch.zeros(1, device='cuda') for _ in range(world)]
+            dist.all_gather(npos, torch.tensor([float(m.roi_head.last_stats['num_pos'])], device='cuda'))
+            assert npos[0].item() == 0 and npos[1].item() >= 40, npos
+            gm = local.get('roi_head.mask_head.convs.0.conv.weight')
+            assert (gm is not None and gm.abs().sum() > 0) if rank == 1 else (gm is None or gm.abs().sum() == 0)
         # (1) the summed gradient in the arena equals the sum of both ranks' local gradients
         names = [n for n, p in m.named_parameters() if p.requires_grad]
         for n, p in m.named_parameters():
@@ -102,6 +115,23 @@ def test_loft_trainer_two_ranks_one_gpu():
 
 
 @pytest.mark.timeout(900)
+def test_loft_trainer_two_ranks_imbalanced():
+    """One rank without a single gt box, the other with 40: no deadlock, the mask / FOA gradients are rank 1's alone, the
+    parameters stay bit-identical (default 25 MiB buckets)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 'imbalanced')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=800) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg, _ in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'
+
+
+@pytest.mark.timeout(900)
 def test_bench_launch_contract_two_ranks():
     """The driver's multi-GPU command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...) end to end with N = 2 ranks sharing the one GPU (gloo instead of RCCL):
@@ -121,3 +151,4 @@ def test_bench_launch_contract_two_ranks():
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 2 and j['warmup'] == 1
     assert j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
     assert 'roofline' in j and 'cpu_baseline' not in j
+    assert j['comm']['rccl_ranks_seen'] == 2 and j['comm']['buckets'] >= 8 and j['comm']['bucket_mib'] <= 52

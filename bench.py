@@ -159,11 +159,14 @@ def main():
     from bonai_amd.synth import make_batch
     K.L.load()
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', args.config))
+    fp16 = cfg.get('fp16')                                 # the reference's fp16 recipe (config 5): binary16 build of the library
+    if fp16:
+        K.L.set_act16(torch.float16)
     headline = args.config == 'loft_foa_r50_fpn_2x_bonai.py' 
     torch.manual_seed(0)                                   # same random-init weights on every rank
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
     trainer = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
-                      max_norm=cfg.optimizer_config.grad_clip.max_norm)
+                      max_norm=cfg.optimizer_config.grad_clip.max_norm, loss_scale=(fp16 or {}).get('loss_scale', 1.0))
     data = make_batch(args.batch, args.size, args.num_gt, rank=rank, device='cuda')
     n_pos, n_roi = [], []
     comm = None
@@ -293,7 +296,7 @@ def main():
         f_img = f_train_gflop(mean_roi, mean_pos, sparse_rpn_backward=model.rpn_head.sparse_backward)
         res = dict(metric='training img/s at 1024x1024 LOFT R50-FPN', value=round(value, 3), unit='img/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='fp16' if fp16 else 'bf16', data='synthetic',
                    value_at_npos256=sat,
                    config=dict(workload=f'{arch}, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
                                         f'({"BASELINE configs[1]" if headline else args.config}), {args.num_gt} gt/img, full train step '

@@ -255,7 +255,7 @@ void conv_tap_kernel(const ConvArgs a) {
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = LOFT_MFMA_32x32x16(wf[i], xf[j], acc[i][j]);
         }
     };
     using buf0_t = std::integral_constant<int, 0>;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
                     for (int i = 0; i < 2; ++i) {
                         const int wri = wr + i * 32;
                         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                        acc[i] = LOFT_MFMA_32x32x16(wf, xf, acc[i]);
                     }
                 }
             }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
     const int nsteps = (mend - mbeg + 63) / 64;
     stage(mbeg, 0);
     for (int s = 0; s < nsteps; ++s) {
@@ -733,12 +733,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xf[j], acc[i][j]);
             if (do_db) {   // static register selects (a runtime-indexed fragment array would be demoted to scratch)
                 bf16x8 gsel = gf[0];
 #pragma unroll
                 for (int i = 1; i < NI; ++i) gsel = (wc == i) ? gf[i] : gsel;
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gsel, ones, accb, 0, 0, 0);
+                accb = LOFT_MFMA_32x32x16(gsel, ones, accb);
             }
         }
     }
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
     const bool do_db = a.db != nullptr && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
     const int nsteps = (mend - mbeg + 63) / 64;
     stage(mbeg, 0);
     for (int s = 0; s < nsteps; ++s) {
@@ -837,8 +837,8 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flo[0]), "+v"(flo[1]), "+v"(fhi[0]), "+v"(fhi[1]));
             const bf16x8 gf = tr_join(flo[0], fhi[0]);
             const bf16x8 xf = tr_join(flo[1], fhi[1]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc, 0, 0, 0);
-            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ones, accb, 0, 0, 0);
+            acc = LOFT_MFMA_32x32x16(gf, xf, acc);
+            if (do_db) accb = LOFT_MFMA_32x32x16(gf, ones, accb);
         }
     }
     if (do_db && (lane & 31) == 0) {
@@ -932,7 +932,7 @@ void conv_wgrad64_patch_kernel(const WgradArgs a, int ptx, int pty, int npatch,
     const bool do_db = a.db != nullptr && wc == 0;
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
     // this lane's fragment rows inside a 16-pixel k block: patch row 2*ks + (gl >> 1), patch columns (il >> 2) and (il >> 2) + 4
     const int il = lane & 15, gl = lane >> 4;
     const int fcol = 16 * (gl & 1) + (il & 3) * 4;
@@ -950,13 +950,13 @@ void conv_wgrad64_patch_kernel(const WgradArgs a, int ptx, int pty, int npatch,
             const int py = 2 * ks + fpy;                       // k = py * 8 + px
             const int gr0 = py * 8 + fpx;
             const bf16x8 gf = patch_frag(gb, gr0, gr0 + 4, wn * 32 + fcol);
-            if (do_db) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ones, accb, 0, 0, 0);
+            if (do_db) accb = LOFT_MFMA_32x32x16(gf, ones, accb);
 #pragma unroll
             for (int t = 0; t < 9; ++t)
                 if (t < a.T) {
                     const int hr0 = (py + 1 + a.dy[t]) * 10 + fpx + 1 + a.dx[t];
                     const bf16x8 xf = patch_frag(xb, hr0, hr0 + 4, wc * 32 + fcol);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, xf, acc[t], 0, 0, 0);
+                    acc[t] = LOFT_MFMA_32x32x16(gf, xf, acc[t]);
                 }
         }
     }
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
             for (int i = 0; i < 2; ++i) {
                 const int brow = i * 32 + frow;
                 const bf16x8 wf = *reinterpret_cast<const bf16x8*>(bbuf + brow * 128 + swz(brow, q) * 16);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+                acc[i] = LOFT_MFMA_32x32x16(wf, xf, acc[i]);
             }
         }
     }

@@ -395,8 +395,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             constexpr int J = decltype(jc)::value;
             if constexpr (NOMFMA) { asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2 + J])); }
             else {
-                acc[0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[2 + J], acc[0][J], 0, 0, 0);
-                acc[1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[2 + J], acc[1][J], 0, 0, 0);
+                acc[0][J] = LOFT_MFMA_32x32x16(f[0], f[2 + J], acc[0][J]);
+                acc[1][J] = LOFT_MFMA_32x32x16(f[1], f[2 + J], acc[1][J]);
             }
         };
         using k0_t = std::integral_constant<int, 0>;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     };
     auto mm = [&](bf16x8 w_, bf16x8 x_, f32x16 c_) {
         if constexpr (NOMFMA) { asm volatile("" :: "v"(w_), "v"(x_)); return c_; }
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_, x_, c_, 0, 0, 0);
+        else return LOFT_MFMA_32x32x16(w_, x_, c_);
     };
     auto tile = [&](auto bufc, int t, bool has1, bool has2) {
         constexpr int B = decltype(bufc)::value;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3f80;
+    for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
 
     // ---- fragment addressing (tr_frag of conv_mfma.hip with everything lane-constant folded): lane l -> channel
     // col0 + 16*((l>>4)&1) + 4*(l&3) + [0,4) of pixel rows ks*16 + 8*(l>>5) + ((l&15)>>2) (+4 for the second half); the swizzle
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     auto mm2 = [&](s16x4 (&f)[12], auto ic) {
         constexpr int I = decltype(ic)::value;
         const bf16x8 gv = frag(f, I);
-        acc[I][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv, frag(f, 4), acc[I][0], 0, 0, 0);
-        acc[I][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv, frag(f, 5), acc[I][1], 0, 0, 0);
+        acc[I][0] = LOFT_MFMA_32x32x16(gv, frag(f, 4), acc[I][0]);
+        acc[I][1] = LOFT_MFMA_32x32x16(gv, frag(f, 5), acc[I][1]);
     };
     auto mmb = [&](s16x4 (&f)[12]) {
         if (do_db) {   // static register selects (a runtime-indexed fragment array would be demoted to scratch)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
             gsel = (wc == 1) ? frag(f, 1) : gsel;
             gsel = (wc == 2) ? frag(f, 2) : gsel;
             gsel = (wc == 3) ? frag(f, 3) : gsel;
-            accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gsel, ones, accb, 0, 0, 0);
+            accb = LOFT_MFMA_32x32x16(gsel, ones, accb);
         }
     };
 

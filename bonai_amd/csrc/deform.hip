@@ -53,10 +53,7 @@ struct Item {
 
 __device__ __forceinline__ void ld8v(const bf16_t* p, float v[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    unpack8_16(t, v);
 }
 __device__ __forceinline__ void ld8v(const float* p, float v[8]) { ld4(p, v); ld4(p + 4, v + 4); }
 __device__ __forceinline__ void st8v(bf16_t* p, const float v[8]) { st4(p, v); st4(p + 4, v + 4); }
@@ -392,7 +389,7 @@ template <> struct RowLd<1> { static __device__ __forceinline__ void ld(const bf
 template <> struct RowLd<2> {
     static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
         const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
-        v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xffff0000u);
+        unpack2_16(t, v[0], v[1]);
     }
 };
 template <> struct RowLd<4> { static __device__ __forceinline__ void ld(const bf16_t* p, float* v) { ld4(p, v); } };
@@ -645,6 +642,7 @@ int mdcn_check(const MdcnArgs& a) {
 LOFT_EXPORT int loft_mdcn_sample_fwd(const void* x, const float* offmask, void* col, int dtype, int B, int IH, int IW, int C,
                                      int OH, int OW, int kh, int kw, int stride, int pad, int dil, int deform_groups,
                                      int offmask_stride, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     MdcnArgs a{B, IH, IW, C, OH, OW, kh, kw, stride, pad, dil, deform_groups, offmask_stride, (long)B * OH * OW};
     if (int e = mdcn_check(a)) return e;
     if (a.M <= 0) return 0;
@@ -698,6 +696,7 @@ LOFT_EXPORT int loft_mdcn_sample_bwd(const void* x, const float* offmask, const 
                                      int dtype, int B, int IH, int IW, int C, int OH, int OW, int kh, int kw, int stride,
                                      int pad, int dil, int deform_groups, int offmask_stride, void* workspace,
                                      void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     MdcnArgs a{B, IH, IW, C, OH, OW, kh, kw, stride, pad, dil, deform_groups, offmask_stride, (long)B * OH * OW};
     if (int e = mdcn_check(a)) return e;
     if (a.M <= 0) return 0;

@@ -15,18 +15,10 @@
 
 __device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    unpack8_16(t, v);
 }
 __device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
-    uint4 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-    *reinterpret_cast<uint4*>(p) = t;
+    *reinterpret_cast<uint4*>(p) = pack8_16(v);
 }
 
 // fp32 parity mode: the same 8-channel groups, as two 16-byte accesses
@@ -346,6 +338,8 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
         st8(dst + i * 8, v);
     }
 }
+LOFT_EXPORT int loft_act16_dtype(void) { return LOFT_ACT16; }
+
 LOFT_EXPORT int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     if (n <= 0) return 0;
     if (n % 8) return (int)hipErrorInvalidValue;

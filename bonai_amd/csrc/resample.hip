@@ -18,10 +18,7 @@ namespace {
 
 __device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    unpack8_16(t, v);
 }
 __device__ __forceinline__ void ld8(const float* p, float v[8]) { ld4(p, v); ld4(p + 4, v + 4); }
 __device__ __forceinline__ void st8(bf16_t* p, const float v[8]) { st4(p, v); st4(p + 4, v + 4); }
@@ -358,6 +355,7 @@ __global__ __launch_bounds__(256) void stem3x3s2_wgrad_kernel(const float* __res
 
 LOFT_EXPORT int loft_fuse_sum_relu(const void* const* terms, const int* shifts, int n_terms, void* out, int dtype, int B, int H,
                                    int W, int C, int relu, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (n_terms < 1 || n_terms > 4 || (C % 8)) return (int)hipErrorInvalidValue;
     FuseArgs a;
     for (int j = 0; j < 4; ++j) { a.src[j] = j < n_terms ? terms[j] : nullptr; a.shift[j] = j < n_terms ? shifts[j] : 0; }
@@ -374,6 +372,7 @@ LOFT_EXPORT int loft_fuse_sum_relu(const void* const* terms, const int* shifts, 
 
 LOFT_EXPORT int loft_blocksum_masked(const void* g, const void* y, void* out, int dtype, int B, int Hc, int Wc, int C, int shift,
                                      void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if ((C % 8) || shift < 0) return (int)hipErrorInvalidValue;
     const long nvec = (long)B * Hc * Wc * (C / 8);
     if (nvec <= 0) return 0;
@@ -389,6 +388,7 @@ LOFT_EXPORT int loft_blocksum_masked(const void* g, const void* y, void* out, in
 
 LOFT_EXPORT int loft_bilinear_up_slot(const void* src, void* dst, int dtype, int B, int h, int w, int C, int shift, int Ctot,
                                       int coff, int backward, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if ((C % 8) || (Ctot % 8) || (coff % 8) || shift < 0) return (int)hipErrorInvalidValue;
     if (!backward) {
         const long nvec = (long)B * (h << shift) * (w << shift) * (C / 8);
@@ -415,6 +415,7 @@ LOFT_EXPORT int loft_bilinear_up_slot(const void* src, void* dst, int dtype, int
 
 LOFT_EXPORT int loft_avgpool(const void* src, void* dst, int dtype, int B, int Ho, int Wo, int C, int shift, int backward,
                              int accumulate, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if ((C % 8) || shift < 0) return (int)hipErrorInvalidValue;
     if (!backward) {
         const long nvec = (long)B * Ho * Wo * (C / 8);
@@ -441,6 +442,7 @@ LOFT_EXPORT int loft_avgpool(const void* src, void* dst, int dtype, int B, int H
 
 LOFT_EXPORT int loft_stem3x3s2_bn_relu(const float* img, const float* w, const float* scale, const float* shift, void* out,
                                        int dtype, int B, int H, int W, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(loft_cdiv(Wo, 16), loft_cdiv(Ho, 16), B);
     if (dtype == LOFT_F32)
@@ -455,6 +457,7 @@ LOFT_EXPORT int loft_stem3x3s2_bn_relu(const float* img, const float* w, const f
 
 LOFT_EXPORT int loft_stem3x3s2_wgrad(const float* img, const void* g, const void* y, float* dwp, float* db, int dtype, int B,
                                      int H, int W, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int tiles_x = loft_cdiv(Wo, 16), tiles_y = loft_cdiv(Ho, 16);
     int blocks = tiles_x * tiles_y * B;

@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[i], xl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xh[j], acc[i][j]);
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xl[j], acc[i][j]);
                         }
                 }
             }
@@ -670,14 +670,15 @@ static RoiLevels make_levels(const void* const* feats, const int* H, const int* 
 LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const int* W, const float* scales,
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
                                    int P, int n_rot, void* out, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (K <= 0) return 0;
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4)) return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(feats, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
     static const bool sample_form = getenv("LOFT_ROI_SAMPLE_FWD") != nullptr;      // A/B switch
-    if (dtype == LOFT_BF16 && !sample_form)
+    if (dtype == LOFT_ACT16 && !sample_form)
         hipLaunchKernelGGL(roi_align_fwd_sep_kernel, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out);
-    else if (dtype == LOFT_BF16)
+    else if (dtype == LOFT_ACT16)
         hipLaunchKernelGGL(roi_align_fwd_kernel<bf16_t>, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out);
     else if (dtype == LOFT_F32)
         hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (float*)out);
@@ -691,9 +692,10 @@ LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const 
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
                                    int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
                                    void* workspace, int grad_dtype, void* stream) {
+    if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || P > RB_MAXP)
         return (int)hipErrorInvalidValue;
-    if (grad_dtype != LOFT_F32 && !(grad_dtype == LOFT_BF16 && dtype == LOFT_BF16)) return (int)hipErrorInvalidValue;
+    if (grad_dtype != LOFT_F32 && !(grad_dtype == LOFT_ACT16 && dtype == LOFT_ACT16)) return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(nullptr, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
     int4* rec = (int4*)workspace;
@@ -704,13 +706,13 @@ LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const 
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
         static const bool valu_form = getenv("LOFT_ROI_VALU_BWD") != nullptr;          // A/B switch
-        if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16 && C == 256 && !valu_form)
+        if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form)
             hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, rois, K, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
-        else if (dtype == LOFT_BF16 && grad_dtype == LOFT_BF16)
+        else if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16)
             hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
-        else if (dtype == LOFT_BF16)
+        else if (dtype == LOFT_ACT16)
             hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, float>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, (float*)grad_feats[l], accumulate, rec, rois_sorted);
         else if (dtype == LOFT_F32)

@@ -19,7 +19,13 @@ struct SparseLevels {
     int n;
 };
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#ifdef LOFT_ACT_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 act16x2_t;
+#define LOFT_ATOMIC_ADD_PK16(p, v) __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) act16x2_t*)(p), __builtin_bit_cast(act16x2_t, v))
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 act16x2_t;
+#define LOFT_ATOMIC_ADD_PK16(p, v) __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) act16x2_t*)(p), __builtin_bit_cast(act16x2_t, v))
+#endif
 
 // rows: int32 [nsel][4] = (b, level, y, x); level < 0 marks an inactive row (output zeros / no scatter)
 __global__ void rpn_gather_rows_kernel(const SparseLevels lv, const int* __restrict__ rows, int nsel, int C, int K,
@@ -59,8 +65,7 @@ __global__ void rpn_scatter_add_kernel(const SparseLevels lv, const int* __restr
         const uint32_t v = *reinterpret_cast<const uint32_t*>(src + i * 2);
         if (v == 0u) continue;
         bf16_t* dst = reinterpret_cast<bf16_t*>(lv.ptr[rw.y]) + (((long)rw.x * H + y) * W + x) * C + c2 * 2;
-        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2_t*)dst,
-                                                   __builtin_bit_cast(bf16x2_t, v));
+        LOFT_ATOMIC_ADD_PK16(dst, v);
     }
 }
 

@@ -146,7 +146,7 @@ class _RoIAlign(torch.autograd.Function):
         P, strides, fs, n_rot, shapes, dt = ctx.meta
         g = g.contiguous(memory_format=torch.channels_last)
         grads = roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot,
-                              out_dtype=dt if (dt == torch.bfloat16 and g.dtype == torch.bfloat16) else torch.float32)
+                              out_dtype=dt if (dt == L.act16() and g.dtype == L.act16()) else torch.float32)
         return (None, None, None, None, None) + tuple(x.to(dt) for x in grads)
 
 
@@ -260,16 +260,16 @@ def zero_page(device):
     return _ZERO_PAGES[key]
 
 
-def pack_w_fwd(w, dtype=torch.bfloat16):
+def pack_w_fwd(w, dtype=None):
     """[Cout,Cin,R,S] (reference / checkpoint layout) -> bf16 [R*S, Cout, Cin]."""
     co, ci, r, s = w.shape
-    return w.permute(2, 3, 0, 1).reshape(r * s, co, ci).to(dtype).contiguous()
+    return w.permute(2, 3, 0, 1).reshape(r * s, co, ci).to(dtype or L.act16()).contiguous()
 
 
 def pack_w_dgrad(w):
     """[Cout,Cin,R,S] -> bf16 [R*S, Cin, Cout] (transposed for the data-gradient pass)."""
     co, ci, r, s = w.shape
-    return w.permute(2, 3, 1, 0).reshape(r * s, ci, co).to(torch.bfloat16).contiguous()
+    return w.permute(2, 3, 1, 0).reshape(r * s, ci, co).to(L.act16()).contiguous()
 
 
 def unpack_dw(dwp, shape):
@@ -279,8 +279,8 @@ def unpack_dw(dwp, shape):
 
 
 def _bf16(t):
-    if t.dtype != torch.bfloat16:
-        raise L.LoftHipError(f'expected bfloat16, got {t.dtype}')
+    if t.dtype != L.act16():
+        raise L.LoftHipError(f'expected {L.act16()} (the 16-bit type of the loaded library), got {t.dtype}')
     return t
 
 
@@ -337,14 +337,14 @@ def conv_out_size(i, k, stride, pad):
     return (i + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=torch.bfloat16, groups=1):
+def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=None, groups=1):
     """x [G*B,Cin,IH,IW] channels_last bf16, wp [G][R*S,Cout,Cin] bf16 -> [G*B,Cout,OH,OW] channels_last."""
     x = _nhwc(x)
     GB, Cin, IH, IW = x.shape
     B = GB // groups
     Cout = wp.shape[-2]
     OH, OW = conv_out_size(IH, R, stride, pad), conv_out_size(IW, S, stride, pad)
-    out = empty_nhwc(GB, Cout, OH, OW, out_dtype, x.device)
+    out = empty_nhwc(GB, Cout, OH, OW, out_dtype or L.act16(), x.device)
     taps = [(r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
     conv_tap(x, wp, out, B, IH, IW, Cin, Cout, OH, OW, OH, OW, taps, ss=stride, bias=bias, residual=residual,
              relu=relu, groups=groups, src_gs=B * IH * IW * Cin, wgt_gs=R * S * Cout * Cin,
@@ -352,7 +352,7 @@ def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, ou
     return out
 
 
-def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=torch.bfloat16, groups=1,
+def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=None, groups=1,
                  out=None, accumulate=False, mask=None):
     """g [G*B,Cout,OH,OW] channels_last bf16, wpt [G][R*S,Cin,Cout] -> grad of the conv input [G*B,Cin,IH,IW]."""
     g = _nhwc(g)
@@ -361,7 +361,7 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
     Cin = wpt.shape[-2]
     IH, IW = in_hw
     if out is None:
-        out = empty_nhwc(GB, Cin, IH, IW, out_dtype, g.device)
+        out = empty_nhwc(GB, Cin, IH, IW, out_dtype or L.act16(), g.device)
     gs = dict(groups=groups, src_gs=B * OH * OW * Cout, wgt_gs=R * S * Cin * Cout, out_gs=B * IH * IW * Cin)
     if stride == 1:
         taps = [(pad - r, pad - s, r * S + s) for r in range(R) for s in range(S)]
@@ -546,13 +546,14 @@ def maxpool3x3s2(x):
     return out
 
 
-def stem7x7_bn_relu(img, w, scale, shift, out_dtype=torch.bfloat16):
+def stem7x7_bn_relu(img, w, scale, shift, out_dtype=None):
     """img fp32 NCHW [B,3,H,W] -> bf16 (or fp32: parity mode) channels_last [B,64,H/2,W/2]."""
     lib = L.load()
     L.dev_check(img, w, scale, shift)
     img = img.float().contiguous()
     w, scale, shift = w.float().contiguous(), scale.float().contiguous(), shift.float().contiguous()
     B, _, H, W = img.shape
+    out_dtype = out_dtype or L.act16()
     out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, out_dtype, img.device)
     L.check(lib.loft_stem7x7_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale),
                                      L.ptr(shift), L.ptr(out), B, H, W, int(out_dtype == torch.float32), L.stream()),
@@ -565,11 +566,11 @@ def stem7x7_mfma(img, w, scale, shift):
     lib = L.load()
     L.dev_check(img, w, scale, shift)
     img = img.float().contiguous()
-    wp = torch.zeros(64, 192, dtype=torch.bfloat16, device=img.device)
-    wp[:, :147] = (w.float() * scale.float()[:, None, None, None]).reshape(64, 147).to(torch.bfloat16)
+    wp = torch.zeros(64, 192, dtype=L.act16(), device=img.device)
+    wp[:, :147] = (w.float() * scale.float()[:, None, None, None]).reshape(64, 147).to(L.act16())
     bias = shift.float().contiguous()
     B, _, H, W = img.shape
-    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, torch.bfloat16, img.device)
+    out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, L.act16(), img.device)
     L.check(lib.loft_stem7x7_mfma(L.ptr(img), L.ptr(wp), L.ptr(bias), L.ptr(out), B, H, W, L.stream()),
             'loft_stem7x7_mfma')
     return out
@@ -578,7 +579,7 @@ def stem7x7_mfma(img, w, scale, shift):
 def cast_bf16(x_f32):
     lib = L.load()
     L.dev_check(x_f32)
-    out = torch.empty_like(x_f32, dtype=torch.bfloat16)
+    out = torch.empty_like(x_f32, dtype=L.act16())
     L.check(lib.loft_cast_f32_to_bf16(L.ptr(x_f32), L.ptr(out), c_int64(x_f32.numel()), L.stream()),
             'loft_cast_f32_to_bf16')
     return out
@@ -829,7 +830,7 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
 def _sparse_levels(maps):
     maps = [_nhwc(m) for m in maps]
     for m in maps:
-        if m.dtype != torch.bfloat16 or m.shape[1] != maps[0].shape[1]:
+        if m.dtype != L.act16() or m.shape[1] != maps[0].shape[1]:
             raise L.LoftHipError('sparse RPN rows: bf16 maps with one channel count')
     ptrs = (c_void_p * len(maps))(*[m.data_ptr() for m in maps])
     return maps, ptrs, L.arr(c_int, [m.shape[2] for m in maps]), L.arr(c_int, [m.shape[3] for m in maps])
@@ -841,7 +842,7 @@ def rpn_gather_rows(maps, rows, K=3):
     maps, ptrs, H, W = _sparse_levels(maps)
     L.dev_check(rows, *maps)
     C = maps[0].shape[1]
-    out = torch.empty(rows.shape[0], K * K * C, dtype=torch.bfloat16, device=rows.device)
+    out = torch.empty(rows.shape[0], K * K * C, dtype=L.act16(), device=rows.device)
     L.check(lib.loft_rpn_gather_rows(ptrs, H, W, len(maps), L.ptr(rows), rows.shape[0], C, K, L.ptr(out), L.stream()),
             'loft_rpn_gather_rows')
     return out
@@ -853,7 +854,7 @@ def rpn_scatter_add_rows_(maps, rows, src, K=3):
     maps, ptrs, H, W = _sparse_levels(maps)
     L.dev_check(rows, src)
     C = maps[0].shape[1]
-    if src.dtype != torch.bfloat16 or tuple(src.shape) != (rows.shape[0], K * K * C) or not src.is_contiguous():
+    if src.dtype != L.act16() or tuple(src.shape) != (rows.shape[0], K * K * C) or not src.is_contiguous():
         raise L.LoftHipError('rpn_scatter_add_rows_: src must be contiguous bf16 [nsel, K*K*C]')
     L.check(lib.loft_rpn_scatter_add_rows(ptrs, H, W, len(maps), L.ptr(rows), rows.shape[0], C, K, L.ptr(src), L.stream()),
             'loft_rpn_scatter_add_rows')
@@ -936,13 +937,14 @@ def avgpool_bwd(g, shift):
     return out
 
 
-def stem3x3s2_bn_relu(img, w, scale, shift, out_dtype=torch.bfloat16):
+def stem3x3s2_bn_relu(img, w, scale, shift, out_dtype=None):
     """img fp32 NCHW [B,3,H,W], w fp32 [64,3,3,3] -> channels_last [B,64,H/2,W/2] = relu(conv * scale + shift)."""
     lib = L.load()
     L.dev_check(img, w, scale, shift)
     img = img.float().contiguous()
     w, scale, shift = w.float().contiguous(), scale.float().contiguous(), shift.float().contiguous()
     B, _, H, W = img.shape
+    out_dtype = out_dtype or L.act16()
     out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, out_dtype, img.device)
     L.check(lib.loft_stem3x3s2_bn_relu(L.ptr(img), L.ptr(w), L.ptr(scale), L.ptr(shift), L.ptr(out), L.dtype_code(out), B, H, W,
                                        L.stream()), 'loft_stem3x3s2_bn_relu')
@@ -1003,11 +1005,12 @@ def mdcn_sample_bwd(x, om, dcol, kh, kw, stride=1, pad=0, dil=1, deform_groups=1
 # ------------------------------------------------------------------ weight fold + pack
 
 def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None,
-              out_bias=None, dtype=torch.bfloat16, cout_pad=None, cin_pad=None):
+              out_bias=None, dtype=None, cout_pad=None, cin_pad=None):
     """w fp32 [Cout,Cin,R,S]; bn = (gamma, beta, mean, var) or None -> (wp_fwd bf16 [T,Cout,Cin] | None,
     wp_dgrad bf16 [T,Cin,Cout] | None, bias fp32 [Cout])."""
     lib = L.load()
     L.dev_check(w, conv_bias)
+    dtype = dtype or L.act16()
     w = w.contiguous()
     Cout, Cin, R, S = w.shape
     T = R * S
@@ -1062,8 +1065,8 @@ class PrepackRegistry:
                 Cout, Cin = ws[0].shape[0], ws[0].shape[1]
                 RS = T = (ws[0].shape[2] * ws[0].shape[3]) if ws[0].dim() == 4 else 1
                 kin = cin_p
-            grp = dict(wp=torch.empty(G, T, cout_p, kin, dtype=torch.bfloat16, device=dev),
-                       wpt=torch.empty(G, T, kin, cout_p, dtype=torch.bfloat16, device=dev) if want_dgrad else None,
+            grp = dict(wp=torch.empty(G, T, cout_p, kin, dtype=L.act16(), device=dev),
+                       wpt=torch.empty(G, T, kin, cout_p, dtype=L.act16(), device=dev) if want_dgrad else None,
                        bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2, members=[], flat=flat_chw)
             for g in range(G):
                 grp['members'].append(dict(w=ws[g], cb=conv_biases[g], bn=bn, eps=float(eps), dims=(Cout, Cin, RS, cout_p, cin_p),
@@ -1266,7 +1269,7 @@ def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     w2 = w.reshape(Cout, Cin).float().contiguous()
-    gx = empty_nhwc(N, Cin, H, W, torch.bfloat16, x.device) if need_gx else None
+    gx = empty_nhwc(N, Cin, H, W, L.act16(), x.device) if need_gx else None
     dw = pooled_zeros((Cout, Cin), x.device) if need_dw else None
     db = pooled_zeros((Cout,), x.device) if need_db else None
     L.check(lib.loft_narrow_head_bwd(L.ptr(g), int(g.shape[1]), L.ptr(x), L.ptr(w2), c_int64(N * H * W), Cin, Cout, int(relu_in),

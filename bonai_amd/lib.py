@@ -1,4 +1,8 @@
-"""ctypes binding of libloft_hip.so (include/loft_hip.h) -- the ONLY compute backend.
+"""ctypes binding of libloft_hip.so / libloft_hip_f16.so (include/loft_hip.h) -- the ONLY compute backend.
+
+The library exists in two builds of the same sources (bonai_amd/build.py): 16-bit type bfloat16 (default) or IEEE binary16.
+``set_act16(torch.float16)`` switches the process to the second one (the reference's fp16 configs); ``load()`` returns the
+library of the current mode and every 16-bit tensor handed to a kernel must be of that type (the library rejects the other).
 
 There is deliberately no CPU or eager-PyTorch fallback: if the shared library is missing, or an
 op is called with tensors that are not on a HIP device, this module raises.
@@ -10,10 +14,13 @@ import torch
 
 # LOFT_HIP_LIB: an alternative build of the same library (A/B timing of kernel variants on one box)
 _LIB_PATH = os.environ.get('LOFT_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libloft_hip.so')
+_LIB_PATH_F16 = os.environ.get('LOFT_HIP_LIB_F16') or os.path.join(os.path.dirname(_LIB_PATH), 'libloft_hip_f16.so')
 _lib = None
+_libs = {}
+_act16 = torch.bfloat16
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -22,22 +29,43 @@ class LoftHipError(RuntimeError):
     pass
 
 
+def act16():
+    """The 16-bit activation / operand dtype of the current mode (torch.bfloat16 | torch.float16)."""
+    return _act16
+
+
+def set_act16(dtype):
+    """Switch the process between the bfloat16 and the binary16 build of the library.  Returns the previous dtype."""
+    global _act16, _lib
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise LoftHipError(f'the 16-bit type is torch.bfloat16 or torch.float16, not {dtype}')
+    prev, _act16 = _act16, dtype
+    _lib = None
+    return prev
+
+
 def load():
-    """Load (once) and return the CDLL.  Raises LoftHipError when the extension is not built."""
+    """Load (once per build) and return the CDLL of the current 16-bit mode.  Raises LoftHipError when it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise LoftHipError(
-                f'{_LIB_PATH} is missing: build it with `python -m bonai_amd.build` '
-                '(hipcc --offload-arch=gfx950).  bonai_amd has no CPU / eager fallback.')
-        lib = ctypes.CDLL(_LIB_PATH)
-        lib.loft_nms_workspace_bytes.restype = c_int64
-        lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64]
-        lib.loft_soft_nms_workspace_bytes.restype = c_int64
-        lib.loft_random_sample_workspace_bytes.restype = c_int64
-        lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64
-        lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
-        lib.loft_mdcn_bwd_workspace_bytes.restype = c_int64
+        path = _LIB_PATH if _act16 == torch.bfloat16 else _LIB_PATH_F16
+        lib = _libs.get(path)
+        if lib is None:
+            if not os.path.exists(path):
+                raise LoftHipError(
+                    f'{path} is missing: build it with `python -m bonai_amd.build` '
+                    '(hipcc --offload-arch=gfx950).  bonai_amd has no CPU / eager fallback.')
+            lib = ctypes.CDLL(path)
+            lib.loft_nms_workspace_bytes.restype = c_int64
+            lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64]
+            lib.loft_soft_nms_workspace_bytes.restype = c_int64
+            lib.loft_random_sample_workspace_bytes.restype = c_int64
+            lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64
+            lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
+            lib.loft_mdcn_bwd_workspace_bytes.restype = c_int64
+            if lib.loft_act16_dtype() != _DT[_act16]:
+                raise LoftHipError(f'{path} was built for another 16-bit type (loft_act16_dtype() = {lib.loft_act16_dtype()})')
+            _libs[path] = lib
         _lib = lib
     return _lib
 

@@ -195,7 +195,7 @@ class ResNet(nn.Module):
         """img fp32 NCHW [B,3,H,W] -> tuple of bf16 NHWC-in-memory maps (C2..C5)."""
         with torch.set_grad_enabled(self.frozen_stages < 0 and torch.is_grad_enabled()):
             scale, shift = self.bn1.fold()
-            if getattr(self, 'compute_dtype', torch.bfloat16) == torch.float32:   # forward-only parity mode
+            if getattr(self, 'compute_dtype', None) == torch.float32:   # fp32 parity mode (else: the library's 16-bit type)
                 x = K.stem7x7_bn_relu(img, self.conv1.weight, scale, shift, out_dtype=torch.float32)
             else:
                 x = K.stem7x7_mfma(img, self.conv1.weight, scale, shift)

@@ -99,7 +99,7 @@ class LOFT(nn.Module):
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       gt_offsets=None, **kwargs):
         x = self.extract_feat(img)
-        if F2.HUB_ENABLED and x[0].is_cuda and x[0].dtype == torch.bfloat16:
+        if F2.HUB_ENABLED and x[0].is_cuda and x[0].dtype == F2.K.L.act16():
             # one shared gradient map per pyramid level for the RPN head and the three RoI extractors (nn.feat_hub)
             x = F2.feat_hub(x, 4)
         losses = dict()

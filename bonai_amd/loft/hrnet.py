@@ -15,6 +15,7 @@ loft_bilinear_up_slot / loft_avgpool.
 import torch
 from torch import nn
 
+from .. import kernels as K
 from .. import nn as F2
 from .backbone import Bottleneck, ConvW, FrozenStatBN
 from .builder import BACKBONES, NECKS
@@ -157,7 +158,7 @@ class HRNet(nn.Module):
         if in_channels != 3 or conv_cfg is not None or not norm_eval or norm_cfg.get('type', 'BN') != 'BN':
             raise NotImplementedError('native HRNet: 3-channel input, plain conv, frozen-statistics BN (norm_eval=True)')
         self.extra, self.zero_init_residual = extra, zero_init_residual
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = None       # torch.float32: fp32 parity mode; anything else: the library's 16-bit type
         self.conv1 = ConvW(3, 64, 3)
         self.bn1 = FrozenStatBN(64)
         self.conv2 = ConvW(64, 64, 3)
@@ -223,7 +224,7 @@ class HRNet(nn.Module):
         return layer(t)
 
     def forward(self, img):
-        x = F2.stem3x3s2(img, self.conv1.weight, self.bn1, self.compute_dtype)
+        x = F2.stem3x3s2(img, self.conv1.weight, self.bn1, torch.float32 if self.compute_dtype == torch.float32 else K.L.act16())
         x = F2.conv2d(x, self.conv2.weight, bn=self.bn2, stride=2, pad=1, relu=True)
         x = self.layer1(x)
         y = [x]

@@ -242,7 +242,7 @@ class RPNHead(nn.Module):
     sparse_backward = os.environ.get('LOFT_RPN_DENSE_BWD') is None      # A/B switch; the dense path is the plain autograd one
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
-        if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == torch.bfloat16 and x[0].shape[1] % 128 == 0:
+        if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == K.L.act16() and x[0].shape[1] % 128 == 0:
             if (proposal_cfg is not None and x[0].is_cuda and K.PROFILE is None and not os.environ.get('LOFT_NO_SIDE_STREAM')
                     and not os.environ.get('LOFT_NO_RPN_SIDE_STREAM')):
                 return self._forward_train_two_streams(x, img_metas, gt_bboxes, gt_bboxes_ignore, proposal_cfg)

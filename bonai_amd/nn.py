@@ -109,7 +109,7 @@ class _ConvFn(torch.autograd.Function):
             Cin = x.shape[1]
             Cout = cout_pad or Cout
         dev = x.device
-        pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
+        pdt = torch.float32 if x.dtype == torch.float32 else K.L.act16()
         key = None
         if frozen:
             key = (pdt,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
@@ -117,7 +117,7 @@ class _ConvFn(torch.autograd.Function):
                 key += tuple((t.data_ptr(), t._version) for t in bn_stats[:2])
         if key is not None and key in _PACK_CACHE:
             wp, wpt, bias = _PACK_CACHE[key]
-        elif PREPACK is not None and key is None and pdt == torch.bfloat16 and Cout % 2 == 0 and Cin % 2 == 0 and \
+        elif PREPACK is not None and key is None and pdt == K.L.act16() and Cout % 2 == 0 and Cin % 2 == 0 and \
                 all(isinstance(w, torch.nn.Parameter) for w in ws):
             bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
             wp, wpt, bias = PREPACK.request(ws, bs, bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
@@ -136,7 +136,7 @@ class _ConvFn(torch.autograd.Function):
                 _PACK_CACHE[key] = (wp, wpt, bias)
         use_bias = has_b or bn_stats is not None
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
-                         out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else torch.bfloat16, groups=G)
+                         out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else K.L.act16(), groups=G)
         ctx.meta = meta
         ctx.params = tensors            # the Parameter objects themselves (their .grad may be an arena slot)
         for k, t in enumerate(tensors):  # uses per step of each parameter: the gradient sink fires after the last one
@@ -277,7 +277,7 @@ class _LinearFn(torch.autograd.Function):
             weff = w if flat_chw is None else w.view(O, *flat_chw).permute(0, 2, 3, 1).reshape(O, Kd)
             wp, wpt, bias = K.fold_pack(weff.reshape(O, Kd, 1, 1), b, None, 1e-5, want_dgrad=need_dgrad)
             wp, wpt, bias = wp[None], None if wpt is None else wpt[None], bias[None]
-        y = K.conv2d_fwd(x4, wp, bias if b is not None else None, 1, 1, 1, 0, relu=relu, out_dtype=torch.bfloat16)
+        y = K.conv2d_fwd(x4, wp, bias if b is not None else None, 1, 1, 1, 0, relu=relu, out_dtype=K.L.act16())
         ctx.cfg = (relu, input_relu, flat_chw, tuple(x.shape))
         ctx.params = (w, b)
         for k, t in enumerate((w, b)):
@@ -296,8 +296,8 @@ class _LinearFn(torch.autograd.Function):
         N, O = g.shape
         Kd = w.shape[1]
         g4 = g.reshape(N, O, 1, 1).contiguous(memory_format=torch.channels_last)
-        if g4.dtype != torch.bfloat16:
-            g4 = g4.to(torch.bfloat16)
+        if g4.dtype != K.L.act16():
+            g4 = g4.to(K.L.act16())
         if relu and not _premasked(g, y):
             g4 = K.relu_bwd(g4, y)
         gx = None
@@ -333,7 +333,7 @@ class _LinearFn(torch.autograd.Function):
 def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
     """x [N,K] bf16 (row-major), w [O,K] fp32 -> [N,O]."""
     N, Kd = x2d.shape
-    if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and not out_f32 and x2d.dtype == torch.bfloat16 and not _NO_LINEAR_FN:
+    if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and not out_f32 and x2d.dtype == K.L.act16() and not _NO_LINEAR_FN:
         return _LinearFn.apply(x2d, w, b, relu, input_relu, None)
     y = conv2d(x2d.reshape(N, Kd, 1, 1).contiguous(memory_format=torch.channels_last), w.view(w.shape[0], Kd, 1, 1), b,
                relu=relu, out_f32=out_f32, input_relu=input_relu)
@@ -343,7 +343,7 @@ def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
 def linear_after_flatten(x, w, b=None, relu=True, input_relu=False):
     """``x.flatten(1)`` of an NCHW-shaped map followed by nn.Linear, on NHWC memory (x bf16 [N,C,H,W] channels_last)."""
     N, C, H, W = x.shape
-    if isinstance(w, torch.nn.Parameter) and x.dtype == torch.bfloat16 and not _NO_LINEAR_FN:
+    if isinstance(w, torch.nn.Parameter) and x.dtype == K.L.act16() and not _NO_LINEAR_FN:
         return _LinearFn.apply(x, w, b, relu, input_relu, (C, H, W))
     wperm = w.view(-1, C, H, W).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     return linear(x.permute(0, 2, 3, 1).reshape(N, -1), wperm, b, relu=relu, input_relu=input_relu)
@@ -376,7 +376,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         stride, pad = ctx.sp
         Cout, Cin, R, S = w.shape
         if R == 1 and S == 1 and stride == 1 and pad == 0 and Cout <= 8 and Cin % 4 == 0 and Cin <= 1024 and \
-                x.dtype == torch.bfloat16 and not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
+                x.dtype == K.L.act16() and not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
             # one pass over x: gx (with the producer's ReLU mask when x is a ReLU output), dW and db together
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=ctx.input_relu, need_gx=ctx.needs_input_grad[0],
@@ -415,7 +415,7 @@ def narrow_head_prepack(w, b, dtype):
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
     c4 = (w.shape[0] + 3) // 4 * 4
-    pdt = torch.float32 if dtype == torch.float32 else torch.bfloat16
+    pdt = torch.float32 if dtype == torch.float32 else K.L.act16()
     with torch.no_grad():
         wp, _, bias = K.fold_pack(w, b, None, 1e-5, want_dgrad=False, dtype=pdt, cout_pad=c4)
     return wp[None], bias
@@ -449,7 +449,7 @@ class _MdcnSampleFn(torch.autograd.Function):
         if g.dtype != x.dtype:
             g = g.to(x.dtype)
         dx, dom = K.mdcn_sample_bwd(x, om, g, kh, kw, stride, pad, dil, dg)
-        return (K.cast_bf16(dx) if x.dtype == torch.bfloat16 else dx), dom, None
+        return (K.cast_bf16(dx) if x.dtype == K.L.act16() else dx), dom, None
 
 
 def mdcn_sample(x, om, kh, kw, stride=1, pad=0, dil=1, deform_groups=1):
@@ -595,26 +595,26 @@ class _RoIAlignFn(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         P, strides, fs, n_rot, shapes, dt = ctx.meta
         g = to_nhwc(g)
-        direct = dt == torch.bfloat16 and g.dtype == torch.bfloat16 and not _os.environ.get('LOFT_ROI_FP32_BWD')   # bf16 maps straight from fp32 registers
+        direct = dt == K.L.act16() and g.dtype == K.L.act16() and not _os.environ.get('LOFT_ROI_FP32_BWD')   # bf16 maps straight from fp32 registers
         keys = ctx.hub_keys
         if direct and HUB is not None and all(k is not None and k in HUB for k in keys):
             have = [HUB[k] for k in keys]
             if all(h is None for h in have):          # first consumer of these maps: the kernel writes every pixel
-                grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True, out_dtype=torch.bfloat16)
+                grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True, out_dtype=K.L.act16())
                 for k, x in zip(keys, grads):
                     HUB[k] = x
                 return (None, None, None, None, None) + tuple(grads)
             ret = []
             for i, k in enumerate(keys):               # levels nobody has touched yet start from zeros
                 if have[i] is None:
-                    have[i] = HUB[k] = K.zeros_nhwc(*shapes[i], torch.bfloat16, g.device)
+                    have[i] = HUB[k] = K.zeros_nhwc(*shapes[i], K.L.act16(), g.device)
                     ret.append(have[i])
                 else:
                     ret.append(None)
             K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, grad_feats=have, rois_sorted=True)
             return (None, None, None, None, None) + tuple(ret)
         grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True,       # (rois in bbox2roi order)
-                                out_dtype=torch.bfloat16 if direct else torch.float32)
+                                out_dtype=K.L.act16() if direct else torch.float32)
         return (None, None, None, None, None) + tuple(x if x.dtype == dt else K.cast_bf16(x) for x in grads)   # (fp32 maps: as is)
 
 
@@ -769,7 +769,7 @@ class _Stem3x3Fn(torch.autograd.Function):
         return None, dw, dg, dbeta, None, None, None, None
 
 
-def stem3x3s2(img, w, bn, out_dtype=torch.bfloat16):
+def stem3x3s2(img, w, bn, out_dtype=None):
     return _Stem3x3Fn.apply(img, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, out_dtype)
 
 
@@ -812,13 +812,13 @@ class _SparseRPNFn(torch.autograd.Function):
         C = w_conv.shape[0]
         # output-gradient rows in the fused head's channel order (cls 0..A-1, reg A..5A-1), zero padded to 128 channels
         idx = torch.cat([slot[:, None], A + 4 * slot[:, None] + torch.arange(4, device=dev)[None]], 1)
-        g_rows = torch.zeros(nsel, P, dtype=torch.float32, device=dev).scatter_(1, idx, g.float()).to(torch.bfloat16)
+        g_rows = torch.zeros(nsel, P, dtype=torch.float32, device=dev).scatter_(1, idx, g.float()).to(K.L.act16())
         w_head = torch.zeros(P, C, dtype=torch.float32, device=dev)
         w_head[:A] = w_cls.view(A, C)
         w_head[A:5 * A] = w_reg.view(4 * A, C)
         gimg = _as_img(g_rows)
         # gh = relu'(h) * (g_rows x W_head): data gradient of the 1x1 heads with the ReLU mask in the epilogue
-        gh = K.conv2d_dgrad(gimg, w_head.t().contiguous().to(torch.bfloat16)[None, None], (nsel, 1), 1, 1, mask=_as_img(h_sel))
+        gh = K.conv2d_dgrad(gimg, w_head.t().contiguous().to(K.L.act16())[None, None], (nsel, 1), 1, 1, mask=_as_img(h_sel))
         dwp, db = K.conv2d_wgrad(gimg, _as_img(h_sel), 1, 1, with_bias=True)
         g_wcls, g_wreg = dwp[0, 0, :A].reshape(w_cls.shape), dwp[0, 0, A:5 * A].reshape(w_reg.shape)
         g_bcls, g_breg = db[0, :A], db[0, A:5 * A]
@@ -826,12 +826,12 @@ class _SparseRPNFn(torch.autograd.Function):
         xg = K.rpn_gather_rows(list(xs), rows, 3)
         dwc, dbc = K.conv2d_wgrad(gh, _as_img(xg), 1, 1, with_bias=True)
         g_wconv = dwc[0, 0].view(C, 9, C).permute(0, 2, 1).reshape(w_conv.shape)
-        wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(torch.bfloat16).contiguous()     # [(tap, cin), cout]
+        wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(K.L.act16()).contiguous()     # [(tap, cin), cout]
         dxs = K.conv2d_fwd(_as_img(gh2d), wd[None, None], None, 1, 1)
         dxs = dxs.permute(0, 2, 3, 1).reshape(nsel, 9 * C)
         dxl, ret = [], []
         for x in xs:                                   # hub-managed maps: scatter into the shared gradient map of the level
-            k = x.data_ptr() if (HUB is not None and x.data_ptr() in HUB and x.dtype == torch.bfloat16) else None
+            k = x.data_ptr() if (HUB is not None and x.data_ptr() in HUB and x.dtype == K.L.act16()) else None
             if k is not None and HUB[k] is not None:
                 dxl.append(HUB[k])
                 ret.append(None)
@@ -862,7 +862,7 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
             tuple((t.data_ptr(), t._version) for t in stats)
         if key in _PACK_CACHE:
             return _PACK_CACHE[key]
-    if PREPACK is not None and key is None and pdt == torch.bfloat16 and cout_p % 2 == 0 and cin_p % 2 == 0 and \
+    if PREPACK is not None and key is None and pdt == K.L.act16() and cout_p % 2 == 0 and cin_p % 2 == 0 and \
             isinstance(w, torch.nn.Parameter):
         return PREPACK.request((w,), (None,), (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
     out = K.fold_pack(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, want_fwd=True, want_dgrad=need_dgrad, dtype=pdt,
@@ -926,7 +926,7 @@ class _ResBlockFn(torch.autograd.Function):
         _note_use(x)
         main_specs, sc_spec = specs
         n = len(main_specs)
-        pdt = torch.float32 if x.dtype == torch.float32 else torch.bfloat16
+        pdt = torch.float32 if x.dtype == torch.float32 else K.L.act16()
         need_dx = ctx.needs_input_grad[0]
         acts, packs = [x], []
         h = x

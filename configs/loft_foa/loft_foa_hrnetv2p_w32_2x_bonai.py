@@ -13,6 +13,7 @@ model = dict(
             stage4=dict(num_modules=3, num_branches=4, block='BASIC', num_blocks=(4, 4, 4, 4),
                         num_channels=(32, 64, 128, 256)))),
     neck=dict(_delete_=True, type='HRFPN', in_channels=[32, 64, 128, 256], out_channels=256))
-# BASELINE config 5 is the reference's fp16 recipe (configs/fp16/*: Fp16OptimizerHook, static loss scale).  Activations run
-# in bf16 here (dtype >= the reference's fp16); the static loss scale is honoured by bonai_amd.engine.Trainer.
+# BASELINE config 5 is the reference's fp16 recipe (configs/fp16/*: Fp16OptimizerHook, static loss scale): bench.py and
+# tools/train.py switch to the binary16 build of the kernels (bonai_amd.lib.set_act16(torch.float16) -> libloft_hip_f16.so,
+# v_mfma_f32_32x32x16_f16) and bonai_amd.engine.Trainer applies the static scale; masters, losses, RoIAlign, coders stay fp32.
 fp16 = dict(loss_scale=512.)

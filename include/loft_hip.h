@@ -28,6 +28,13 @@ extern "C" {
 
 #define LOFT_F32 0
 #define LOFT_BF16 1
+#define LOFT_F16 2
+/* The library is built twice from the same sources: libloft_hip.so (16-bit type = bfloat16) and libloft_hip_f16.so (IEEE
+ * binary16, for the reference's `fp16 = dict(loss_scale=512.)` configs, mmdet/core/fp16/hooks.py:11-135).  Both export this
+ * same header; wherever a name or a comment below says "bf16" read "the 16-bit type of the library at hand", and wherever a
+ * dtype code is taken the 16-bit code accepted is the library's own (LOFT_BF16 resp. LOFT_F16; the other one is rejected with
+ * hipErrorInvalidValue).  MFMA: v_mfma_f32_32x32x16_bf16 resp. v_mfma_f32_32x32x16_f16 -- same rate, fp32 accumulation. */
+int loft_act16_dtype(void);   /* LOFT_BF16 or LOFT_F16: which build this is */
 
 /* ---- RoIAlign ---------------------------------------------------------------------------
  * Replaces SingleRoIExtractor.forward's per-level loop over mmcv.ops.RoIAlign

@@ -10,12 +10,28 @@ from bonai_amd import lib as L
 def test_header_symbols_exported():
     names = L.exported_symbols()
     assert len(names) >= 5
-    if not os.path.exists(L._LIB_PATH):
+    if not (os.path.exists(L._LIB_PATH) and os.path.exists(L._LIB_PATH_F16)):
         from bonai_amd import build
         build.build()
-    cdll = ctypes.CDLL(L._LIB_PATH)
-    missing = [n for n in names if not hasattr(cdll, n)]
-    assert not missing, f'symbols declared in include/loft_hip.h but not exported: {missing}'
+    for path, code in ((L._LIB_PATH, L.BF16), (L._LIB_PATH_F16, L.F16)):      # the bfloat16 and the binary16 build: same C-ABI
+        cdll = ctypes.CDLL(path)
+        missing = [n for n in names if not hasattr(cdll, n)]
+        assert not missing, f'symbols declared in include/loft_hip.h but not exported by {path}: {missing}'
+        assert cdll.loft_act16_dtype() == code
+
+
+def test_act16_mode_switch():
+    import pytest
+    assert L.act16() == torch.bfloat16
+    prev = L.set_act16(torch.float16)
+    try:
+        assert prev == torch.bfloat16 and L.act16() == torch.float16
+        assert L.load().loft_act16_dtype() == L.F16
+    finally:
+        L.set_act16(prev)
+    assert L.load().loft_act16_dtype() == L.BF16
+    with pytest.raises(L.LoftHipError):
+        L.set_act16(torch.float32)
 
 
 def test_no_cpu_fallback():

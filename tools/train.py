@@ -48,6 +48,9 @@ def main():
         dist.init_process_group(cfg.dist_params.get('backend', 'nccl'))
     torch.manual_seed(args.seed)
     from bonai_amd.checkpoint import load_checkpoint, save_checkpoint
+    if cfg.get('fp16'):                                    # Fp16OptimizerHook recipe: half activations, fp32 masters, static scale
+        from bonai_amd import lib as L
+        L.set_act16(torch.float16)
     if args.pretrained:
         cfg.model['pretrained'] = args.pretrained
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()

@@ -35,6 +35,9 @@ def main():
     if not args.bitmap_masks:
         cfg.test_cfg.rcnn['rle_masks'] = True
     torch.manual_seed(0)
+    if cfg.get('fp16'):                                    # tools/test.py:104-106 wrap_fp16_model
+        from bonai_amd import lib as L
+        L.set_act16(torch.float16)
     model = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     if args.checkpoint:
         from bonai_amd.checkpoint import load_checkpoint

@@ -661,8 +661,7 @@ struct MdcnTiling { int TH, TW, tiles_x, tiles_y, WH, WW, splits, cpl, nslab; lo
 
 static bool mdcn_tiling(int B, int C, int OH, int OW, int kh, int kw, int stride, int dil, int deform_groups, int omc,
                         MdcnTiling* t) {
-    static const bool force_generic = getenv("LOFT_MDCN_GENERIC_BWD") != nullptr;
-    if (force_generic || deform_groups != 1 || C % 64 != 0 || dil != 1) return false;
+    if (deform_groups != 1 || C % 64 != 0 || dil != 1) return false;
     // 8x8 output tiles at stride 1, 4x4 at stride 2: the receptive field + margin fits the 15x15 LDS window
     t->TH = t->TW = (stride == 1 ? 8 : 4);
     t->WH = (t->TH - 1) * stride + (kh - 1) * dil + 2 * MDCN_MARGIN + 2;
@@ -705,16 +704,11 @@ LOFT_EXPORT int loft_mdcn_sample_bwd(const void* x, const float* offmask, const 
         const unsigned ntiles = (unsigned)(t.tiles_x * t.tiles_y * B);
         float* ws = (float*)workspace;
         float* domp = ws + t.win_floats;
-        static const bool window_kernel = getenv("LOFT_MDCN_WINDOW_BWD") != nullptr;
         int parts = t.splits;
         if (dtype == LOFT_F32)
             hipLaunchKernelGGL(mdcn_sample_bwd_tile_kernel<float>, dim3(ntiles, t.splits), dim3(512), 0, (hipStream_t)stream,
                                (const float*)x, offmask, (const float*)dcol, dx, doffmask, a, t.TH, t.TW, t.tiles_x, t.tiles_y, ws,
                                domp);
-        else if (window_kernel)
-            hipLaunchKernelGGL(mdcn_sample_bwd_tile_kernel<bf16_t>, dim3(ntiles, t.splits), dim3(512), 0, (hipStream_t)stream,
-                               (const bf16_t*)x, offmask, (const bf16_t*)dcol, dx, doffmask, a, t.TH, t.TW, t.tiles_x, t.tiles_y,
-                               ws, domp);
         else {
             parts = t.nslab;
             const dim3 bg(ntiles, t.nslab);

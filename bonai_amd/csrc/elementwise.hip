@@ -946,7 +946,7 @@ LOFT_EXPORT int loft_narrow_head_bwd(const float* g, int g_stride, const void* x
     // >= 16 pixel rounds per block (each block ends with an LDS reduction and Cout * Cin atomics), at most 2048 blocks
     // (measured: 8192 blocks +0.7 ms per step, 512..2048 equal)
     long blocks = (M + (long)ppi * 16 - 1) / ((long)ppi * 16);
-    static const long cap = getenv("LOFT_NHB_BLOCKS") ? atol(getenv("LOFT_NHB_BLOCKS")) : 2048;
+    const long cap = 2048;
     if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
 #define NHB(N, VV) hipLaunchKernelGGL((narrow_head_bwd_kernel<N, VV>), dim3((unsigned)blocks), dim3(256), 0, s, g, g_stride, \

@@ -667,15 +667,16 @@ static RoiLevels make_levels(const void* const* feats, const int* H, const int* 
     return L;
 }
 
-LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const int* W, const float* scales,
-                                   int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
-                                   int P, int n_rot, void* out, void* stream) {
+LOFT_EXPORT int loft_roi_align_fwd_v(const void* const* feats, const int* H, const int* W, const float* scales,
+                                     int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
+                                     int P, int n_rot, void* out, int variant, void* stream) {
     if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (K <= 0) return 0;
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4)) return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(feats, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
-    static const bool sample_form = getenv("LOFT_ROI_SAMPLE_FWD") != nullptr;      // A/B switch
+    if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_FWD_SAMPLE) return (int)hipErrorInvalidValue;
+    const bool sample_form = variant == LOFT_ROI_FWD_SAMPLE;      // the sample-order kernel also for the 16-bit type (tests, A/B)
     if (dtype == LOFT_ACT16 && !sample_form)
         hipLaunchKernelGGL(roi_align_fwd_sep_kernel, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out);
     else if (dtype == LOFT_ACT16)
@@ -688,10 +689,18 @@ LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const
     return 0;
 }
 
-LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const int* W, const float* scales,
+LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const int* W, const float* scales,
                                    int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
-                                   int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
-                                   void* workspace, int grad_dtype, void* stream) {
+                                   int P, int n_rot, void* out, void* stream) {
+    return loft_roi_align_fwd_v(feats, H, W, scales, num_levels, finest_scale, C, dtype, rois, K, P, n_rot, out, LOFT_ROI_AUTO, stream);
+}
+
+LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, const int* W, const float* scales,
+                                     int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
+                                     int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
+                                     void* workspace, int grad_dtype, int variant, void* stream) {
+    if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_BWD_VALU) return (int)hipErrorInvalidValue;
+    const bool valu_form = variant == LOFT_ROI_BWD_VALU;          // the tile-owner VALU kernel instead of the per-pair GEMMs
     if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || P > RB_MAXP)
         return (int)hipErrorInvalidValue;
@@ -705,7 +714,6 @@ LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const 
     }
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
-        static const bool valu_form = getenv("LOFT_ROI_VALU_BWD") != nullptr;          // A/B switch
         if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form)
             hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, rois, K, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
@@ -723,6 +731,14 @@ LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const 
         LOFT_LAUNCH_CHECK();
     }
     return 0;
+}
+
+LOFT_EXPORT int loft_roi_align_bwd(void* const* grad_feats, const int* H, const int* W, const float* scales,
+                                   int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
+                                   int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
+                                   void* workspace, int grad_dtype, void* stream) {
+    return loft_roi_align_bwd_v(grad_feats, H, W, scales, num_levels, finest_scale, C, dtype, rois, K, P, n_rot, grad_out, B,
+                                accumulate, rois_sorted, workspace, grad_dtype, LOFT_ROI_AUTO, stream);
 }
 
 LOFT_EXPORT int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out,

@@ -91,6 +91,12 @@ def _level_args(feats, strides):
     return H, W, S
 
 
+# include/loft_hip.h LOFT_ROI_*: kernel selector of loft_roi_align_{fwd,bwd}_v (0 = the shipped choice); tests set these
+ROI_AUTO, ROI_FWD_SAMPLE, ROI_BWD_VALU = 0, 1, 1
+ROI_FWD_VARIANT = ROI_AUTO
+ROI_BWD_VARIANT = ROI_AUTO
+
+
 def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
     lib = L.load()
     L.dev_check(rois, *feats)
@@ -102,8 +108,8 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
         return out
     H, W, S = _level_args(feats, strides)
     fp = L.arr(c_void_p, [f.data_ptr() for f in feats])
-    L.check(lib.loft_roi_align_fwd(fp, H, W, S, len(feats), int(finest_scale), C, L.dtype_code(feats[0]), L.ptr(rois),
-                                   K, int(P), int(n_rot), L.ptr(out), L.stream()), 'loft_roi_align_fwd')
+    L.check(lib.loft_roi_align_fwd_v(fp, H, W, S, len(feats), int(finest_scale), C, L.dtype_code(feats[0]), L.ptr(rois),
+                                     K, int(P), int(n_rot), L.ptr(out), int(ROI_FWD_VARIANT), L.stream()), 'loft_roi_align_fwd_v')
     return out
 
 
@@ -126,10 +132,10 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     S = L.arr(c_float, [1.0 / s for s in strides])
     gp = L.arr(c_void_p, [g.data_ptr() for g in grad_feats])
     ws = torch.empty(16 * K, dtype=torch.uint8, device=rois.device)
-    L.check(lib.loft_roi_align_bwd(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
-                                   L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
-                                   int(accumulate), int(rois_sorted), L.ptr(ws), L.dtype_code(grad_feats[0]), L.stream()),
-            'loft_roi_align_bwd')
+    L.check(lib.loft_roi_align_bwd_v(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
+                                     L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
+                                     int(accumulate), int(rois_sorted), L.ptr(ws), L.dtype_code(grad_feats[0]),
+                                     int(ROI_BWD_VARIANT), L.stream()), 'loft_roi_align_bwd_v')
     return grad_feats
 
 

@@ -25,6 +25,9 @@ from .core import pad_gts
 from .losses import accuracy
 
 
+TENSOR_TARGETS = False   # tests: the tensor formulation of the sampled-RoI lists / targets instead of loft_roi_sample_targets
+
+
 @ROI_EXTRACTORS.register_module()
 class SingleRoIExtractor(nn.Module):
     def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56):
@@ -388,7 +391,7 @@ class LoftRoIHead(nn.Module):
             lab_pad = torch.zeros(B, Kmax, dtype=torch.long, device=dev)
             for i, l in enumerate(gt_labels):
                 lab_pad[i, :l.shape[0]] = l.to(dev)
-        fused_targets = dev.type == 'cuda' and not os.environ.get('LOFT_ROI_TORCH_TARGETS')
+        fused_targets = dev.type == 'cuda' and not TENSOR_TARGETS
         if fused_targets:
             # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53), labels and bbox targets: one launch
             with torch.no_grad():

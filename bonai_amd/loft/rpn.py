@@ -25,6 +25,9 @@ from .builder import HEADS, build_anchor_generator, build_assigner, build_bbox_c
 from .core import pad_gts
 
 
+TENSOR_GATHER = False   # tests: the tensor formulation of the sampled-anchor gather instead of loft_rpn_sample_gather
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256, anchor_generator=None, bbox_coder=None, reg_decoded_bbox=False,
@@ -117,7 +120,7 @@ class RPNHead(nn.Module):
             num_pos = pval.sum(1).clamp(min=1).sum()
             num_neg = nval.sum(1).clamp(min=1).sum()
             avg = (num_pos + num_neg).float()
-        if sparse is not None and fused[0].is_cuda and not os.environ.get('LOFT_RPN_TORCH_GATHER'):
+        if sparse is not None and fused[0].is_cuda and not TENSOR_GATHER:
             # one launch: level / pixel / slot of every sampled anchor, its logit + deltas straight from the fused head outputs,
             # labels, weights and the positives' regression targets
             xs, hs = sparse
@@ -239,7 +242,7 @@ class RPNHead(nn.Module):
         return [props[i, :int(n)] for i, n in enumerate(counts.tolist())]
 
     # ---------------------------------------------------------------- train / test entry points
-    sparse_backward = os.environ.get('LOFT_RPN_DENSE_BWD') is None      # A/B switch; the dense path is the plain autograd one
+    sparse_backward = True      # False (tests, A/B): the plain dense autograd path
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
         if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == K.L.act16() and x[0].shape[1] % 128 == 0:

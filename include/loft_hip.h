@@ -56,6 +56,18 @@ int loft_roi_align_bwd(void* const* grad_feats_host, const int* H_host, const in
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                        int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,
                        int grad_dtype, void* stream);
+/* The same with the kernel chosen by the caller (tests / A-B timing; no environment variable is read anywhere in the library):
+ * LOFT_ROI_AUTO = the shipped choice (16-bit forward: separable kernel; 16-bit maps with C == 256: per-(RoI, tile) GEMMs). */
+#define LOFT_ROI_AUTO 0
+#define LOFT_ROI_FWD_SAMPLE 1   /* forward: the sample-order kernel also for the 16-bit type */
+#define LOFT_ROI_BWD_VALU 1     /* backward: the tile-owner VALU kernel also where the MFMA form applies */
+int loft_roi_align_fwd_v(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
+                         int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
+                         int n_rot, void* out, int variant, void* stream);
+int loft_roi_align_bwd_v(void* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
+                         int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
+                         int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,
+                         int grad_dtype, int variant, void* stream);
 /* map_roi_levels alone (single_level_roi_extractor.py:32-51) -> int32 [K]. */
 int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out, void* stream);
 

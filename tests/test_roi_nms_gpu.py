@@ -193,3 +193,38 @@ def test_roi_align_bwd_mfma_matches_scalar_form(P, n_rot):
     for tt, ww in zip(twice, want):
         scale = max(1.0, ww.abs().max().item())
         assert (tt.float() - 2 * ww).abs().max().item() <= 2e-2 * scale
+
+
+def test_roi_align_variants_selected_in_process():
+    """include/loft_hip.h LOFT_ROI_*: the explicit kernel selectors of loft_roi_align_{fwd,bwd}_v (no environment variables):
+    the sample-order forward against the separable one, the tile-owner VALU backward against the per-pair GEMMs, 16-bit maps."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(11)
+    B, C, size, P = 2, 256, 256, 7
+    strides = [4, 8, 16, 32]
+    rois = _rand_rois(rng, 300, B, size)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous().cuda()
+    torch.manual_seed(3)
+    feats = [torch.randn(B, C, size // s, size // s, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+             for s in strides]
+    g = torch.randn(rois.shape[0], C, P, P, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+    shapes = [tuple(f.shape) for f in feats]
+    try:
+        sep = K.roi_align_fwd(feats, rois, P, strides)
+        mfma = K.roi_align_bwd(g, rois, shapes, P, strides, rois_sorted=True, out_dtype=torch.bfloat16)
+        K.ROI_FWD_VARIANT, K.ROI_BWD_VARIANT = K.ROI_FWD_SAMPLE, K.ROI_BWD_VALU
+        smp = K.roi_align_fwd(feats, rois, P, strides)
+        valu = K.roi_align_bwd(g, rois, shapes, P, strides, rois_sorted=True, out_dtype=torch.bfloat16)
+    finally:
+        K.ROI_FWD_VARIANT = K.ROI_BWD_VARIANT = K.ROI_AUTO
+    assert (sep.float() - smp.float()).abs().max().item() <= 2 ** -6 * max(1.0, smp.float().abs().max().item())
+    assert (sep.float() - smp.float()).abs().mean().item() <= 2e-3
+    for a, b in zip(mfma, valu):
+        scale = max(1.0, b.float().abs().max().item())
+        assert (a.float() - b.float()).abs().max().item() <= 8e-3 * scale
+    K.ROI_FWD_VARIANT = 7
+    try:
+        with pytest.raises(K.L.LoftHipError):
+            K.roi_align_fwd(feats, rois, P, strides)
+    finally:
+        K.ROI_FWD_VARIANT = K.ROI_AUTO

@@ -162,7 +162,11 @@ class ResNet(nn.Module):
         self._freeze_stages()
 
     def _freeze_stages(self):
-        """resnet.py:573-589."""
+        """resnet.py:573-589.  frozen_stages < 0 (a trainable stem) is not built: the stem kernels have no backward, and its
+        parameters would sit in the optimiser arena receiving weight decay with a zero gradient (configs/loft_foa use 1)."""
+        if self.frozen_stages < 0:
+            raise NotImplementedError('ResNet(frozen_stages=-1): the 7x7 stem has no weight-gradient kernel; use frozen_stages >= 0 '
+                                      '(configs/_base_/models/bonai_loft_foa_r50_fpn_basic.py:24 sets 1)')
         if self.frozen_stages >= 0:
             for p in list(self.conv1.parameters()) + list(self.bn1.parameters()):
                 p.requires_grad = False
@@ -193,7 +197,7 @@ class ResNet(nn.Module):
 
     def forward(self, img):
         """img fp32 NCHW [B,3,H,W] -> tuple of bf16 NHWC-in-memory maps (C2..C5)."""
-        with torch.set_grad_enabled(self.frozen_stages < 0 and torch.is_grad_enabled()):
+        with torch.no_grad():                               # frozen stem (frozen_stages >= 0, enforced in _freeze_stages)
             scale, shift = self.bn1.fold()
             if getattr(self, 'compute_dtype', None) == torch.float32:   # fp32 parity mode (else: the library's 16-bit type)
                 x = K.stem7x7_bn_relu(img, self.conv1.weight, scale, shift, out_dtype=torch.float32)

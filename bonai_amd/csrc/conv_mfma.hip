@@ -638,9 +638,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     int t, grp, mbeg, mend;
     if constexpr (PM) {
         grp = by;
-        t = 0;
-        while (t + 1 < a.T && bz >= a.pm_blk0[t + 1]) ++t;
-        mbeg = (bz - a.pm_blk0[t]) * a.pm_pps[t];
+        t = a.pm_tap[bz];
+        mbeg = (int)a.pm_split[bz] * a.pm_pps[t];
         mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
     } else {
         t = by % a.T; grp = by / a.T;
@@ -752,7 +751,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
         }
     }
 
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+    const int sidx = PM ? (int)a.pm_split[bz] : bz;
+    const int ns_t = PM ? a.pm_blk0[t + 1] - a.pm_blk0[t] : (int)gridDim.z;
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
+    const int nzero = (a.partial && sidx == ns_t - 1) ? a.nslots - ns_t : 0;      // this tap's unused slots (WgradArgs::partial)
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -761,7 +763,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * (TN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[i][j][r]);
+                float* p = dw + (long)n * a.Cin + c;
+                if (a.partial) {
+                    *p = acc[i][j][r];
+                    for (int z = 1; z <= nzero; ++z) p[(long)z * a.split_stride] = 0.f;
+                } else {
+                    unsafeAtomicAdd(p, acc[i][j][r]);
+                }
             }
         }
 }
@@ -1043,15 +1051,30 @@ LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* 
 
 int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStream_t s);     // conv_wgrad_pipe.hip
 
-LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
-                                       int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
-                                       const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
-                                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
-                                       int splits, float* db, int db_tap, int variant, void* stream) {
+// mode 0: launch, split-K combined with fp32 atomics into the zeroed dw.  mode 1: no launch, *nslots_out = the number of
+// split slots a partial-sum launch of this shape writes (0: this shape has no such form -- narrow channels, repeated or missing
+// weight taps, a tap without a valid row).  mode 2: launch, every workgroup STORES its tile into its split's slot of
+// dw = [group][nslots][T][Cout][Cin] (dw_gs = nslots * T * Cout * Cin); see WgradArgs::partial.
+static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                      int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                      const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                      const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                      int splits, float* db, int db_tap, int variant, void* stream, int mode, int* nslots_out) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 8) || (Cout % 8) || groups < 1) return (int)hipErrorInvalidValue;
     if (variant < LOFT_WGRAD_AUTO || variant > LOFT_WGRAD_T128) return (int)hipErrorInvalidValue;
     const bool narrow = (Cin % 128) || (Cout % 128);
+    bool slots_ok = !narrow;
+    {   // every weight tap written by exactly one tap of the table (else a slot would be written twice, or never)
+        unsigned seen = 0;
+        for (int t = 0; t < T; ++t) {
+            if (wt_host[t] < 0 || wt_host[t] >= T || (seen >> wt_host[t] & 1u)) slots_ok = false;
+            else seen |= 1u << wt_host[t];
+        }
+    }
+    if (nslots_out) *nslots_out = 0;
+    if (mode == 2 && !slots_ok) return (int)hipErrorInvalidValue;
     WgradArgs a;
+    a.partial = mode == 2; a.nslots = 1; a.split_stride = (long)T * Cout * Cin;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = GH; a.GW = GW; a.Cout = Cout; a.XH = XH; a.XW = XW; a.Cin = Cin; a.OH = OH; a.OW = OW;
     a.gos = gos; a.ss = ss; a.T = T;
@@ -1061,7 +1084,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, 
     a.g_gs = g_gs; a.x_gs = x_gs; a.dw_gs = dw_gs;
     a.db = db; a.db_tap = db ? db_tap : -1;
     const long M = (long)B * OH * OW;
-    if (M <= 0) return 0;
+    if (M <= 0) return mode == 2 ? (int)hipErrorInvalidValue : 0;
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
@@ -1095,7 +1118,7 @@ LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, 
     if (!narrow && T > 1 && gos == 1 && ss == 1 && B >= 128 && OH * OW <= 1024) {
         // valid rectangle of every tap; K-splits per tap proportional to its rows: the smallest common K length L (multiple of
         // the 64-row K-step) with sum_t ceil(rows_t / L) <= the workgroup budget per group
-        const long budget = (long)splits * T;
+        const long budget = std::min<long>((long)splits * T, WGRAD_PM_MAX_BLOCKS);    // (pm_tap / pm_split hold one byte per block)
         long rows[CONV_MAX_TAPS], total = 0;
         for (int t = 0; t < T; ++t) {
             const int ylo = std::max(0, std::max(-a.goy[t], -a.dy[t])), yhi = std::min(OH, std::min(GH - a.goy[t], XH - a.dy[t]));
@@ -1122,16 +1145,45 @@ LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, 
                 blk += (int)ns;
             }
             a.pm_blk0[T] = blk;
+            if (blk > WGRAD_PM_MAX_BLOCKS) return (int)hipErrorInvalidValue;      // (budget = 256 / (tiles * groups) at most)
+            {   // interleave the taps: sort (tap, split) by the split's relative position (s + 0.5) / ns_t, ties by tap
+                int ns[CONV_MAX_TAPS], nxt[CONV_MAX_TAPS];
+                for (int t = 0; t < T; ++t) { ns[t] = a.pm_blk0[t + 1] - a.pm_blk0[t]; nxt[t] = 0; }
+                for (int j = 0; j < blk; ++j) {
+                    int best = -1;
+                    for (int t = 0; t < T; ++t) {
+                        if (nxt[t] >= ns[t]) continue;
+                        // (2 nxt + 1) / (2 ns) compared by cross-multiplication
+                        if (best < 0 || (long)(2 * nxt[t] + 1) * ns[best] < (long)(2 * nxt[best] + 1) * ns[t]) best = t;
+                    }
+                    a.pm_tap[j] = (unsigned char)best;
+                    a.pm_split[j] = (unsigned char)nxt[best]++;
+                }
+            }
             fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
+            int maxns = 0;
+            bool every = true;
+            for (int t = 0; t < T; ++t) {
+                const int ns = a.pm_blk0[t + 1] - a.pm_blk0[t];
+                maxns = std::max(maxns, ns);
+                every = every && ns >= 1;
+            }
+            a.nslots = maxns;
+            if (mode == 1) { if (nslots_out) *nslots_out = (slots_ok && every) ? maxns : 0; return 0; }
+            if (mode == 2 && (!every || dw_gs != (int64_t)maxns * a.split_stride)) return (int)hipErrorInvalidValue;
             dim3 grid(tiles, groups, blk);
             if (piped) return loft_launch_conv_wgrad_stream(a, grid, true, (hipStream_t)stream);
             if (big) hipLaunchKernelGGL((conv_wgrad_kernel<256, 8, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((conv_wgrad_kernel<128, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
             LOFT_LAUNCH_CHECK();
+            return 0;
         }
-        return 0;
+        return mode == 2 ? (int)hipErrorInvalidValue : 0;     // (no tap has a valid row: dw stays as the caller left it)
     }
     splits = (int)((M + pps - 1) / pps);
+    a.nslots = splits;
+    if (mode == 1) { if (nslots_out) *nslots_out = slots_ok ? splits : 0; return 0; }
+    if (mode == 2 && dw_gs != (int64_t)splits * a.split_stride) return (int)hipErrorInvalidValue;
     dim3 grid(tiles, T * groups, splits);
     if (piped) return loft_launch_conv_wgrad_stream(a, grid, false, (hipStream_t)stream);
     if (narrow)
@@ -1142,6 +1194,34 @@ LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, 
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                                       int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                       const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                                       int splits, float* db, int db_tap, int variant, void* stream) {
+    return wgrad_impl(g, x, dw, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host, dx_host,
+                      wt_host, groups, g_gs, x_gs, dw_gs, splits, db, db_tap, variant, stream, 0, nullptr);
+}
+
+LOFT_EXPORT int loft_conv_wgrad_slots(int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss,
+                                      int T, const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                      const int* wt_host, int groups, int splits, int variant) {
+    int n = 0;
+    const int e = wgrad_impl(nullptr, nullptr, nullptr, nullptr, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host,
+                             gox_host, dy_host, dx_host, wt_host, groups, 0, 0, 0, splits, nullptr, -1, variant, nullptr, 1, &n);
+    return e ? -e : n;
+}
+
+LOFT_EXPORT int loft_conv_wgrad_bf16_slots(const void* g, const void* x, float* dw_slots, const void* zero_page, int B, int GH,
+                                           int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                           const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                           const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int nslots,
+                                           int splits, float* db, int db_tap, int variant, void* stream) {
+    return wgrad_impl(g, x, dw_slots, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host,
+                      dx_host, wt_host, groups, g_gs, x_gs, (int64_t)nslots * T * Cout * Cin, splits, db, db_tap, variant, stream, 2,
+                      nullptr);
 }
 
 LOFT_EXPORT int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,

@@ -135,6 +135,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
 // ---- weight gradient (conv_mfma.hip conv_wgrad_kernel, conv_wgrad_pipe.hip): argument block and LDS swizzle
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+#define WGRAD_PM_MAX_BLOCKS 256
 struct WgradArgs {
     const bf16_t* g;
     const bf16_t* x;
@@ -153,6 +154,17 @@ struct WgradArgs {
     // 14x14 one) are never staged, and every tap gets a number of K-splits proportional to its valid rows so that all
     // workgroups run the same number of K-steps.  Workgroup j of a group serves tap t with pm_blk0[t] <= j < pm_blk0[t+1].
     int pm_blk0[CONV_MAX_TAPS + 1], pm_pps[CONV_MAX_TAPS], pm_rows[CONV_MAX_TAPS];
+    // Block order of the PM form: block j (position in the launch, after the XCD-aware remap) -> tap pm_tap[j], K-split
+    // pm_split[j] of that tap, sorted by the split's relative position in its tap's rows.  The taps of one pixel range then sit
+    // next to each other -- on one XCD, which fetches the G / X rows they share into its L2 once instead of once per tap.
+    unsigned char pm_tap[WGRAD_PM_MAX_BLOCKS], pm_split[WGRAD_PM_MAX_BLOCKS];
+    // Split-K combination.  partial == 0: fp32 atomics into dw (the caller zeroed it).  partial == 1: workgroup (tap, tile, split s)
+    // STORES its tile into slot s of dw viewed as [group][nslots][wtap][Cout][Cin] (split_stride = wtaps * Cout * Cin elements),
+    // nothing is pre-zeroed and the consumer (loft_fold_unpack_bwd_multi) sums the slots while it reads: an fp32 atomic costs the
+    // L2 one channel-cycle per 4 bytes (measured 0.29 T atomics/s over the chip, tools/probes/atomic_scope.hip), a store 1/16 of
+    // that.  The last split of a tap with fewer than nslots splits also zero-fills that tap's remaining slots.
+    int partial, nslots;
+    long split_stride;
     int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
     unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
 };

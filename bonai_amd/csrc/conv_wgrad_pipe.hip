@@ -43,9 +43,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     int t, grp, mbeg, mend;
     if constexpr (PM) {
         grp = by;
-        t = 0;
-        while (t + 1 < a.T && bz >= a.pm_blk0[t + 1]) ++t;
-        mbeg = (bz - a.pm_blk0[t]) * a.pm_pps[t];
+        t = a.pm_tap[bz];
+        mbeg = (int)a.pm_split[bz] * a.pm_pps[t];
         mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
     } else {
         t = by % a.T; grp = by / a.T;
@@ -255,7 +254,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
             unsafeAtomicAdd(db + n, accb[r]);
         }
     }
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+    const int sidx = PM ? (int)a.pm_split[bz] : bz;
+    const int ns_t = PM ? a.pm_blk0[t + 1] - a.pm_blk0[t] : (int)gridDim.z;
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
+    const int nzero = (a.partial && sidx == ns_t - 1) ? a.nslots - ns_t : 0;      // this tap's unused slots
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -264,7 +266,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                unsafeAtomicAdd(dw + (long)n * a.Cin + c, acc[i][j][r]);
+                float* p = dw + (long)n * a.Cin + c;
+                if (a.partial) {
+                    *p = acc[i][j][r];
+                    for (int z = 1; z <= nzero; ++z) p[(long)z * a.split_stride] = 0.f;
+                } else {
+                    unsafeAtomicAdd(p, acc[i][j][r]);
+                }
             }
         }
 }

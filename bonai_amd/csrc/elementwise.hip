@@ -714,11 +714,39 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
     float* dw = reinterpret_cast<float*>(d[6]);
     float* dgamma = reinterpret_cast<float*>(d[7]);
     float* dbeta = reinterpret_cast<float*>(d[8]);
-    const float eps = __int_as_float((int)d[9]);
+    const float eps = __int_as_float((int)(d[9] & 0xffffffffl));
+    const int nsp = (int)(d[9] >> 32) > 1 ? (int)(d[9] >> 32) : 1;   // split-K slots of dwp to sum (loft_conv_wgrad_bf16_slots), else 1
     const int Cin = (int)d[11], CoutP = (int)d[13], CinP = (int)d[14];
     const bool nmajor = d[12] < 0;             // dwp is [n][t][c] (weight gradient of a Linear over an NHWC-flattened map)
     const int RS = (int)(nmajor ? -d[12] : d[12]);
     const int n = (int)(blockIdx.x - d[15]);
+    const long sps = (long)RS * CoutP * CinP;  // elements per slot
+    // (four slots per round: independent loads in flight instead of one load-add chain per slot)
+    auto ld1 = [&](const float* p) {
+        float v = *p;
+        int q = 1;
+        for (; q + 3 < nsp; q += 4) {
+            const float u0 = p[q * sps], u1 = p[(q + 1) * sps], u2 = p[(q + 2) * sps], u3 = p[(q + 3) * sps];
+            v += (u0 + u1) + (u2 + u3);
+        }
+        for (; q < nsp; ++q) v += p[q * sps];
+        return v;
+    };
+    auto ld4s = [&](const float* p) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        int q = 1;
+        for (; q + 3 < nsp; q += 4) {
+            const float4 u0 = *reinterpret_cast<const float4*>(p + q * sps), u1 = *reinterpret_cast<const float4*>(p + (q + 1) * sps);
+            const float4 u2 = *reinterpret_cast<const float4*>(p + (q + 2) * sps), u3 = *reinterpret_cast<const float4*>(p + (q + 3) * sps);
+            v.x += (u0.x + u1.x) + (u2.x + u3.x); v.y += (u0.y + u1.y) + (u2.y + u3.y);
+            v.z += (u0.z + u1.z) + (u2.z + u3.z); v.w += (u0.w + u1.w) + (u2.w + u3.w);
+        }
+        for (; q < nsp; ++q) {
+            const float4 u = *reinterpret_cast<const float4*>(p + q * sps);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        return v;
+    };
     const float rs = gamma ? rsqrtf(var[n] + eps) : 1.f;
     const float scale = gamma ? gamma[n] * rs : 1.f;
     float acc = 0.f;
@@ -728,7 +756,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         extern __shared__ float urow[];
         for (int j = threadIdx.x; j < per; j += blockDim.x) {
             const int t = j / CinP, c = j - t * CinP;
-            urow[c * RS + t] = dwp[(long)n * per + j];
+            urow[c * RS + t] = ld1(dwp + (long)n * per + j);
         }
         __syncthreads();
         for (int j = threadIdx.x; j < per; j += blockDim.x) {
@@ -745,7 +773,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         if ((Cin & 3) == 0 && (CinP & 3) == 0) {          // 16-byte accesses on both sides
             for (int j = threadIdx.x * 4; j < per; j += blockDim.x * 4) {
                 const int t = j / Cin, c = j - t * Cin;
-                const float4 v = *reinterpret_cast<const float4*>(dwp + ((long)t * CoutP + n) * CinP + c);
+                const float4 v = ld4s(dwp + ((long)t * CoutP + n) * CinP + c);
                 urow[c * RS + t] = v.x; urow[(c + 1) * RS + t] = v.y; urow[(c + 2) * RS + t] = v.z; urow[(c + 3) * RS + t] = v.w;
             }
             __syncthreads();
@@ -765,7 +793,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         } else {
             for (int j = threadIdx.x; j < per; j += blockDim.x) {
                 const int t = j / Cin, c = j - t * Cin;
-                urow[c * RS + t] = dwp[((long)t * CoutP + n) * CinP + c];
+                urow[c * RS + t] = ld1(dwp + ((long)t * CoutP + n) * CinP + c);
             }
             __syncthreads();
             for (int j = threadIdx.x; j < per; j += blockDim.x) {
@@ -777,7 +805,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
         }
     } else if (RS == 1 && (Cin & 3) == 0 && (CinP & 3) == 0) {
         for (int j = threadIdx.x * 4; j < per; j += blockDim.x * 4) {     // 1x1 / Linear: same order on both sides
-            const float4 g = *reinterpret_cast<const float4*>(dwp + (long)n * CinP + j);
+            const float4 g = ld4s(dwp + (long)n * CinP + j);
             const long wi = (long)n * per + j;
             if (dw) {
                 float4 o = *reinterpret_cast<float4*>(dw + wi);
@@ -792,7 +820,7 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
     } else
     for (int j = threadIdx.x; j < per; j += blockDim.x) {
         const int c = j / RS, t = j - c * RS;       // j indexes dw[n][c][t] (coalesced writes)
-        const float g = dwp[((long)t * CoutP + n) * CinP + c];
+        const float g = ld1(dwp + ((long)t * CoutP + n) * CinP + c);
         const long wi = (long)n * per + j;
         if (dw) dw[wi] += g * scale;
         if (gamma) acc += g * w[wi];

@@ -46,10 +46,42 @@ def zero_pool_begin(device):
     if zp.buf is not None:
         zp.buf.zero_()
     zp.off, zp.need, zp.active = 0, 0, zp.buf is not None
+    sp = _ScratchPool
+    if sp.need > 0 and (sp.buf is None or sp.need > sp.buf.numel() or sp.buf.device != torch.device(device)):
+        sp.buf = None                                   # (release before the larger request)
+        sp.buf = torch.empty(int(sp.need * 1.05) + 1024, dtype=torch.float32, device=device)
+    sp.off, sp.need, sp.active = 0, 0, sp.buf is not None
 
 
 def zero_pool_end():
     _ZeroPool.active = False
+    _ScratchPool.active = False
+
+
+class _ScratchPool:
+    """The same per-step slab for buffers that need NO initialisation (the split-K slots of the weight gradients: ~3 GB per step
+    at batch 8 x 1024^2, each written completely by its launch and read once by the batched unpack).  Bump allocation, reset
+    with the zero pool at the start of a step; without it every slot buffer is a caching-allocator block that several streams
+    touch (record_stream delays its reuse), and the allocator keeps growing and trimming."""
+    buf = None
+    off = 0
+    need = 0
+    active = False
+
+
+def pooled_scratch(shape, device):
+    """Uninitialised fp32 of `shape`: a view of the step's scratch slab when the trainer opened one, else torch.empty."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    n64 = (n + 63) // 64 * 64
+    sp = _ScratchPool
+    sp.need += n64
+    if sp.active and sp.buf.device == torch.device(device) and sp.off + n64 <= sp.buf.numel():
+        v = sp.buf[sp.off:sp.off + n].view(*shape)
+        sp.off += n64
+        return v
+    return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
 def pooled_zeros(shape, device):
@@ -404,10 +436,21 @@ import os as _os
 _WGRAD_NO_PATCH = bool(_os.environ.get('LOFT_WGRAD_NO_PATCH'))     # A/B switch
 
 
+# Split-K combination of the weight gradients whose consumer is the batched unpack: False = fp32 atomics into a zeroed buffer
+# (shipped), True = per-split slots written with plain stores and summed by the unpack while it reads.  Measured (MI355X, bench
+# step, same box): the slots take 1.2 ms of KERNEL time off a step in the serialised profile (conv_wgrad_kernel<128,4> 72 -> 57 us,
+# stream kernels -35..-45 us per launch, unpack 0.39 -> 0.9 ms) but the step itself is unchanged at 30.2 ms -- with the branch /
+# weight-gradient streams overlapped the atomic tails (L2-bound, no HBM, no MFMA) were already hidden behind other kernels, while
+# 3 GB of slot stores + reads per step compete for HBM with them.  Kept selectable and tested; not the default.
+WGRAD_SLOTS = False
+
+
 def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,
-               splits=0, dw=None, db=None, db_tap=-1):
+               splits=0, dw=None, db=None, db_tap=-1, slots_ok=False):
     """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index).
-    db: optional zeroed fp32 [groups, Cout] -> bias gradient accumulated in the same pass."""
+    db: optional zeroed fp32 [groups, Cout] -> bias gradient accumulated in the same pass.
+    slots_ok: the caller sums split-K slots itself (UnpackQueue): the result may then be fp32 [groups, S, n_wtaps, Cout, Cin],
+    every slot written with plain stores (loft_conv_wgrad_bf16_slots), instead of [groups, n_wtaps, Cout, Cin]."""
     lib = L.load()
     L.dev_check(g, x)
     A = lambda i: L.arr(c_int, [t[i] for t in taps])
@@ -422,13 +465,13 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
             db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
         return dw
     _bf16(g), _bf16(x)
-    if dw is None:
-        dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
     _ev = _prof_begin()
     if (Cout <= 64 and Cin <= 64 and len(taps) <= 9 and gos == 1 and ss == 1 and (GH, GW) == (OH, OW) == (XH, XW)
             and B * OH * OW >= 65536 and all(t[0] == 0 and t[1] == 0 and abs(t[2]) <= 1 and abs(t[3]) <= 1 for t in taps)
             and (db is None or db_tap != -1) and not _WGRAD_NO_PATCH):
         # narrow stride-1 convs at high resolution: all taps from one staged pixel patch (loft_conv_wgrad_patch_bf16)
+        if dw is None:
+            dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
         ws = torch.empty(lib.loft_conv_wgrad_patch_workspace_bytes(B, OH, OW, Cout, Cin, len(taps), groups), dtype=torch.uint8,
                          device=g.device)
         L.check(lib.loft_conv_wgrad_patch_bf16(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, OH, OW, Cout, Cin,
@@ -437,6 +480,21 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                 'loft_conv_wgrad_patch_bf16')
         _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
         return dw
+    if slots_ok and WGRAD_SLOTS and dw is None and n_wtaps == len(taps):
+        S = lib.loft_conv_wgrad_slots(B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4),
+                                      groups, splits, int(WGRAD_VARIANT))
+        if S < 0:
+            L.check(-S, 'loft_conv_wgrad_slots')
+        if S >= 1:
+            dw = pooled_scratch((groups, S, n_wtaps, Cout, Cin), g.device)
+            L.check(lib.loft_conv_wgrad_bf16_slots(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
+                                                   XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
+                                                   c_int64(g_gs), c_int64(x_gs), S, splits, L.ptr(db), int(db_tap),
+                                                   int(WGRAD_VARIANT), L.stream()), 'loft_conv_wgrad_bf16_slots')
+            _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
+            return dw
+    if dw is None:
+        dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)
     L.check(lib.loft_conv_wgrad_bf16_v(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                        XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
                                        c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
@@ -446,8 +504,9 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     return dw
 
 
-def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0, with_bias=False):
-    """-> fp32 [G, R*S, Cout, Cin] (packed layout; see unpack_dw); with_bias: also -> fp32 [G, Cout] bias gradient."""
+def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0, with_bias=False, slots_ok=False):
+    """-> fp32 [G, R*S, Cout, Cin] (packed layout; see unpack_dw); with_bias: also -> fp32 [G, Cout] bias gradient.
+    slots_ok: see conv_wgrad (-> possibly [G, S, R*S, Cout, Cin])."""
     g, x = _nhwc(g), _nhwc(x)
     GB, Cout, OH, OW = g.shape
     _, Cin, IH, IW = x.shape
@@ -460,7 +519,7 @@ def conv2d_wgrad(g, x, R, S, stride=1, pad=0, groups=1, splits=0, with_bias=Fals
             raise L.LoftHipError('fused bias gradient needs a tap with zero offset')
         db, db_tap = pooled_zeros((groups, Cout), g.device), centre[0]
     dw = conv_wgrad(g, x, B, OH, OW, Cout, IH, IW, Cin, OH, OW, taps, R * S, gos=1, ss=stride, groups=groups,
-                    g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits, db=db, db_tap=db_tap)
+                    g_gs=B * OH * OW * Cout, x_gs=B * IH * IW * Cin, splits=splits, db=db, db_tap=db_tap, slots_ok=slots_ok)
     return (dw, db) if with_bias else dw
 
 
@@ -1296,11 +1355,11 @@ class UnpackQueue:
         self.home_raw = L.stream().value if self.home is not None else None
         self.events = []
 
-    def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None):
+    def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None, nsplit=1):
         """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
         launch that served this job has been enqueued (the reducer's gradient-ready notifications).
         flat_chw = (C, H, W): w is a Linear weight [O, C*H*W] and dwp [O, H*W*C] its gradient in NHWC-flattened K order."""
-        self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw))
+        self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw, int(nsplit)))     # nsplit > 1: dwp = [nsplit][...] split-K slots
         if self.home is not None and L.stream().value != self.home_raw:
             ev = torch.cuda.Event()
             ev.record()                       # (on the producing side stream)
@@ -1323,7 +1382,7 @@ class UnpackQueue:
             import struct
             rows, blk = [], 0
             p = lambda t: 0 if t is None else t.data_ptr()
-            for dwp, db, w, bn, eps, (dw, dg, dbeta), flat in self.jobs:
+            for dwp, db, w, bn, eps, (dw, dg, dbeta), flat, nsplit in self.jobs:
                 if flat is not None:
                     Cout, Cin, RS = w.shape[0], flat[0], -(flat[1] * flat[2])
                     coutp, cinp = Cout, Cin
@@ -1333,7 +1392,7 @@ class UnpackQueue:
                     coutp, cinp = dwp.shape[-2], dwp.shape[-1]
                 g, _, m, v = bn if bn is not None else (None, None, None, None)
                 rows.append([p(dwp), p(db), p(w), p(g), p(m), p(v), p(dw), p(dg), p(dbeta),
-                             struct.unpack('<i', struct.pack('<f', eps))[0], Cout, Cin, RS, coutp, cinp, blk])
+                             (struct.unpack('<I', struct.pack('<f', eps))[0]) | (nsplit << 32), Cout, Cin, RS, coutp, cinp, blk])
                 blk += Cout
             desc = h2d(rows, torch.int64, self.jobs[0][2].device)
             # dynamic LDS row: records that interleave taps through LDS (n-major Linear records must fit; conv records with

@@ -170,10 +170,16 @@ class _ConvFn(torch.autograd.Function):
         need_b = (has_b and any(ctx.needs_input_grad[3 + 2 * i + 1] for i in range(G))) or \
             (bn_stats is not None and (ctx.needs_input_grad[3 + 2 * G] or ctx.needs_input_grad[3 + 2 * G + 1]))
         if need_w or need_b:
+            # every group's gradient goes to the batched unpack (which can sum split-K slots while it reads) when all of its
+            # parameters have arena slots; else the atomically combined form every other consumer expects
+            queued = UNPACK_Q is not None and need_w and all(
+                _direct_slot(ctx.params[2 * i]) is not None for i in range(G)) and (
+                bn_stats is None or (_direct_slot(ctx.params[2 * G]) is not None and _direct_slot(ctx.params[2 * G + 1]) is not None))
             if need_b:
-                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, with_bias=True)
+                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, with_bias=True, slots_ok=queued)
             else:
-                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G), None
+                dwp, db = K.conv2d_wgrad(g, x, R, S, stride, pad, groups=G, slots_ok=queued), None
+            nsp = _nsplit(dwp)
             bn = None
             if bn_stats is not None:
                 bn = (tensors[2 * G], tensors[2 * G + 1], bn_stats[0], bn_stats[1])
@@ -197,7 +203,7 @@ class _ConvFn(torch.autograd.Function):
                             sinks += [ctx.params[2 * G], ctx.params[2 * G + 1]]
                         _mark_sunk(*sinks)
                         UNPACK_Q.add(dwp[i], None if db is None else db[i], ws[i], bn, eps, (slot_w, slot_g, slot_b),
-                                     [(lambda q=q: _sink_done(q)) for q in sinks])
+                                     [(lambda q=q: _sink_done(q)) for q in sinks], nsplit=nsp)
                         if has_b and db is not None and bn is None and slot_b is None:
                             ngrads[2 * i + 1] = db[i][:ws[i].shape[0]]
                         continue
@@ -313,14 +319,15 @@ class _LinearFn(torch.autograd.Function):
         gw = gb = None
         need_w, need_b = ctx.needs_input_grad[1], pb is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
-            dwp, db = K.conv2d_wgrad(g4, x4, 1, 1, 1, 0, with_bias=True)
             slot_w = _direct_slot(pw) if need_w else None
             slot_b = _direct_slot(pb) if need_b else None
-            if UNPACK_Q is not None and slot_w is not None and (not need_b or slot_b is not None):
+            queued = UNPACK_Q is not None and slot_w is not None and (not need_b or slot_b is not None)
+            dwp, db = K.conv2d_wgrad(g4, x4, 1, 1, 1, 0, with_bias=True, slots_ok=queued)
+            if queued:
                 sinks = [pw] + ([pb] if need_b else [])
                 _mark_sunk(*sinks)
-                UNPACK_Q.add(dwp[0, 0], db[0], w, None, 1e-5, (slot_w, None, slot_b), [(lambda q=q: _sink_done(q)) for q in sinks],
-                             flat_chw=flat_chw)
+                UNPACK_Q.add(dwp[0, :, 0] if dwp.dim() == 5 else dwp[0, 0], db[0], w, None, 1e-5, (slot_w, None, slot_b),
+                             [(lambda q=q: _sink_done(q)) for q in sinks], flat_chw=flat_chw, nsplit=_nsplit(dwp))
             else:
                 gw = dwp[0, 0, :O, :Kd]
                 if flat_chw is not None:
@@ -873,6 +880,11 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
     return out
 
 
+def _nsplit(dwp):
+    """Split-K slots of a weight gradient that came back as [G, S, T, Cout, Cin] (kernels.conv_wgrad(slots_ok=True)), else 1."""
+    return dwp.shape[1] if dwp.dim() == 5 else 1
+
+
 def _rb_param_grads(g, x, w, bn, k, stride, pad, needs):
     """Weight / gamma / beta gradients of one conv+bn from the (already ReLU-masked) output gradient g and the conv input x.
     Returns (dw, dgamma, dbeta) for autograd, or Nones when the kernels accumulated straight into the trainer's arena."""
@@ -892,14 +904,16 @@ def _rb_param_grads(g, x, w, bn, k, stride, pad, needs):
         x.record_stream(WGRAD_STREAM)
         _mark_sunk(w, bn.weight, bn.bias)
         with torch.cuda.stream(WGRAD_STREAM):
-            dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True)
-            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)])
+            dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True, slots_ok=True)
+            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)],
+                         nsplit=_nsplit(dwp))
         return None, None, None
-    dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True)
+    dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True, slots_ok=sunk and UNPACK_Q is not None)
     if sunk:
         _mark_sunk(w, bn.weight, bn.bias)
         if UNPACK_Q is not None:
-            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)])
+            UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)],
+                         nsplit=_nsplit(dwp))
             return None, None, None
         K.fold_unpack_bwd(dwp[0], db[0], w, bnt, bn.eps, out=slots)
         _sink_done(w), _sink_done(bn.weight), _sink_done(bn.bias)

@@ -188,6 +188,21 @@ int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* 
                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                          const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs, int splits,
                          float* db, int db_tap, int variant, void* stream);
+/* Split-K without atomics.  An fp32 atomic costs the L2 a channel-cycle per 4 bytes (0.29 T atomics/s over the chip), a store
+ * 1/16 of that, so the weight gradient can also be left as per-split partial sums: loft_conv_wgrad_slots -> the number of slots S
+ * such a launch of this shape writes (0: no such form -- narrow channels, repeated / missing weight taps, a tap without a valid
+ * row; < 0: -hipError_t); loft_conv_wgrad_bf16_slots writes dw_slots = fp32 [groups][S][T][Cout][Cin] completely (nothing needs to
+ * be zeroed; db is still accumulated with atomics into a zeroed buffer); loft_fold_unpack_bwd_multi sums the S slots while it
+ * reads (descriptor word 9: eps bits | S << 32). */
+int loft_conv_wgrad_slots(int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host, const int* wt_host,
+                          int groups, int splits, int variant);
+int loft_conv_wgrad_bf16_slots(const void* g, const void* x, float* dw_slots, const void* zero_page, int B, int GH, int GW,
+                               int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T, const int* goy_host,
+                               const int* gox_host, const int* dy_host, const int* dx_host, const int* wt_host, int groups,
+                               int64_t g_gs, int64_t x_gs, int nslots, int splits, float* db, int db_tap, int variant,
+                               void* stream);
+
 /* loft_conv_wgrad_patch_bf16: the same weight (+ bias) gradient for stride-1, same-size convs with <= 64 input and output
  * channels and taps within +-1 pixel (HRNet's high-resolution 3x3 branches, hrnet.py:12-60 via resnet.py:13-92 BasicBlock): every
  * workgroup walks 8x8-pixel patches and feeds ALL taps from one staged patch of g and its 10x10 halo of x.  g [groups*B,H,W,Cout],

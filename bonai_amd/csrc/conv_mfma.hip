@@ -523,6 +523,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.pixmajor = pix_ok;
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
+        a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
         return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_STREAM256 ? 1 : 0, (variant >> 12) & 0xf, s);
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {

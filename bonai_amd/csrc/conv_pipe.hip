@@ -294,34 +294,61 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const bf16_t* st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
     // (stream mode: the weight pieces are issued one K-tile ahead of the activation pieces -> their own tap / channel state)
     int sw_t = st_t, sw_c = 0;
+    // K order.  Chunk-major (default): for every 64-channel chunk, all taps.  The three dx taps of an input row -- and the rows a
+    // tile shares with its neighbours -- then re-read the same 128-byte segments within a few K-tiles, while they are still in
+    // the XCD's L2; in tap-major order (a.tap_major: the lock-step kernels' order, bit-identical sums) a re-read comes kchunks
+    // K-tiles later, after the 32 CUs of the XCD have streamed ~4 MB through that L2: measured 5.2x the input bytes fetched
+    // from HBM per 3x3 launch (tools/pmc_traffic_shapes.sh).
+    const int first_t = st_t;
+    auto next_tap = [&](int t) {
+        ++t;
+        while (t < a.T && !((tmask >> t) & 1u)) ++t;
+        return t;
+    };
     auto advance_w = [&]() {
-        sw_c += BK;
-        if (sw_c == a.Cin) {
-            sw_c = 0;
-            ++sw_t;
-            while (sw_t < a.T && !((tmask >> sw_t) & 1u)) ++sw_t;
-            if (sw_t < a.T) st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
+        if (a.tap_major) {
+            sw_c += BK;
+            if (sw_c == a.Cin) {
+                sw_c = 0;
+                sw_t = next_tap(sw_t);
+                if (sw_t < a.T) st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
+            }
+        } else {
+            sw_t = next_tap(sw_t);
+            if (sw_t >= a.T) { sw_t = first_t; sw_c += BK; }
+            st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
         }
     };
     auto advance_x = [&]() {
-        st_c += BK;
-        if (st_c == a.Cin) {
-            st_c = 0;
-            ++st_t;
-            while (st_t < a.T && !((tmask >> st_t) & 1u)) ++st_t;
-            if (st_t < a.T) st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+        if (a.tap_major) {
+            st_c += BK;
+            if (st_c == a.Cin) {
+                st_c = 0;
+                st_t = next_tap(st_t);
+                if (st_t < a.T) st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+            }
+        } else {
+            st_t = next_tap(st_t);
+            if (st_t >= a.T) { st_t = first_t; st_c += BK; }
+            st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
         }
     };
     auto advance = [&]() {
-        st_c += BK;
-        if (st_c == a.Cin) {
-            st_c = 0;
-            ++st_t;
-            while (st_t < a.T && !((tmask >> st_t) & 1u)) ++st_t;
-            if (st_t < a.T) {
-                st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
-                st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
+        if (a.tap_major) {
+            st_c += BK;
+            if (st_c == a.Cin) {
+                st_c = 0;
+                st_t = next_tap(st_t);
+                if (st_t < a.T) {
+                    st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+                    st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
+                }
             }
+        } else {
+            st_t = next_tap(st_t);
+            if (st_t >= a.T) { st_t = first_t; st_c += BK; }
+            st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
+            st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
         }
     };
     bool in_loop = false;

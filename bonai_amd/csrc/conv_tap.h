@@ -32,6 +32,7 @@ struct ConvArgs {
     int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
     void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
+    int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
 };
 
 // n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)

@@ -140,6 +140,7 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400
+#define LOFT_CONV_FLAG_TAP_MAJOR 0x800   /* pipelined kernels: K order (tap, channel chunk) -- the lock-step kernels' order -- instead of (chunk, tap) */
 int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual, const void* relu_mask,
                          void* out,
                          const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,

@@ -9,10 +9,14 @@ from bonai_amd.engine import Trainer
 from bonai_amd.loft import build_detector
 from bonai_amd.synth import make_batch
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-cfg = Config.fromfile(os.path.join(ROOT, 'configs/loft_foa/loft_foa_r50_fpn_2x_bonai.py'))
+cfgname = sys.argv[2] if len(sys.argv) > 2 else 'loft_foa_r50_fpn_2x_bonai.py'
+cfg = Config.fromfile(os.path.join(ROOT, 'configs/loft_foa', cfgname))
+if cfg.get('fp16'):
+    from bonai_amd import lib as L
+    L.set_act16(torch.float16)
 torch.manual_seed(0)
 m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-tr = Trainer(m, lr=0.005)
+tr = Trainer(m, lr=0.005, loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0))
 data = make_batch(8, size, 80 if size >= 512 else 8, device='cuda')
 for _ in range(5):
     tr.train_step(data)

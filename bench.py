@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL needs between the ranks of a node on this driver
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

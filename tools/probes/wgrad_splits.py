@@ -31,6 +31,6 @@ for name, B, Cin, Cout, H, R in SHAPES:
         row = f'{name:22s} {vn:10s}'
         for sp in (1, 2, 4, 8, 16, 32, 64, 128):
             us = timeit(lambda: K.conv2d_wgrad(g, x, R, R, 1, R // 2, splits=sp))
-            row += f'  s{sp}:{us:6.1f}us/{gf / us * 1e-3:5.0f}TF'
+            row += f'  s{sp}:{us:6.1f}us/{gf / us * 1e3:5.0f}TF'
         print(row, flush=True)
 K.WGRAD_VARIANT = K.WGRAD_AUTO

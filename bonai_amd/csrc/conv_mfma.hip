@@ -521,6 +521,17 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
         if (Cout % 256 || out_f32 || accumulate) return (int)hipErrorInvalidValue;
         a.pixmajor = pix_ok;
+        a.pm_S = B; a.pm_P = OH * OW;
+        if (pix_ok) {
+            // RoI blocks of >= 256 rows per pixel position (ConvArgs::pm_S): padded row count nb * P * S >= P * B
+            const int nb = std::max(1, B / 256);
+            a.pm_S = (B + nb - 1) / nb;
+            const long Mp = (long)nb * a.pm_P * a.pm_S;
+            if (Mp > 0x7fffffffL) return (int)hipErrorInvalidValue;
+            a.M = (int)Mp;
+        }
+        fastdiv_setup((unsigned)a.pm_S, &a.pms_mul, &a.pms_sh);
+        fastdiv_setup((unsigned)a.pm_P, &a.pmp_mul, &a.pmp_sh);
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;

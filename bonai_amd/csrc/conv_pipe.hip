@@ -60,10 +60,18 @@ constexpr int PW_OFF = 0, PX_OFF = 65536, PBUF = 32768, PLDS = 131072;
 // the same way.  The direct form stores 8 bytes per lane to 64 different rows per instruction, 32 instructions per wave --
 // measured 25-27k cycles per workgroup on the 8 x 256^2 P2 conv against 108k for its whole K loop; this form: see DESIGN.md.
 // LDS image: row r (tile pixel row) x 32 chunks of 16 B, logical chunk c at position c ^ (r & 31).
+// row m of the launch -> (image / RoI b, pixel index rem inside its map); b >= a.B marks a padding row (blocked pixel-major order)
+__device__ __forceinline__ void pipe_row_decode(const ConvArgs& a, int m, int ohw, int& b, int& rem) {
+    if (a.pixmajor) {
+        const int seg = fastdiv(m, a.pms_mul, a.pms_sh), blk = fastdiv(seg, a.pmp_mul, a.pmp_sh);
+        rem = seg - blk * a.pm_P;
+        b = blk * a.pm_S + (m - seg * a.pm_S);
+    } else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
+}
 __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const bf16_t* base, long out_g, int m, int n0, int ohw) {
     int b, rem;
-    if (a.pixmajor) { rem = fastdiv(m, a.b_mul, a.b_sh); b = m - rem * a.B; }
-    else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
+    pipe_row_decode(a, m, ohw, b, rem);
+    if (b >= a.B) return nullptr;
     const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
     const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
     return base + out_g + opix * a.Cout + n0;
@@ -82,7 +90,10 @@ __device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t
         const int c = (lane & 31) ^ (r & 31);                 // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
         const int m = m0 + r;
         const bf16_t* p = a.zero_page;
-        if (m < a.M) p = pipe_row_ptr(a, t, out_g, m, n0, ohw) + c * 8;
+        if (m < a.M) {
+            const bf16_t* rp = pipe_row_ptr(a, t, out_g, m, n0, ohw);
+            if (rp) p = rp + c * 8;
+        }
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * 32 + it * 2) * 512), 16, 0, 0);
     }
 }
@@ -147,10 +158,11 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
         const int r = wave * 32 + it * 2 + (lane >> 5);
         const int c = (lane & 31) ^ (r & 31);
         const int m = m0 + r;
-        if (m < a.M) {
+        const bf16_t* rp = m >= a.M ? nullptr : (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
+                                                       : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw));
+        if (rp) {
             uint4 v = rowv[it];
-            const bf16_t* p = (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
-                                     : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw)) + c * 8;
+            const bf16_t* p = rp + c * 8;
             if (mask) {
                 const uint4 mk = *reinterpret_cast<const uint4*>(mask + (p - reinterpret_cast<const bf16_t*>(a.out)));
                 // keep a bf16 lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
@@ -231,10 +243,9 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         a_ptr[i] = src;
         a_mask[i] = 0u;
         a_iy[i] = -(1 << 20); a_ix[i] = -(1 << 20);
-        if (m < a.M) {
-            int b, rem;
-            if (a.pixmajor) { rem = fastdiv(m, a.b_mul, a.b_sh); b = m - rem * a.B; }
-            else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
+        int b = a.B, rem = 0;
+        if (m < a.M) pipe_row_decode(a, m, ohw, b, rem);
+        if (b < a.B) {
             const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
             a_iy[i] = oy * a.ss; a_ix[i] = ox * a.ss;
             a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + swz(row, lchunk) * 8);
@@ -245,10 +256,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         // pixel-major rows: m = position * B + RoI with B >= 256, so the 256 rows of a tile sit on at most TWO pixel positions
         // and the tap masks are functions of the position only: two wave-uniform (scalar) passes over the taps instead of a
         // per-lane loop of T x 4 rows (3-4k cycles per workgroup on the 7x7 / 14x14 RoI maps)
-        const int rem0 = fastdiv(m0, a.b_mul, a.b_sh);
+        // (blocked order: "position" = segment m / pm_S, its pixel = segment % pm_P; a tile still spans at most two segments)
+        const int seg0 = fastdiv(m0, a.pms_mul, a.pms_sh);
+        const int rem0 = seg0 - fastdiv(seg0, a.pmp_mul, a.pmp_sh) * a.pm_P;
         unsigned mk0 = 0u, mk1 = 0u;
         const int oy0 = fastdiv(rem0, a.ow_mul, a.ow_sh), ox0 = rem0 - oy0 * a.OW;
-        const int rem1 = rem0 + 1;
+        const int rem1 = rem0 + 1 == a.pm_P ? 0 : rem0 + 1;
         const int oy1 = fastdiv(rem1, a.ow_mul, a.ow_sh), ox1 = rem1 - oy1 * a.OW;
         for (int t = 0; t < a.T; ++t) {
             const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + i * 64 + srow;
-            if (m < a.M) a_mask[i] = (fastdiv(m, a.b_mul, a.b_sh) == rem0) ? mk0 : mk1;
+            if (a_iy[i] >= 0) a_mask[i] = (fastdiv(m, a.pms_mul, a.pms_sh) == seg0) ? mk0 : mk1;      // (padding rows keep mask 0)
         }
     } else {
         for (int t = 0; t < a.T; ++t) {

@@ -33,6 +33,14 @@ struct ConvArgs {
     void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
     int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
+    // conv_pipe.hip, pixel-major rows in RoI BLOCKS: row m -> segment m / pm_S (pm_S rows = the RoIs of one block at one pixel
+    // position), block = segment / pm_P, position = segment % pm_P, RoI = block * pm_S + m % pm_S (rows with RoI >= B are
+    // padding: pm_S = ceil(B / number of blocks) >= 256).  The 49 / 196 positions of a block's RoIs are then CONSECUTIVE tiles --
+    // one XCD at a time works on one block, whose rows (1.4 MB per 64-channel chunk) stay in its L2 while the taps and the
+    // neighbouring positions re-read them; with position-major order over all B RoIs each tile's 9 taps touched rows that no
+    // concurrently running tile shared (fetch 4.1x the input, tools/pmc_traffic_shapes.sh).  M counts the padded rows.
+    int pm_S, pm_P;
+    unsigned pms_mul, pms_sh, pmp_mul, pmp_sh;
 };
 
 // n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)

@@ -651,8 +651,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     if constexpr (PM) {
         grp = by;
         t = a.pm_tap[bz];
-        mbeg = (int)a.pm_split[bz] * a.pm_pps[t];
-        mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
+        mbeg = 0;
+        mend = a.pm_rows[t];            // local rows of this split: (position, RoI of the split's range); see WgradArgs
     } else {
         t = by % a.T; grp = by / a.T;
         mbeg = bz * a.pix_per_split;
@@ -666,6 +666,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
     const unsigned pm_mul = PM ? a.pm_rw_mul[t] : 0u, pm_sh = PM ? a.pm_rw_sh[t] : 0u;
+    const int pm_rb = PM ? a.pm_pps[t] : 1, pm_b0 = PM ? (int)a.pm_split[bz] * pm_rb : 0;
+    const unsigned rb_mul = PM ? a.pm_pps_mul[t] : 0u, rb_sh = PM ? a.pm_pps_sh[t] : 0u;
 
     const int lrow = lane / CPR, lchunk = lane % CPR;
     auto stage = [&](int m_base, int buf) {
@@ -679,12 +681,14 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
             const bf16_t* pg = a.zero_page;
             const bf16_t* px = a.zero_page;
             if (m < mend) {
-                if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * B + RoI; stride 1, all in bounds
-                    const int p = fastdiv(m, a.b_mul, a.b_sh), b = m - p * a.B;
+                if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * RoIs-per-split + RoI; stride 1, in bounds
+                    const int p = fastdiv(m, rb_mul, rb_sh), b = pm_b0 + (m - p * pm_rb);
                     const int ry = fastdiv(p, pm_mul, pm_sh), rx = p - ry * pm_rw;
                     const int oy = pm_y0 + ry, ox = pm_x0 + rx;
-                    pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + q;
-                    px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + q;
+                    if (b < a.B) {
+                        pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + q;
+                        px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + q;
+                    }
                 } else {
                 const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
                 const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
@@ -1128,32 +1132,43 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     pps = ((pps + 63) / 64) * 64;
     a.pix_per_split = pps;
     if (!narrow && T > 1 && gos == 1 && ss == 1 && B >= 128 && OH * OW <= 1024) {
-        // valid rectangle of every tap; K-splits per tap proportional to its rows: the smallest common K length L (multiple of
-        // the 64-row K-step) with sum_t ceil(rows_t / L) <= the workgroup budget per group
+        // valid rectangle of every tap; K-splits over RoI ranges (WgradArgs: split s of tap t = RoIs [s * rb_t, (s + 1) * rb_t) at all
+        // of the tap's positions), rb_t chosen per tap for a common K length: the smallest L (rows per split, multiple of the
+        // 64-row K-step) with sum_t ceil(B / floor(L / positions_t)) <= the workgroup budget per group
         const long budget = std::min<long>((long)splits * T, WGRAD_PM_MAX_BLOCKS);    // (pm_tap / pm_split hold one byte per block)
-        long rows[CONV_MAX_TAPS], total = 0;
+        long npos[CONV_MAX_TAPS], total = 0;
         for (int t = 0; t < T; ++t) {
             const int ylo = std::max(0, std::max(-a.goy[t], -a.dy[t])), yhi = std::min(OH, std::min(GH - a.goy[t], XH - a.dy[t]));
             const int xlo = std::max(0, std::max(-a.gox[t], -a.dx[t])), xhi = std::min(OW, std::min(GW - a.gox[t], XW - a.dx[t]));
             const int rh = std::max(0, yhi - ylo), rw = std::max(0, xhi - xlo);
             a.pm_y0[t] = ylo; a.pm_x0[t] = xlo; a.pm_rw[t] = rw > 0 ? rw : 1;
             fastdiv_setup((unsigned)a.pm_rw[t], &a.pm_rw_mul[t], &a.pm_rw_sh[t]);
-            rows[t] = (long)rh * rw * B;
-            a.pm_rows[t] = (int)rows[t];
-            total += rows[t];
+            npos[t] = (long)rh * rw;
+            total += npos[t] * B;
         }
         if (total > 0) {
             long L = ((total + budget - 1) / budget + 63) / 64 * 64;
             for (;; L += 64) {
                 long nb = 0;
-                for (int t = 0; t < T; ++t) nb += (rows[t] + L - 1) / L;
+                for (int t = 0; t < T; ++t)
+                    if (npos[t] > 0) {
+                        const long rb = std::max<long>(1, L / npos[t]);
+                        nb += (B + rb - 1) / rb;
+                    }
                 if (nb <= budget) break;
             }
             int blk = 0;
             for (int t = 0; t < T; ++t) {
-                const long ns = (rows[t] + L - 1) / L;
+                long ns = 0, rb = 1;
+                if (npos[t] > 0) {
+                    rb = std::max<long>(1, L / npos[t]);
+                    ns = (B + rb - 1) / rb;
+                    rb = (B + ns - 1) / ns;                      // same number of splits, evenly sized RoI ranges
+                }
                 a.pm_blk0[t] = blk;
-                a.pm_pps[t] = ns ? (int)(((rows[t] + ns - 1) / ns + 63) / 64 * 64) : 64;
+                a.pm_pps[t] = (int)rb;
+                a.pm_rows[t] = (int)(npos[t] * rb);
+                fastdiv_setup((unsigned)rb, &a.pm_pps_mul[t], &a.pm_pps_sh[t]);
                 blk += (int)ns;
             }
             a.pm_blk0[T] = blk;

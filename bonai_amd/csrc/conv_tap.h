@@ -158,11 +158,17 @@ struct WgradArgs {
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW and OW via multiply-high (host-computed)
     float* db;      // optional bias gradient db[g][n] += sum_pixels G (fp32 atomics), fused: see db_tap
     int db_tap;     // tap whose X gather is never out of bounds (its G rows are complete); -2 = every tap; -1 = off
-    // PM form (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs; stride 1): the K dimension of tap t runs over
-    // (position inside the tap's valid rectangle, RoI) -- rows whose tap leaves the map (18 % of a 7x7 map's 3x3 taps, 9 % of a
-    // 14x14 one) are never staged, and every tap gets a number of K-splits proportional to its valid rows so that all
-    // workgroups run the same number of K-steps.  Workgroup j of a group serves tap t with pm_blk0[t] <= j < pm_blk0[t+1].
+    // PM form (RoI maps of 7x7 / 14x14 pixels, hundreds of RoIs; stride 1): rows whose tap leaves the map (18 % of a 7x7 map's
+    // 3x3 taps, 9 % of a 14x14 one) are never staged.  K-split s of tap t reduces over RoIs [s * pm_pps[t], (s + 1) * pm_pps[t])
+    // at ALL positions of the tap's valid rectangle, local row j -> (position j / pm_pps[t], RoI s * pm_pps[t] + j % pm_pps[t]),
+    // pm_rows[t] = positions * pm_pps[t] rows per split (RoIs >= B are padding rows); pm_pps[t] is chosen per tap so that all
+    // workgroups run the same number of K-steps (more splits for taps with more valid positions).  With the RoI range outermost,
+    // the splits of the nine taps that run side by side on one XCD (pm_tap / pm_split below) walk the SAME RoIs, a few positions
+    // apart: a G / X row is re-read by another tap within ~1 MB of traffic and comes from that XCD's L2 (position-major order over
+    // all B RoIs put 3.6 MB between two taps' reads of one row: 5x the operand bytes fetched per launch).
+    // Workgroup j of a group serves tap pm_tap[j]; tap t has pm_blk0[t+1] - pm_blk0[t] splits.
     int pm_blk0[CONV_MAX_TAPS + 1], pm_pps[CONV_MAX_TAPS], pm_rows[CONV_MAX_TAPS];
+    unsigned pm_pps_mul[CONV_MAX_TAPS], pm_pps_sh[CONV_MAX_TAPS];
     // Block order of the PM form: block j (position in the launch, after the XCD-aware remap) -> tap pm_tap[j], K-split
     // pm_split[j] of that tap, sorted by the split's relative position in its tap's rows.  The taps of one pixel range then sit
     // next to each other -- on one XCD, which fetches the G / X rows they share into its L2 once instead of once per tap.

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     if constexpr (PM) {
         grp = by;
         t = a.pm_tap[bz];
-        mbeg = (int)a.pm_split[bz] * a.pm_pps[t];
-        mend = min(a.pm_rows[t], mbeg + a.pm_pps[t]);
+        mbeg = 0;
+        mend = a.pm_rows[t];            // local rows of this split: (position, RoI of the split's range); see WgradArgs
     } else {
         t = by % a.T; grp = by / a.T;
         mbeg = bz * a.pix_per_split;
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
     const unsigned pm_mul = PM ? a.pm_rw_mul[t] : 0u, pm_sh = PM ? a.pm_rw_sh[t] : 0u;
+    const int pm_rb = PM ? a.pm_pps[t] : 1, pm_b0 = PM ? (int)a.pm_split[bz] * pm_rb : 0;
+    const unsigned rb_mul = PM ? a.pm_pps_mul[t] : 0u, rb_sh = PM ? a.pm_pps_sh[t] : 0u;
 
     // ---- staging: thread -> pixel rows i*16 + wave*2 + (lane>>5), i = 0..3, 16-byte chunk lane & 31 (swizzled on the source)
     const int srow = wave * 2 + (lane >> 5);
@@ -68,12 +70,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     auto decode = [&](int m, const bf16_t*& pg, const bf16_t*& px) {
         pg = a.zero_page; px = a.zero_page;
         if (m < mend) {
-            if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * B + RoI; stride 1, all in bounds
-                const int p = fastdiv(m, a.b_mul, a.b_sh), b = m - p * a.B;
+            if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * RoIs-per-split + RoI; stride 1, in bounds
+                const int p = fastdiv(m, rb_mul, rb_sh), b = pm_b0 + (m - p * pm_rb);
                 const int ry = fastdiv(p, pm_mul, pm_sh), rx = p - ry * pm_rw;
                 const int oy = pm_y0 + ry, ox = pm_x0 + rx;
-                pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + schunk * 8;
-                px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + schunk * 8;
+                if (b < a.B) {
+                    pg = G + ((long)(b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + schunk * 8;
+                    px = X + ((long)(b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + schunk * 8;
+                }
             } else {
                 const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
                 const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;

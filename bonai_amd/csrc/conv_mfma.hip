@@ -1066,6 +1066,7 @@ LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* 
 
 
 int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStream_t s);     // conv_wgrad_pipe.hip
+int loft_launch_conv_wgrad_ring(const WgradArgs& a, dim3 grid, hipStream_t s);                 // conv_wgrad_pipe.hip
 
 // mode 0: launch, split-K combined with fp32 atomics into the zeroed dw.  mode 1: no launch, *nslots_out = the number of
 // split slots a partial-sum launch of this shape writes (0: this shape has no such form -- narrow channels, repeated or missing
@@ -1077,7 +1078,7 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
                       int splits, float* db, int db_tap, int variant, void* stream, int mode, int* nslots_out) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 8) || (Cout % 8) || groups < 1) return (int)hipErrorInvalidValue;
-    if (variant < LOFT_WGRAD_AUTO || variant > LOFT_WGRAD_T128) return (int)hipErrorInvalidValue;
+    if (variant < LOFT_WGRAD_AUTO || variant > LOFT_WGRAD_RING128) return (int)hipErrorInvalidValue;
     const bool narrow = (Cin % 128) || (Cout % 128);
     bool slots_ok = !narrow;
     {   // every weight tap written by exactly one tap of the table (else a slot would be written twice, or never)
@@ -1108,9 +1109,9 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     // 256x256 tiles only when >= 256 workgroups can each run >= ~32 K-steps (else the 65k-atomic epilogue dominates)
     const bool big_ok = (Cout % 256 == 0) && (Cin % 256 == 0);
     if ((variant == LOFT_WGRAD_STREAM256 || variant == LOFT_WGRAD_T256) && !big_ok) return (int)hipErrorInvalidValue;
-    if (variant == LOFT_WGRAD_T128 && narrow) return (int)hipErrorInvalidValue;
+    if ((variant == LOFT_WGRAD_T128 || variant == LOFT_WGRAD_RING128) && narrow) return (int)hipErrorInvalidValue;
     const bool big = variant == LOFT_WGRAD_AUTO ? (big_ok && M * (long)(Cout / 256) * (Cin / 256) * T * groups >= 524288L)
-                                                : (variant != LOFT_WGRAD_T128);
+                                                : (variant != LOFT_WGRAD_T128 && variant != LOFT_WGRAD_RING128);
     const bool piped = big && variant != LOFT_WGRAD_T256;       // the software-pipelined form (conv_wgrad_pipe.hip)
     const int TNv = narrow ? 64 : (big ? 256 : 128);
     a.ctiles = (Cin + TNv - 1) / TNv;
@@ -1118,7 +1119,10 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     if (splits <= 0) {
         // split-K factor: ~512 workgroups (two resident 128-tile workgroups per CU).  More splits only add fp32 atomic
         // traffic to dW -- measured on the 1x1 shapes: 1024 workgroups 202-222 TFLOP/s, 512: 279-305, 256: 261-274.
-        const long tgt_small = 512;
+        // (the four-stage ring kernel with its decode-free row addressing: ~288 workgroups are best on every backbone shape,
+        //  tools/probes/wgrad_splits.py -- layer3 1x1 37.6 us at 256 against 46 at 512, layer3 3x3 78 at 288 against 91 / 99)
+        const bool ring = !narrow && variant != LOFT_WGRAD_T128 && gos == 1 && ss == 1 && GH == OH && GW == OW && XH == OH && XW == OW;
+        const long tgt_small = ring ? 288 : 512;
         const long tgt_big = 256;   // 256-tile: one workgroup per CU
         // (big tile, measured: 256 workgroups 708-791 TFLOP/s on the FOA / mask / P2-P3 3x3 shapes, 512: 606-754, 1024: 474-719)
         // (also measured: a single-stage 128-tile form at four workgroups per CU -- what helped the K-shallow forward convs --
@@ -1217,6 +1221,8 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
         hipLaunchKernelGGL(conv_wgrad64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (big)
         hipLaunchKernelGGL((conv_wgrad_kernel<256, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else if (variant != LOFT_WGRAD_T128)
+        return loft_launch_conv_wgrad_ring(a, grid, (hipStream_t)stream);          // four-stage ring (conv_wgrad_pipe.hip)
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
     LOFT_LAUNCH_CHECK();

@@ -288,3 +288,232 @@ int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStr
     LOFT_LAUNCH_CHECK();
     return 0;
 }
+
+// =====================================================================================
+// conv_wgrad_ring_kernel -- the 128 x 128 tile (Cout / Cin multiples of 128 but not of 256, or too little K per tile for the
+// 256 form: the backbone's 1x1 and 3x3 layers) with a FOUR-stage ring of 32-pixel K-steps instead of conv_wgrad_kernel<128,4>'s
+// two 64-pixel stages.  The lock-step kernel prefetches one K-step ahead; one workgroup per CU then runs a K-step in ~2300
+// cycles against 512 of MFMA issue (tools/probes/wgrad_splits.py) because an L2 / HBM round trip under load is longer than the
+// one K-step of compute that is supposed to cover it.  Here three K-steps (96 pixels) are in flight behind the one being
+// consumed, retired by a COUNTED s_waitcnt (vmcnt(8): this thread's four copies of the oldest of three stages), same 64 KiB of LDS, two
+// workgroups per CU.  LDS: 4 x [G 32 px x 256 B][X 32 px x 256 B], 16-byte chunk q of pixel row r at q ^ ((r & 3) << 2).
+// 2 x 2 waves of 64 (n) x 64 (c); per 16-pixel sub-step 2 G + 2 X fragments (transposing reads, inline asm), 4 MFMAs.
+// =====================================================================================
+namespace {
+constexpr int RG_STAGE = 16384, RG_X = 8192, RG_LDS = 65536;
+}
+
+// DENSE: one tap at offset zero, unit strides, G / X / output maps of one size (every 1x1 layer of the backbone): reduction row
+// m IS pixel m of both operands -- no per-row decode (two exact divisions, bounds tests and 64-bit address arithmetic per staged
+// row: ~60 VALU instructions per 32-pixel K-step, more issue time than the step's 8 MFMAs at one wave per SIMD).
+// SAME (MODE 2): unit strides, G / X / output maps of one size, taps with arbitrary offsets on the X side only (every 3x3 / pad 1
+// layer): the G row of reduction row m is pixel m, the X row is pixel m + dy * W + dx when (oy + dy, ox + dx) is inside the map;
+// (oy, ox) of the two rows a thread stages are carried from K-step to K-step (+32 pixels, at most one row wrap when W >= 32).
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a) {
+    constexpr bool DENSE = MODE == 1, SAME = MODE == 2;
+    __shared__ __attribute__((aligned(16))) char lds[RG_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bx = V % gridDim.x, by = (V / gridDim.x) % gridDim.y, bz = V / (gridDim.x * gridDim.y);
+    const int nt = bx / a.ctiles, ct = bx - nt * a.ctiles;
+    const int t = by % a.T, grp = by / a.T;
+    const int mbeg = bz * a.pix_per_split, mend = min(a.M, mbeg + a.pix_per_split);
+    const int n0 = nt * 128, c0 = ct * 128;
+    if (mbeg >= mend) return;
+    const bf16_t* G = a.g + (long)grp * a.g_gs;
+    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const int ohw = a.OH * a.OW;
+    const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
+
+    // staging: a wave-level copy = 4 pixel rows x 256 B; thread -> rows i*16 + wave*4 + (lane >> 4), i = 0, 1, chunk lane & 15
+    const int lrow = lane >> 4, lchunk = lane & 15;
+    int s_oy[2] = {0, 0}, s_ox[2] = {0, 0};           // SAME: map position of this thread's rows of the NEXT stage() call
+    const int xshift = dy * a.XW + dx;
+    if constexpr (SAME) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mbeg + i * 16 + wave * 4 + lrow;
+            const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+            s_oy[i] = fastdiv(rem, a.ow_mul, a.ow_sh);
+            s_ox[i] = rem - s_oy[i] * a.OW;
+        }
+    }
+    auto stage = [&](int step, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        char* gbuf = lds + B * RG_STAGE;
+        char* xbuf = gbuf + RG_X;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 16 + wave * 4 + lrow;
+            const int m = mbeg + step * 32 + row;
+            const int q = wswz(row, lchunk) * 8;
+            const bf16_t* pg = a.zero_page;
+            const bf16_t* px = a.zero_page;
+            if constexpr (DENSE) {
+                if (m < mend) {
+                    pg = G + (long)m * a.Cout + n0 + q;
+                    px = X + (long)m * a.Cin + c0 + q;
+                }
+            } else if constexpr (SAME) {
+                const int iy = s_oy[i] + dy, ix = s_ox[i] + dx;
+                if ((m < mend) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                    pg = G + (long)m * a.Cout + n0 + q;
+                    px = X + (long)(m + xshift) * a.Cin + c0 + q;
+                }
+                s_ox[i] += 32;                                  // the row this thread stages at the next K-step
+                if (s_ox[i] >= a.OW) {
+                    s_ox[i] -= a.OW;
+                    s_oy[i] = s_oy[i] + 1 == a.OH ? 0 : s_oy[i] + 1;
+                }
+            } else
+            if (m < mend) {
+                const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                const int gy = oy * a.gos + goy, gx = ox * a.gos + gox;
+                const int iy = oy * a.ss + dy, ix = ox * a.ss + dx;
+                if ((gy >= 0) & (gy < a.GH) & (gx >= 0) & (gx < a.GW) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                    pg = G + ((long)(b * a.GH + gy) * a.GW + gx) * a.Cout + n0 + q;
+                    px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + q;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(gbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)px, (lds_ptr_t)(xbuf + (i * 16 + wave * 4) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wn = wave >> 1, wc = wave & 1;
+    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);      // wave (wn, wc) takes n-block wn*2 + wc
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
+
+    // per-lane bases of the transposing reads (tr_frag_issue of conv_mfma.hip, rows of 256 B): rows r0 = 8*(gl>>1) + (il>>2) and
+    // r0 + 4 of a 16-pixel sub-step, 16-byte chunk (col >> 3) ^ ((r & 3) << 2), + (col & 7) * 2
+    const int il = lane & 15, gl = lane >> 4;
+    const int r0 = 8 * (gl >> 1) + (il >> 2);
+    unsigned gaddr[2], xaddr[2];           // fragment i of G / X: byte offset inside a stage's G / X tile for sub-step 0, row r0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int colg = wn * 64 + i * 32 + 16 * (gl & 1) + (il & 3) * 4;
+        const int colx = wc * 64 + i * 32 + 16 * (gl & 1) + (il & 3) * 4;
+        gaddr[i] = (unsigned)(size_t)(lds + r0 * 256 + wswz(r0, colg >> 3) * 16 + (colg & 7) * 2);
+        xaddr[i] = (unsigned)(size_t)(lds + RG_X + r0 * 256 + wswz(r0, colx >> 3) * 16 + (colx & 7) * 2);
+    }
+    // (rows r0 + 4, r0 + 16, r0 + 20 have the same (row & 3) as r0: their chunks differ only through the row offset)
+
+    const int nsteps = (mend - mbeg + 31) / 32;
+    using b0_t = std::integral_constant<int, 0>;
+    using b1_t = std::integral_constant<int, 1>;
+    using b2_t = std::integral_constant<int, 2>;
+    using b3_t = std::integral_constant<int, 3>;
+    stage(0, b0_t{}); stage(1, b1_t{}); stage(2, b2_t{});           // (steps past the range copy the zero page: uniform counts)
+    // Fragments are read ONE SUB-STEP AHEAD of their MFMAs (two register sets), also across the K-step boundary: with one wave per
+    // SIMD and workgroup the read -> wait -> MFMA chain of a sub-step was ~400 cycles for 128 of MFMA issue.
+    s16x4 lo[2][4], hi[2][4];
+    // (a macro, not a generic lambda: clang rejects inline-asm operands that name captured locals inside one)
+#define RG_RD(S, B, KS)                                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                             \
+        TR_READ(lo[S][i_], gaddr[i_], (B) * RG_STAGE + (KS) * 4096);                                                               \
+        TR_READ(hi[S][i_], gaddr[i_], (B) * RG_STAGE + (KS) * 4096 + 1024);                                                        \
+        TR_READ(lo[S][2 + i_], xaddr[i_], (B) * RG_STAGE + (KS) * 4096);                                                           \
+        TR_READ(hi[S][2 + i_], xaddr[i_], (B) * RG_STAGE + (KS) * 4096 + 1024);                                                    \
+    }
+    auto mm = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        bf16x8 f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i][0] = lo[S][i][0]; f[i][1] = lo[S][i][1]; f[i][2] = lo[S][i][2]; f[i][3] = lo[S][i][3];
+            f[i][4] = hi[S][i][0]; f[i][5] = hi[S][i][1]; f[i][6] = hi[S][i][2]; f[i][7] = hi[S][i][3];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = LOFT_MFMA_32x32x16(f[i], f[2 + j], acc[i][j]);
+        if (do_db) accb = LOFT_MFMA_32x32x16(wc == 0 ? f[0] : f[1], ones, accb);
+    };
+#define RG_WAIT(S) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[S][0]), "+v"(lo[S][1]), "+v"(lo[S][2]), "+v"(lo[S][3]), \
+                                "+v"(hi[S][0]), "+v"(hi[S][1]), "+v"(hi[S][2]), "+v"(hi[S][3]))
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // stage 0 landed (this thread's copies) ...
+    __syncthreads();                                                // ... and everybody's
+    RG_RD(0, 0, 0);                                                 // F(0, 0) -> set 0
+    // K-step s (stage buffer B, stage s visible, set 0 = F(s, 0) in flight):
+    //   read F(s,1) -> set 1 | MFMA set 0 | own copies of stage s+1 landed (vmcnt 4), own reads of stage s complete | barrier
+    //   | issue stage s+3 (into the buffer of stage s-1) | read F(s+1,0) -> set 0 | MFMA set 1
+#define RG_STEP(s, B, NB, FREEC)                                                                     \
+    do {                                                                                             \
+        RG_WAIT(0);                                                                                  \
+        RG_RD(1, B, 1);                                                                              \
+        WSB();                                                                                       \
+        mm(b0_t{});                                                                                  \
+        WSB();                                                                                       \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
+        RG_WAIT(1);                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                \
+        WSB();                                                                                       \
+        stage((s) + 3, FREEC);                                                                       \
+        RG_RD(0, NB, 0);                                                                             \
+        WSB();                                                                                       \
+        mm(b1_t{});                                                                                  \
+        WSB();                                                                                       \
+    } while (0)
+    for (int s = 0; s < nsteps; s += 4) {
+        RG_STEP(s, 0, 1, b3_t{});
+        if (s + 1 < nsteps) RG_STEP(s + 1, 1, 2, b0_t{});
+        if (s + 2 < nsteps) RG_STEP(s + 2, 2, 3, b1_t{});
+        if (s + 3 < nsteps) RG_STEP(s + 3, 3, 0, b2_t{});
+    }
+    RG_WAIT(0);
+#undef RG_WAIT
+#undef RG_STEP
+#undef RG_RD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (zero-page copies of the steps past the range)
+
+    if (do_db && (lane & 31) == 0) {
+        float* db = a.db + (long)grp * a.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            unsafeAtomicAdd(db + n, accb[r]);
+        }
+    }
+    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)bz * a.split_stride : 0l);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* p = dw + (long)n * a.Cin + c;
+                if (a.partial) *p = acc[i][j][r];
+                else unsafeAtomicAdd(p, acc[i][j][r]);
+            }
+        }
+}
+
+int loft_launch_conv_wgrad_ring(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    const bool dense = a.T == 1 && a.gos == 1 && a.ss == 1 && a.goy[0] == 0 && a.gox[0] == 0 && a.dy[0] == 0 && a.dx[0] == 0 &&
+                       a.GH == a.OH && a.GW == a.OW && a.XH == a.OH && a.XW == a.OW;
+    bool same = a.gos == 1 && a.ss == 1 && a.GH == a.OH && a.GW == a.OW && a.XH == a.OH && a.XW == a.OW && a.OW >= 32;
+    for (int t = 0; t < a.T; ++t) same = same && a.goy[t] == 0 && a.gox[t] == 0;
+    if (dense) hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (same) hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_ring_kernel<0>, grid, dim3(256), 0, s, a);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}

@@ -328,8 +328,12 @@ CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_
     CONV_STREAM256 = range(10)
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT, CONV_FLAG_TAP_MAJOR = 0x100, 0x200, 0x400, 0x800
 CONV_VARIANT = CONV_AUTO
-WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128 = range(4)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
-WGRAD_VARIANT = WGRAD_AUTO
+WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128, WGRAD_RING128 = range(5)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
+WGRAD_VARIANT = WGRAD_AUTO      # a code, or a callable (groups, B, OH, OW, Cin, Cout, T, ss, gos) -> code
+
+
+def _wgrad_variant(*shape):
+    return WGRAD_VARIANT(*shape) if callable(WGRAD_VARIANT) else WGRAD_VARIANT
 
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
@@ -482,7 +486,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
         return dw
     if slots_ok and WGRAD_SLOTS and dw is None and n_wtaps == len(taps):
         S = lib.loft_conv_wgrad_slots(B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4),
-                                      groups, splits, int(WGRAD_VARIANT))
+                                      groups, splits, int(_wgrad_variant(groups, B, OH, OW, Cin, Cout, len(taps), ss, gos)))
         if S < 0:
             L.check(-S, 'loft_conv_wgrad_slots')
         if S >= 1:
@@ -490,7 +494,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
             L.check(lib.loft_conv_wgrad_bf16_slots(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                                    XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
                                                    c_int64(g_gs), c_int64(x_gs), S, splits, L.ptr(db), int(db_tap),
-                                                   int(WGRAD_VARIANT), L.stream()), 'loft_conv_wgrad_bf16_slots')
+                                                   int(_wgrad_variant(groups, B, OH, OW, Cin, Cout, len(taps), ss, gos)), L.stream()), 'loft_conv_wgrad_bf16_slots')
             _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
             return dw
     if dw is None:
@@ -498,7 +502,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     L.check(lib.loft_conv_wgrad_bf16_v(L.ptr(g), L.ptr(x), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH,
                                        XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups,
                                        c_int64(g_gs), c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), splits, L.ptr(db),
-                                       int(db_tap), int(WGRAD_VARIANT), L.stream()),
+                                       int(db_tap), int(_wgrad_variant(groups, B, OH, OW, Cin, Cout, len(taps), ss, gos)), L.stream()),
             'loft_conv_wgrad_bf16_v')
     _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
     return dw

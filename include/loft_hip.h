@@ -183,7 +183,8 @@ int loft_conv_wgrad_bf16(const void* g, const void* x, float* dw, const void* ze
 #define LOFT_WGRAD_AUTO 0
 #define LOFT_WGRAD_STREAM256 1   /* 256x256 tile, software-pipelined stream (Cout, Cin multiples of 256) */
 #define LOFT_WGRAD_T256 2        /* 256x256 tile, lockstep double buffer */
-#define LOFT_WGRAD_T128 3        /* 128x128 tile (Cout, Cin multiples of 128) */
+#define LOFT_WGRAD_T128 3        /* 128x128 tile (Cout, Cin multiples of 128), lock-step double buffer */
+#define LOFT_WGRAD_RING128 4     /* 128x128 tile, four-stage ring of 32-pixel K-steps (the AUTO choice where the 256 forms do not apply) */
 int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW,
                          int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                          const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,

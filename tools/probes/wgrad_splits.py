@@ -24,7 +24,7 @@ for name, B, Cin, Cout, H, R in SHAPES:
     x = torch.randn(B, Cin, H, H, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
     g = torch.randn(B, Cout, H, H, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
     gf = 2.0 * B * H * H * Cin * Cout * R * R / 1e9
-    for var, vn in ((K.WGRAD_T128, 't128'), (K.WGRAD_STREAM256, 'stream256')):
+    for var, vn in ((K.WGRAD_T128, 't128'), (K.WGRAD_RING128, 'ring128'), (K.WGRAD_STREAM256, 'stream256')):
         if var == K.WGRAD_STREAM256 and (Cin % 256 or Cout % 256):
             continue
         K.WGRAD_VARIANT = var

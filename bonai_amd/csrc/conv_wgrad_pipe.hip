@@ -31,8 +31,12 @@ constexpr int WG_OFF = 0, WX_OFF = 65536, WBUF = 32768, WLDS = 131072;
 // one transposing read: 4 consecutive pixels (k) of one channel for each lane of a 16-lane group -- half of an MFMA operand
 #define TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 
-template <bool PM>
+// MODE 0: generic taps (per-row decode); 1: PM (RoI maps, WgradArgs); 2: DENSE and 3: SAME -- the decode-free row addressing of
+// conv_wgrad_ring_kernel below (1x1 layers / FCs: reduction row m is pixel m of both operands; stride-1 same-size taps: G row =
+// pixel m, X row = pixel m + dy * W + dx inside the map, (oy, ox) of a thread's four rows carried from K-step to K-step).
+template <int MODE>
 __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs a) {
+    constexpr bool PM = MODE == 1, DENSE = MODE == 2, SAME = MODE == 3;
     __shared__ __attribute__((aligned(16))) char lds[WLDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,9 +70,40 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     const int srow = wave * 2 + (lane >> 5);
     const int schunk = (lane & 31) ^ ((srow & 3) << 2);           // rows 16 apart share (row & 3)
     const bf16_t* px_next[4];                                      // X pointers of the K-step whose G rows were issued last
+    int s_oy[4] = {0, 0, 0, 0}, s_ox[4] = {0, 0, 0, 0};         // SAME: map position of row i at its next decode
+    const int xshift = dy * a.XW + dx;
+    if constexpr (SAME) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbeg + i * 16 + srow;
+            const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+            s_oy[i] = fastdiv(rem, a.ow_mul, a.ow_sh);
+            s_ox[i] = rem - s_oy[i] * a.OW;
+        }
+    }
     // decode pixel m of the reduction range once: G pointer (or the zero page), X pointer (or the zero page)
-    auto decode = [&](int m, const bf16_t*& pg, const bf16_t*& px) {
+    auto decode = [&](int m, const bf16_t*& pg, const bf16_t*& px, int i) {
         pg = a.zero_page; px = a.zero_page;
+        if constexpr (DENSE) {
+            if (m < mend) {
+                pg = G + (long)m * a.Cout + n0 + schunk * 8;
+                px = X + (long)m * a.Cin + c0 + schunk * 8;
+            }
+            return;
+        }
+        if constexpr (SAME) {
+            const int iy = s_oy[i] + dy, ix = s_ox[i] + dx;
+            if ((m < mend) & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW)) {
+                pg = G + (long)m * a.Cout + n0 + schunk * 8;
+                px = X + (long)(m + xshift) * a.Cin + c0 + schunk * 8;
+            }
+            s_ox[i] += 64;                                          // this row's pixel at the next K-step (OW >= 64: one wrap at most)
+            if (s_ox[i] >= a.OW) {
+                s_ox[i] -= a.OW;
+                s_oy[i] = s_oy[i] + 1 == a.OH ? 0 : s_oy[i] + 1;
+            }
+            return;
+        }
         if (m < mend) {
             if constexpr (PM) {     // m = (position inside the valid rectangle of tap t) * RoIs-per-split + RoI; stride 1, in bounds
                 const int p = fastdiv(m, rb_mul, rb_sh), b = pm_b0 + (m - p * pm_rb);
@@ -97,7 +132,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
 #pragma unroll
         for (int i = I0; i < I0 + 2; ++i) {
             const bf16_t* pg;
-            decode(mbeg + step * 64 + i * 16 + srow, pg, px_next[i]);
+            decode(mbeg + step * 64 + i * 16 + srow, pg, px_next[i], i);
             __builtin_amdgcn_global_load_lds((gptr_t)pg, (lds_ptr_t)(lds + WG_OFF + B * WBUF + (i * 16 + wave * 2) * 512), 16, 0, 0);
         }
     };
@@ -283,8 +318,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
 
 // host side: launched from loft_conv_wgrad_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0 and Cin % 256 == 0.
 int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStream_t s) {
-    if (pm) hipLaunchKernelGGL(conv_wgrad_stream_kernel<true>, grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_stream_kernel<false>, grid, dim3(512), 0, s, a);
+    const bool samesize = a.gos == 1 && a.ss == 1 && a.GH == a.OH && a.GW == a.OW && a.XH == a.OH && a.XW == a.OW;
+    bool same = samesize && a.OW >= 64;
+    for (int t = 0; t < a.T; ++t) same = same && a.goy[t] == 0 && a.gox[t] == 0;
+    const bool dense = samesize && a.T == 1 && a.goy[0] == 0 && a.gox[0] == 0 && a.dy[0] == 0 && a.dx[0] == 0;
+    if (pm) hipLaunchKernelGGL(conv_wgrad_stream_kernel<1>, grid, dim3(512), 0, s, a);
+    else if (dense) hipLaunchKernelGGL(conv_wgrad_stream_kernel<2>, grid, dim3(512), 0, s, a);
+    else if (same) hipLaunchKernelGGL(conv_wgrad_stream_kernel<3>, grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_stream_kernel<0>, grid, dim3(512), 0, s, a);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

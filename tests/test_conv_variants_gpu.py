@@ -170,6 +170,10 @@ WGRAD = [
     ('mask_3x3_pm.wgrad256', (1, 873, 256, 256, 14, 14, 3, 1, 1)),
     ('layer1_3x3_64.wgrad64_patch', (1, 8, 64, 64, 256, 256, 3, 1, 1)),
     ('layer2_3x3_s2.wgrad128', (1, 8, 128, 128, 256, 256, 3, 2, 1)),
+    ('layer2_3x3.ring_same', (1, 8, 128, 128, 128, 128, 3, 1, 1)),
+    ('layer4_3x3.ring_same_w32', (1, 8, 512, 512, 32, 32, 3, 1, 1)),
+    ('layer2_reduce_512_128.ring_dense', (1, 8, 512, 128, 128, 128, 1, 1, 0)),
+    ('p5_3x3.stream_generic_w32', (1, 8, 256, 256, 32, 32, 3, 1, 1)),
 ]
 
 
@@ -183,7 +187,8 @@ def test_wgrad_bench_size_sampled_values(name, shape):
     x = _cl(torch.randn(G * B, Cin, H, W, device='cuda', generator=gsd).bfloat16())
     OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
     g = _cl(torch.randn(G * B, Cout, OH, OW, device='cuda', generator=gsd).bfloat16())
-    variants = [K.WGRAD_AUTO] + ([K.WGRAD_STREAM256, K.WGRAD_T256] if Cin % 256 == 0 and Cout % 256 == 0 else [])
+    variants = [K.WGRAD_AUTO] + ([K.WGRAD_STREAM256, K.WGRAD_T256] if Cin % 256 == 0 and Cout % 256 == 0 else []) + \
+        ([K.WGRAD_RING128, K.WGRAD_T128] if Cin % 128 == 0 and Cout % 128 == 0 else [])
     outs = []
     for v in variants:
         K.WGRAD_VARIANT = v

@@ -494,7 +494,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     a.nfast = !(variant & LOFT_CONV_FLAG_NO_NFAST);
     const long big_blocks = (long)loft_cdiv(M, 256) * (Cout / 256) * groups;
     const long Kdim = (long)T * Cin;
-    const bool deepk = Kdim >= 2048;      // >= 32 K-steps: hoisted addressing (FAST) amortises its prologue
+    const bool deepk = Kdim >= 1024;      // >= 16 K-steps: hoisted addressing (FAST) amortises its prologue (round 2: 8x64x64 1024->256 32.8 vs 34.6 us)
     // pixel-major enumeration of RoI-map tiles (FAST / pipelined 256-row kernels): taps that leave the map are skipped per tile
     const bool pix_ok = !(variant & LOFT_CONV_FLAG_NO_PIXMAJOR) && T > 1 && T <= 32 && B >= 256 && OH * OW <= 1024 && os == 1 &&
                         ss == 1 && OHf == OH && OWf == OW;
@@ -510,7 +510,8 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         else if (Cout % 128 == 0) {
             const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
             const bool two_tiles = residual && relu_mask && dense_out;        // needs both halves of the double buffer
-            if (!two_tiles && a.staged_out && Kdim <= 256) k = LOFT_CONV_T128_SINGLE;
+            // (single-stage form at four workgroups per CU: K <= 512 since round 2 -- 8x128x128 512->128: 37.8 against 48.8 us)
+            if (!two_tiles && a.staged_out && Kdim <= 512) k = LOFT_CONV_T128_SINGLE;
             else k = deepk ? LOFT_CONV_T128_FAST : LOFT_CONV_T128;
         } else k = LOFT_CONV_T128x64;
     }

@@ -209,8 +209,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nblk = gridDim.x * gridDim.y * gridDim.z;
     const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
-    const int bz = V / (gridDim.x * gridDim.y), Vg = V - bz * (gridDim.x * gridDim.y);
-    const int bx = a.nfast ? Vg / gridDim.y : Vg % gridDim.x, by = a.nfast ? Vg % gridDim.y : Vg / gridDim.x;
+    // (host-computed multiply-high constants: five runtime integer divisions at kernel entry were ~1k cycles per workgroup)
+    const int bz = fastdiv(V, a.gxy_mul, a.gxy_sh), Vg = V - bz * (int)(gridDim.x * gridDim.y);
+    int bx, by;
+    if (a.nfast) { bx = fastdiv(Vg, a.gy_mul, a.gy_sh); by = Vg - bx * (int)gridDim.y; }
+    else { by = fastdiv(Vg, a.gx_mul, a.gx_sh); bx = Vg - by * (int)gridDim.x; }
     const int m0 = bx * 256, n0 = by * 256;
     const int g = bz;
     const bf16_t* src = a.src + (long)g * a.src_gs;
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // counter costs a ~200-cycle round trip each (the tap-mask loop of round 1's kernels: 36 of them, 7k cycles per workgroup),
     // and inside the K loop it would make hipcc wait lgkmcnt(0), i.e. for every fragment read in flight.
     int tab_dy = 0, tab_dx = 0, tab_a = 0, tab_w = 0;
-    if (lane < a.T) {
+    if (a.pointwise) tab_w = a.wt[0] * a.Cout * a.Cin;          // (1x1 / FC: no per-lane table loads; offsets are zero)
+    else if (lane < a.T) {
         tab_dy = a.dy[lane]; tab_dx = a.dx[lane];
         tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
         tab_w = a.wt[lane] * a.Cout * a.Cin;
@@ -244,6 +248,14 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         a_mask[i] = 0u;
         a_iy[i] = -(1 << 20); a_ix[i] = -(1 << 20);
         int b = a.B, rem = 0;
+        if (a.pointwise) {                       // input pixel index = m: no decode, the one tap is always inside the map
+            if (m < a.M) {
+                a_iy[i] = 0; a_ix[i] = 0;
+                a_mask[i] = 1u;
+                a_ptr[i] = src + ((long)m * a.Cin + swz(row, lchunk) * 8);
+            }
+            continue;
+        }
         if (m < a.M) pipe_row_decode(a, m, ohw, b, rem);
         if (b < a.B) {
             const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             const int m = m0 + i * 64 + srow;
             if (a_iy[i] >= 0) a_mask[i] = (fastdiv(m, a.pms_mul, a.pms_sh) == seg0) ? mk0 : mk1;      // (padding rows keep mask 0)
         }
-    } else {
+    } else if (!a.pointwise) {
         for (int t = 0; t < a.T; ++t) {
             const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
 #pragma unroll
@@ -735,8 +747,13 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
-int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, hipStream_t s) {
+int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, hipStream_t s) {
+    ConvArgs a = a_in;
     dim3 grid(loft_cdiv(a.M, 256), a.Cout / 256, groups);
+    fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
+    fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
+    fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);
+    a.pointwise = a.T == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.ss == 1 && !a.pixmajor && a.IH == a.OH && a.IW == a.OW;
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
     if (mode == 1) {
         switch (var) {

@@ -33,6 +33,8 @@ struct ConvArgs {
     void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
     int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
+    unsigned gxy_mul, gxy_sh, gx_mul, gx_sh, gy_mul, gy_sh;   // conv_pipe.hip: exact division by grid.x * grid.y, grid.x, grid.y
+    int pointwise;   // conv_pipe.hip: one tap at offset 0, unit strides, input map = output map: row m reads input pixel m
     // conv_pipe.hip, pixel-major rows in RoI BLOCKS: row m -> segment m / pm_S (pm_S rows = the RoIs of one block at one pixel
     // position), block = segment / pm_P, position = segment % pm_P, RoI = block * pm_S + m % pm_S (rows with RoI >= B are
     // padding: pm_S = ceil(B / number of blocks) >= 256).  The 49 / 196 positions of a block's RoIs are then CONSECUTIVE tiles --

@@ -49,6 +49,8 @@ def main():
         print(f'{name:14s}' + ''.join(f'{gflop / best[n]:14.1f}' for n, _ in variants), flush=True)
     if os.environ.get('STREAM_TRACE'):
         name, B, Cin, Cout, H, W, R, st, pad, G = SHAPES[0]
+        if os.environ.get('TRACE_SHAPE'):       # e.g. TRACE_SHAPE=8,256,1024,64,64,1,1,0,1 (B,Cin,Cout,H,W,R,stride,pad,groups)
+            B, Cin, Cout, H, W, R, st, pad, G = [int(v) for v in os.environ['TRACE_SHAPE'].split(',')]
         x = torch.randn(B, Cin, H, W, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
         wp = K.pack_w_fwd(torch.randn(Cout, Cin, R, R, device='cuda') * 0.02)[None]
         tr = torch.zeros(2 * 8 * 64, dtype=torch.int64, device='cuda')
@@ -59,14 +61,15 @@ def main():
         raw = tr.cpu().numpy().reshape(2, 8, 64)[0]
         print('stream trace, K-tiles 8 and 9; per tile: ks0 [start, after 1st MFMA pair], ks1 [..], ks2 [..], sync [before wait, '
               'after wait], ks3 [after barrier, after 1st pair], end')
-        t0 = raw[:, :24][raw[:, :24] > 0].min()
+        have_tiles = bool((raw[:, :24] > 0).any())      # (K-shallow launches have no K-tiles 8 / 9: kernel-level stamps only)
+        t0 = raw[:, :24][raw[:, :24] > 0].min() if have_tiles else 0
         for wv in range(8):
             r = raw[wv, :24].astype(np.int64)
-            for tl in range(2):
+            for tl in range(2 if have_tiles else 0):
                 v = r[12 * tl:12 * tl + 11] - t0
                 print(f'w{wv} simd{(int(raw[wv, 63]) >> 4) & 3} tile{8 + tl}: ' + ' '.join(f'{int(q):6d}' for q in v))
             k = raw[wv, 32:37].astype(np.int64)
-            print(f'w{wv} kernel: setup {k[4] - k[0]}  first loads {k[1] - k[4]}  loop {k[2] - k[1]} ({(k[2] - k[1]) / 36:.0f} per K-tile)  epilogue+drain {k[3] - k[2]}')
+            print(f'w{wv} kernel: setup {k[4] - k[0]}  first loads {k[1] - k[4]}  loop {k[2] - k[1]} ({(k[2] - k[1]) / max(1, R * R * Cin // 64):.0f} per K-tile)  epilogue+drain {k[3] - k[2]}')
             e = raw[wv, 40:49].astype(np.int64)
             print(f'   setup: entry->decode {e[0] - k[0]}  decode {e[1] - e[0]}  masks {e[2] - e[1]}  rest {k[4] - e[2]} | epilogue: '
                   f'sync {e[4] - k[2]}  bias+relu {e[5] - e[4]}  lds write {e[6] - e[5]}  barrier {e[7] - e[6]}  stores issued {e[8] - e[7]}  drain {k[3] - e[8]}')

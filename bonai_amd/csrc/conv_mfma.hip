@@ -1284,20 +1284,20 @@ __device__ __forceinline__ void stem_gather(const float* patch, char* abuf, int 
     const float* pm = patch + 2 * (m >> 4) * STEM_PP + 2 * (m & 15);
 #pragma unroll
     for (int q8 = 0; q8 < 4; ++q8) {
-        bf16x8 v;
+        float xv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             constexpr int kb = CHUNK * 64 + KH * 32;
             const int k = kb + q8 * 8 + e;
-            float x = 0.f;
+            xv[e] = 0.f;
             if (k < 147) {
                 const int c = k / 49, rs = k - c * 49, r = rs / 7, s2 = rs - r * 7;
-                x = pm[(c * STEM_PR + r) * STEM_PP + s2];
+                xv[e] = pm[(c * STEM_PR + r) * STEM_PP + s2];
             }
-            v[e] = (short)f32_to_bf16(x);
         }
+        // (hardware conversion, two values per instruction: the software form's NaN branch was ten instructions per element)
         const int q = KH * 4 + q8;
-        *reinterpret_cast<bf16x8*>(abuf + m * 128 + swz(m, q) * 16) = v;
+        *reinterpret_cast<uint4*>(abuf + m * 128 + swz(m, q) * 16) = pack8_16(xv);
     }
 }
 

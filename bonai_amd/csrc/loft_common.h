@@ -52,25 +52,29 @@ __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return c.f;
 }
 
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
+// two fp32 -> packed pair with the hardware conversion (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN) -- the
+// software form below costs a compare + divergent branch per element, which in the conv epilogues meant thousands of tiny basic
+// blocks (and register spills) per workgroup
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const loft_f32x2 v = {lo, hi};
+    const loft_bf16x2 r = __builtin_convertvector(v, loft_bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast); on the device the hardware conversion
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu);
+#else
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
 }
 __device__ __forceinline__ void unpack2_16(uint32_t w, float& lo, float& hi) {
     lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
-}
-// two fp32 -> packed pair with the hardware conversion (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN) -- the
-// software form above costs a compare + divergent branch per element, which in the conv epilogues meant thousands of tiny basic
-// blocks (and register spills) per workgroup
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    const loft_f32x2 v = {lo, hi};
-    const loft_bf16x2 r = __builtin_convertvector(v, loft_bf16x2);
-    return __builtin_bit_cast(uint32_t, r);
 }
 #define LOFT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif

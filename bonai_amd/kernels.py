@@ -484,7 +484,8 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                 'loft_conv_wgrad_patch_bf16')
         _prof_end(_ev, 'conv_wgrad', 2.0 * groups * B * OH * OW * Cout * Cin * len(taps), (groups, B, OH, OW, Cin, Cout, len(taps), ss, gos))
         return dw
-    if slots_ok and WGRAD_SLOTS and dw is None and n_wtaps == len(taps):
+    use_slots = WGRAD_SLOTS(groups, B, OH, OW, Cin, Cout, len(taps), ss, gos) if callable(WGRAD_SLOTS) else WGRAD_SLOTS
+    if slots_ok and use_slots and dw is None and n_wtaps == len(taps):
         S = lib.loft_conv_wgrad_slots(B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4),
                                       groups, splits, int(_wgrad_variant(groups, B, OH, OW, Cin, Cout, len(taps), ss, gos)))
         if S < 0:

@@ -796,7 +796,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
 // LDS row per pixel holds BOTH operands side by side -- columns 0..63 = 64 channels of G, columns 64..127 = 64 channels of X --
 // so the same bank-conflict-free swizzle and the same transposing fragment reader apply.  2 x 2 waves of one 32 x 32 MFMA tile;
 // channels past Cout / Cin read the zero page and are masked in the epilogue.
+// MODE 1 (dense: one zero-offset tap, unit strides, one map size) / 2 (same: stride-1 same-size taps, OW >= 64): the decode-free
+// row addressing of conv_wgrad_ring_kernel (conv_wgrad_pipe.hip) -- reduction row m is pixel m of G, pixel m (+ dy * W + dx) of X.
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
+    constexpr bool DENSE = MODE == 1, SAME = MODE == 2;
     constexpr int RB = 256, TILE_BYTES = 64 * RB;
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -815,6 +819,17 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int lrow = lane >> 4, lchunk = lane & 15;
+    int s_oy[4] = {0, 0, 0, 0}, s_ox[4] = {0, 0, 0, 0};       // SAME: map position of this thread's rows at the next stage() call
+    const int xshift = dy * a.XW + dx;
+    if constexpr (SAME) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mbeg + i * 16 + wave * 4 + lrow;
+            const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+            s_oy[i] = fastdiv(rem, a.ow_mul, a.ow_sh);
+            s_ox[i] = rem - s_oy[i] * a.OW;
+        }
+    }
     auto stage = [&](int m_base, int buf) {
         char* tb = lds + buf * TILE_BYTES;
 #pragma unroll
@@ -823,6 +838,25 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
             const int m = m_base + row;
             const int q = wswz(row, lchunk);                    // logical 16-byte chunk held at this physical position
             const bf16_t* p = a.zero_page;
+            if constexpr (DENSE || SAME) {
+                bool ok = m < mend;
+                if constexpr (SAME) {
+                    const int iy = s_oy[i] + dy, ix = s_ox[i] + dx;
+                    ok = ok & (iy >= 0) & (iy < a.XH) & (ix >= 0) & (ix < a.XW);
+                    s_ox[i] += 64;
+                    if (s_ox[i] >= a.OW) {
+                        s_ox[i] -= a.OW;
+                        s_oy[i] = s_oy[i] + 1 == a.OH ? 0 : s_oy[i] + 1;
+                    }
+                }
+                if (ok) {
+                    if (q < 8) {
+                        if (n0 + q * 8 < a.Cout) p = G + (long)m * a.Cout + n0 + q * 8;
+                    } else {
+                        if (c0 + (q - 8) * 8 < a.Cin) p = X + (long)(m + (SAME ? xshift : 0)) * a.Cin + c0 + (q - 8) * 8;
+                    }
+                }
+            } else
             if (m < mend) {
                 const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
                 const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
@@ -1218,8 +1252,15 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     if (mode == 2 && dw_gs != (int64_t)splits * a.split_stride) return (int)hipErrorInvalidValue;
     dim3 grid(tiles, T * groups, splits);
     if (piped) return loft_launch_conv_wgrad_stream(a, grid, false, (hipStream_t)stream);
-    if (narrow)
-        hipLaunchKernelGGL(conv_wgrad64_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (narrow) {
+        const bool samesize = gos == 1 && ss == 1 && GH == OH && GW == OW && XH == OH && XW == OW;
+        bool same = samesize && OW >= 64;
+        for (int t = 0; t < T; ++t) same = same && a.goy[t] == 0 && a.gox[t] == 0;
+        const bool dense = samesize && T == 1 && a.goy[0] == 0 && a.gox[0] == 0 && a.dy[0] == 0 && a.dx[0] == 0;
+        if (dense) hipLaunchKernelGGL(conv_wgrad64_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (same) hipLaunchKernelGGL(conv_wgrad64_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv_wgrad64_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     else if (big)
         hipLaunchKernelGGL((conv_wgrad_kernel<256, 8>), grid, dim3(512), 0, (hipStream_t)stream, a);
     else if (variant != LOFT_WGRAD_T128)

@@ -292,3 +292,50 @@ def test_wgrad_roi_maps_valid_rows_only(B, Cin, Cout, H, W, R, pad):
     want_b = g.sum(dim=(0, 2, 3))
     assert (db[0].cpu() - want_b).abs().max().item() < 2e-3 * max(1.0, want_b.abs().max().item())
     assert (K.unpack_dw(dwp[0], w.shape).cpu() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,hw,groups', [(64, 64, 3, 1, 1, 20, 1), (256, 128, 1, 2, 0, 17, 1), (32, 64, 3, 2, 1, 9, 1),
+                                                      (96, 256, 1, 1, 0, 7, 1), (64, 64, 3, 1, 1, 7, 4)])
+def test_fp32_parity_backward_kernels(cin, cout, k, s, p, hw, groups):
+    """parity_f32.hip, the backward of the fp32 parity mode: loft_conv_wgrad_f32 (v_mfma_f32_32x32x2_f32, exact fp32 products) and
+    the fp32 data gradient through loft_conv_tap_f32 against fp64 autograd of the same convolution; the fp32 ReLU-backward and
+    the FPN adjoints (2x2 block sum, stride-2 scatter) against their definitions -- fp32 rounding only."""
+    import torch.nn.functional as F
+    from bonai_amd import kernels as K
+    torch.manual_seed(cin + cout + k + groups)
+    B = 2
+    x = torch.randn(groups * B, cin, hw, hw, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(groups, cout, cin, k, k, dtype=torch.float64) * 0.05).requires_grad_(True)
+    oh = (hw + 2 * p - k) // s + 1
+    g = torch.randn(groups * B, cout, oh, oh, dtype=torch.float64)
+    ys = [F.conv2d(x[i * B:(i + 1) * B], w[i], None, s, p) for i in range(groups)]
+    torch.cat(ys).backward(g)
+    xc = x.detach().float().cuda().contiguous(memory_format=torch.channels_last)
+    gc = g.float().cuda().contiguous(memory_format=torch.channels_last)
+    dwp, db = K.conv2d_wgrad(gc, xc, k, k, s, p, groups=groups, with_bias=True)
+    assert dwp.dtype == torch.float32
+    for i in range(groups):
+        dw = K.unpack_dw(dwp[i], (cout, cin, k, k)).cpu()
+        want = w.grad[i].float()
+        assert (dw - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (i, (dw - want).abs().max().item())
+    want_b = g.view(groups, B, cout, -1).sum(dim=(1, 3)).float()
+    assert (db[:, :cout].cpu() - want_b).abs().max().item() <= 2e-5 * max(1.0, want_b.abs().max().item())
+    if groups == 1:
+        wpt = w[0].detach().float().cuda().permute(2, 3, 1, 0).reshape(k * k, cin, cout).contiguous()[None]   # fp32 [T, Cin, Cout]
+        gx = K.conv2d_dgrad(gc, wpt, (hw, hw), k, k, s, p, out_dtype=torch.float32)
+        assert (gx.cpu() - x.grad.float()).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+    # elementwise adjoints of the parity mode
+    y = torch.randn(B, 16, 10, 12).cuda().contiguous(memory_format=torch.channels_last)
+    gg = torch.randn_like(y)
+    assert torch.equal(K.relu_bwd(gg, y), gg * (y > 0))
+    fine = torch.randn(B, 16, 10, 12).cuda().contiguous(memory_format=torch.channels_last)
+    coarse = torch.randn(B, 16, 5, 6).cuda().contiguous(memory_format=torch.channels_last)
+    want = coarse + fine.view(B, 16, 5, 2, 6, 2).sum(dim=(3, 5))
+    got = K.downsum2x_add_(coarse.clone(memory_format=torch.channels_last), fine)
+    assert (got - want).abs().max().item() <= 1e-5
+    big = torch.randn(B, 16, 9, 11).cuda().contiguous(memory_format=torch.channels_last)
+    small = torch.randn(B, 16, 5, 6).cuda().contiguous(memory_format=torch.channels_last)
+    want = big.clone()
+    want[:, :, ::2, ::2] += small
+    got = K.subsample2_adjoint_add_(big.clone(memory_format=torch.channels_last), small)
+    assert (got - want).abs().max().item() <= 1e-6

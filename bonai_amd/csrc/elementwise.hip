@@ -558,8 +558,12 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
             const int nn = local_chunk, per = Cin * RS;
             const float sc = gamma ? gamma[nn] * rsqrtf(var[nn] + eps) : 1.f;
             __syncthreads();
+            // (j / RS by multiply-high: exact for j < 2^16 when per < 2^16 -- a runtime integer division is ~40 instructions per
+            //  element, and the two 12544 x 1024 FC records are 25.7 M elements per step)
+            const unsigned rs_mul = RS == 1 ? 0u : 0xFFFFFFFFu / (unsigned)RS + 1u;
+            const bool small = per < 65536;
             for (int j = threadIdx.x; j < per; j += 256) {
-                const int cc = j / RS, t = j - cc * RS;
+                const int cc = RS == 1 ? j : (small ? (int)__umulhi((unsigned)j, rs_mul) : j / RS), t = j - cc * RS;
                 row[t * Cin + cc] = f32_to_bf16(w[(long)nn * per + j] * sc);
             }
             __syncthreads();
@@ -754,8 +758,10 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
     if (nmajor) {
         // dwp row [t][c] read contiguously, permuted to the parameter's (c, t) order through LDS, added contiguously
         extern __shared__ float urow[];
+        const unsigned cp_mul = CinP == 1 ? 0u : 0xFFFFFFFFu / (unsigned)CinP + 1u;     // j / CinP by multiply-high (j < 2^16)
+        const bool small = per < 65536;
         for (int j = threadIdx.x; j < per; j += blockDim.x) {
-            const int t = j / CinP, c = j - t * CinP;
+            const int t = CinP == 1 ? j : (small ? (int)__umulhi((unsigned)j, cp_mul) : j / CinP), c = j - t * CinP;
             urow[c * RS + t] = ld1(dwp + (long)n * per + j);
         }
         __syncthreads();

@@ -42,3 +42,11 @@ def test_no_cpu_fallback():
     feat = torch.zeros(1, 4, 8, 8).contiguous(memory_format=torch.channels_last)
     with pytest.raises(L.LoftHipError):
         K.roi_align_fwd([feat], rois, 7, [4])
+
+
+def test_library_sources_read_no_environment():
+    """The kernel library takes its variants as explicit arguments (the *_v entry points of include/loft_hip.h): no getenv in csrc."""
+    import glob
+    csrc = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), 'csrc')
+    offenders = [f for f in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) if 'getenv' in open(f).read()]
+    assert not offenders, offenders

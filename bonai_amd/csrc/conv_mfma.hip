@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
     }
 }
 
-int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, hipStream_t s);     // conv_pipe.hip
+int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, int mj, hipStream_t s);     // conv_pipe.hip
 
 LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,
                                      const void* relu_mask, void* out,
@@ -444,7 +444,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_STREAM256 || (variant & ~0xffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM128 || (variant & ~0xffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -500,7 +500,11 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                         ss == 1 && OHf == OH && OWf == OW;
     int k = kern;
     if (k == LOFT_CONV_AUTO) {
-        if (Cout % 256 == 0 && big_blocks >= 192 && !out_f32 && !accumulate) {
+        const long half_blocks = (long)loft_cdiv(M, 128) * (Cout / 256) * groups;
+        if (Cout % 256 == 0 && big_blocks < 192 && half_blocks >= 192 && Kdim >= 1024 && !out_f32 && !accumulate) {
+            // too few 256-pixel tiles to fill the chip (layer3's 64 x 64 maps): the stream kernel on 128-pixel tiles
+            k = LOFT_CONV_STREAM128;
+        } else if (Cout % 256 == 0 && big_blocks >= 192 && !out_f32 && !accumulate) {
             // bf16 output: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue (conv_pipe.hip; +26..43 %
             // over the lockstep 256-tile kernel on the 3x3 / FC shapes, +15..35 % over the 128-tile kernels on the K-shallow 1x1s)
             k = LOFT_CONV_STREAM256;
@@ -516,6 +520,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else k = LOFT_CONV_T128x64;
     }
     switch (k) {
+    case LOFT_CONV_STREAM128:
     case LOFT_CONV_STREAM256:
     case LOFT_CONV_PIPE256:
         // software-pipelined 256x256 kernels (conv_pipe.hip)
@@ -536,7 +541,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
-        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_STREAM256 ? 1 : 0, (variant >> 12) & 0xf, s);
+        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf, k == LOFT_CONV_STREAM128 ? 2 : 4, s);
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still

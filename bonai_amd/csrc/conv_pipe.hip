@@ -82,11 +82,13 @@ __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const b
 // are dead by then.  RES: the residual tile (bottleneck shortcut, resnet.py:294-296; shortcut gradient of a fused block) comes in
 // through LDS with whole-row copies first; every lane reads its 8-byte pieces from there, adds in fp32 and overwrites them with
 // the result in place.
+template <int MJ>
 __device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int ohw, int wave, int lane,
                                               char* lds) {
+    constexpr int RW = 8 * MJ;                    // tile rows copied by one wave (8 waves cover 64 MJ rows)
 #pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-        const int r = wave * 32 + it * 2 + (lane >> 5);
+    for (int it = 0; it < RW / 2; ++it) {
+        const int r = wave * RW + it * 2 + (lane >> 5);
         const int c = (lane & 31) ^ (r & 31);                 // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
         const int m = m0 + r;
         const bf16_t* p = a.zero_page;
@@ -94,13 +96,14 @@ __device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t
             const bf16_t* rp = pipe_row_ptr(a, t, out_g, m, n0, ohw);
             if (rp) p = rp + c * 8;
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * 32 + it * 2) * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * RW + it * 2) * 512), 16, 0, 0);
     }
 }
 
-template <bool RES, typename StampFn>
+template <bool RES, int MJ, typename StampFn>
 __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[2][4], char* lds, int g, int m0, int n0, int wave,
                                                      int lane, int ohw, StampFn&& kstamp) {
+    constexpr int RW = 8 * MJ;
     const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
     const long out_g = (long)g * a.out_gs;
     // (no bias: read zeros -- a branch around the adds makes hipcc keep two copies of the 128 accumulator registers)
@@ -108,14 +111,14 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     // This lane's 8-byte piece (4 couts) of block (i, gq) in tile row r = wm*128 + j*32 + frow is piece p = wn*16 + i*8 + 2*gq + fq,
     // i.e. 16-byte chunk wn*8 + k (k = i*4 + gq) at position chunk ^ (r & 31) = ((wn ^ (frow>>3)) << 3) | (k ^ (frow & 7)):
     // eight per-lane offsets, the row block j is a ds immediate (j * 16 KiB).
-    char* rowb = lds + (wm * 128 + frow) * 512 + fq * 8 + (((wn ^ (frow >> 3)) << 3) << 4);
+    char* rowb = lds + (wm * (32 * MJ) + frow) * 512 + fq * 8 + (((wn ^ (frow >> 3)) << 3) << 4);
     const int f7 = frow & 7;
     const float lo = a.relu ? 0.f : -__builtin_inff();          // ReLU as a branch-free max
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // every wave is done with the K loop's fragments
     kstamp(44);
     if constexpr (RES) {
-        pipe_stage_in(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
+        pipe_stage_in<MJ>(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -125,7 +128,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
         const float4 bv = *reinterpret_cast<const float4*>(bias + i * 32 + 8 * gq);
         char* q = rowb + ((k ^ f7) << 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
             float v[4];
             v[0] = acc[i][j][gq * 4 + 0] + bv.x; v[1] = acc[i][j][gq * 4 + 1] + bv.y;
             v[2] = acc[i][j][gq * 4 + 2] + bv.z; v[3] = acc[i][j][gq * 4 + 3] + bv.w;
@@ -147,15 +150,15 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     // lgkmcnt wait for the whole tile instead of a read -> wait -> store chain per row pair.
     const bf16_t* mask = a.mask;
     const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m: no decode
-    uint4 rowv[16];
+    uint4 rowv[RW / 2];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int r = wave * 32 + it * 2 + (lane >> 5);
+    for (int it = 0; it < RW / 2; ++it) {
+        const int r = wave * RW + it * 2 + (lane >> 5);
         rowv[it] = *reinterpret_cast<const uint4*>(lds + r * 512 + (lane & 31) * 16);
     }
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int r = wave * 32 + it * 2 + (lane >> 5);
+    for (int it = 0; it < RW / 2; ++it) {
+        const int r = wave * RW + it * 2 + (lane >> 5);
         const int c = (lane & 31) ^ (r & 31);
         const int m = m0 + r;
         const bf16_t* rp = m >= a.M ? nullptr : (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
@@ -185,8 +188,14 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
 //   4 OLDORDER   fragment reads 12 / 4 / 8 / 0 per phase (W c0 read in L0 instead of the previous tile's L3)
 // MODE 0: "phase" schedule above.  MODE 1: "stream" schedule (below, after the phase loop's description): every wave runs ONE
 // software-pipelined instruction stream with a single barrier per K-tile.
-template <int MODE, int VAR>
+// MJ: 32-pixel blocks per wave.  4: the 256-pixel tile.  2 (stream schedule only): a 128-pixel x 256-cout tile for launches whose
+// 256-pixel tiles cannot fill the chip (layer3's 64 x 64 maps: 128 tiles) -- same staging, swizzle, schedule and epilogue, wave
+// tile 64 x 64; LDS reads and copies per FLOP rise by a third, twice as many workgroups.
+template <int MODE, int VAR, int MJ = 4>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
+    static_assert(MJ == 4 || (MJ == 2 && MODE == 1 && !(VAR & 2)), "the 128-pixel tile exists for the stream schedule");
+    constexpr int NI = MJ;                                          // activation rows staged per thread (64 rows apart)
+    constexpr int BM = 64 * MJ;
     constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
     constexpr bool TRACE = VAR & 1, NOPRIO = !ABL && (VAR & 2), OLDORDER = !ABL && (VAR & 4);
     constexpr bool NOGLDS = ABL && ((VAR >> 1) & 3) == 0, NOREADS = ABL && ((VAR >> 1) & 3) == 1, NOMFMA = ABL && ((VAR >> 1) & 3) == 2,
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     int bx, by;
     if (a.nfast) { bx = fastdiv(Vg, a.gy_mul, a.gy_sh); by = Vg - bx * (int)gridDim.y; }
     else { by = fastdiv(Vg, a.gx_mul, a.gx_sh); bx = Vg - by * (int)gridDim.x; }
-    const int m0 = bx * 256, n0 = by * 256;
+    const int m0 = bx * BM, n0 = by * 256;
     const int g = bz;
     const bf16_t* src = a.src + (long)g * a.src_gs;
     const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     unsigned a_mask[4];
     int a_iy[4], a_ix[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int row = i * 64 + srow;
         const int m = m0 + row;
         a_ptr[i] = src;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             mk1 |= ((iy1_ >= 0) & (iy1_ < a.IH) & (ix1_ >= 0) & (ix1_ < a.IW)) ? (1u << t) : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int m = m0 + i * 64 + srow;
             if (a_iy[i] >= 0) a_mask[i] = (fastdiv(m, a.pms_mul, a.pms_sh) == seg0) ? mk0 : mk1;      // (padding rows keep mask 0)
         }
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         for (int t = 0; t < a.T; ++t) {
             const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                 a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
             }
@@ -302,7 +311,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     int nk = a.T * kchunks;
     if (a.pixmajor) {
         unsigned* wor = reinterpret_cast<unsigned*>(lds + PLDS - 64);   // inside X buf1's last row: first overwritten in slot 4
-        unsigned mm = a_mask[0] | a_mask[1] | a_mask[2] | a_mask[3];
+        unsigned mm = a_mask[0] | a_mask[1];
+        if constexpr (NI == 4) mm |= a_mask[2] | a_mask[3];
         for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
         if (lane == 0) wor[wave] = mm;
         __syncthreads();
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     auto issue_x = [&](auto halfc, auto bufc) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
+        if constexpr (2 * H >= NI) return;                        // (128-pixel tile: the second half does not exist)
         const long aoff = st_aoff + st_c;
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i) {
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const char* wb[4];
     const char* xb[4];
     {
-        const int rw = wn * 64 + frow, rx = wm * 128 + frow;
+        const int rw = wn * 64 + frow, rx = wm * (32 * MJ) + frow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int q = ks * 2 + fq;
@@ -439,13 +450,15 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         bf16x8 fa[6], fb[6];
         auto rd1 = [&](bf16x8 (&f)[6], auto bufc, auto ksc, auto idxc) {      // fragment idx of set F(., KS): 0,1 = W c0,c1; 2..5 = X
             constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
-            if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
+            if constexpr (I >= 2 + MJ) { }                                     // (128-pixel tile: two activation fragments)
+            else if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
             else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBUF + I * 4096);
             else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBUF + (I - 2) * 4096);
         };
         auto mm2 = [&](bf16x8 (&f)[6], auto jc) {                               // the two MFMAs of pixel block j
             constexpr int J = decltype(jc)::value;
-            if constexpr (NOMFMA) { asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2 + J])); }
+            if constexpr (J >= MJ) { }
+            else if constexpr (NOMFMA) { asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2 + J])); }
             else {
                 acc[0][J] = LOFT_MFMA_32x32x16(f[0], f[2 + J], acc[0][J]);
                 acc[1][J] = LOFT_MFMA_32x32x16(f[1], f[2 + J], acc[1][J]);
@@ -563,8 +576,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         if constexpr (VAR & 2)
             conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
                                          a.pixmajor != 0);
-        else if (a.residual) pipe_epilogue_staged<true>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-        else pipe_epilogue_staged<false>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else if (a.residual) pipe_epilogue_staged<true, MJ>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else pipe_epilogue_staged<false, MJ>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long kst3 = __builtin_amdgcn_s_memtime();
@@ -742,20 +755,23 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
     if (wm == 0) PIPE_BARRIER();          // barrier counts of the two groups match again
 
-    if (a.residual) pipe_epilogue_staged<true>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-    else pipe_epilogue_staged<false>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    if (a.residual) pipe_epilogue_staged<true, 4>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    else pipe_epilogue_staged<false, 4>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
-int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, hipStream_t s) {
+int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, hipStream_t s) {
     ConvArgs a = a_in;
-    dim3 grid(loft_cdiv(a.M, 256), a.Cout / 256, groups);
+    if (mj != 4 && !(mj == 2 && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
+    dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / 256, groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
     fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);
     a.pointwise = a.T == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.ss == 1 && !a.pixmajor && a.IH == a.OH && a.IW == a.OW;
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
-    if (mode == 1) {
+    if (mode == 1 && mj == 2) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2>), grid, dim3(512), 0, s, a);
+    } else if (mode == 1) {
         switch (var) {
         case 0: PIPE_LAUNCH(1, 0); break;
         case 1: PIPE_LAUNCH(1, 1); break;

@@ -69,6 +69,9 @@ FWD = [
     ('fc1_12544_1024.stream256', (1, 8192, 12544, 1024, 1, 1, 1, 1, 0), 'CONV_STREAM256'),
     ('layer4_3x3_512.stream256', (1, 8, 512, 512, 32, 32, 3, 1, 1), 'CONV_STREAM256'),
     ('rpn_narrow_16.t128x64', (1, 8, 256, 16, 128, 128, 1, 1, 0), 'CONV_T128x64'),
+    ('layer3_3x3.stream128', (1, 8, 256, 256, 64, 64, 3, 1, 1), 'CONV_STREAM128'),
+    ('layer3_reduce_1024_256.stream128', (1, 8, 1024, 256, 64, 64, 1, 1, 0), 'CONV_STREAM128'),
+    ('mask_3x3_pixmajor.stream128', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM128'),
 ]
 
 
@@ -80,7 +83,7 @@ def test_fwd_bench_size_sampled_values(name, shape, variant):
     wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
     K.CONV_VARIANT = getattr(K, variant)
     try:
-        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256')
+        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128')
         out = K.conv2d_fwd(x, wp, bias, R, R, stride, pad, out_dtype=torch.bfloat16 if bf16_only else torch.float32, groups=G)
     finally:
         K.CONV_VARIANT = K.CONV_AUTO
@@ -137,7 +140,7 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         res = _cl(torch.randn(B, Cout, H, W, device='cuda').bfloat16())
         outs = []
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_T256, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR,
-                  K.CONV_STREAM256, K.CONV_PIPE256):
+                  K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128):
             K.CONV_VARIANT = v
             try:
                 # (the pipelined kernels serve bf16 outputs; fp32 / accumulating launches stay on the lockstep ones)
@@ -150,10 +153,10 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
             finally:
                 K.CONV_VARIANT = K.CONV_AUTO
             outs.append((o16, gm, o16p, o16r, grm))
-        for o in outs[1:4]:
+        for o in outs[1:5]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)
-        for o in outs[4:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
+        for o in outs[5:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
             for got, want in zip(o, outs[0]):
                 if want is None:
                     assert got is None

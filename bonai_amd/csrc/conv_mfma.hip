@@ -444,7 +444,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_STREAM128 || (variant & ~0xffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM128 || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -530,7 +530,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.pm_S = B; a.pm_P = OH * OW;
         if (pix_ok) {
             // RoI blocks of >= 256 rows per pixel position (ConvArgs::pm_S): padded row count nb * P * S >= P * B
-            const int nb = std::max(1, B / 256);
+            const int nb = (variant & LOFT_CONV_FLAG_NO_ROI_BLOCKS) ? 1 : std::max(1, B / 256);
             a.pm_S = (B + nb - 1) / nb;
             const long Mp = (long)nb * a.pm_P * a.pm_S;
             if (Mp > 0x7fffffffL) return (int)hipErrorInvalidValue;

@@ -444,7 +444,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_STREAM128 || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM64 || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -504,6 +504,9 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         if (Cout % 256 == 0 && big_blocks < 192 && half_blocks >= 192 && Kdim >= 1024 && !out_f32 && !accumulate) {
             // too few 256-pixel tiles to fill the chip (layer3's 64 x 64 maps): the stream kernel on 128-pixel tiles
             k = LOFT_CONV_STREAM128;
+        } else if (Cout % 256 == 0 && half_blocks < 192 && (long)loft_cdiv(M, 64) * (Cout / 256) * groups >= 192 && Kdim >= 2048 &&
+                   !out_f32 && !accumulate) {
+            k = LOFT_CONV_STREAM64;           // layer4's 32 x 32 maps
         } else if (Cout % 256 == 0 && big_blocks >= 192 && !out_f32 && !accumulate) {
             // bf16 output: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue (conv_pipe.hip; +26..43 %
             // over the lockstep 256-tile kernel on the 3x3 / FC shapes, +15..35 % over the 128-tile kernels on the K-shallow 1x1s)
@@ -520,6 +523,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else k = LOFT_CONV_T128x64;
     }
     switch (k) {
+    case LOFT_CONV_STREAM64:
     case LOFT_CONV_STREAM128:
     case LOFT_CONV_STREAM256:
     case LOFT_CONV_PIPE256:
@@ -541,7 +545,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
-        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf, k == LOFT_CONV_STREAM128 ? 2 : 4, s);
+        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf, k == LOFT_CONV_STREAM128 ? 2 : (k == LOFT_CONV_STREAM64 ? 1 : 4), s);
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still

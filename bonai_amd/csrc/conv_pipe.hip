@@ -188,12 +188,12 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
 //   4 OLDORDER   fragment reads 12 / 4 / 8 / 0 per phase (W c0 read in L0 instead of the previous tile's L3)
 // MODE 0: "phase" schedule above.  MODE 1: "stream" schedule (below, after the phase loop's description): every wave runs ONE
 // software-pipelined instruction stream with a single barrier per K-tile.
-// MJ: 32-pixel blocks per wave.  4: the 256-pixel tile.  2 (stream schedule only): a 128-pixel x 256-cout tile for launches whose
+// MJ: 32-pixel blocks per wave.  4: the 256-pixel tile.  2 / 1 (stream schedule only): a 128- / 64-pixel x 256-cout tile for launches whose
 // 256-pixel tiles cannot fill the chip (layer3's 64 x 64 maps: 128 tiles) -- same staging, swizzle, schedule and epilogue, wave
 // tile 64 x 64; LDS reads and copies per FLOP rise by a third, twice as many workgroups.
 template <int MODE, int VAR, int MJ = 4>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
-    static_assert(MJ == 4 || (MJ == 2 && MODE == 1 && !(VAR & 2)), "the 128-pixel tile exists for the stream schedule");
+    static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
     constexpr int NI = MJ;                                          // activation rows staged per thread (64 rows apart)
     constexpr int BM = 64 * MJ;
     constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     int nk = a.T * kchunks;
     if (a.pixmajor) {
         unsigned* wor = reinterpret_cast<unsigned*>(lds + PLDS - 64);   // inside X buf1's last row: first overwritten in slot 4
-        unsigned mm = a_mask[0] | a_mask[1];
+        unsigned mm = a_mask[0];
+        if constexpr (NI >= 2) mm |= a_mask[1];
         if constexpr (NI == 4) mm |= a_mask[2] | a_mask[3];
         for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
         if (lane == 0) wor[wave] = mm;
@@ -399,10 +400,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     auto issue_x = [&](auto halfc, auto bufc) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
-        if constexpr (2 * H >= NI) return;                        // (128-pixel tile: the second half does not exist)
+        if constexpr (2 * H >= NI) return;                        // (128- / 64-pixel tiles: the second half does not exist)
         const long aoff = st_aoff + st_c;
 #pragma unroll
-        for (int i = 2 * H; i < 2 * H + 2; ++i) {
+        for (int i = 2 * H; i < (2 * H + 2 < NI ? 2 * H + 2 : NI); ++i) {
             const bf16_t* p = (NOSEL || ((a_mask[i] >> st_t) & 1u)) ? a_ptr[i] + aoff : a.zero_page;
             __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PX_OFF + B * PBUF + (i * 64 + wave * 8) * 128), 16, 0, 0);
         }
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, hipStream_t s) {
     ConvArgs a = a_in;
-    if (mj != 4 && !(mj == 2 && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
+    if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
     dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / 256, groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
@@ -771,6 +772,8 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
     if (mode == 1 && mj == 2) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2>), grid, dim3(512), 0, s, a);
+    } else if (mode == 1 && mj == 1) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1>), grid, dim3(512), 0, s, a);
     } else if (mode == 1) {
         switch (var) {
         case 0: PIPE_LAUNCH(1, 0); break;

@@ -72,6 +72,8 @@ FWD = [
     ('layer3_3x3.stream128', (1, 8, 256, 256, 64, 64, 3, 1, 1), 'CONV_STREAM128'),
     ('layer3_reduce_1024_256.stream128', (1, 8, 1024, 256, 64, 64, 1, 1, 0), 'CONV_STREAM128'),
     ('mask_3x3_pixmajor.stream128', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM128'),
+    ('layer4_3x3_512.stream64', (1, 8, 512, 512, 32, 32, 3, 1, 1), 'CONV_STREAM64'),
+    ('foa_3x3_groups4_pixmajor.stream64', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_STREAM64'),
 ]
 
 
@@ -83,7 +85,7 @@ def test_fwd_bench_size_sampled_values(name, shape, variant):
     wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
     K.CONV_VARIANT = getattr(K, variant)
     try:
-        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128')
+        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128', 'CONV_STREAM64')
         out = K.conv2d_fwd(x, wp, bias, R, R, stride, pad, out_dtype=torch.bfloat16 if bf16_only else torch.float32, groups=G)
     finally:
         K.CONV_VARIANT = K.CONV_AUTO
@@ -140,7 +142,8 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         res = _cl(torch.randn(B, Cout, H, W, device='cuda').bfloat16())
         outs = []
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_T256, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR,
-                  K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128):
+                  K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM64 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256,
+                  K.CONV_STREAM128):
             K.CONV_VARIANT = v
             try:
                 # (the pipelined kernels serve bf16 outputs; fp32 / accumulating launches stay on the lockstep ones)
@@ -153,10 +156,10 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
             finally:
                 K.CONV_VARIANT = K.CONV_AUTO
             outs.append((o16, gm, o16p, o16r, grm))
-        for o in outs[1:5]:
+        for o in outs[1:6]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)
-        for o in outs[5:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
+        for o in outs[6:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
             for got, want in zip(o, outs[0]):
                 if want is None:
                     assert got is None

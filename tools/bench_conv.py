@@ -56,11 +56,11 @@ def main():
         g = torch.randn_like(y)
         row = f'{name:28s} {gflop:8.1f} '
         for wh in which:
-            if wh in ('pipe', 'stream', 'stream128'):
+            if wh in ('pipe', 'stream', 'stream128', 'stream64'):
                 if Cout % 256:
                     row += f'{"-":>10s} {"-":>8s} '
                     continue
-                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe' else (K.CONV_STREAM128 if wh == 'stream128' else K.CONV_STREAM256)
+                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe' else (K.CONV_STREAM128 if wh == 'stream128' else (K.CONV_STREAM64 if wh == 'stream64' else K.CONV_STREAM256))
                 ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
                 K.CONV_VARIANT = K.CONV_AUTO
             elif wh in ('pipe_dgrad', 'stream_dgrad'):

@@ -514,7 +514,9 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else if (Cout % 256 == 0 && big_blocks >= 192 && Kdim >= 512) {
             k = deepk ? LOFT_CONV_T256_FAST : LOFT_CONV_T256;
         }
-        else if (Cout % 128 == 0) {
+        else if (Cout % 128 == 0 && !out_f32 && !accumulate && Kdim >= 1024 && (long)loft_cdiv(M, 256) * (Cout / 128) * groups >= 192) {
+            k = LOFT_CONV_STREAM256;          // 128-cout tiles of the stream kernel (layer2's 3x3 convs and their data gradients)
+        } else if (Cout % 128 == 0) {
             const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
             const bool two_tiles = residual && relu_mask && dense_out;        // needs both halves of the double buffer
             // (single-stage form at four workgroups per CU: K <= 512 since round 2 -- 8x128x128 512->128: 37.8 against 48.8 us)
@@ -529,7 +531,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     case LOFT_CONV_PIPE256:
         // software-pipelined 256x256 kernels (conv_pipe.hip)
         // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
-        if (Cout % 256 || out_f32 || accumulate) return (int)hipErrorInvalidValue;
+        if ((Cout % 256 && !(k == LOFT_CONV_STREAM256 && Cout % 128 == 0)) || out_f32 || accumulate) return (int)hipErrorInvalidValue;
         a.pixmajor = pix_ok;
         a.pm_S = B; a.pm_P = OH * OW;
         if (pix_ok) {

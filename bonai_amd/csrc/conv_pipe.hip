@@ -82,48 +82,54 @@ __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const b
 // are dead by then.  RES: the residual tile (bottleneck shortcut, resnet.py:294-296; shortcut gradient of a fused block) comes in
 // through LDS with whole-row copies first; every lane reads its 8-byte pieces from there, adds in fp32 and overwrites them with
 // the result in place.
-template <int MJ>
+// NW = 32-cout blocks per wave: 2 -> 256 couts per tile (512-byte rows, 32 chunks), 1 -> 128 couts (256-byte rows, 16 chunks).
+template <int MJ, int NW>
 __device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int ohw, int wave, int lane,
                                               char* lds) {
     constexpr int RW = 8 * MJ;                    // tile rows copied by one wave (8 waves cover 64 MJ rows)
+    constexpr int CPR = 16 * NW, RPI = 64 / CPR;  // 16-byte chunks per row; rows per wave-level copy
 #pragma unroll 1
-    for (int it = 0; it < RW / 2; ++it) {
-        const int r = wave * RW + it * 2 + (lane >> 5);
-        const int c = (lane & 31) ^ (r & 31);                 // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
+    for (int it = 0; it < RW / RPI; ++it) {
+        const int r = wave * RW + it * RPI + lane / CPR;
+        const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));   // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
         const int m = m0 + r;
         const bf16_t* p = a.zero_page;
         if (m < a.M) {
             const bf16_t* rp = pipe_row_ptr(a, t, out_g, m, n0, ohw);
             if (rp) p = rp + c * 8;
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * RW + it * 2) * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * RW + it * RPI) * (CPR * 16)), 16, 0, 0);
     }
 }
 
-template <bool RES, int MJ, typename StampFn>
+template <bool RES, int MJ, int NW, typename StampFn>
 __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[2][4], char* lds, int g, int m0, int n0, int wave,
                                                      int lane, int ohw, StampFn&& kstamp) {
     constexpr int RW = 8 * MJ;
+    constexpr int CPR = 16 * NW, ROWB = CPR * 16, RPI = 64 / CPR;      // chunks per row, bytes per row, rows per wave-level access
     const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
     const long out_g = (long)g * a.out_gs;
     // (no bias: read zeros -- a branch around the adds makes hipcc keep two copies of the 128 accumulator registers)
-    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs + n0 + wn * 64 + 4 * fq : reinterpret_cast<const float*>(a.zero_page) + 4 * fq;
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs + n0 + wn * (32 * NW) + 4 * fq
+                               : reinterpret_cast<const float*>(a.zero_page) + 4 * fq;
     // This lane's 8-byte piece (4 couts) of block (i, gq) in tile row r = wm*128 + j*32 + frow is piece p = wn*16 + i*8 + 2*gq + fq,
     // i.e. 16-byte chunk wn*8 + k (k = i*4 + gq) at position chunk ^ (r & 31) = ((wn ^ (frow>>3)) << 3) | (k ^ (frow & 7)):
     // eight per-lane offsets, the row block j is a ds immediate (j * 16 KiB).
-    char* rowb = lds + (wm * (32 * MJ) + frow) * 512 + fq * 8 + (((wn ^ (frow >> 3)) << 3) << 4);
-    const int f7 = frow & 7;
+    // (NW = 1: the wave's 32 couts are the four chunks wn*4 + gq of a 16-chunk row: position ((wn ^ ((frow>>2)&3)) << 2) | (gq ^ (frow&3)))
+    char* rowb = lds + (wm * (32 * MJ) + frow) * ROWB + fq * 8 +
+                 (NW == 2 ? (((wn ^ (frow >> 3)) << 3) << 4) : (((wn ^ ((frow >> 2) & 3)) << 2) << 4));
+    const int f7 = NW == 2 ? (frow & 7) : (frow & 3);
     const float lo = a.relu ? 0.f : -__builtin_inff();          // ReLU as a branch-free max
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // every wave is done with the K loop's fragments
     kstamp(44);
     if constexpr (RES) {
-        pipe_stage_in<MJ>(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
+        pipe_stage_in<MJ, NW>(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4 * NW; ++k) {
         const int i = k >> 2, gq = k & 3;
         const float4 bv = *reinterpret_cast<const float4*>(bias + i * 32 + 8 * gq);
         char* q = rowb + ((k ^ f7) << 4);
@@ -134,11 +140,11 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
             v[2] = acc[i][j][gq * 4 + 2] + bv.z; v[3] = acc[i][j][gq * 4 + 3] + bv.w;
             if constexpr (RES) {
                 float rv[4];
-                ld4(reinterpret_cast<const bf16_t*>(q + j * 16384), rv);
+                ld4(reinterpret_cast<const bf16_t*>(q + j * (32 * ROWB)), rv);
                 v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
             }
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
-            st4(reinterpret_cast<bf16_t*>(q + j * 16384), v);
+            st4(reinterpret_cast<bf16_t*>(q + j * (32 * ROWB)), v);
             if constexpr (RES) PIPE_SB();
         }
     }
@@ -150,16 +156,16 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     // lgkmcnt wait for the whole tile instead of a read -> wait -> store chain per row pair.
     const bf16_t* mask = a.mask;
     const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m: no decode
-    uint4 rowv[RW / 2];
+    uint4 rowv[RW / RPI];
 #pragma unroll
-    for (int it = 0; it < RW / 2; ++it) {
-        const int r = wave * RW + it * 2 + (lane >> 5);
-        rowv[it] = *reinterpret_cast<const uint4*>(lds + r * 512 + (lane & 31) * 16);
+    for (int it = 0; it < RW / RPI; ++it) {
+        const int r = wave * RW + it * RPI + lane / CPR;
+        rowv[it] = *reinterpret_cast<const uint4*>(lds + r * ROWB + (lane & (CPR - 1)) * 16);
     }
 #pragma unroll
-    for (int it = 0; it < RW / 2; ++it) {
-        const int r = wave * RW + it * 2 + (lane >> 5);
-        const int c = (lane & 31) ^ (r & 31);
+    for (int it = 0; it < RW / RPI; ++it) {
+        const int r = wave * RW + it * RPI + lane / CPR;
+        const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));
         const int m = m0 + r;
         const bf16_t* rp = m >= a.M ? nullptr : (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
                                                        : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw));
@@ -191,9 +197,13 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
 // MJ: 32-pixel blocks per wave.  4: the 256-pixel tile.  2 / 1 (stream schedule only): a 128- / 64-pixel x 256-cout tile for launches whose
 // 256-pixel tiles cannot fill the chip (layer3's 64 x 64 maps: 128 tiles) -- same staging, swizzle, schedule and epilogue, wave
 // tile 64 x 64; LDS reads and copies per FLOP rise by a third, twice as many workgroups.
-template <int MODE, int VAR, int MJ = 4>
+// NW: 32-cout blocks per wave.  2: 256 couts per tile.  1 (stream schedule only): 128 couts per tile (layer2's 128-channel convs: Cout
+// is not a multiple of 256) -- one weight fragment per sub-step, 256-byte output rows in the staged epilogue.
+template <int MODE, int VAR, int MJ = 4, int NW = 2>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
+    static_assert(NW == 2 || (NW == 1 && MODE == 1 && !(VAR & 2)), "the 128-cout tile exists for the stream schedule");
+    constexpr int BN = 128 * NW;
     constexpr int NI = MJ;                                          // activation rows staged per thread (64 rows apart)
     constexpr int BM = 64 * MJ;
     constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     int bx, by;
     if (a.nfast) { bx = fastdiv(Vg, a.gy_mul, a.gy_sh); by = Vg - bx * (int)gridDim.y; }
     else { by = fastdiv(Vg, a.gx_mul, a.gx_sh); bx = Vg - by * (int)gridDim.x; }
-    const int m0 = bx * BM, n0 = by * 256;
+    const int m0 = bx * BM, n0 = by * BN;
     const int g = bz;
     const bf16_t* src = a.src + (long)g * a.src_gs;
     const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     auto issue_w = [&](auto halfc, auto bufc) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
+        if constexpr (2 * H >= 2 * NW) return;                    // (128-cout tile: the second half does not exist)
         const bf16_t* wt = st_w + (MODE == 1 ? sw_c : st_c) + b_off0;
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i)
@@ -425,7 +436,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const char* wb[4];
     const char* xb[4];
     {
-        const int rw = wn * 64 + frow, rx = wm * (32 * MJ) + frow;
+        const int rw = wn * (32 * NW) + frow, rx = wm * (32 * MJ) + frow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int q = ks * 2 + fq;
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         bf16x8 fa[6], fb[6];
         auto rd1 = [&](bf16x8 (&f)[6], auto bufc, auto ksc, auto idxc) {      // fragment idx of set F(., KS): 0,1 = W c0,c1; 2..5 = X
             constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
-            if constexpr (I >= 2 + MJ) { }                                     // (128-pixel tile: two activation fragments)
+            if constexpr (I >= 2 + MJ || (I == 1 && NW == 1)) { }              // (smaller tiles: fewer activation / weight fragments)
             else if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
             else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBUF + I * 4096);
             else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBUF + (I - 2) * 4096);
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             else if constexpr (NOMFMA) { asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2 + J])); }
             else {
                 acc[0][J] = LOFT_MFMA_32x32x16(f[0], f[2 + J], acc[0][J]);
-                acc[1][J] = LOFT_MFMA_32x32x16(f[1], f[2 + J], acc[1][J]);
+                if constexpr (NW == 2) acc[1][J] = LOFT_MFMA_32x32x16(f[1], f[2 + J], acc[1][J]);
             }
         };
         using k0_t = std::integral_constant<int, 0>;
@@ -515,7 +526,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             advance_w(); advance_x();
             issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
             advance_w();
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but W(1)'s copies has landed
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -577,8 +589,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         if constexpr (VAR & 2)
             conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
                                          a.pixmajor != 0);
-        else if (a.residual) pipe_epilogue_staged<true, MJ>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-        else pipe_epilogue_staged<false, MJ>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else pipe_epilogue_staged<false, MJ, NW>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long kst3 = __builtin_amdgcn_s_memtime();
@@ -756,21 +768,25 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
     if (wm == 0) PIPE_BARRIER();          // barrier counts of the two groups match again
 
-    if (a.residual) pipe_epilogue_staged<true, 4>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-    else pipe_epilogue_staged<false, 4>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    if (a.residual) pipe_epilogue_staged<true, 4, 2>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    else pipe_epilogue_staged<false, 4, 2>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, hipStream_t s) {
     ConvArgs a = a_in;
     if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
-    dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / 256, groups);
+    const int nw = a.Cout % 256 == 0 ? 2 : 1;                       // 128-cout tiles for Cout = 128 (mod 256)
+    if (nw == 1 && !(mode == 1 && var == 0 && mj == 4 && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
+    dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / (128 * nw), groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
     fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);
     a.pointwise = a.T == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.ss == 1 && !a.pixmajor && a.IH == a.OH && a.IW == a.OW;
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
-    if (mode == 1 && mj == 2) {
+    if (nw == 1) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 1>), grid, dim3(512), 0, s, a);
+    } else if (mode == 1 && mj == 2) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2>), grid, dim3(512), 0, s, a);
     } else if (mode == 1 && mj == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1>), grid, dim3(512), 0, s, a);

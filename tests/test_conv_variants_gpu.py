@@ -72,6 +72,8 @@ FWD = [
     ('layer3_3x3.stream128', (1, 8, 256, 256, 64, 64, 3, 1, 1), 'CONV_STREAM128'),
     ('layer3_reduce_1024_256.stream128', (1, 8, 1024, 256, 64, 64, 1, 1, 0), 'CONV_STREAM128'),
     ('mask_3x3_pixmajor.stream128', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM128'),
+    ('layer2_3x3_128.stream_n128', (1, 8, 128, 128, 128, 128, 3, 1, 1), 'CONV_STREAM256'),
+    ('layer2_reduce_512_128.stream_n128', (1, 8, 512, 128, 128, 128, 1, 1, 0), 'CONV_STREAM256'),
     ('layer4_3x3_512.stream64', (1, 8, 512, 512, 32, 32, 3, 1, 1), 'CONV_STREAM64'),
     ('foa_3x3_groups4_pixmajor.stream64', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_STREAM64'),
 ]
@@ -103,6 +105,8 @@ DGRAD = [
     ('foa_3x3_groups4_pixmajor.pipe256', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_PIPE256'),
     ('fpn_p2_3x3.stream256', (1, 8, 256, 256, 256, 256, 3, 1, 1), 'CONV_STREAM256'),
     ('mask_3x3_pixmajor.stream256', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM256'),
+    ('layer2_expand_128_512.stream_n128', (1, 8, 128, 512, 128, 128, 1, 1, 0), 'CONV_STREAM256'),      # dgrad: 512 -> 128 channels
+    ('layer2_3x3_128.stream_n128', (1, 8, 128, 128, 128, 128, 3, 1, 1), 'CONV_STREAM256'),
 ]
 
 
@@ -282,3 +286,25 @@ def test_trainer_step_with_split_slots_matches_atomics():
     a, b = grads
     assert torch.isfinite(b).all()
     assert (a - b).norm().item() <= 5e-4 * a.norm().item(), ((a - b).norm().item(), a.norm().item())   # measured 1.4e-4 (sum order)
+
+
+def test_stream_kernel_128_cout_tiles_bit_identical_to_lockstep_128():
+    """Cout = 128 (mod 256): the stream kernel's 128-cout tile (one weight fragment per sub-step, 256-byte rows in the staged
+    epilogue) in tap-major K order against conv_tap_kernel<128,128,...,FAST>: same sums, same epilogue arithmetic -> bit-identical,
+    incl. residual, ReLU-backward mask, ragged M."""
+    from bonai_amd import kernels as K
+    for (B, Cin, Cout, H, W, R, pad) in [(2, 128, 128, 37, 41, 3, 1), (3, 256, 384, 20, 20, 1, 0), (1, 64, 128, 9, 9, 3, 1)]:
+        x, w, bias = _mk(1, B, Cin, Cout, H, W, R, seed=B + 10)
+        wp = K.pack_w_fwd(w[0])[None]
+        res = _cl(torch.randn(B, Cout, H, W, device='cuda').bfloat16())
+        outs = []
+        for v in (K.CONV_T128_FAST, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR):
+            K.CONV_VARIANT = v
+            try:
+                outs.append((K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True),
+                             K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, residual=res),
+                             K.conv2d_fwd(x, wp, None, R, R, 1, pad)))
+            finally:
+                K.CONV_VARIANT = K.CONV_AUTO
+        for got, want in zip(outs[1], outs[0]):
+            assert torch.equal(got, want), (B, Cin, Cout, H, W, R)

@@ -460,10 +460,19 @@ __device__ __forceinline__ int nth_set_bit(unsigned m, int n) {      // position
 
 #define RBM_CHUNK 32      // bins per operand chunk: 24 KiB of LDS per block -> 6 blocks per CU hide the staging latency
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, const float* __restrict__ rois,
-                                                                 int K, int P, int n_rot, const bf16_t* __restrict__ gout,
-                                                                 bf16_t* __restrict__ grad, int accumulate,
-                                                                 const int4* __restrict__ rec, int sorted) {
+// Up to RBM_SETS RoI lists (the three extractors of the LOFT head share one pyramid) scatter into the same maps in ONE
+// launch: the tile owner walks list after list into the same fp32 accumulators and writes each pixel once.
+#define RBM_SETS 3
+struct RoiBwdSets {
+    const float* rois[RBM_SETS];
+    const bf16_t* gout[RBM_SETS];
+    const int4* rec[RBM_SETS];
+    int K[RBM_SETS], P[RBM_SETS], n_rot[RBM_SETS], sorted[RBM_SETS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, RoiBwdSets S,
+                                                                 bf16_t* __restrict__ grad, int accumulate) {
     constexpr int C = 256;
     __shared__ __attribute__((aligned(16))) char gbuf[RBM_CHUNK * 512];      // [bin][256 ch] bf16, 16-byte chunks swizzled
     __shared__ __attribute__((aligned(16))) char abuf[RBM_CHUNK * 256];      // [bin][64 px hi | 64 px lo] bf16
@@ -476,16 +485,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 2) {
-        int lo = 0, hi = K;
-        const int key = b + tid;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
-        range[tid] = lo;
-    }
     for (int i = tid; i < RBM_CHUNK * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < RBM_CHUNK * 256 / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const int kbeg = sorted ? range[0] : 0, kend = sorted ? range[1] : K;
     rf32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -493,6 +494,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* rois = nullptr;
+    const bf16_t* gout = nullptr;
+    const int4* rec = nullptr;
+    int K = 0, P = 0, n_rot = 1;
 
     // 1-D weight tables of one RoI for this tile + which bin rows / columns have any weight in it (wave ballots: waves 0-1
     // hold the 8 tile rows of bins 0-7 / 8-13, waves 2-3 the tile columns)
@@ -515,6 +520,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         return 1.f / g.count;
     };
 
+#pragma unroll 1
+    for (int si = 0; si < S.n; ++si) {
+    rois = S.rois[si]; gout = S.gout[si]; rec = S.rec[si];
+    K = S.K[si]; P = S.P[si]; n_rot = S.n_rot[si];
+    __syncthreads();                         // (previous list: its last reads of range[] and the tables are done)
+    if (tid < 2) {
+        int lo = 0, hi = K;
+        const int key = b + tid;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
+        range[tid] = lo;
+    }
+    __syncthreads();
+    const int kbeg = S.sorted[si] ? range[0] : 0, kend = S.sorted[si] ? range[1] : K;
     for (int base = kbeg; base < kend; base += RB_LIST) {
         // ---- deterministic compaction of the RoIs that touch this tile
         const int k = base + tid;
@@ -624,6 +642,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             if (li + 1 < n) inv = tables(list[li + 1], buf ^ 1);
         }
     }
+    }   // lists
     // ---- flush: lane holds pixel 32j + (lane & 31) and 4 x 4 consecutive channels per (i, gq)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -712,11 +731,13 @@ LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, cons
         hipLaunchKernelGGL(roi_prep_kernel, dim3(loft_cdiv(K, 256)), dim3(256), 0, s, L, rois, K, P, rec);
         LOFT_LAUNCH_CHECK();
     }
+    RoiBwdSets one = {};
+    one.rois[0] = rois; one.gout[0] = (const bf16_t*)grad_out; one.rec[0] = rec;
+    one.K[0] = K; one.P[0] = P; one.n_rot[0] = n_rot; one.sorted[0] = rois_sorted; one.n = 1;
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
         if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form)
-            hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, rois, K, P, n_rot,
-                               (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
+            hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, one, (bf16_t*)grad_feats[l], accumulate);
         else if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16)
             hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
@@ -728,6 +749,47 @@ LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, cons
                                (const float*)grad_out, (float*)grad_feats[l], accumulate, rec, rois_sorted);
         else
             return (int)hipErrorInvalidValue;
+        LOFT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// Several RoI lists over the same pyramid in one pass per level (16-bit maps, C = 256: the LOFT head's three extractors).
+// Every list brings its own rois / K / P / n_rot / grad_out / sorted flag / 16*K-byte workspace; other configurations
+// run list after list through loft_roi_align_bwd_v (the later ones accumulating).
+LOFT_EXPORT int loft_roi_align_bwd_multi(void* const* grad_feats, const int* H, const int* W, const float* scales,
+                                         int num_levels, int finest_scale, int C, int dtype, int nsets,
+                                         const float* const* rois, const int* K, const int* P, const int* n_rot,
+                                         const void* const* grad_out, int B, int accumulate, const int* rois_sorted,
+                                         void* const* workspace, int grad_dtype, void* stream) {
+    if (nsets < 1) return (int)hipErrorInvalidValue;
+    const bool fused = dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && nsets <= RBM_SETS;
+    if (!fused) {
+        for (int i = 0; i < nsets; ++i) {
+            int rc = loft_roi_align_bwd_v(grad_feats, H, W, scales, num_levels, finest_scale, C, dtype, rois[i], K[i], P[i],
+                                          n_rot[i], grad_out[i], B, accumulate || i > 0, rois_sorted[i], workspace[i],
+                                          grad_dtype, LOFT_ROI_AUTO, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    if (num_levels < 1 || num_levels > 4) return (int)hipErrorInvalidValue;
+    RoiLevels L = make_levels(nullptr, H, W, scales, num_levels, finest_scale);
+    hipStream_t s = (hipStream_t)stream;
+    RoiBwdSets S = {};
+    for (int i = 0; i < nsets; ++i) {
+        if ((n_rot[i] != 1 && n_rot[i] != 4) || P[i] > RB_MAXP || K[i] < 0) return (int)hipErrorInvalidValue;
+        if (K[i] == 0) continue;
+        const int j = S.n++;
+        S.rois[j] = rois[i]; S.gout[j] = (const bf16_t*)grad_out[i]; S.rec[j] = (const int4*)workspace[i];
+        S.K[j] = K[i]; S.P[j] = P[i]; S.n_rot[j] = n_rot[i]; S.sorted[j] = rois_sorted[i];
+        hipLaunchKernelGGL(roi_prep_kernel, dim3(loft_cdiv(K[i], 256)), dim3(256), 0, s, L, rois[i], K[i], P[i],
+                           (int4*)workspace[i]);
+        LOFT_LAUNCH_CHECK();
+    }
+    for (int l = 0; l < num_levels; ++l) {
+        dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
+        hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, S, (bf16_t*)grad_feats[l], accumulate);
         LOFT_LAUNCH_CHECK();
     }
     return 0;

@@ -171,6 +171,33 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     return grad_feats
 
 
+def roi_align_bwd_multi(sets, feat_shapes, strides, finest_scale=56, grad_feats=None, out_dtype=None, out=None):
+    """Backward of several RoIAlign calls over the same pyramid, each map pixel written once (loft_roi_align_bwd_multi).
+
+    sets: [(grad_out, rois, P, n_rot, rois_sorted), ...]; writes (or with grad_feats accumulates into) NHWC maps."""
+    lib = L.load()
+    out_dtype = out_dtype or L.act16()
+    dev = sets[0][0].device
+    accumulate = grad_feats is not None
+    if grad_feats is None:      # (out: preallocated maps to write instead of fresh ones)
+        grad_feats = out if out is not None else [empty_nhwc(s[0], s[1], s[2], s[3], out_dtype, dev) for s in feat_shapes]
+    gos = [_nhwc(s[0]) for s in sets]
+    rois = [s[1].float().contiguous() for s in sets]
+    L.dev_check(*gos, *rois)
+    Ks = [r.shape[0] for r in rois]
+    wss = [torch.empty(max(16 * k, 16), dtype=torch.uint8, device=dev) for k in Ks]
+    n = len(sets)
+    L.check(lib.loft_roi_align_bwd_multi(
+        L.arr(c_void_p, [g.data_ptr() for g in grad_feats]), L.arr(c_int, [s[2] for s in feat_shapes]),
+        L.arr(c_int, [s[3] for s in feat_shapes]), L.arr(c_float, [1.0 / s for s in strides]), len(grad_feats),
+        int(finest_scale), int(gos[0].shape[1]), L.dtype_code(gos[0]), n,
+        L.arr(c_void_p, [r.data_ptr() for r in rois]), L.arr(c_int, Ks), L.arr(c_int, [int(s[2]) for s in sets]),
+        L.arr(c_int, [int(s[3]) for s in sets]), L.arr(c_void_p, [g.data_ptr() for g in gos]), int(feat_shapes[0][0]),
+        int(accumulate), L.arr(c_int, [int(bool(s[4])) for s in sets]), L.arr(c_void_p, [w.data_ptr() for w in wss]),
+        L.dtype_code(grad_feats[0]), L.stream()), 'loft_roi_align_bwd_multi')
+    return grad_feats
+
+
 class _RoIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, P, strides, finest_scale, n_rot, *feats):

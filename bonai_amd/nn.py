@@ -557,6 +557,7 @@ class _FeatHubFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        _hub_flush()                          # (lists of extractors whose siblings never ran a backward)
         out = []
         for l in range(ctx.nf):
             parts = [gs[c * ctx.nf + l] for c in range(ctx.n) if gs[c * ctx.nf + l] is not None]
@@ -578,7 +579,33 @@ def feat_hub(feats, n):
     fork = FeatFork(outs[:nf])
     fork.branches = tuple(tuple(outs[c * nf:(c + 1) * nf]) for c in range(n))
     HUB = {f.data_ptr(): None for f in feats}
+    HUB.update(_pending=[], _fresh=set(), _expected=0, _seen=0)
     return fork
+
+
+ROI_BWD_FUSED = True   # hub-managed RoIAlign backward calls wait for each other and run as ONE pass per level
+
+
+def _hub_flush():
+    """Launch the RoIAlign backward lists the hub has collected: one pass per pyramid level over all of them, every pixel
+    of the shared maps written once (kernels.roi_align_bwd_multi).  Called when the last expected list has arrived, and
+    before anything else touches the maps (the sparse RPN backward, the hub node's own backward)."""
+    if HUB is None or not HUB.get('_pending'):
+        return
+    pend, HUB['_pending'] = HUB['_pending'], []
+    while pend:
+        keys, shapes, strides, fs = pend[0][:4]
+        group = [p for p in pend if p[:4] == pend[0][:4]][:3]
+        pend = [p for p in pend if not any(p is q for q in group)]
+        maps = [HUB[k] for k in keys]
+        fresh = [k in HUB['_fresh'] for k in keys]
+        if not all(fresh):
+            for m, f in zip(maps, fresh):
+                if f:
+                    m.zero_()
+        K.roi_align_bwd_multi([p[4:] + (True,) for p in group], shapes, strides, fs,
+                              grad_feats=None if all(fresh) else maps, out_dtype=K.L.act16(), out=maps)
+        HUB['_fresh'].difference_update(keys)
 
 
 def _hub_slots(tensors):
@@ -595,6 +622,8 @@ class _RoIAlignFn(torch.autograd.Function):
         ctx.save_for_backward(rois)
         ctx.meta = (P, tuple(strides), finest_scale, n_rot, [tuple(f.shape) for f in feats], feats[0].dtype)
         ctx.hub_keys = _hub_slots(feats)
+        if HUB is not None and all(k is not None for k in ctx.hub_keys):
+            HUB['_expected'] += 1
         return K.roi_align_fwd(list(feats), rois, P, strides, finest_scale, n_rot)
 
     @staticmethod
@@ -605,6 +634,20 @@ class _RoIAlignFn(torch.autograd.Function):
         direct = dt == K.L.act16() and g.dtype == K.L.act16() and not _os.environ.get('LOFT_ROI_FP32_BWD')   # bf16 maps straight from fp32 registers
         keys = ctx.hub_keys
         if direct and HUB is not None and all(k is not None and k in HUB for k in keys):
+            if ROI_BWD_FUSED:                         # wait for the other extractors' lists; the last one launches
+                ret = []
+                for i, k in enumerate(keys):
+                    if HUB[k] is None:
+                        HUB[k] = K.empty_nhwc(*shapes[i], K.L.act16(), g.device)
+                        HUB['_fresh'].add(k)
+                        ret.append(HUB[k])
+                    else:
+                        ret.append(None)
+                HUB['_pending'].append((tuple(keys), tuple(shapes), strides, fs, g, rois, P, n_rot))
+                HUB['_seen'] += 1
+                if HUB['_seen'] >= HUB['_expected']:
+                    _hub_flush()
+                return (None, None, None, None, None) + tuple(ret)
             have = [HUB[k] for k in keys]
             if all(h is None for h in have):          # first consumer of these maps: the kernel writes every pixel
                 grads = K.roi_align_bwd(g, rois, shapes, P, strides, fs, n_rot, rois_sorted=True, out_dtype=K.L.act16())
@@ -836,6 +879,7 @@ class _SparseRPNFn(torch.autograd.Function):
         wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(K.L.act16()).contiguous()     # [(tap, cin), cout]
         dxs = K.conv2d_fwd(_as_img(gh2d), wd[None, None], None, 1, 1)
         dxs = dxs.permute(0, 2, 3, 1).reshape(nsel, 9 * C)
+        _hub_flush()                                   # the RoI extractors' maps are complete before rows are added
         dxl, ret = [], []
         for x in xs:                                   # hub-managed maps: scatter into the shared gradient map of the level
             k = x.data_ptr() if (HUB is not None and x.data_ptr() in HUB and x.dtype == K.L.act16()) else None

@@ -68,6 +68,16 @@ int loft_roi_align_bwd_v(void* const* grad_feats_host, const int* H_host, const 
                          int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                          int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,
                          int grad_dtype, int variant, void* stream);
+/* nsets RoI lists over the SAME pyramid in one pass per level: the LOFT head runs three SingleRoIExtractors (bbox 7x7,
+ * mask 14x14, FOA 14x14 x 4 rotations: loft_foa.py:126-176 calls bbox_roi_extractor / mask_roi_extractor / the offset
+ * head's extractor on the same FPN maps), so their backward passes add into the same four maps; fused (16-bit maps,
+ * C == 256, nsets <= 3) every map pixel is written once.  Per-list arguments are host arrays of length nsets;
+ * workspace[i] holds 16*K[i] bytes.  Other configurations run list after list, accumulating. */
+int loft_roi_align_bwd_multi(void* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
+                             int num_levels, int finest_scale, int C, int dtype, int nsets,
+                             const float* const* rois_host, const int* K_host, const int* P_host, const int* n_rot_host,
+                             const void* const* grad_out_host, int B, int accumulate, const int* rois_sorted_host,
+                             void* const* workspace_host, int grad_dtype, void* stream);
 /* map_roi_levels alone (single_level_roi_extractor.py:32-51) -> int32 [K]. */
 int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_scale, int32_t* out, void* stream);
 

@@ -228,3 +228,44 @@ def test_roi_align_variants_selected_in_process():
             K.roi_align_fwd(feats, rois, P, strides)
     finally:
         K.ROI_FWD_VARIANT = K.ROI_AUTO
+
+
+def test_roi_align_bwd_multi_matches_sum_of_lists():
+    """loft_roi_align_bwd_multi: the three extractors' lists (7x7; 14x14; 14x14 x 4 rotations) in one pass per level ==
+    the fp32 maps of the three lists added up (each pinned to the oracle above), incl. an empty list, the accumulate mode,
+    and the list-after-list route the library takes for C != 256."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(23)
+    B, size = 2, 256
+    strides = [4, 8, 16, 32]
+    for C in (256, 64):
+        shapes = [(B, C, size // s, size // s) for s in strides]
+        sets = []
+        for n, P, n_rot in ((500, 7, 1), (90, 14, 1), (0, 14, 1), (60, 14, 4)):
+            rois = _rand_rois(rng, n, B, size) if n else torch.zeros(0, 5)
+            rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous().cuda()
+            g = torch.randn(n_rot * n, C, P, P, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+            sets.append((g, rois, P, n_rot, True))
+        want = [torch.zeros(s[0], s[2], s[3], s[1], device='cuda').permute(0, 3, 1, 2) for s in shapes]
+        for g, rois, P, n_rot, _ in sets:
+            if rois.shape[0]:
+                for w, x in zip(want, K.roi_align_bwd(g, rois, shapes, P, strides, n_rot=n_rot, rois_sorted=True,
+                                                      out_dtype=torch.float32)):
+                    w += x
+        for group in (sets[:3], [sets[0], sets[1], sets[3]], [sets[2]]):
+            ref = [torch.zeros_like(w) for w in want]
+            for g, rois, P, n_rot, _ in group:
+                if rois.shape[0]:
+                    for w, x in zip(ref, K.roi_align_bwd(g, rois, shapes, P, strides, n_rot=n_rot, rois_sorted=True,
+                                                          out_dtype=torch.float32)):
+                        w += x
+            got = K.roi_align_bwd_multi(group, shapes, strides)
+            for gg, ww in zip(got, ref):
+                assert gg.dtype == torch.bfloat16 and gg.shape == ww.shape
+                scale = max(1.0, ww.abs().max().item())
+                tol = 6e-3 if C == 256 else 2e-2          # one rounding fused; one per list on the list-after-list route
+                assert (gg.float() - ww).abs().max().item() <= tol * scale
+            twice = K.roi_align_bwd_multi(group, shapes, strides, grad_feats=[x.clone() for x in got])
+            for tt, ww in zip(twice, ref):
+                scale = max(1.0, ww.abs().max().item())
+                assert (tt.float() - 2 * ww).abs().max().item() <= 3e-2 * scale

@@ -268,8 +268,11 @@ def main():
             sd = shapes.setdefault((name, tag), [0.0, 0.0, 0])
             sd[0] += fl; sd[1] += dt; sd[2] += 1
         if os.environ.get('LOFT_DUMP_SHAPES') and rank == 0:
-            for (name, tag), v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
-                print(f'# {name:10s} (G,B,OH,OW,Cin,Cout,T,ss,os)={tag}  n={v[2] // 2:3d}  ms/step={v[1] / 2 * 1e3:7.3f}  TF={v[0] / v[1] / 1e12:7.1f}', file=sys.stderr)
+            for (name, tag), v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:60]:
+                G_, B_, OH_, OW_, Ci_, Co_, T_, ss_, os_ = tag[:9]
+                byt = 2.0 * G_ * B_ * OH_ * OW_ * (Ci_ * ss_ * ss_ / max(1, os_ * os_) + Co_) * v[2]     # operands once (no residual)
+                print(f'# {name:10s} (G,B,OH,OW,Cin,Cout,T,ss,os)={tag}  n={v[2] // 2:3d}  ms/step={v[1] / 2 * 1e3:7.3f}  '
+                      f'us={v[1] / v[2] * 1e6:6.1f}  TF={v[0] / v[1] / 1e12:7.1f}  TB/s>={byt / v[1] / 1e12:5.2f}', file=sys.stderr)
         K.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
         ach = fam[dom][0] / fam[dom][1] / 1e12

@@ -232,23 +232,42 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(RoiLevels L, con
                 for (int q = 0; q < 4; ++q) { a0[q] = a1[q]; a1[q] = a2[q]; a2[q] = 0.f; }
                 ++p;
             };
-            for (int x = 0; x < Fw && p < P; ++x) {
-                while (p < P && xhi[p] < x) emit();           // block-uniform: bins whose support ended before this column
-                if (p >= P) break;                            // (bins without any valid sample have xhi = -1)
-                float cs[4] = {0.f, 0.f, 0.f, 0.f};
-                if (cact) {
+            // Column sums of TWO columns at a time, up to four rows each: the (wave-uniform) loads of a pair are all issued
+            // before the first one is consumed -- one load per loop trip left the kernel waiting out an L2 round trip per
+            // row (the launch was latency-bound at a few percent of the cache bandwidth).
+            const int nrow = yb - ya + 1;
+            for (int x = 0; x < Fw && p < P; x += 2) {
+                float cs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                const bool two = x + 1 < Fw;
+                if (cact && nrow > 0) {
                     const bf16_t* fp = fb + ((size_t)(y0 + ya) * W + (x0 + x)) * C + c0;
-                    for (int y = ya; y <= yb; ++y, fp += (size_t)W * C) {
-                        float t[4];
-                        ld4(fp, t);
-                        const float wy = WY[py][y];
+                    for (int yb0 = 0; yb0 < nrow; yb0 += 4) {
+                        float t[2][4][4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) cs[q] += wy * t[q];
+                        for (int r = 0; r < 4; ++r) {
+                            const bool in = yb0 + r < nrow;
+                            const bf16_t* rp = fp + (size_t)(yb0 + (in ? r : 0)) * W * C;
+                            ld4(rp, t[0][r]);
+                            ld4(two ? rp + C : rp, t[1][r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float wy = (yb0 + r < nrow) ? WY[py][ya + yb0 + r] : 0.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { cs[0][q] += wy * t[0][r][q]; cs[1][q] += wy * t[1][r][q]; }
+                        }
                     }
                 }
-                const float w0 = WX[p][x], w1 = WX[p + 1][x], w2 = WX[p + 2][x];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { a0[q] += w0 * cs[q]; a1[q] += w1 * cs[q]; a2[q] += w2 * cs[q]; }
+                for (int c = 0; c < 2; ++c) {
+                    const int xc = x + c;
+                    if (xc >= Fw) break;
+                    while (p < P && xhi[p] < xc) emit();      // block-uniform: bins whose support ended before this column
+                    if (p >= P) break;                        // (bins without any valid sample have xhi = -1)
+                    const float w0 = WX[p][xc], w1 = WX[p + 1][xc], w2 = WX[p + 2][xc];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a0[q] += w0 * cs[c][q]; a1[q] += w1 * cs[c][q]; a2[q] += w2 * cs[c][q]; }
+                }
             }
             while (p < P) emit();
         }

@@ -161,13 +161,31 @@ class RandomSampler:
         return dict(pos_idx=pidx.clamp(max=N - 1), pos_valid=pvalid, neg_idx=nidx.clamp(max=N - 1), neg_valid=nvalid)
 
 
+def pad_rows(rows, device, dtype, kmax=None):
+    """list[[K_i, ...]] -> [B, Kmax, ...] zero-padded.  One kernel when every K_i equals Kmax (stack); otherwise one cat and
+    one indexed copy -- not one copy kernel per image."""
+    B = len(rows)
+    ks = [int(r.shape[0]) for r in rows]
+    kmax = kmax or max(1, max(ks))
+    rows = [r.to(device=device, dtype=dtype) for r in rows]
+    if all(k == kmax for k in ks):
+        return torch.stack(rows)
+    out = torch.zeros((B, kmax) + tuple(rows[0].shape[1:]), dtype=dtype, device=device)
+    if sum(ks):
+        idx = K.h2d([i * kmax + j for i, k in enumerate(ks) for j in range(k)], torch.int64, device)
+        out.flatten(0, 1).index_copy_(0, idx, torch.cat(rows))
+    return out
+
+
+_PAD_GTS_CACHE = [None, None, None]      # the RPN head and the RoI head pad the same list in the same step
+
+
 def pad_gts(gt_bboxes, device):
     """list[[K_i,4]] -> (gts [B,Kmax,4] fp32, ngt int32 [B])."""
-    B = len(gt_bboxes)
-    kmax = max(1, max(int(g.shape[0]) for g in gt_bboxes))
-    gts = torch.zeros(B, kmax, 4, dtype=torch.float32, device=device)
-    for i, g in enumerate(gt_bboxes):
-        if g.shape[0]:
-            gts[i, :g.shape[0]] = g.to(device=device, dtype=torch.float32)
+    key = (str(device),) + tuple((g.data_ptr(), g._version, tuple(g.shape)) for g in gt_bboxes)
+    if _PAD_GTS_CACHE[0] == key:
+        return _PAD_GTS_CACHE[2]
+    gts = pad_rows(gt_bboxes, device, torch.float32)
     ngt = K.h2d([int(g.shape[0]) for g in gt_bboxes], torch.int32, device)
+    _PAD_GTS_CACHE[:] = [key, list(gt_bboxes), (gts, ngt)]      # (the tensors are kept alive: their addresses are the key)
     return gts, ngt

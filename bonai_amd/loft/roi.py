@@ -21,7 +21,7 @@ from .. import nn as F2
 from .backbone import ConvW
 from .builder import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head, build_loss,
                       build_roi_extractor, build_sampler)
-from .core import pad_gts
+from .core import pad_gts, pad_rows
 from .losses import accuracy
 
 
@@ -388,9 +388,7 @@ class LoftRoIHead(nn.Module):
                 gt_inds, cand = gi_p, props[..., :4]
             smp = self.bbox_sampler.sample_batched(gt_inds)
             pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
-            lab_pad = torch.zeros(B, Kmax, dtype=torch.long, device=dev)
-            for i, l in enumerate(gt_labels):
-                lab_pad[i, :l.shape[0]] = l.to(dev)
+            lab_pad = pad_rows(gt_labels, dev, torch.long, Kmax)
         fused_targets = dev.type == 'cuda' and not TENSOR_TARGETS
         if fused_targets:
             # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53), labels and bbox targets: one launch
@@ -478,9 +476,7 @@ class LoftRoIHead(nn.Module):
                 losses.update(mask_branch())
 
         with torch.no_grad():
-            off_pad = torch.zeros(B, Kmax, 2, device=dev)
-            for i, o in enumerate(gt_offsets):
-                off_pad[i, :o.shape[0]] = o.to(dev)
+            off_pad = pad_rows(gt_offsets, dev, torch.float32, Kmax)
             pos_gt_off = off_pad[pos_b, pos_gt_i]
         offset_pred = self._offset_forward(xo, pos_rois)
         with torch.no_grad():

@@ -61,10 +61,30 @@ class BucketedAllReduce:
         self.enabled = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size() > 1 or os.environ.get('LOFT_FORCE_REDUCER') == '1')
         self.buckets, self.param_bucket = [], {}
+        # The LAST buckets (the arena's tail: the backbone's first trainable layers, whose gradients finish last) are cut small,
+        # from the end: what an N-rank step cannot hide is the collective of whatever is released at the very end of backward
+        # (tools/probes/bucket_timeline.py: a 22 MiB last bucket became ready 0.1 ms before the optimizer).
+        span = lambda p: (arena.offsets[id(p)], arena.offsets[id(p)] + (p.numel() + 7) // 8 * 8)
+        tail, caps, n_tail = [], [bucket_bytes // 6, bucket_bytes // 3, bucket_bytes * 2 // 3], len(arena.order)
+        pend = []
+        for p in reversed(arena.order):
+            if not caps:
+                break
+            if pend and (span(pend[0])[1] - span(p)[0]) * 4 > caps[0]:
+                tail.append(dict(start=span(pend[-1])[0], end=span(pend[0])[1], params=pend[::-1]))
+                n_tail -= len(pend)
+                pend = []
+                caps.pop(0)
+                if not caps:
+                    break
+            pend.append(p)
+        if len(tail) < 3 or n_tail < len(arena.order) // 2:      # tiny models (tests): no taper
+            tail, n_tail = [], len(arena.order)
+        head = arena.order[:n_tail]
+        head_end = tail[-1]['start'] if tail else arena.numel
         start, pending = 0, []
-        for p in arena.order:
-            o = arena.offsets[id(p)]
-            end = o + (p.numel() + 7) // 8 * 8
+        for p in head:
+            o, end = span(p)
             if pending and (end - start) * 4 > bucket_bytes:     # a bucket exceeds the cap only for one oversized tensor (fc1)
                 self.buckets.append(dict(start=start, end=o, params=pending))
                 start, pending = o, []
@@ -73,7 +93,8 @@ class BucketedAllReduce:
                 self.buckets.append(dict(start=start, end=end, params=pending))
                 start, pending = end, []
         if pending:
-            self.buckets.append(dict(start=start, end=arena.numel, params=pending))
+            self.buckets.append(dict(start=start, end=head_end, params=pending))
+        self.buckets += tail[::-1]
         for bi, b in enumerate(self.buckets):
             for p in b['params']:
                 self.param_bucket[id(p)] = bi
@@ -91,8 +112,21 @@ class BucketedAllReduce:
         self._next = 0
         self.works = []
         self._streams = [dict() for _ in self.buckets]
+        self._queued, self._nq = set(), [0] * len(self.buckets)
         if self.on_gpu:
             self._dev = torch.cuda.current_device()
+
+    def note_queued(self, params):
+        """kernels.UnpackQueue.add: these parameters' gradient deposits now sit in the unpack queue (not launched yet).
+        -> True when the next bucket in line has nothing else outstanding, i.e. the queue should flush NOW: buckets are
+        released when their last gradient is computed, not when the queue happens to fill up."""
+        for p in params:
+            k = id(p)
+            if getattr(p, '_loft_pending', 1) <= 1 and k not in self._seen and k not in self._queued and k in self.param_bucket:
+                self._queued.add(k)
+                self._nq[self.param_bucket[k]] += 1
+        nb = self._next
+        return nb < len(self.buckets) and self._remaining[nb] > 0 and self._remaining[nb] == self._nq[nb]
 
     def _autograd_hook(self, p):
         """autograd's post-accumulate callback.  It also runs for parameters whose Function returned None because a kernel
@@ -109,6 +143,9 @@ class BucketedAllReduce:
         self._seen.add(id(p))
         bi = self.param_bucket[id(p)]
         self._remaining[bi] -= 1
+        if id(p) in self._queued:
+            self._queued.discard(id(p))
+            self._nq[bi] -= 1
         if self.on_gpu:
             # the RoI head's mask / bbox branches replay their backward on a second stream: a bucket can hold gradients
             # deposited on different streams, and its collective has to wait for the tail of every one of them
@@ -232,7 +269,8 @@ class Trainer:
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
         if F2.GRAD_SINK is not None and not os.environ.get('LOFT_NO_UNPACK_QUEUE'):
             # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
-            F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48)
+            F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48,
+                                        note=self.reducer.note_queued if self.reducer.enabled else None)
             if not os.environ.get('LOFT_NO_SIDE_STREAM') and not os.environ.get('LOFT_NO_WGRAD_STREAM'):
                 if getattr(self, '_wgrad_stream', None) is None:
                     self._wgrad_stream = torch.cuda.Stream()

@@ -1379,8 +1379,9 @@ class UnpackQueue:
     """Deferred loft_fold_unpack_bwd jobs of the trainer's direct gradient sink, flushed as ONE launch
     (loft_fold_unpack_bwd_multi) every ``limit`` jobs and at the end of the backward pass."""
 
-    def __init__(self, limit=48):
+    def __init__(self, limit=48, note=None):
         self.limit = limit
+        self.note = note       # callable(params) -> bool: "flush now" (the reducer: a gradient bucket is complete in the queue)
         self.jobs, self.done = [], []
         # jobs may be produced on a side stream (the mask branch runs beside the FOA branch); the batched launch always goes to
         # the stream the queue was created on and waits for an event per foreign job
@@ -1388,7 +1389,7 @@ class UnpackQueue:
         self.home_raw = L.stream().value if self.home is not None else None
         self.events = []
 
-    def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None, nsplit=1):
+    def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None, nsplit=1, params=()):
         """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
         launch that served this job has been enqueued (the reducer's gradient-ready notifications).
         flat_chw = (C, H, W): w is a Linear weight [O, C*H*W] and dwp [O, H*W*C] its gradient in NHWC-flattened K order."""
@@ -1401,7 +1402,7 @@ class UnpackQueue:
                 if t is not None:
                     t.record_stream(self.home)
         self.done.extend(on_done)
-        if len(self.jobs) >= self.limit:
+        if len(self.jobs) >= self.limit or (self.note is not None and self.note(params)):
             self.flush()
 
     def flush(self):

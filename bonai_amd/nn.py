@@ -203,7 +203,7 @@ class _ConvFn(torch.autograd.Function):
                             sinks += [ctx.params[2 * G], ctx.params[2 * G + 1]]
                         _mark_sunk(*sinks)
                         UNPACK_Q.add(dwp[i], None if db is None else db[i], ws[i], bn, eps, (slot_w, slot_g, slot_b),
-                                     [(lambda q=q: _sink_done(q)) for q in sinks], nsplit=nsp)
+                                     [(lambda q=q: _sink_done(q)) for q in sinks], nsplit=nsp, params=sinks)
                         if has_b and db is not None and bn is None and slot_b is None:
                             ngrads[2 * i + 1] = db[i][:ws[i].shape[0]]
                         continue
@@ -327,7 +327,7 @@ class _LinearFn(torch.autograd.Function):
                 sinks = [pw] + ([pb] if need_b else [])
                 _mark_sunk(*sinks)
                 UNPACK_Q.add(dwp[0, :, 0] if dwp.dim() == 5 else dwp[0, 0], db[0], w, None, 1e-5, (slot_w, None, slot_b),
-                             [(lambda q=q: _sink_done(q)) for q in sinks], flat_chw=flat_chw, nsplit=_nsplit(dwp))
+                             [(lambda q=q: _sink_done(q)) for q in sinks], flat_chw=flat_chw, nsplit=_nsplit(dwp), params=sinks)
             else:
                 gw = dwp[0, 0, :O, :Kd]
                 if flat_chw is not None:
@@ -950,14 +950,14 @@ def _rb_param_grads(g, x, w, bn, k, stride, pad, needs):
         with torch.cuda.stream(WGRAD_STREAM):
             dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True, slots_ok=True)
             UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)],
-                         nsplit=_nsplit(dwp))
+                         nsplit=_nsplit(dwp), params=(w, bn.weight, bn.bias))
         return None, None, None
     dwp, db = K.conv2d_wgrad(g, x, k, k, stride, pad, with_bias=True, slots_ok=sunk and UNPACK_Q is not None)
     if sunk:
         _mark_sunk(w, bn.weight, bn.bias)
         if UNPACK_Q is not None:
             UNPACK_Q.add(dwp[0], db[0], w, bnt, bn.eps, slots, [(lambda q=q: _sink_done(q)) for q in (w, bn.weight, bn.bias)],
-                         nsplit=_nsplit(dwp))
+                         nsplit=_nsplit(dwp), params=(w, bn.weight, bn.bias))
             return None, None, None
         K.fold_unpack_bwd(dwp[0], db[0], w, bnt, bn.eps, out=slots)
         _sink_done(w), _sink_done(bn.weight), _sink_done(bn.bias)

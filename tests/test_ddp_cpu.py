@@ -89,3 +89,27 @@ def test_step_lr_schedule():
     assert abs(step_lr(0.005, 300, 0) - 0.005) < 1e-12
     assert abs(step_lr(0.005, 150, 0) - 0.005 * (1 - 0.5 * 0.999)) < 1e-12
     assert abs(step_lr(0.005, 10**6, 16) - 0.0005) < 1e-12 and abs(step_lr(0.005, 10**6, 22) - 0.00005) < 1e-12
+
+
+def test_bucket_layout_covers_the_arena_and_tapers_at_the_end():
+    """BucketedAllReduce's layout alone (no process group): contiguous cover of the arena in arena order, every parameter in
+    exactly one bucket, no bucket above the cap except a single oversized tensor, and the LAST buckets cut small (what is
+    released at the very end of backward cannot be overlapped)."""
+    import torch.nn as nn
+    from bonai_amd.engine import FlatArena, BucketedAllReduce
+    m = nn.Sequential(*[nn.Linear(512, 512) for _ in range(20)], nn.Linear(2048, 2048), *[nn.Linear(512, 512) for _ in range(20)])   # a 16 MiB tensor among 1 MiB ones
+    arena = FlatArena(m)
+    cap = 4 << 20
+    red = BucketedAllReduce(arena, bucket_bytes=cap)
+    spans = [(b['start'], b['end']) for b in red.buckets]
+    assert spans[0][0] == 0 and spans[-1][1] == arena.numel
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    flat = [id(p) for b in red.buckets for p in b['params']]
+    assert flat == [id(p) for p in arena.order]
+    for b in red.buckets:
+        assert (b['end'] - b['start']) * 4 <= cap or len(b['params']) == 1
+    sizes = [(b['end'] - b['start']) * 4 for b in red.buckets]
+    assert sizes[-1] <= cap // 3 and sizes[-1] <= sizes[-2] <= sizes[-3] <= cap
+    # a model too small for a taper keeps the plain greedy layout
+    small = BucketedAllReduce(FlatArena(nn.Sequential(nn.Linear(64, 64), nn.Linear(64, 64))), bucket_bytes=cap)
+    assert len(small.buckets) == 1 and small.buckets[0]['end'] == 2 * (64 * 64 + 64)

@@ -137,9 +137,9 @@ class LOFT(nn.Module):
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = value.mean() if value.numel() != 1 else value.reshape(())     # (the mean of one element: no launch)
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                log_vars[name] = sum(v.mean() if v.numel() != 1 else v.reshape(()) for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)

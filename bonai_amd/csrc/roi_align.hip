@@ -288,11 +288,17 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(RoiLevels L, con
 #define RB_LIST 256
 #define RB_MAXP 14
 
+// rec[K]: (image, level | empty << 8, x0 | x1 << 16, y0 | y1 << 16) footprints; behind them geo[2K]: the RoI's sampling geometry
+// (start_h, start_w, bin_h, bin_w | grid_h, grid_w as int bits, count, 1 / count) so that the per-(RoI, tile) tables read 32 bytes instead
+// of redoing roi_geom's square root, logarithm and divisions for every tile the RoI touches.  48 bytes of workspace per RoI.
 __global__ void roi_prep_kernel(RoiLevels L, const float* __restrict__ rois, int K, int P, int4* __restrict__ rec) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float* roi = rois + 5 * (size_t)k;
     const RoiGeom g = roi_geom(roi, L, P);
+    float4* geo = reinterpret_cast<float4*>(rec + K);
+    geo[2 * k] = make_float4(g.start_h, g.start_w, g.bin_h, g.bin_w);
+    geo[2 * k + 1] = make_float4(__int_as_float(g.grid_h), __int_as_float(g.grid_w), g.count, 1.f / g.count);
     const int H = L.H[g.level], W = L.W[g.level];
     const float end_w = g.start_w + g.bin_w * (float)P, end_h = g.start_h + g.bin_h * (float)P;
     const float lo_x = fminf(g.start_w, end_w) - 1.f, hi_x = fmaxf(g.start_w, end_w) + 1.f;
@@ -472,11 +478,36 @@ __device__ __forceinline__ rbf16x8 roi_tr_frag(const char* tile, int kbase, int 
     return f;
 }
 
+template <int RB>
+__device__ __forceinline__ const char* roi_tr_frag_ptr(const char* tile, int col0, int lane) {     // roi_tr_frag's p0 at kbase = 0
+    const int il = lane & 15, gl = lane >> 4;
+    const int col = col0 + 16 * (gl & 1) + (il & 3) * 4;
+    const int r0 = 8 * (gl >> 1) + (il >> 2);
+    return tile + r0 * RB + rwswz(r0, col >> 3) * 16 + (col & 7) * 2;
+}
+
+template <int RB, int KS>
+__device__ __forceinline__ rbf16x8 roi_tr_frag_at(const char* p0) {                                // kbase = KS (a multiple of 16)
+    static_assert(KS % 16 == 0, "the row swizzle repeats every 4 rows");
+    rs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)(p0 + KS * RB));
+    rs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rs16x4*)(p0 + (KS + 4) * RB));
+    rbf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 __device__ __forceinline__ int nth_set_bit(unsigned m, int n) {      // position of the n-th (0-based) set bit of m
     for (int i = 0; i < n; ++i) m &= m - 1u;
     return __builtin_ctz(m);
 }
 
+#ifndef RBM_ABL
+#define RBM_ABL 0         // timing ablations of the backward kernel (results WRONG): 1 no MFMAs (the compiler then drops the staging
+#endif                    // too), 2 no operand build, 3 no gout staging, 5 no pairs at all (tools/probes/roi_bwd_ablate.sh)
+#ifndef RBM_WAVES
+#define RBM_WAVES 4
+#endif
 #define RBM_CHUNK 32      // bins per operand chunk: 24 KiB of LDS per block -> 6 blocks per CU hide the staging latency
 
 // Up to RBM_SETS RoI lists (the three extractors of the LOFT head share one pyramid) scatter into the same maps in ONE
@@ -490,7 +521,7 @@ struct RoiBwdSets {
     int n;
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, RoiBwdSets S,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBM_WAVES))) void roi_align_bwd_mfma_kernel(RoiLevels L, int level, RoiBwdSets S,
                                                                  bf16_t* __restrict__ grad, int accumulate) {
     constexpr int C = 256;
     __shared__ __attribute__((aligned(16))) char gbuf[RBM_CHUNK * 512];      // [bin][256 ch] bf16, 16-byte chunks swizzled
@@ -499,13 +530,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     __shared__ int wcnt[4];
     __shared__ int range[2];
     __shared__ float WY[2][RB_MAXP][RB_TILE], WX[2][RB_MAXP][RB_TILE];       // double-buffered per pair
-    __shared__ unsigned long long anyb[2][4];                                // per wave: ballot of "weight != 0"
+    __shared__ unsigned rnpt[16];
+    __shared__ unsigned anyb[2][4];                                          // per wave: which of its 8 bins have any weight
     const int H = L.H[level], W = L.W[level];
     const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < RBM_CHUNK * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < RBM_CHUNK * 256 / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < 16) rnpt[tid] = tid > 1 ? (65536u + (unsigned)tid - 1u) / (unsigned)tid : 65536u;   // ceil(2^16 / n): x / n for x < 256
+    // fragment addresses of the transposing reads: k-steps start at multiples of 16 rows, so the row swizzle does not depend on
+    // the step and a lane's six addresses are computed once (roi_tr_frag_at adds the step as an immediate)
+    const char* gfp[2];
+    const char* afp[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gfp[i] = roi_tr_frag_ptr<512>(gbuf, wave * 64 + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        afp[j] = roi_tr_frag_ptr<256>(abuf, j * 32, lane);
+        afp[2 + j] = roi_tr_frag_ptr<256>(abuf, 64 + j * 32, lane);
+    }
     rf32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -521,7 +565,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     // 1-D weight tables of one RoI for this tile + which bin rows / columns have any weight in it (wave ballots: waves 0-1
     // hold the 8 tile rows of bins 0-7 / 8-13, waves 2-3 the tile columns)
     auto tables = [&](int kk, int buf) {
-        const RoiGeom g = roi_geom(rois + 5 * (size_t)kk, L, P);
+        const float4* geo = reinterpret_cast<const float4*>(rec + K);
+        const float4 g0 = geo[2 * kk], g1 = geo[2 * kk + 1];
+        RoiGeom g;
+        g.start_h = g0.x; g.start_w = g0.y; g.bin_h = g0.z; g.bin_w = g0.w;
+        g.grid_h = __float_as_int(g1.x); g.grid_w = __float_as_int(g1.y); g.count = g1.z;
         const int t = tid & 127;
         const int p = t >> 3, pix = t & 7;
         float w = 0.f;
@@ -534,9 +582,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                 WX[buf][p][pix] = w;
             }
         }
-        const unsigned long long bal = __ballot(w != 0.f);
-        if (lane == 0) anyb[buf][wave] = bal;
-        return 1.f / g.count;
+        // bit p of the wave's mask = "bin 8*(wave&1) + p has weight on some row / column of this tile": byte p of the ballot is
+        // non-zero (wave-uniform -> scalar ALU; the nine-shift fold + multiply gathers bit 0 of every byte into the top byte)
+        unsigned long long bt = __ballot(w != 0.f);
+        bt |= bt >> 4; bt |= bt >> 2; bt |= bt >> 1;
+        bt &= 0x0101010101010101ull;
+        if (lane == 0) anyb[buf][wave] = (unsigned)((bt * 0x0102040810204080ull) >> 56);
+        return g1.w;
     };
 
 #pragma unroll 1
@@ -574,30 +626,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         __syncthreads();
         float inv = 0.f;
         if (n > 0) inv = tables(list[0], 0);
+#if RBM_ABL == 5
+        if (n > 0) acc[0][0][0] += inv;          // (timing ablation: the scan alone)
+        for (int li = 0; li < 0; ++li) {
+#else
         for (int li = 0; li < n; ++li) {
+#endif
             const int kk = list[li];
             const int buf = li & 1;
             __syncthreads();                 // tables of this pair are ready; the previous pair's fragment reads are done
-            unsigned rmask = 0u, cmask = 0u;
-            for (int p = 0; p < P; ++p) {
-                rmask |= (((anyb[buf][p >> 3] >> (8 * (p & 7))) & 0xffull) != 0ull) ? (1u << p) : 0u;
-                cmask |= (((anyb[buf][2 + (p >> 3)] >> (8 * (p & 7))) & 0xffull) != 0ull) ? (1u << p) : 0u;
-            }
+            const unsigned rmask = anyb[buf][0] | (anyb[buf][1] << 8), cmask = anyb[buf][2] | (anyb[buf][3] << 8);
             const int npy = __popc(rmask), npx = __popc(cmask);
+            // ab / npx for ab < 256, npx <= 14 as a multiply-high: exact (the error term stays below 1/256 of a unit)
+            const unsigned rnp = rnpt[npx];
             const int ka = npy * npx;            // active bins of this (RoI, tile) pair
             const float inv_cur = inv;
+
             for (int kc = 0; kc < ka; kc += RBM_CHUNK) {          // one chunk unless P = 14 with small bins
                 const int kn = min(RBM_CHUNK, ka - kc);
                 const int kpad = (kn + 15) & ~15;
                 if (kc > 0) __syncthreads();                      // the previous chunk's fragment reads are done
                 // ---- A[bin][pix]: one (bin, tile row) = 8 pixels = one 16-byte chunk of hi and one of lo per task
 #pragma unroll 1
-                for (int t = tid; t < kpad * 8; t += 256) {
+                for (int t = tid; t < (RBM_ABL == 2 ? 0 : kpad * 8); t += 256) {
                     const int kb = t >> 3, y = t & 7;
                     uint32_t hi4[4] = {0, 0, 0, 0}, lo4[4] = {0, 0, 0, 0};
                     if (kb < kn) {
                         const int ab = kc + kb;
-                        const int py = nth_set_bit(rmask, ab / npx), px = nth_set_bit(cmask, ab % npx);
+                        const int qy = (int)(((unsigned)ab * rnp) >> 16);
+                        const int py = nth_set_bit(rmask, qy), px = nth_set_bit(cmask, ab - qy * npx);
                         const float wy = WY[buf][py][y] * inv_cur;
 #pragma unroll
                         for (int x = 0; x < 8; ++x) {
@@ -613,10 +670,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                 }
                 // ---- gout rows of the active bins (FOA: the four rotations summed in fp32, rounded once)
 #pragma unroll 1
-                for (int t = tid; t < kn * 32; t += 256) {
+                for (int t = tid; t < (RBM_ABL == 3 ? 0 : kn * 32); t += 256) {
                     const int kb = t >> 5, q = t & 31;
                     const int ab = kc + kb;
-                    const int py = nth_set_bit(rmask, ab / npx), px = nth_set_bit(cmask, ab % npx);
+                    const int qy = (int)(((unsigned)ab * rnp) >> 16);
+                    const int py = nth_set_bit(rmask, qy), px = nth_set_bit(cmask, ab - qy * npx);
                     uint4 v;
                     if (n_rot == 1) {
                         v = *reinterpret_cast<const uint4*>(gout + ((size_t)kk * P * P + py * P + px) * C + q * 8);
@@ -638,24 +696,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                     *reinterpret_cast<uint4*>(gbuf + kb * 512 + rwswz(kb, q) * 16) = v;
                 }
                 __syncthreads();
-#pragma unroll 1
-                for (int ks = 0; ks < kpad; ks += 16) {
-                    rbf16x8 gf[2], xh[2], xl[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) gf[i] = roi_tr_frag<512>(gbuf, ks, wave * 64 + i * 32, lane);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        xh[j] = roi_tr_frag<256>(abuf, ks, j * 32, lane);
-                        xl[j] = roi_tr_frag<256>(abuf, ks, 64 + j * 32, lane);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xh[j], acc[i][j]);
-                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xl[j], acc[i][j]);
-                        }
+#define RBM_KSTEP(KS)                                                                                         \
+                do {                                                                                          \
+                    rbf16x8 gf[2], xh[2], xl[2];                                                              \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) gf[i] = roi_tr_frag_at<512, KS>(gfp[i]);    \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
+                        xh[j] = roi_tr_frag_at<256, KS>(afp[j]);                                              \
+                        xl[j] = roi_tr_frag_at<256, KS>(afp[2 + j]);                                          \
+                    }                                                                                         \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xh[j], acc[i][j]);                          \
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xl[j], acc[i][j]);                          \
+                        }                                                                                     \
+                } while (0)
+                if (RBM_ABL != 1) {
+                    RBM_KSTEP(0);
+                    if (kpad > 16) RBM_KSTEP(16);
                 }
+#undef RBM_KSTEP
             }
             // the next pair's tables ride behind this pair's MFMAs (other buffer; its readers finished two barriers ago)
             if (li + 1 < n) inv = tables(list[li + 1], buf ^ 1);
@@ -774,7 +833,7 @@ LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, cons
 }
 
 // Several RoI lists over the same pyramid in one pass per level (16-bit maps, C = 256: the LOFT head's three extractors).
-// Every list brings its own rois / K / P / n_rot / grad_out / sorted flag / 16*K-byte workspace; other configurations
+// Every list brings its own rois / K / P / n_rot / grad_out / sorted flag / 48*K-byte workspace; other configurations
 // run list after list through loft_roi_align_bwd_v (the later ones accumulating).
 LOFT_EXPORT int loft_roi_align_bwd_multi(void* const* grad_feats, const int* H, const int* W, const float* scales,
                                          int num_levels, int finest_scale, int C, int dtype, int nsets,

@@ -163,7 +163,7 @@ def roi_align_bwd(grad_out, rois, feat_shapes, P, strides, finest_scale=56, n_ro
     W = L.arr(c_int, [s[3] for s in feat_shapes])
     S = L.arr(c_float, [1.0 / s for s in strides])
     gp = L.arr(c_void_p, [g.data_ptr() for g in grad_feats])
-    ws = torch.empty(16 * K, dtype=torch.uint8, device=rois.device)
+    ws = torch.empty(48 * K, dtype=torch.uint8, device=rois.device)
     L.check(lib.loft_roi_align_bwd_v(gp, H, W, S, len(grad_feats), int(finest_scale), C, L.dtype_code(grad_out),
                                      L.ptr(rois), K, int(P), int(n_rot), L.ptr(grad_out), int(feat_shapes[0][0]),
                                      int(accumulate), int(rois_sorted), L.ptr(ws), L.dtype_code(grad_feats[0]),
@@ -185,7 +185,7 @@ def roi_align_bwd_multi(sets, feat_shapes, strides, finest_scale=56, grad_feats=
     rois = [s[1].float().contiguous() for s in sets]
     L.dev_check(*gos, *rois)
     Ks = [r.shape[0] for r in rois]
-    wss = [torch.empty(max(16 * k, 16), dtype=torch.uint8, device=dev) for k in Ks]
+    wss = [torch.empty(max(48 * k, 48), dtype=torch.uint8, device=dev) for k in Ks]
     n = len(sets)
     L.check(lib.loft_roi_align_bwd_multi(
         L.arr(c_void_p, [g.data_ptr() for g in grad_feats]), L.arr(c_int, [s[2] for s in feat_shapes]),

@@ -47,7 +47,7 @@ int loft_act16_dtype(void);   /* LOFT_BF16 or LOFT_F16: which build this is */
  * bwd: grad_out has the layout of out; grad_feats[l] are fp32 NHWC maps [B,H[l],W[l],C], every pixel
  * of which is written (accumulate=0) or added to (accumulate=1) exactly once -- no atomics reach HBM.
  * rois_sorted=1 promises the RoIs are ordered by batch index (bbox2roi order) so each tile scans only its
- * image's RoIs; workspace: 16*K bytes.  H/W/scales are HOST arrays of num_levels entries.  grad_dtype: LOFT_F32, or LOFT_BF16 (only with dtype ==
+ * image's RoIs; workspace: 48*K bytes (16-byte aligned).  H/W/scales are HOST arrays of num_levels entries.  grad_dtype: LOFT_F32, or LOFT_BF16 (only with dtype ==
  * LOFT_BF16): the gradient maps are written directly in bf16 (each pixel exactly once from fp32 registers). */
 int loft_roi_align_fwd(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                        int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
@@ -72,7 +72,7 @@ int loft_roi_align_bwd_v(void* const* grad_feats_host, const int* H_host, const 
  * mask 14x14, FOA 14x14 x 4 rotations: loft_foa.py:126-176 calls bbox_roi_extractor / mask_roi_extractor / the offset
  * head's extractor on the same FPN maps), so their backward passes add into the same four maps; fused (16-bit maps,
  * C == 256, nsets <= 3) every map pixel is written once.  Per-list arguments are host arrays of length nsets;
- * workspace[i] holds 16*K[i] bytes.  Other configurations run list after list, accumulating. */
+ * workspace[i] holds 48*K[i] bytes.  Other configurations run list after list, accumulating. */
 int loft_roi_align_bwd_multi(void* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
                              int num_levels, int finest_scale, int C, int dtype, int nsets,
                              const float* const* rois_host, const int* K_host, const int* P_host, const int* n_rot_host,

@@ -679,14 +679,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBM_WAVES))
                     if (n_rot == 1) {
                         v = *reinterpret_cast<const uint4*>(gout + ((size_t)kk * P * P + py * P + px) * C + q * 8);
                     } else {
+                        // all four rotations' rows are requested before the first is summed (a dependent load per rotation made
+                        // an FOA pair five times as expensive as a bbox pair); same r = 0..3 fp32 summation order
                         float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                        for (int r = 0; r < n_rot; ++r) {
-                            const bf16_t* gp = gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + q * 8;
-                            float t0[4], t1[4];
-                            ld4(gp, t0); ld4(gp + 4, t1);
+                        uint4 rv[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { sacc[e] += t0[e]; sacc[4 + e] += t1[e]; }
+                        for (int r = 0; r < 4; ++r)
+                            rv[r] = *reinterpret_cast<const uint4*>(gout + (((size_t)r * K + kk) * P * P + rot_pos(py, px, P, r)) * C + q * 8);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float tv[8];
+                            unpack8_16(rv[r], tv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sacc[e] += tv[e];
                         }
                         v.x = (uint32_t)f32_to_bf16(sacc[0]) | ((uint32_t)f32_to_bf16(sacc[1]) << 16);
                         v.y = (uint32_t)f32_to_bf16(sacc[2]) | ((uint32_t)f32_to_bf16(sacc[3]) << 16);

@@ -16,6 +16,11 @@ STREAM_VARS=0,8,10,12 PIPE_VARS=0 timeout 300 python tools/pipe_trace.py 2>&1 | 
 timeout 300 python tools/probes/copy_sites.py > "$OUT/copy_sites.txt" 2>&1
 timeout 300 python tools/probes/roi_bwd_time.py > "$OUT/roi_align_time.txt" 2>&1
 timeout 300 python tools/probes/roi_pairs.py > "$OUT/roi_pairs.txt" 2>&1
+# timing ablations of the RoIAlign backward: build the variant libraries first, HERE:  bash tools/probes/roi_bwd_ablate.sh build
+[ -d tools/probes/_abl ] && timeout 500 bash tools/probes/roi_bwd_ablate.sh run > "$OUT/roi_bwd_ablations.txt" 2>&1
+timeout 300 python tools/probes/bucket_timeline.py 2>&1 | grep -E "^  bucket|reducer.begin" > "$OUT/bucket_timeline.txt"
+timeout 300 python tools/probes/hipblaslt_ref.py > "$OUT/hipblaslt_ref.txt" 2>&1
+timeout 300 python tools/probes/aten_sites.py > "$OUT/aten_sites.txt" 2>&1
 ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/fill_prof
   timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/fill_prof -- python "$ROOT/bench.py" --no-cpu-baseline --no-saturate --no-roofline > /dev/null 2>&1
   f=$(find /tmp/fill_prof -name '*kernel_trace.csv' | head -1)

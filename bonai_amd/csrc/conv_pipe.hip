@@ -210,7 +210,15 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     constexpr bool TRACE = VAR & 1, NOPRIO = !ABL && (VAR & 2), OLDORDER = !ABL && (VAR & 4);
     constexpr bool NOGLDS = ABL && ((VAR >> 1) & 3) == 0, NOREADS = ABL && ((VAR >> 1) & 3) == 1, NOMFMA = ABL && ((VAR >> 1) & 3) == 2,
                    NOSEL = ABL && ((VAR >> 1) & 3) == 3;
-    __shared__ __attribute__((aligned(16))) char lds[PLDS];
+    // Stage ring.  The 256-pixel tile double-buffers (4 x 32 KiB).  The 128- / 64-pixel tiles (layer3 / layer4: few workgroups, one per
+    // CU, K-tiles of only 256-512 MFMA cycles) take THREE stages: a K-tile's copies are requested two tiles ahead and retired
+    // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
+    // 20-35 % of the MFMA rate).  Weights 3 x 32 KiB, activations 3 x MJ x 8 KiB behind them.
+    constexpr int NS = (MODE == 1 && VAR == 0 && MJ <= 2 && NW == 2) ? 3 : 2;
+    constexpr int PBW = PBUF, PBX = NS == 3 ? MJ * 8192 : PBUF;
+    constexpr int PXO = NS == 3 ? 3 * PBUF : PX_OFF;
+    constexpr int LDSZ = NS == 3 ? 3 * PBUF + 3 * PBX : PLDS;
+    __shared__ __attribute__((aligned(16))) char lds[LDSZ];
     unsigned long long kst0 = 0ull, kst1 = 0ull, kst2 = 0ull;
     const int trace_b0 = gridDim.x > 1100 ? 1024 : 0;        // TRACE: a workgroup of a later round (steady state) when there is one
     auto kstamp = [&](int slot) {                             // TRACE, outside the K loop: time stamp straight to the buffer
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     unsigned tmask = 0xffffffffu;
     int nk = a.T * kchunks;
     if (a.pixmajor) {
-        unsigned* wor = reinterpret_cast<unsigned*>(lds + PLDS - 64);   // inside X buf1's last row: first overwritten in slot 4
+        unsigned* wor = reinterpret_cast<unsigned*>(lds + LDSZ - 64);   // inside X buf1's last row: first overwritten in slot 4
         unsigned mm = a_mask[0];
         if constexpr (NI >= 2) mm |= a_mask[1];
         if constexpr (NI == 4) mm |= a_mask[2] | a_mask[3];
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wt + (long)i * b_step),
-                                             (lds_ptr_t)(lds + PW_OFF + B * PBUF + (i * 64 + wave * 8) * 128), 16, 0, 0);
+                                             (lds_ptr_t)(lds + PW_OFF + B * PBW + (i * 64 + wave * 8) * 128), 16, 0, 0);
     };
     auto issue_x = [&](auto halfc, auto bufc) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 2 * H; i < (2 * H + 2 < NI ? 2 * H + 2 : NI); ++i) {
             const bf16_t* p = (NOSEL || ((a_mask[i] >> st_t) & 1u)) ? a_ptr[i] + aoff : a.zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PX_OFF + B * PBUF + (i * 64 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PXO + B * PBX + (i * 64 + wave * 8) * 128), 16, 0, 0);
         }
     };
     using c0_t = std::integral_constant<int, 0>;
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         for (int ks = 0; ks < 4; ++ks) {
             const int q = ks * 2 + fq;
             wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
-            xb[ks] = lds + PX_OFF + rx * 128 + swz(rx, q) * 16;
+            xb[ks] = lds + PXO + rx * 128 + swz(rx, q) * 16;
         }
     }
 
@@ -464,8 +472,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
             if constexpr (I >= 2 + MJ || (I == 1 && NW == 1)) { }              // (smaller tiles: fewer activation / weight fragments)
             else if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
-            else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBUF + I * 4096);
-            else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBUF + (I - 2) * 4096);
+            else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBW + I * 4096);
+            else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBX + (I - 2) * 4096);
         };
         auto mm2 = [&](bf16x8 (&f)[6], auto jc) {                               // the two MFMAs of pixel block j
             constexpr int J = decltype(jc)::value;
@@ -517,9 +525,59 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             PIPE_SB();
         };
         auto nop = [] {};
-        // prologue: W(0), X(0), W(1)
         unsigned long long kst_setup = 0ull;
         if constexpr (TRACE) kst_setup = __builtin_amdgcn_s_memtime();
+        if constexpr (NS == 3) {
+            // ---- three-stage ring: per K-tile t (buffer B = t % 3)
+            //   ks0: MFMA fa | read F(t,1) | request X(t+2) -> buffer (B+2) % 3      (free since SYNC(t-1): last read by tile t-1)
+            //   ks1: MFMA fb | read F(t,2) | request W(t+2) -> buffer (B+2) % 3
+            //   ks2: MFMA fa | read F(t,3)
+            //   SYNC: s_waitcnt vmcnt(copies of ONE tile) -> tile t+1 (requested during tile t-1) has landed, tile t+2 stays in
+            //         flight; lgkmcnt(0); s_barrier
+            //   ks3: MFMA fb | read F(t+1,0) from buffer (B+1) % 3
+            using c2_t = std::integral_constant<int, 2>;
+            using z_t = std::integral_constant<int, 0>;
+            constexpr int NXW = NI + 2 * NW;                         // global->LDS copy instructions of one K-tile, per wave
+            issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
+            issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
+            if (nk > 1) {
+                advance_w(); advance_x();
+                issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
+                issue_x(c0_t{}, c1_t{}); issue_x(c1_t{}, c1_t{});
+                advance_w(); advance_x();
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXW) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PIPE_BARRIER();
+            in_loop = true;
+            rd1(fa, c0_t{}, k0_t{}, k0_t{}); rd1(fa, c0_t{}, k0_t{}, k1_t{}); rd1(fa, c0_t{}, k0_t{}, k2_t{});
+            rd1(fa, c0_t{}, k0_t{}, k3_t{}); rd1(fa, c0_t{}, k0_t{}, i4_t{}); rd1(fa, c0_t{}, k0_t{}, i5_t{});
+            auto rtile = [&](auto bufc, bool has1, bool has2) {
+                constexpr int B = decltype(bufc)::value;
+                using next_t = std::integral_constant<int, (B + 1) % 3>;
+                using tgt_t = std::integral_constant<int, (B + 2) % 3>;
+                substep(fa, fb, bufc, k1_t{}, true,
+                        [&] { if (has2) issue_x(c0_t{}, tgt_t{}); },
+                        [&] { if (has2) { issue_x(c1_t{}, tgt_t{}); advance_x(); } }, z_t{});
+                substep(fb, fa, bufc, k2_t{}, true,
+                        [&] { if (has2) issue_w(c0_t{}, tgt_t{}); },
+                        [&] { if (has2) { issue_w(c1_t{}, tgt_t{}); advance_w(); } }, z_t{});
+                substep(fa, fb, bufc, k3_t{}, true, nop, nop, z_t{});
+                if (has1) {
+                    if (has2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NXW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    PIPE_BARRIER();
+                }
+                substep(fb, fa, next_t{}, k0_t{}, has1, nop, nop, z_t{});
+            };
+            for (int t = 0; t < nk; t += 3) {
+                rtile(c0_t{}, t + 1 < nk, t + 2 < nk);
+                if (t + 1 < nk) rtile(c1_t{}, t + 2 < nk, t + 3 < nk);
+                if (t + 2 < nk) rtile(c2_t{}, t + 3 < nk, t + 4 < nk);
+            }
+        } else {
+        // prologue: W(0), X(0), W(1)
         issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
         issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
         if (nk > 1) {
@@ -584,6 +642,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         for (int t = 0; t < nk; t += 2) {
             stile(c0_t{}, t + 1 < nk, t + 2 < nk);
             if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+        }
         }
         if constexpr (TRACE) kst2 = __builtin_amdgcn_s_memtime();
         if constexpr (VAR & 2)

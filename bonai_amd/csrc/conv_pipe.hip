@@ -213,11 +213,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // Stage ring.  The 256-pixel tile double-buffers (4 x 32 KiB).  The 128- / 64-pixel tiles (layer3 / layer4: few workgroups, one per
     // CU, K-tiles of only 256-512 MFMA cycles) take THREE stages: a K-tile's copies are requested two tiles ahead and retired
     // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
-    // 20-35 % of the MFMA rate).  Weights 3 x 32 KiB, activations 3 x MJ x 8 KiB behind them.
-    constexpr int NS = (MODE == 1 && VAR == 0 && MJ <= 2 && NW == 2) ? 3 : 2;
-    constexpr int PBW = PBUF, PBX = NS == 3 ? MJ * 8192 : PBUF;
-    constexpr int PXO = NS == 3 ? 3 * PBUF : PX_OFF;
-    constexpr int LDSZ = NS == 3 ? 3 * PBUF + 3 * PBX : PLDS;
+    // 20-35 % of the MFMA rate).  Weights 3 x NW x 16 KiB, activations 3 x MJ x 8 KiB behind them; also the 128-cout tile (NW = 1).
+    constexpr int NS = (MODE == 1 && VAR == 0 && ((MJ <= 2 && NW == 2) || (MJ == 4 && NW == 1))) ? 3 : 2;
+    constexpr int PBW = NS == 3 ? NW * 16384 : PBUF, PBX = NS == 3 ? MJ * 8192 : PBUF;
+    constexpr int PXO = NS == 3 ? 3 * PBW : PX_OFF;
+    constexpr int LDSZ = NS == 3 ? 3 * PBW + 3 * PBX : PLDS;
     __shared__ __attribute__((aligned(16))) char lds[LDSZ];
     unsigned long long kst0 = 0ull, kst1 = 0ull, kst2 = 0ull;
     const int trace_b0 = gridDim.x > 1100 ? 1024 : 0;        // TRACE: a workgroup of a later round (steady state) when there is one

@@ -1072,6 +1072,45 @@ __global__ void roi_sample_targets_kernel(const float* __restrict__ cand, int Nc
     reinterpret_cast<float4*>(tgt)[o] = t;
     reinterpret_cast<float4*>(tgt_w)[o] = make_float4(tw, tw, tw, tw);
 }
+// The four tables of loft_roi_sample_targets from the sampler's validity flags, on the device: tab[0][b] = positives of image b,
+// tab[1][b] = negatives, tab[2][b] = first row of image b in the RoI list, tab[3][b] = first row in the positives' list.  With
+// this the host read of the counts is no longer in front of the launch: the caller sizes the outputs for the worst case, lets
+// the first RoIAlign run on them, and fetches the counts meanwhile (bonai_amd.kernels.roi_sample_targets_begin).
+__global__ __launch_bounds__(256) void roi_sample_offsets_kernel(const uint8_t* __restrict__ pval, const uint8_t* __restrict__ nval,
+                                                                 int B, int P, int Q, int32_t* __restrict__ tab) {
+    __shared__ int red[4];
+    __shared__ int cnt[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = 0; b < B; ++b)
+        for (int w = 0; w < 2; ++w) {
+            const uint8_t* v = w == 0 ? pval + (long)b * P : nval + (long)b * Q;
+            const int n = w == 0 ? P : Q;
+            int c = 0;
+            for (int i = tid; i < n; i += 256) c += v[i] ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            __syncthreads();
+            if (lane == 0) red[wave] = c;
+            __syncthreads();
+            if (tid == 0) cnt[w][b] = red[0] + red[1] + red[2] + red[3];
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0, np = 0;
+        for (int b = 0; b < B; ++b) {
+            tab[b] = cnt[0][b]; tab[B + b] = cnt[1][b]; tab[2 * B + b] = m; tab[3 * B + b] = np;
+            m += cnt[0][b] + cnt[1][b]; np += cnt[0][b];
+        }
+    }
+}
+LOFT_EXPORT int loft_roi_sample_offsets(const uint8_t* pos_valid, const uint8_t* neg_valid, int B, int P, int Q, int32_t* tab,
+                                        void* stream) {
+    if (B <= 0) return 0;
+    if (B > 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(roi_sample_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pos_valid, neg_valid, B, P, Q, tab);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 LOFT_EXPORT int loft_roi_sample_targets(const float* cand, int Ncand, const int64_t* gt_inds, const float* gts,
                                         const int64_t* gt_labels, int Kmax, const int64_t* pos_idx, const int64_t* neg_idx, int P,
                                         int Q, int B, const int32_t* npos_dev, const int32_t* nneg_dev, const int32_t* roi_off_dev,

@@ -1294,28 +1294,48 @@ def rpn_sample_gather(heads, lvl_off, A, anchors, gts, gt_inds, pidx, pval, nidx
     return vals, rows, slot, tgt, label, weight
 
 
-def roi_sample_targets(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, num_classes, means, stds):
-    """Sampled RoIs, labels and regression targets of a batch in one launch (loft_roi_sample_targets) after ONE host read of the
-    per-image counts.  -> dict(rois [M,5], labels, label_weights, bbox_targets, bbox_weights, pos_rois [Np,5], pos_b, pos_gt_i,
-    pos_sel)."""
+class _RoiTargets:
+    """roi_sample_targets_begin's handle: ``rois_max`` (the first B * num_expected rows of the worst-case list; rows beyond the
+    real count are zero boxes) can feed launches right away; ``finish()`` waits for the counts (the step's one host sync of the RoI head) and returns the
+    exactly-sized views."""
+
+    def __init__(self, out, counts_host, event, B, expected):
+        self._out, self._counts, self._event, self._B = out, counts_host, event, B
+        self.rois_max = out['rois'][:expected]      # the list a full sampler produces (num per image); zero boxes if it falls short
+
+    def finish(self):
+        self._event.synchronize()
+        c = self._counts.tolist()
+        B = self._B
+        M = sum(c[0][:B]) + sum(c[1][:B])
+        Np = sum(c[0][:B])
+        o = self._out
+        return dict(rois=o['rois'][:M], labels=o['labels'][:M], label_weights=o['label_weights'][:M],
+                    bbox_targets=o['bbox_targets'][:M], bbox_weights=o['bbox_weights'][:M], pos_rois=o['pos_rois'][:Np],
+                    pos_b=o['pos_b'][:Np], pos_gt_i=o['pos_gt_i'][:Np], pos_sel=o['pos_sel'][:Np])
+
+
+def roi_sample_targets_begin(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, num_classes, means, stds, num_expected=None):
+    """Sampled RoIs, labels and regression targets of a batch (loft_roi_sample_offsets + loft_roi_sample_targets), launched
+    WITHOUT reading the per-image counts first: outputs are sized for the worst case (every sampler slot valid), the counts travel
+    to pinned host memory behind the kernels.  -> _RoiTargets."""
     lib = L.load()
-    L.dev_check(cand, gt_inds, gts, gt_labels, pidx, nidx)
+    L.dev_check(cand, gt_inds, gts, gt_labels, pidx, nidx, pval, nval)
     B, Ncand = gt_inds.shape
     P, Q = pidx.shape[1], nidx.shape[1]
     dev = gt_inds.device
-    counts = torch.stack([pval.sum(1), nval.sum(1)], 1).tolist()          # the step's one host sync of the RoI head
-    npos, nneg = [int(c[0]) for c in counts], [int(c[1]) for c in counts]
-    roff, poff, M, Np = [], [], 0, 0
-    for b in range(B):
-        roff.append(M); poff.append(Np)
-        M += npos[b] + nneg[b]; Np += npos[b]
-    tab = h2d([npos, nneg, roff, poff], torch.int32, dev)
-    out = dict(rois=torch.empty(M, 5, device=dev), labels=torch.empty(M, dtype=torch.int64, device=dev),
-               label_weights=torch.empty(M, device=dev), bbox_targets=torch.empty(M, 4, device=dev),
-               bbox_weights=torch.empty(M, 4, device=dev), pos_rois=torch.empty(Np, 5, device=dev),
-               pos_b=torch.empty(Np, dtype=torch.int64, device=dev), pos_gt_i=torch.empty(Np, dtype=torch.int64, device=dev),
-               pos_sel=torch.empty(Np, dtype=torch.int64, device=dev))
-    if M > 0:
+    pv = pval.contiguous().view(torch.uint8) if pval.dtype == torch.bool else pval.contiguous()
+    nv = nval.contiguous().view(torch.uint8) if nval.dtype == torch.bool else nval.contiguous()
+    tab = torch.empty(4, B, dtype=torch.int32, device=dev)
+    L.check(lib.loft_roi_sample_offsets(L.ptr(pv), L.ptr(nv), B, P, Q, L.ptr(tab), L.stream()), 'loft_roi_sample_offsets')
+    Mx, Nx = B * (P + Q), B * P
+    # (rois zero-filled: rows beyond the real count must be harmless boxes for a launch that runs before the count is known)
+    out = dict(rois=torch.zeros(Mx, 5, device=dev), labels=torch.empty(Mx, dtype=torch.int64, device=dev),
+               label_weights=torch.empty(Mx, device=dev), bbox_targets=torch.empty(Mx, 4, device=dev),
+               bbox_weights=torch.empty(Mx, 4, device=dev), pos_rois=torch.empty(Nx, 5, device=dev),
+               pos_b=torch.empty(Nx, dtype=torch.int64, device=dev), pos_gt_i=torch.empty(Nx, dtype=torch.int64, device=dev),
+               pos_sel=torch.empty(Nx, dtype=torch.int64, device=dev))
+    if Mx > 0:
         L.check(lib.loft_roi_sample_targets(L.ptr(cand.float().contiguous()), Ncand, L.ptr(gt_inds.contiguous()),
                                             L.ptr(gts.float().contiguous()), L.ptr(gt_labels.contiguous()), int(gts.shape[1]),
                                             L.ptr(pidx.contiguous()), L.ptr(nidx.contiguous()), P, Q, B, L.ptr(tab[0]), L.ptr(tab[1]),
@@ -1324,7 +1344,16 @@ def roi_sample_targets(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, nu
                                             L.ptr(out['label_weights']), L.ptr(out['bbox_targets']), L.ptr(out['bbox_weights']),
                                             L.ptr(out['pos_rois']), L.ptr(out['pos_b']), L.ptr(out['pos_gt_i']), L.ptr(out['pos_sel']),
                                             L.stream()), 'loft_roi_sample_targets')
-    return out
+    host = torch.empty(2, B, dtype=torch.int32, pin_memory=True)
+    host.copy_(tab[:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return _RoiTargets(out, host, ev, B, Mx if num_expected is None else min(Mx, B * int(num_expected)))
+
+
+def roi_sample_targets(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, num_classes, means, stds):
+    """-> dict(rois [M,5], labels, label_weights, bbox_targets, bbox_weights, pos_rois [Np,5], pos_b, pos_gt_i, pos_sel)."""
+    return roi_sample_targets_begin(cand, gt_inds, gts, gt_labels, pidx, pval, nidx, nval, num_classes, means, stds).finish()
 
 
 _SAMPLE_CALLS = [0]

@@ -26,6 +26,7 @@ from .losses import accuracy
 
 
 TENSOR_TARGETS = False   # tests: the tensor formulation of the sampled-RoI lists / targets instead of loft_roi_sample_targets
+SPECULATIVE_BBOX_ROIALIGN = True   # tests / A-B: the bbox RoIAlign on the worst-case list in front of the count read
 
 
 @ROI_EXTRACTORS.register_module()
@@ -390,11 +391,20 @@ class LoftRoIHead(nn.Module):
             pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
             lab_pad = pad_rows(gt_labels, dev, torch.long, Kmax)
         fused_targets = dev.type == 'cuda' and not TENSOR_TARGETS
+        spec_feats = None
         if fused_targets:
             # per image [pos..., neg...] (SamplingResult.bboxes, sampling_result.py:50-53), labels and bbox targets: one launch
             with torch.no_grad():
-                tg = K.roi_sample_targets(cand, gt_inds, gts, lab_pad, pidx, pval, nidx, nval, self.bbox_head.num_classes,
-                                          self.bbox_head.bbox_coder.means, self.bbox_head.bbox_coder.stds)
+                pending = K.roi_sample_targets_begin(cand, gt_inds, gts, lab_pad, pidx, pval, nidx, nval,
+                                                     self.bbox_head.num_classes, self.bbox_head.bbox_coder.means,
+                                                     self.bbox_head.bbox_coder.stds, num_expected=self.bbox_sampler.num)
+            # The bbox extractor runs on the worst-case RoI list BEFORE the host learns the counts: the GPU has ~0.3 ms of work
+            # while the host waits for them and then enqueues the branches (the read used to leave the device idle).  Every
+            # sampler slot is filled in all but degenerate batches; otherwise the result is dropped and recomputed below.
+            if SPECULATIVE_BBOX_ROIALIGN and pending.rois_max.shape[0] > 0:
+                xb_ = x.branches[1] if isinstance(x, F2.FeatFork) else x
+                spec_feats = self.bbox_roi_extractor(xb_[:self.bbox_roi_extractor.num_inputs], pending.rois_max)
+            tg = pending.finish()
             rois, labels, label_weights = tg['rois'], tg['labels'], tg['label_weights']
             bbox_targets, bbox_weights = tg['bbox_targets'], tg['bbox_weights']
             pos_rois, pos_b, pos_gt_i, pos_sel = tg['pos_rois'], tg['pos_b'], tg['pos_gt_i'], tg['pos_sel']
@@ -430,7 +440,10 @@ class LoftRoIHead(nn.Module):
         if isinstance(x, F2.FeatFork):       # own aliases per extractor: their backward kernels share one gradient map per level
             xb, xm, xo = x.branches[1], x.branches[2], x.branches[3]
         feats = xb[:self.bbox_roi_extractor.num_inputs]
-        bbox_feats = self.bbox_roi_extractor(feats, rois)
+        if spec_feats is not None and spec_feats.shape[0] == rois.shape[0]:
+            bbox_feats = spec_feats
+        else:
+            bbox_feats = self.bbox_roi_extractor(feats, rois)
 
         def bbox_branch():
             cls_score, bbox_pred = self.bbox_head(bbox_feats)

@@ -479,6 +479,10 @@ int loft_fused_loss(int mode, const float* pred, const void* target, const float
  * arrays built from ONE host read of the counts).  Writes, per image [pos..., neg...]: rois [M,5] (b, x1, y1, x2, y2), labels int64
  * [M] (num_classes for negatives), label_weights [M] = 1, bbox_targets / bbox_weights [M,4] (bbox2delta for positives, weight 1),
  * and the positives' lists pos_rois [Np,5], pos_img / pos_gt / pos_row int64 [Np] (image, assigned gt, row in rois). */
+/* The tables loft_roi_sample_targets reads, computed on the device from the sampler's validity flags (uint8 [B,P] / [B,Q]):
+ * tab int32 [4][B] = {positives, negatives, first RoI row, first positive row} per image, B <= 64.  Lets the caller launch
+ * loft_roi_sample_targets (outputs sized for the worst case) without first reading the counts on the host. */
+int loft_roi_sample_offsets(const uint8_t* pos_valid, const uint8_t* neg_valid, int B, int P, int Q, int32_t* tab, void* stream);
 int loft_roi_sample_targets(const float* cand, int Ncand, const int64_t* gt_inds, const float* gts,
                             const int64_t* gt_labels, int Kmax, const int64_t* pos_idx, const int64_t* neg_idx, int P,
                             int Q, int B, const int32_t* npos_dev, const int32_t* nneg_dev, const int32_t* roi_off_dev,

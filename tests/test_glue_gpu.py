@@ -386,6 +386,15 @@ def test_roi_sample_targets_matches_tensor_formulation():
     w = torch.zeros(rois.shape[0], 4, device='cuda')
     w[pos_sel] = 1.0
     assert torch.equal(got['bbox_weights'], w) and bool((got['label_weights'] == 1).all())
+    # the two-phase form (launch without the counts, read them later): the list a full sampler would produce is available at
+    # once -- here two images fall short, so it carries the real rows first and zero boxes behind them
+    h = K.roi_sample_targets_begin(cand, gt_inds, gts, lab, pidx, pval, nidx, nval, 3, means, stds, num_expected=num)
+    early = h.rois_max.clone()
+    fin = h.finish()
+    M = rois.shape[0]
+    assert M < B * num and early.shape[0] == B * num
+    assert torch.equal(early[:M], rois) and bool((early[M:] == 0).all())
+    assert all(torch.equal(fin[k], got[k]) for k in got)
 
 
 def test_premasked_gradient_with_two_consumers_any_order():

@@ -38,3 +38,38 @@ for t, d, i in pts:
 print(f'step wall {(t1 - t0) / 1e6:.3f} ms   idle {idle / 1e6:.3f} ms   thin (<128 workgroups in flight) {thin_total / 1e6:.3f} ms   launches {len(st)}')
 for n, v in thin.most_common(28):
     print(f'   {v / 1e3:8.1f} us  {n}')
+
+# ---- contiguous under-filled windows (idle or thin, gaps of filled time < 5 us bridged): where the serial sections are
+segs, cur_s, cur_e, names = [], None, None, []
+last = t0
+live = set()
+for t, d, i in pts:
+    dt = t - last
+    if dt > 0:
+        fill = sum(min(256, st[j][3]) for j in live)
+        if fill < 128:
+            if cur_s is None or last - cur_e > 5000:
+                if cur_s is not None:
+                    segs.append((cur_s, cur_e, names))
+                cur_s, names = last, []
+            cur_e = t
+            for j in live:
+                if st[j][2][:40] not in names:
+                    names.append(st[j][2][:40])
+    last = t
+    if d == 1: live.add(i)
+    else: live.discard(i)
+if cur_s is not None:
+    segs.append((cur_s, cur_e, names))
+print(f'under-filled windows: {len(segs)}, total {sum(e - s for s, e, _ in segs) / 1e6:.3f} ms')
+for s_, e_, nm in sorted(segs, key=lambda x: -(x[1] - x[0]))[:14]:
+    print(f'   at {(s_ - t0) / 1e6:6.2f} ms  {(e_ - s_) / 1e3:7.1f} us  {len(nm):2d} kernels: ' + ' | '.join(nm[:7]))
+
+# ---- launch by launch inside the largest windows
+for s_, e_, nm in sorted(segs, key=lambda x: -(x[1] - x[0]))[:int(sys.argv[2]) if len(sys.argv) > 2 else 0]:
+    print(f'--- window at {(s_ - t0) / 1e6:.2f} ms, {(e_ - s_) / 1e3:.0f} us')
+    prev_end = s_
+    for a, b, n, w in st:
+        if b >= s_ and a <= e_:
+            print(f'    +{(a - s_) / 1e3:7.1f} us  gap {(a - prev_end) / 1e3:6.1f}  dur {(b - a) / 1e3:6.1f} us  wg {w:6d}  {n[:80]}')
+            prev_end = max(prev_end, b)

@@ -109,13 +109,14 @@ class Shared2FCBBoxHead(nn.Module):
         o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), w, b).reshape(N, -1)
         return o[:, :ncls], o[:, ncls:ncls + nreg]
 
-    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights):
-        """bbox_head.py:140-185."""
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, from_get_targets=False):
+        """bbox_head.py:140-185.  from_get_targets: the weights are BBoxHead.get_targets' own (label_weights all one, bbox_weights
+        one exactly on the foreground rows, bbox_head.py:84-138) -- the count of valid rows and the foreground mask are then
+        known without the nine small launches that recompute them."""
         losses = dict()
-        avg = (label_weights > 0).sum().float().clamp(min=1.)
+        avg = float(max(int(label_weights.shape[0]), 1)) if from_get_targets else (label_weights > 0).sum().float().clamp(min=1.)
         losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg)
         losses['acc'] = accuracy(cls_score, labels)
-        pos = (labels >= 0) & (labels < self.num_classes)
         n = bbox_pred.shape[0]
         pred = bbox_pred.view(n, -1, 4)
         if pred.shape[1] == 1:          # one class (BONAI): nothing to select -- no gather / scatter-back launches
@@ -123,7 +124,11 @@ class Shared2FCBBoxHead(nn.Module):
         else:
             idx = labels.clamp(max=pred.shape[1] - 1)
             pred = pred[torch.arange(n, device=pred.device), idx]
-        w = bbox_weights * pos[:, None].float()
+        if from_get_targets:
+            w = bbox_weights
+        else:
+            pos = (labels >= 0) & (labels < self.num_classes)
+            w = bbox_weights * pos[:, None].float()
         losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, w, avg_factor=float(max(n, 1)))
         return losses
 
@@ -447,7 +452,8 @@ class LoftRoIHead(nn.Module):
 
         def bbox_branch():
             cls_score, bbox_pred = self.bbox_head(bbox_feats)
-            return self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights)
+            return self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
+                                       from_get_targets=fused_targets)
         bbox_on_side = self.with_mask and not os.environ.get('LOFT_NO_BBOX_SIDE_STREAM')   # the bbox head's 512-workgroup GEMMs ride along
         if not bbox_on_side:
             losses.update(bbox_branch())
@@ -474,8 +480,8 @@ class LoftRoIHead(nn.Module):
                     masks, moffs = _masks_to_device(gt_masks, dev)
                     H, W = masks[0].shape[1], masks[0].shape[2]
                     pb = pos_rois[:, 1:].clone()
-                    pb[:, [0, 2]] = pb[:, [0, 2]].clamp(0, W)
-                    pb[:, [1, 3]] = pb[:, [1, 3]].clamp(0, H)
+                    pb[:, 0::2].clamp_(0, W)      # (strided views: list indices would cost two H2D copies and six launches)
+                    pb[:, 1::2].clamp_(0, H)
                     gidx = pos_gt_i + K.h2d(moffs[:-1], torch.int64, dev)[pos_b]
                     mask_targets = K.mask_target(masks, pb, gidx, int(self.train_cfg.mask_size))
                 return self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel])

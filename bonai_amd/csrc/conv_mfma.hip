@@ -433,7 +433,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
     }
 }
 
-int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, int mj, hipStream_t s);     // conv_pipe.hip
+int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, int mj, int nw_force, hipStream_t s);     // conv_pipe.hip
 
 LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,
                                      const void* relu_mask, void* out,
@@ -444,7 +444,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_STREAM64 || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM64N || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -507,6 +507,9 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else if (Cout % 256 == 0 && half_blocks < 192 && (long)loft_cdiv(M, 64) * (Cout / 256) * groups >= 192 && Kdim >= 2048 &&
                    !out_f32 && !accumulate) {
             k = LOFT_CONV_STREAM64;           // layer4's 32 x 32 maps
+        } else if (Cout % 256 == 0 && (long)loft_cdiv(M, 64) * (Cout / 256) * groups < 192 &&
+                   (long)loft_cdiv(M, 64) * (Cout / 128) * groups >= 192 && Kdim >= 2048 && !out_f32 && !accumulate) {
+            k = LOFT_CONV_STREAM64N;          // 256 couts on a 32 x 32 map: 64-pixel x 128-cout tiles fill the chip (P5 3x3: 50 -> 2x as many workgroups)
         } else if (Cout % 256 == 0 && big_blocks >= 192 && !out_f32 && !accumulate) {
             // bf16 output: the software-pipelined kernel with the LDS-staged, row-contiguous epilogue (conv_pipe.hip; +26..43 %
             // over the lockstep 256-tile kernel on the 3x3 / FC shapes, +15..35 % over the 128-tile kernels on the K-shallow 1x1s)
@@ -525,6 +528,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else k = LOFT_CONV_T128x64;
     }
     switch (k) {
+    case LOFT_CONV_STREAM64N:
     case LOFT_CONV_STREAM64:
     case LOFT_CONV_STREAM128:
     case LOFT_CONV_STREAM256:
@@ -547,7 +551,9 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
-        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf, k == LOFT_CONV_STREAM128 ? 2 : (k == LOFT_CONV_STREAM64 ? 1 : 4), s);
+        return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf,
+                                         k == LOFT_CONV_STREAM128 ? 2 : ((k == LOFT_CONV_STREAM64 || k == LOFT_CONV_STREAM64N) ? 1 : 4),
+                                         k == LOFT_CONV_STREAM64N ? 1 : 0, s);
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still

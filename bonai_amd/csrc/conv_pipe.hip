@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // CU, K-tiles of only 256-512 MFMA cycles) take THREE stages: a K-tile's copies are requested two tiles ahead and retired
     // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
     // 20-35 % of the MFMA rate).  Weights 3 x NW x 16 KiB, activations 3 x MJ x 8 KiB behind them; also the 128-cout tile (NW = 1).
-    constexpr int NS = (MODE == 1 && VAR == 0 && ((MJ <= 2 && NW == 2) || (MJ == 4 && NW == 1))) ? 3 : 2;
+    constexpr int NS = (MODE == 1 && VAR == 0 && !(MJ == 4 && NW == 2)) ? 3 : 2;
     constexpr int PBW = NS == 3 ? NW * 16384 : PBUF, PBX = NS == 3 ? MJ * 8192 : PBUF;
     constexpr int PXO = NS == 3 ? 3 * PBW : PX_OFF;
     constexpr int LDSZ = NS == 3 ? 3 * PBW + 3 * PBX : PLDS;
@@ -832,18 +832,20 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
-int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, hipStream_t s) {
+int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s) {
     ConvArgs a = a_in;
     if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
-    const int nw = a.Cout % 256 == 0 ? 2 : 1;                       // 128-cout tiles for Cout = 128 (mod 256)
-    if (nw == 1 && !(mode == 1 && var == 0 && mj == 4 && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
+    const int nw = nw_force == 1 ? 1 : (a.Cout % 256 == 0 ? 2 : 1);       // 128-cout tiles: Cout = 128 (mod 256), or by choice with 64-pixel tiles
+    if (nw == 1 && !(mode == 1 && var == 0 && (mj == 4 || mj == 1) && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
     dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / (128 * nw), groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
     fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);
     a.pointwise = a.T == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.ss == 1 && !a.pixmajor && a.IH == a.OH && a.IW == a.OW;
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
-    if (nw == 1) {
+    if (nw == 1 && mj == 1) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 1>), grid, dim3(512), 0, s, a);
+    } else if (nw == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 1>), grid, dim3(512), 0, s, a);
     } else if (mode == 1 && mj == 2) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2>), grid, dim3(512), 0, s, a);

@@ -76,6 +76,8 @@ FWD = [
     ('layer2_reduce_512_128.stream_n128', (1, 8, 512, 128, 128, 128, 1, 1, 0), 'CONV_STREAM256'),
     ('layer4_3x3_512.stream64', (1, 8, 512, 512, 32, 32, 3, 1, 1), 'CONV_STREAM64'),
     ('foa_3x3_groups4_pixmajor.stream64', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_STREAM64'),
+    ('fpn_p5_3x3_256.stream64n', (1, 8, 256, 256, 32, 32, 3, 1, 1), 'CONV_STREAM64N'),
+    ('mask_3x3_pixmajor.stream64n', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM64N'),
 ]
 
 
@@ -87,7 +89,7 @@ def test_fwd_bench_size_sampled_values(name, shape, variant):
     wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
     K.CONV_VARIANT = getattr(K, variant)
     try:
-        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128', 'CONV_STREAM64')
+        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128', 'CONV_STREAM64', 'CONV_STREAM64N')
         out = K.conv2d_fwd(x, wp, bias, R, R, stride, pad, out_dtype=torch.bfloat16 if bf16_only else torch.float32, groups=G)
     finally:
         K.CONV_VARIANT = K.CONV_AUTO
@@ -146,8 +148,8 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         res = _cl(torch.randn(B, Cout, H, W, device='cuda').bfloat16())
         outs = []
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_T256, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR,
-                  K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM64 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256,
-                  K.CONV_STREAM128):
+                  K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM64 | K.CONV_FLAG_TAP_MAJOR,
+                  K.CONV_STREAM64N | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128):
             K.CONV_VARIANT = v
             try:
                 # (the pipelined kernels serve bf16 outputs; fp32 / accumulating launches stay on the lockstep ones)
@@ -160,10 +162,10 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
             finally:
                 K.CONV_VARIANT = K.CONV_AUTO
             outs.append((o16, gm, o16p, o16r, grm))
-        for o in outs[1:6]:
+        for o in outs[1:7]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)
-        for o in outs[6:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
+        for o in outs[7:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
             for got, want in zip(o, outs[0]):
                 if want is None:
                     assert got is None

@@ -20,6 +20,7 @@ SHAPES = [
     ('fpn.lat.256-256', 8, 256, 256, 256, 256, 1, 1, 0, 1),
     ('layer4.3x3', 8, 512, 512, 32, 32, 3, 1, 1, 1),
     ('layer4.1x1.512-2048', 8, 512, 2048, 32, 32, 1, 1, 0, 1),
+    ('fpn.P5.3x3', 8, 256, 256, 32, 32, 3, 1, 1, 1),
     ('fpn.P2.3x3', 8, 256, 256, 256, 256, 3, 1, 1, 1),
     ('fpn.P3.3x3', 8, 256, 256, 128, 128, 3, 1, 1, 1),
     ('mask.3x3(872roi)', 872, 256, 256, 14, 14, 3, 1, 1, 1),
@@ -56,11 +57,11 @@ def main():
         g = torch.randn_like(y)
         row = f'{name:28s} {gflop:8.1f} '
         for wh in which:
-            if wh in ('pipe', 'stream', 'stream128', 'stream64'):
+            if wh in ('pipe', 'stream', 'stream128', 'stream64', 'stream64n'):
                 if Cout % 256:
                     row += f'{"-":>10s} {"-":>8s} '
                     continue
-                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe' else (K.CONV_STREAM128 if wh == 'stream128' else (K.CONV_STREAM64 if wh == 'stream64' else K.CONV_STREAM256))
+                K.CONV_VARIANT = K.CONV_PIPE256 if wh == 'pipe' else (K.CONV_STREAM128 if wh == 'stream128' else (K.CONV_STREAM64 if wh == 'stream64' else (K.CONV_STREAM64N if wh == 'stream64n' else K.CONV_STREAM256)))
                 ms = timeit(lambda: K.conv2d_fwd(x, wp, bias, R, R, st, pad, relu=True, groups=G))
                 K.CONV_VARIANT = K.CONV_AUTO
             elif wh in ('pipe_dgrad', 'stream_dgrad'):

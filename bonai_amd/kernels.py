@@ -1386,7 +1386,7 @@ def random_sample(gt_inds, num, max_pos, mode='random'):
         L.check(lib.loft_random_sample(L.ptr(gt_inds), B, N, int(num), int(max_pos), 0 if mode == 'first' else 1,
                                        ctypes.c_uint64(seed), L.ptr(pidx), L.ptr(pval), L.ptr(nidx), L.ptr(nval), L.ptr(ws),
                                        L.stream()), 'loft_random_sample')
-    return pidx, pval.bool(), nidx, nval.bool()
+    return pidx, pval.view(torch.bool), nidx, nval.view(torch.bool)       # (the kernel writes 0 / 1 bytes: bool views, no copies)
 
 
 def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=True):

@@ -215,15 +215,17 @@ class RPNHead(nn.Module):
         # batched_nms: boxes + level * (max_coordinate + 1), one segment per (image, level)
         nlv = len(fused)
         max_coord = cand.view(B, -1).amax(dim=1)
-        shift = (torch.arange(nlv, device=dev, dtype=torch.float32)[None] * (max_coord[:, None] + 1)).reshape(-1)
         key = ('nms_seg', B, tuple(topk))
+        if ('lvl_ar', nlv) not in self._static:
+            self._static[('lvl_ar', nlv)] = torch.arange(nlv, device=dev, dtype=torch.float32)[None]
+        shift = (self._static[('lvl_ar', nlv)] * (max_coord[:, None] + 1)).reshape(-1)
         if key not in self._static:
             self._static[key] = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64,
                                              device=dev)
             self._static[('img_seg', B, C)] = torch.arange(B + 1, dtype=torch.int64, device=dev) * C
         keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk),
                                predicate=cfg.get('nms_predicate', 'device'))
-        masked = torch.where(keep.view(B, C).bool(), cscore, torch.full_like(cscore, -1.0))
+        masked = torch.where(keep.view(B, C).view(torch.bool), cscore, -1.0)        # (keep is 0 / 1 bytes: a bool view, no copy)
         fs, fi = K.segmented_sort_desc(masked.reshape(-1), self._static[('img_seg', B, C)])
         post = min(cfg.nms_post, cfg.max_num) if cfg.get('max_num', 0) > 0 else cfg.nms_post
         post = min(post, C)

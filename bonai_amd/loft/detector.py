@@ -145,9 +145,13 @@ class LOFT(nn.Module):
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         log_vars['loss'] = loss
         vec = torch.stack([v.detach().float().reshape(()) for v in log_vars.values()])
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(vec)
-            vec = vec / dist.get_world_size()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # asynchronous: the collective runs on the process group's own stream behind the forward pass and is waited for
+            # only when somebody reads the values (_LazyLogVars) -- issued synchronously it would make every rank's main stream
+            # wait for the slowest rank between forward and backward.  Same issue order on every rank (before the gradient
+            # buckets of this step), as RCCL requires.
+            work = dist.all_reduce(vec, async_op=True)
+            vec = (vec, work, float(dist.get_world_size()))
         return loss, log_vars, vec
 
     def train_step(self, data, optimizer=None):
@@ -167,6 +171,10 @@ class _LazyLogVars(OrderedDict):
 
     def _materialise(self):
         if not self._done:
+            if isinstance(self._vec, tuple):            # (sum over ranks in flight, its work handle, world size)
+                vec, work, world = self._vec
+                work.wait()
+                self._vec = vec / world
             vals = self._vec.tolist()
             for k, v in zip(list(super().keys()), vals):
                 super().__setitem__(k, v)

@@ -59,7 +59,10 @@ def _worker(rank, world, port, q):
         losses = dict(loss_a=torch.tensor(1.0 + rank), loss_b=[torch.tensor(2.0), torch.tensor(3.0 * rank)], acc=torch.tensor(50.0))
         loss, log_vars, vec = LOFT._parse_losses(losses)
         want = [1.5, 2.0 + 1.5, 50.0, 1.5 + 3.5]
-        assert torch.allclose(vec, torch.tensor(want)), vec
+        # (the collective is asynchronous: the values are complete when they are read, as train_step's log_vars are)
+        from bonai_amd.loft.detector import _LazyLogVars
+        got = list(_LazyLogVars(list(log_vars.keys()), vec).values())
+        assert torch.allclose(torch.tensor(got), torch.tensor(want)), got
         q.put((rank, 'ok'))
     except Exception as e:  # noqa
         import traceback

@@ -117,13 +117,27 @@ def flip_offsets(offsets, direction):
 
 
 def flip_sample(sample, direction='horizontal'):
-    """One training sample (img HxWx3, gt_bboxes, gt_masks [K,H,W] u8, gt_offsets) flipped as RandomFlip.__call__ does."""
+    """One training sample (img HxWx3, gt_bboxes, gt_masks [K,H,W] u8 -- or gt_polygons --, gt_offsets) flipped as
+    RandomFlip.__call__ does (transforms.py:406-456).
+
+    A sample that carries ``gt_polygons`` instead of bitmaps keeps its polygons as they are and records the flip in
+    ``mask_flips``: the reference's pipeline rasterises first (LoadAnnotations(poly2mask=True), loading.py:301-326 ->
+    BitmapMasks) and RandomFlip then mirrors the BITMAP (structures.py:218-229), which is not the same pixels as rasterising
+    mirrored vertices (pycocotools' edge walk is not flip-symmetric); ``to_device_batch`` rasterises on the device and
+    mirrors the bitmap there, in the recorded order -- bit-identical to the host bitmap path."""
+    if direction not in ('horizontal', 'vertical'):
+        raise ValueError(f"Invalid flipping direction '{direction}'")
     h, w = sample['img'].shape[:2]
     ax = 1 if direction == 'horizontal' else 0
     out = dict(sample)
     out['img'] = np.flip(sample['img'], axis=ax).copy()
     out['gt_bboxes'] = flip_bboxes(sample['gt_bboxes'], (h, w), direction)
-    out['gt_masks'] = np.flip(sample['gt_masks'], axis=ax + 1).copy()
+    if sample.get('gt_masks') is not None:
+        out['gt_masks'] = np.flip(sample['gt_masks'], axis=ax + 1).copy()
+    elif 'gt_polygons' in sample:
+        out['mask_flips'] = tuple(sample.get('mask_flips', ())) + (direction,)
+    else:
+        raise KeyError("flip_sample: the sample carries neither 'gt_masks' nor 'gt_polygons'")
     out['gt_offsets'] = flip_offsets(sample['gt_offsets'], direction)
     out['flip'], out['flip_direction'] = True, direction
     return out
@@ -133,7 +147,10 @@ def _masks_of(s, dev):
     if 'gt_polygons' in s and s.get('gt_masks') is None:
         from . import kernels as K
         h, w = s['img'].shape[:2]
-        return K.poly2mask(s['gt_polygons'], h, w, device=dev)
+        m = K.poly2mask(s['gt_polygons'], h, w, device=dev)
+        for d in s.get('mask_flips', ()):                   # flip_sample on a polygon sample: the bitmap is mirrored, as the
+            m = m.flip(2 if d == 'horizontal' else 1)       # reference's RandomFlip does after LoadAnnotations rasterised it
+        return m.contiguous()
     return torch.from_numpy(np.ascontiguousarray(s['gt_masks'], dtype=np.uint8)).to(dev)
 
 

@@ -1,0 +1,64 @@
+"""The A/B switches of the host-side plumbing, in ONE place.
+
+Every switch turns OFF one fusion / stream / pooling decision of the trainer and selects the formulation it replaced; none is a
+fallback for a missing extension (bonai_amd.lib raises when the library does not load) and the kernels never read the
+environment.  The product runs with all of them False.  They exist for same-box A/B timing (DESIGN.md "Same-box A/B switches"),
+for the serialised mode of the roofline instrumentation, and for tests/test_trainer_gpu.py, which checks that each switch alone
+reproduces the default training step.
+
+Set them in-process::
+
+    from bonai_amd.debug import DBG
+    with DBG.override(no_side_stream=True):
+        ...
+
+or from the shell, read ONCE when this module is imported: ``LOFT_NO_SIDE_STREAM=1 python bench.py`` (the environment name is
+``LOFT_`` + the upper-cased field name)."""
+import contextlib
+import os
+
+SWITCHES = {
+    # streams
+    'no_side_stream': 'mask / bbox branches, the RPN proposal chain and the backbone weight gradients all on the main stream '
+                      '(the mode of bench.py\'s roofline instrumentation)',
+    'no_bbox_side_stream': 'the bbox head on the main stream (the mask branch keeps its side stream)',
+    'no_rpn_side_stream': 'the RPN proposal chain (sort, decode, NMS) on the main stream',
+    'no_wgrad_stream': 'backbone weight-gradient launches on the data-gradient stream',
+    # batched launches / pools of the trainer
+    'no_prepack': 'BN fold + operand packing per conv per step instead of one launch per step (kernels.PrepackRegistry)',
+    'no_unpack_queue': 'one loft_fold_unpack_bwd launch per conv instead of the batched unpack (kernels.UnpackQueue)',
+    'no_grad_sink': 'gradients returned to autograd and accumulated by it, not deposited in the arena by the kernels',
+    'no_zero_pool': 'torch.zeros / torch.empty per accumulation buffer instead of the step\'s pre-zeroed / scratch slabs',
+    'no_feat_hub': 'autograd sums the RPN / RoI-extractor gradients of the FPN maps (no shared per-level gradient map)',
+    # autograd-node granularity / previous formulations of three backward ops
+    'no_block_fusion': 'one autograd node per conv of a residual block instead of nn.res_block',
+    'no_linear_fn': 'Linear layers through the generic conv node',
+    'wgrad_no_patch': 'the tap weight-gradient kernel for 64-channel high-resolution layers (no patch kernel)',
+    'roi_fp32_bwd': 'RoIAlign backward into fp32 maps + a cast',
+    'narrow_mfma_bwd': 'narrow (<= 8 output) heads backward as padded MFMA GEMMs',
+}
+
+
+class _Switches:
+    __slots__ = tuple(SWITCHES)
+
+    def __init__(self):
+        for k in SWITCHES:
+            setattr(self, k, bool(os.environ.get('LOFT_' + k.upper())))
+
+    def active(self):
+        return sorted(k for k in SWITCHES if getattr(self, k))
+
+    @contextlib.contextmanager
+    def override(self, **kw):
+        prev = {k: getattr(self, k) for k in kw}      # (AttributeError for an unknown name: __slots__)
+        try:
+            for k, v in kw.items():
+                setattr(self, k, bool(v))
+            yield self
+        finally:
+            for k, v in prev.items():
+                setattr(self, k, v)
+
+
+DBG = _Switches()

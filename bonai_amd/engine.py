@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from .debug import DBG
 
 
 class FlatArena:
@@ -231,18 +232,40 @@ class Trainer:
                 state[idx[id(p)]] = dict(momentum_buffer=a.momentum[o:o + p.numel()].view(p.shape).detach().cpu().clone())
         group = dict(lr=self.lr, momentum=self.mu, dampening=0, weight_decay=self.wd, nesterov=False,
                      params=list(range(len(idx))))
-        return dict(state=state, param_groups=[group], iter=self.iter)
+        # sampler_calls: the RandomSampler kernel's draws are a function of (torch.initial_seed(), call count); a resumed run
+        # continues the uninterrupted run's sequence only if the count travels with the optimizer state
+        return dict(state=state, param_groups=[group], iter=self.iter, sampler_calls=int(K._SAMPLE_CALLS[0]))
 
     def load_optimizer_state(self, sd):
-        """Inverse of optimizer_state_dict (also accepts a reference checkpoint's torch SGD state)."""
+        """Inverse of optimizer_state_dict (also accepts a reference checkpoint's torch SGD state: state index i is the i-th
+        entry of ``model.parameters()``, which tests/test_plugin_cpu.py pins to the reference model's registration order).
+        Every buffer must have exactly its parameter's shape -- an index that points at another tensor of equal size would
+        otherwise be written into the wrong momentum slot without a trace."""
         a = self.arena
         params = list(self.model.parameters())
-        for i, st in sd.get('state', {}).items():
+        state = sd.get('state', {})
+        groups = sd.get('param_groups')
+        if groups and sum(len(g.get('params', ())) for g in groups) != len(params):
+            raise RuntimeError(f"optimizer state covers {sum(len(g['params']) for g in groups)} parameters, the model has "
+                               f'{len(params)}: it was written for a different model')
+        todo = []
+        for i, st in state.items():
+            if not 0 <= int(i) < len(params):
+                raise RuntimeError(f'optimizer state index {i} outside the model\'s {len(params)} parameters')
             p = params[int(i)]
-            if id(p) in a.offsets and st.get('momentum_buffer') is not None:
-                o = a.offsets[id(p)]
-                a.momentum[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1).to(a.momentum.device))
+            buf = st.get('momentum_buffer')
+            if buf is None:
+                continue
+            if tuple(buf.shape) != tuple(p.shape):
+                raise RuntimeError(f'optimizer state {i}: momentum_buffer {tuple(buf.shape)} does not fit parameter '
+                                   f'{tuple(p.shape)} (parameter order differs from the checkpoint\'s)')
+            if id(p) in a.offsets:
+                todo.append((a.offsets[id(p)], p.numel(), buf))
+        for o, n, buf in todo:                              # (nothing is written unless everything fits)
+            a.momentum[o:o + n].copy_(buf.reshape(-1).to(a.momentum.device))
         self.iter = int(sd.get('iter', self.iter))
+        if 'sampler_calls' in sd:
+            K._SAMPLE_CALLS[0] = int(sd['sampler_calls'])
 
     def train_step(self, data, lr=None):
         """One full optimisation step: forward, losses, backward, gradient all-reduce, clip, SGD."""
@@ -254,24 +277,24 @@ class Trainer:
             p._loft_sunk = False
         from . import nn as F2
         prev_pp = F2.PREPACK
-        if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_PREPACK'):
+        if self.arena.data.is_cuda and not DBG.no_prepack:
             F2.PREPACK = self.prepack
             self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
         prev_hub = F2.HUB_ENABLED
-        F2.HUB_ENABLED = self.arena.data.is_cuda and not os.environ.get('LOFT_NO_FEAT_HUB')
+        F2.HUB_ENABLED = self.arena.data.is_cuda and not DBG.no_feat_hub
         try:
             out = self.model.train_step(data)
         finally:
             F2.PREPACK = prev_pp
             F2.HUB_ENABLED = prev_hub
-        prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_GRAD_SINK') else None)
-        if self.arena.data.is_cuda and not os.environ.get('LOFT_NO_ZERO_POOL'):
+        prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not DBG.no_grad_sink else None)
+        if self.arena.data.is_cuda and not DBG.no_zero_pool:
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
-        if F2.GRAD_SINK is not None and not os.environ.get('LOFT_NO_UNPACK_QUEUE'):
+        if F2.GRAD_SINK is not None and not DBG.no_unpack_queue:
             # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
             F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48,
                                         note=self.reducer.note_queued if self.reducer.enabled else None)
-            if not os.environ.get('LOFT_NO_SIDE_STREAM') and not os.environ.get('LOFT_NO_WGRAD_STREAM'):
+            if not DBG.no_side_stream and not DBG.no_wgrad_stream:
                 if getattr(self, '_wgrad_stream', None) is None:
                     self._wgrad_stream = torch.cuda.Stream()
                 F2.WGRAD_STREAM = self._wgrad_stream

@@ -466,7 +466,7 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
 
 
 import os as _os
-_WGRAD_NO_PATCH = bool(_os.environ.get('LOFT_WGRAD_NO_PATCH'))     # A/B switch
+from .debug import DBG as _DBG     # A/B switches (bonai_amd/debug.py)
 
 
 # Split-K combination of the weight gradients whose consumer is the batched unpack: False = fp32 atomics into a zeroed buffer
@@ -501,7 +501,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     _ev = _prof_begin()
     if (Cout <= 64 and Cin <= 64 and len(taps) <= 9 and gos == 1 and ss == 1 and (GH, GW) == (OH, OW) == (XH, XW)
             and B * OH * OW >= 65536 and all(t[0] == 0 and t[1] == 0 and abs(t[2]) <= 1 and abs(t[3]) <= 1 for t in taps)
-            and (db is None or db_tap != -1) and not _WGRAD_NO_PATCH):
+            and (db is None or db_tap != -1) and not _DBG.wgrad_no_patch):
         # narrow stride-1 convs at high resolution: all taps from one staged pixel patch (loft_conv_wgrad_patch_bf16)
         if dw is None:
             dw = pooled_zeros((groups, n_wtaps, Cout, Cin), g.device)

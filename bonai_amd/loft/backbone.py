@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from ..debug import DBG
 from .. import nn as F2
 from .builder import BACKBONES, NECKS
 
@@ -103,10 +104,9 @@ class Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    fused = os.environ.get('LOFT_NO_BLOCK_FUSION') is None     # A/B switch: one autograd node per block (nn.res_block)
-
     def forward(self, x):
-        if self.fused and not isinstance(self.conv2, ModulatedDeformConvPack):
+        # (DBG.no_block_fusion: A/B switch -- one autograd node per conv instead of one per block, nn.res_block)
+        if not DBG.no_block_fusion and not isinstance(self.conv2, ModulatedDeformConvPack):
             main = [(self.conv1.weight, self.bn1, 1, 1, 0, None), (self.conv2.weight, self.bn2, 3, self.stride, 1, None),
                     (self.conv3.weight, self.bn3, 1, 1, 0, None)]
             sc = None if self.downsample is None else (self.downsample[0].weight, self.downsample[1], 1, self.stride, 0, None)

@@ -17,6 +17,7 @@ from torch import nn
 
 from .. import kernels as K
 from .. import nn as F2
+from ..debug import DBG
 from .backbone import Bottleneck, ConvW, FrozenStatBN
 from .builder import BACKBONES, NECKS
 
@@ -55,7 +56,7 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if Bottleneck.fused:     # one autograd node per block: no aten add / separate ReLU-backward per block
+        if not DBG.no_block_fusion:     # one autograd node per block: no aten add / separate ReLU-backward per block
             cp = _p(self.planes)
             main = [(self.conv1.weight, self.bn1, 3, self.stride, 1, cp), (self.conv2.weight, self.bn2, 3, 1, 1, cp)]
             ds = self.downsample

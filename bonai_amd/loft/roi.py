@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from ..debug import DBG
 from .. import nn as F2
 from .backbone import ConvW
 from .builder import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head, build_loss,
@@ -81,9 +82,12 @@ class Shared2FCBBoxHead(nn.Module):
         self.loss_cls = build_loss(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
         self.loss_bbox = build_loss(loss_bbox or dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0))
         area = roi_feat_size * roi_feat_size
-        self.shared_fcs = nn.ModuleList([_FC(in_channels * area, fc_out_channels), _FC(fc_out_channels, fc_out_channels)])
+        # registration order = the reference's (BBoxHead.__init__ creates fc_cls / fc_reg, bbox_head.py:49-56, before
+        # ConvFCBBoxHead adds shared_fcs, convfc_bbox_head.py:53-57): model.parameters() order is part of the checkpoint
+        # format -- torch.optim.SGD's state_dict indexes parameters by position (tests/test_plugin_cpu.py)
         self.fc_cls = _FC(fc_out_channels, num_classes + 1)
         self.fc_reg = _FC(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+        self.shared_fcs = nn.ModuleList([_FC(in_channels * area, fc_out_channels), _FC(fc_out_channels, fc_out_channels)])
 
     def init_weights(self):
         """bbox_head.py:66-73 + convfc_bbox_head.py:126-133."""
@@ -240,10 +244,11 @@ class OffsetHeadExpandFeature(_OffsetBase):
         self.num_convs = num_convs
         if tuple(float(v) for v in offset_coder.get('target_means', (0., 0.))) != (0., 0.):
             raise NotImplementedError('FOA target / fusion kernels take zero offset means (configs/loft_foa)')
-        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
-                     loss_offset, offset_coordinate, reg_decoded_offset)
+        # (convs before fcs / fc_offset: the reference's registration order, offset_head_expand_feature.py:62-107)
         self.expand_convs = nn.ModuleList([nn.ModuleList([ConvW(conv_out_channels, conv_out_channels, 3, bias=True)
                                                           for _ in range(num_convs)]) for _ in range(4)])
+        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
+                     loss_offset, offset_coordinate, reg_decoded_offset)
 
     def init_weights(self):
         """offset_head_expand_feature.py:109-132."""
@@ -285,10 +290,10 @@ class OffsetHead(_OffsetBase):
                  reg_decoded_offset=False, conv_cfg=None, norm_cfg=None, loss_offset=dict(type='MSELoss', loss_weight=1.0)):
         super().__init__()
         self.num_convs = num_convs
-        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
-                     loss_offset, offset_coordinate, reg_decoded_offset)
         self.convs = nn.ModuleList([ConvW(in_channels if i == 0 else conv_out_channels, conv_out_channels, 3, bias=True)
                                     for i in range(num_convs)])
+        self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
+                     loss_offset, offset_coordinate, reg_decoded_offset)
 
     def init_weights(self):
         for c in self.convs:
@@ -448,13 +453,16 @@ class LoftRoIHead(nn.Module):
         if spec_feats is not None and spec_feats.shape[0] == rois.shape[0]:
             bbox_feats = spec_feats
         else:
+            if spec_feats is not None:           # under-filled sampler: the speculative node is dropped, never differentiated
+                F2.roi_align_discard(spec_feats)
+                spec_feats = None
             bbox_feats = self.bbox_roi_extractor(feats, rois)
 
         def bbox_branch():
             cls_score, bbox_pred = self.bbox_head(bbox_feats)
             return self.bbox_head.loss(cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
                                        from_get_targets=fused_targets)
-        bbox_on_side = self.with_mask and not os.environ.get('LOFT_NO_BBOX_SIDE_STREAM')   # the bbox head's 512-workgroup GEMMs ride along
+        bbox_on_side = self.with_mask and not DBG.no_bbox_side_stream   # the bbox head's 512-workgroup GEMMs ride along
         if not bbox_on_side:
             losses.update(bbox_branch())
 
@@ -465,7 +473,7 @@ class LoftRoIHead(nn.Module):
             # chains of launches that each fill 2.6 rounds of the 256 CUs: on two HIP streams their tails fill each other's
             # idle CUs, forward and (autograd replays each node on its forward stream) backward.  RoIAlign stays on the main
             # stream -- its backward accumulates into the shared per-level gradient maps.
-            if dev.type == 'cuda' and torch.is_grad_enabled() and K.PROFILE is None and not os.environ.get('LOFT_NO_SIDE_STREAM'):
+            if dev.type == 'cuda' and torch.is_grad_enabled() and K.PROFILE is None and not DBG.no_side_stream:
                 if getattr(self, '_side_stream', None) is None:
                     self._side_stream = torch.cuda.Stream()
                 side = self._side_stream

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from ..debug import DBG
 from .. import nn as F2
 from .backbone import ConvW
 from .builder import HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler
@@ -248,8 +249,8 @@ class RPNHead(nn.Module):
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
         if self.sparse_backward and torch.is_grad_enabled() and x[0].dtype == K.L.act16() and x[0].shape[1] % 128 == 0:
-            if (proposal_cfg is not None and x[0].is_cuda and K.PROFILE is None and not os.environ.get('LOFT_NO_SIDE_STREAM')
-                    and not os.environ.get('LOFT_NO_RPN_SIDE_STREAM')):
+            if (proposal_cfg is not None and x[0].is_cuda and K.PROFILE is None and not DBG.no_side_stream
+                    and not DBG.no_rpn_side_stream):
                 return self._forward_train_two_streams(x, img_metas, gt_bboxes, gt_bboxes_ignore, proposal_cfg)
             with torch.no_grad():
                 fused, hs = self.forward_fused(x, keep_hidden=True)

@@ -10,10 +10,12 @@ forward-only on the fp32 MFMA kernel (loft_conv_tap_f32) with fp32 operand packi
 with the fp32 reference at 1e-3; the backward of these functions refuses fp32 activations.
 """
 import os as _os
+import weakref as _weakref
 
 import torch
 
 from . import kernels as K
+from .debug import DBG
 
 
 def to_nhwc(t):
@@ -85,7 +87,67 @@ def _premasked(g, y):
 WGRAD_STREAM = None   # the running Trainer's second stream for backbone weight-gradient launches (None = same stream)
 UNPACK_Q = None    # the running Trainer's kernels.UnpackQueue: weight-gradient unpacking of many convs in one launch
 PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
-_PACK_CACHE = {}   # frozen (no-grad) convs: packed operands are reused while the parameter versions do not change
+
+
+# ---- packed operands of FROZEN (requires_grad=False) convs are reused from step to step.  The cache lives ON the weight
+# Parameter object (attribute ``_loft_packs``), so it dies with the model that owns it, and every entry carries the identity
+# (weak reference), version counter, address and geometry of each tensor it was computed from.  Round 2 kept a process-global
+# dict keyed by (data_ptr, _version, shape): a model built after another one had been freed received the freed model's
+# addresses from the caching allocator and silently ran on the PREVIOUS model's stem / layer1 weights
+# (tests/test_lifetime_gpu.py).
+
+def _base_of(t):
+    return t._base if t._base is not None else t
+
+
+def _pack_sig(tensors):
+    sig = []
+    for t in tensors:
+        if t is None:
+            sig.append(None)
+        else:
+            b = _base_of(t)
+            sig.append((_weakref.ref(b), b._version, t.data_ptr(), tuple(t.shape), tuple(t.stride())))
+    return sig
+
+
+def _pack_sig_valid(sig, tensors):
+    if len(sig) != len(tensors):
+        return False
+    for s, t in zip(sig, tensors):
+        if s is None or t is None:
+            if s is not None or t is not None:
+                return False
+            continue
+        b = _base_of(t)
+        if s[0]() is not b or s[1] != b._version or s[2] != t.data_ptr() or s[3] != tuple(t.shape) or s[4] != tuple(t.stride()):
+            return False
+    return True
+
+
+def _pack_cache_get(sub, tensors):
+    """Cached packing for the frozen tensors ``tensors`` (tensors[0] = the first weight = the owner) under sub-key ``sub``."""
+    d = _base_of(tensors[0]).__dict__.get('_loft_packs')
+    e = d.get(sub) if d else None
+    if e is not None and _pack_sig_valid(e[0], tensors):
+        return e[1]
+    return None
+
+
+def _pack_cache_put(sub, tensors, value):
+    owner = _base_of(tensors[0])
+    d = owner.__dict__.get('_loft_packs')
+    if d is None:
+        d = owner._loft_packs = {}
+    if len(d) >= 8 and sub not in d:     # (dtype, padding, dgrad) variants of ONE conv: bounded; stale variants go first
+        d.clear()
+    d[sub] = (_pack_sig(tensors), value)
+
+
+def clear_pack_cache(module):
+    """Drop every cached packing of ``module``'s parameters (frees their device memory; nothing needs this for correctness)."""
+    for p in module.parameters():
+        p.__dict__.pop('_loft_packs', None)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -110,13 +172,13 @@ class _ConvFn(torch.autograd.Function):
             Cout = cout_pad or Cout
         dev = x.device
         pdt = torch.float32 if x.dtype == torch.float32 else K.L.act16()
-        key = None
+        key = cached = None
         if frozen:
-            key = (pdt,) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors if t is not None)
-            if bn_stats is not None:
-                key += tuple((t.data_ptr(), t._version) for t in bn_stats[:2])
-        if key is not None and key in _PACK_CACHE:
-            wp, wpt, bias = _PACK_CACHE[key]
+            key = ('conv', pdt, Cin, Cout, bool(ctx.needs_input_grad[0]))
+            ctens = tuple(tensors) + (tuple(bn_stats[:2]) if bn_stats is not None else ())
+            cached = _pack_cache_get(key, ctens)
+        if cached is not None:
+            wp, wpt, bias = cached
         elif PREPACK is not None and key is None and pdt == K.L.act16() and Cout % 2 == 0 and Cin % 2 == 0 and \
                 all(isinstance(w, torch.nn.Parameter) for w in ws):
             bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
@@ -133,7 +195,7 @@ class _ConvFn(torch.autograd.Function):
                 K.fold_pack(ws[g], bs[g], bn, eps, out_fwd=wp[g], out_dgrad=None if wpt is None else wpt[g], out_bias=bias[g],
                             want_dgrad=need_dgrad, dtype=pdt, cout_pad=Cout, cin_pad=Cin)
             if key is not None:
-                _PACK_CACHE[key] = (wp, wpt, bias)
+                _pack_cache_put(key, ctens, (wp, wpt, bias))
         use_bias = has_b or bn_stats is not None
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
                          out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else K.L.act16(), groups=G)
@@ -258,7 +320,6 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
     return _ConvFn.apply(x, residual, meta, *tensors)
 
 
-_NO_LINEAR_FN = bool(_os.environ.get('LOFT_NO_LINEAR_FN'))     # A/B switch: Linear layers through the generic conv node
 
 
 class _LinearFn(torch.autograd.Function):
@@ -340,7 +401,7 @@ class _LinearFn(torch.autograd.Function):
 def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
     """x [N,K] bf16 (row-major), w [O,K] fp32 -> [N,O]."""
     N, Kd = x2d.shape
-    if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and not out_f32 and x2d.dtype == K.L.act16() and not _NO_LINEAR_FN:
+    if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and not out_f32 and x2d.dtype == K.L.act16() and not DBG.no_linear_fn:
         return _LinearFn.apply(x2d, w, b, relu, input_relu, None)
     y = conv2d(x2d.reshape(N, Kd, 1, 1).contiguous(memory_format=torch.channels_last), w.view(w.shape[0], Kd, 1, 1), b,
                relu=relu, out_f32=out_f32, input_relu=input_relu)
@@ -350,7 +411,7 @@ def linear(x2d, w, b=None, relu=False, out_f32=False, input_relu=False):
 def linear_after_flatten(x, w, b=None, relu=True, input_relu=False):
     """``x.flatten(1)`` of an NCHW-shaped map followed by nn.Linear, on NHWC memory (x bf16 [N,C,H,W] channels_last)."""
     N, C, H, W = x.shape
-    if isinstance(w, torch.nn.Parameter) and x.dtype == K.L.act16() and not _NO_LINEAR_FN:
+    if isinstance(w, torch.nn.Parameter) and x.dtype == K.L.act16() and not DBG.no_linear_fn:
         return _LinearFn.apply(x, w, b, relu, input_relu, (C, H, W))
     wperm = w.view(-1, C, H, W).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     return linear(x.permute(0, 2, 3, 1).reshape(N, -1), wperm, b, relu=relu, input_relu=input_relu)
@@ -383,7 +444,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         stride, pad = ctx.sp
         Cout, Cin, R, S = w.shape
         if R == 1 and S == 1 and stride == 1 and pad == 0 and Cout <= 8 and Cin % 4 == 0 and Cin <= 1024 and \
-                x.dtype == K.L.act16() and not _os.environ.get('LOFT_NARROW_MFMA_BWD'):
+                x.dtype == K.L.act16() and not DBG.narrow_mfma_bwd:
             # one pass over x: gx (with the producer's ReLU mask when x is a ReLU output), dW and db together
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=ctx.input_relu, need_gx=ctx.needs_input_grad[0],
@@ -631,7 +692,7 @@ class _RoIAlignFn(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         P, strides, fs, n_rot, shapes, dt = ctx.meta
         g = to_nhwc(g)
-        direct = dt == K.L.act16() and g.dtype == K.L.act16() and not _os.environ.get('LOFT_ROI_FP32_BWD')   # bf16 maps straight from fp32 registers
+        direct = dt == K.L.act16() and g.dtype == K.L.act16() and not DBG.roi_fp32_bwd   # bf16 maps straight from fp32 registers
         keys = ctx.hub_keys
         if direct and HUB is not None and all(k is not None and k in HUB for k in keys):
             if ROI_BWD_FUSED:                         # wait for the other extractors' lists; the last one launches
@@ -669,7 +730,20 @@ class _RoIAlignFn(torch.autograd.Function):
 
 
 def roi_align(feats, rois, P, strides, finest_scale=56, n_rot=1):
-    return _RoIAlignFn.apply(rois, P, tuple(strides), finest_scale, n_rot, *feats)
+    before = HUB['_expected'] if HUB is not None else None
+    y = _RoIAlignFn.apply(rois, P, tuple(strides), finest_scale, n_rot, *feats)
+    if before is not None and HUB['_expected'] != before:
+        y._loft_hub_counted = True            # (see roi_align_discard)
+    return y
+
+
+def roi_align_discard(y):
+    """The caller drops the RoIAlign result ``y`` without ever differentiating through it (the RoI head's speculative bbox
+    features when the sampler under-fills): the hub must not wait for that node's backward list, or the fused RoIAlign backward
+    would only launch from the fallback flushes (roi.py)."""
+    if HUB is not None and getattr(y, '_loft_hub_counted', False):
+        HUB['_expected'] -= 1
+        y._loft_hub_counted = False
 
 
 class _FpnTopDownFn(torch.autograd.Function):
@@ -909,10 +983,10 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
     tensors = (w, bn.weight, bn.bias)
     key = None
     if all(_cacheable(t) for t in tensors):
-        key = ('rb', pdt, cin_p, cout_p, need_dgrad) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors) + \
-            tuple((t.data_ptr(), t._version) for t in stats)
-        if key in _PACK_CACHE:
-            return _PACK_CACHE[key]
+        key = ('rb', pdt, cin_p, cout_p, bool(need_dgrad))
+        cached = _pack_cache_get(key, tensors + stats)
+        if cached is not None:
+            return cached
     if PREPACK is not None and key is None and pdt == K.L.act16() and cout_p % 2 == 0 and cin_p % 2 == 0 and \
             isinstance(w, torch.nn.Parameter):
         return PREPACK.request((w,), (None,), (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
@@ -920,7 +994,7 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
                       cout_pad=cout_p, cin_pad=cin_p)
     out = (out[0][None], None if out[1] is None else out[1][None], out[2][None])
     if key is not None:
-        _PACK_CACHE[key] = out
+        _pack_cache_put(key, tensors + stats, out)
     return out
 
 

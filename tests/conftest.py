@@ -15,3 +15,24 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+# Collection order: the driver runs `pytest -m gpu -x`, so ONE failing composite test hides every
+# test collected after it.  Oracle-parity files of single kernels come first, whole-model parity next, and the composite
+# trainer / lifetime / multi-process tests -- the ones with the most moving parts -- last.  Files not named here keep their
+# alphabetical place between the two groups.
+_FIRST = ['test_lib_symbols.py', 'test_roi_nms_gpu.py', 'test_glue_gpu.py', 'test_offset_head_gpu.py', 'test_inference_gpu.py',
+          'test_conv_gpu.py', 'test_conv_variants_gpu.py', 'test_fp16_gpu.py', 'test_data_gpu.py', 'test_deform_gpu.py',
+          'test_hrnet_gpu.py', 'test_fullsize_props_gpu.py', 'test_e2e_gpu.py']
+_LAST = ['test_lifetime_gpu.py', 'test_edge_gpu.py', 'test_trainer_gpu.py', 'test_ddp_gpu.py']
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        if name in _FIRST:
+            return (0, _FIRST.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+    items.sort(key=rank)          # stable: the order inside a file (and among unnamed files) is pytest's own

@@ -80,3 +80,39 @@ def test_to_device_batch_with_polygons_trains():
     m = m.cuda().train()
     lv = dict(m.train_step(b_dev)['log_vars'].items())
     assert all(np.isfinite(v) for v in lv.values()) and lv['loss_mask'] > 0
+
+
+def test_flip_of_polygon_samples_equals_bitmap_flip():
+    """RandomFlip on a sample that carries polygons -- the device route (rasterise, then mirror the bitmap)
+    must give exactly what the host route gives (BitmapMasks.flip of the rasterised masks, structures.py:218-229), for both
+    directions and for a double flip; boxes / offsets follow the same rules on both routes."""
+    from bonai_amd.data import flip_sample, parse_bonai_annotations, to_device_batch
+    from bonai_amd.synth import synth_bonai_anns
+    H, W = 192, 256                                            # non-square: a swapped axis cannot pass
+    anns = synth_bonai_anns(size=192)
+    ann = parse_bonai_annotations(dict(width=W, height=H, filename='t.png'), anns)
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 255, (H, W, 3)).astype(np.uint8)
+    base = dict(img=img, gt_bboxes=ann['bboxes'], gt_labels=ann['labels'], gt_offsets=ann['offsets'])
+    host_masks = np.stack([R.poly2mask(m, H, W) for m in ann['masks']])
+    s_host, s_poly = dict(base, gt_masks=host_masks), dict(base, gt_polygons=ann['masks'])
+    for dirs in (('horizontal',), ('vertical',), ('horizontal', 'vertical')):
+        fh, fp = s_host, s_poly
+        for d in dirs:
+            fh, fp = flip_sample(fh, d), flip_sample(fp, d)
+        assert 'gt_masks' not in fp or fp['gt_masks'] is None
+        bh, bp = to_device_batch([fh]), to_device_batch([fp])
+        assert torch.equal(bh['gt_masks'][0], bp['gt_masks'][0]), dirs
+        assert bp['gt_masks'][0].is_contiguous() and int(bp['gt_masks'][0].sum()) == int(host_masks.sum())
+        for k in ('img', ):
+            assert torch.equal(bh[k], bp[k])
+        for k in ('gt_bboxes', 'gt_offsets'):
+            assert torch.equal(bh[k][0], bp[k][0])
+        want = host_masks
+        for d in dirs:
+            want = np.flip(want, axis=2 if d == 'horizontal' else 1)
+        assert np.array_equal(bp['gt_masks'][0].cpu().numpy(), want)
+    with pytest.raises(KeyError):
+        flip_sample(dict(base), 'horizontal')
+    with pytest.raises(ValueError):
+        flip_sample(s_poly, 'diagonal')

@@ -105,12 +105,10 @@ def test_trainer_direct_grad_sink_matches_autograd_accumulation():
         m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
         m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
         return m.cuda().train()
+    from bonai_amd.debug import DBG
     ref = build()
-    os.environ['LOFT_NO_SIDE_STREAM'] = '1'          # reference: one stream, plain autograd accumulation
-    try:
+    with DBG.override(no_side_stream=True):          # reference: one stream, plain autograd accumulation
         ref.train_step(data)['loss'].backward()
-    finally:
-        os.environ.pop('LOFT_NO_SIDE_STREAM', None)
     want = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
     m = build()
     tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)

@@ -20,12 +20,10 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 @pytest.fixture()
 def fp16_mode():
-    from bonai_amd import lib as L, nn as F2
-    prev = L.set_act16(torch.float16)
-    F2._PACK_CACHE.clear()
+    from bonai_amd import lib as L
+    prev = L.set_act16(torch.float16)      # (cached frozen-layer packings are keyed by the 16-bit type: nothing to clear)
     yield
     L.set_act16(prev)
-    F2._PACK_CACHE.clear()
 
 
 @pytest.mark.parametrize('shape', [(2, 256, 256, 24, 20, 3), (3, 128, 64, 17, 33, 1), (1, 64, 128, 40, 40, 3)])

@@ -188,3 +188,62 @@ def test_offset_error_vector_statistics():
     assert dict(zip(g.tolist(), p.tolist())) == {0: 0}             # gt 1's only candidate is taken, gt 2 is below the bar
     g, p = match_by_iou(np.array([[0.6, 0.9], [0.7, 0.2]]), 0.5)
     assert dict(zip(g.tolist(), p.tolist())) == {0: 1, 1: 0}
+
+
+def test_optimizer_state_round_trip_and_loud_mismatch(tmp_path):
+    """ADVICE r2 (engine.py): Trainer.optimizer_state_dict / load_optimizer_state -- torch.optim.SGD layout indexed in
+    model.parameters() order, a save/load round trip through the reference checkpoint layout restores every momentum slot,
+    the iteration and the sampler's call count; a buffer whose shape does not fit its parameter raises instead of landing in
+    another parameter's slot."""
+    from torch import nn
+    from bonai_amd import kernels as K
+    from bonai_amd.checkpoint import save_checkpoint
+    from bonai_amd.engine import Trainer
+
+    def net():
+        torch.manual_seed(0)
+        m = nn.Sequential(nn.Linear(6, 4), nn.ReLU(), nn.Linear(4, 6), nn.ReLU(), nn.Linear(6, 4))
+        m[0].bias.requires_grad_(False)                 # a frozen parameter in the middle of the list (the reference's
+        return m                                        # optimizer is built over all parameters, frozen ones included)
+    a = Trainer(net())
+    assert a.optimizer_state_dict()['state'] == {}      # nothing stepped yet
+    a.arena.momentum.copy_(torch.randn(a.arena.numel, generator=torch.Generator().manual_seed(1)))
+    a.iter = 7
+    K._SAMPLE_CALLS[0] = 41
+    sd = a.optimizer_state_dict()
+    params = list(a.model.parameters())
+    assert sd['param_groups'][0]['params'] == list(range(len(params))) and sd['iter'] == 7 and sd['sampler_calls'] == 41
+    assert sorted(sd['state']) == [i for i, p in enumerate(params) if p.requires_grad]
+    for i, st in sd['state'].items():
+        assert tuple(st['momentum_buffer'].shape) == tuple(params[i].shape)
+    f = str(tmp_path / 'latest.pth')
+    save_checkpoint(a.model, f, optimizer_state=sd, meta=dict(iter=7))
+    ck = torch.load(f, map_location='cpu', weights_only=False)
+    K._SAMPLE_CALLS[0] = 0
+    b = Trainer(net())
+    b.load_optimizer_state(ck['optimizer'])
+    assert b.iter == 7 and K._SAMPLE_CALLS[0] == 41
+    for pa, pb in zip(a.arena.params, b.arena.params):
+        oa, ob = a.arena.offsets[id(pa)], b.arena.offsets[id(pb)]
+        assert torch.equal(a.arena.momentum[oa:oa + pa.numel()], b.arena.momentum[ob:ob + pb.numel()])
+    # torch.optim.SGD's own state_dict of the same model is accepted as it is (what a reference checkpoint holds)
+    m = net()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    m(torch.randn(3, 6)).sum().backward()
+    opt.step()
+    c = Trainer(net())
+    c.load_optimizer_state(opt.state_dict())
+    p0 = c.arena.params[0]
+    o = c.arena.offsets[id(p0)]
+    assert torch.equal(c.arena.momentum[o:o + p0.numel()].view(p0.shape), opt.state_dict()['state'][0]['momentum_buffer'])
+    # same numel, other shape (entries 0 and 2 are [4,6] and [6,4]): loud, and nothing was written
+    bad = {k: v for k, v in sd.items()}
+    bad['state'] = dict(sd['state'])
+    bad['state'][0], bad['state'][2] = sd['state'][2], sd['state'][0]
+    d = Trainer(net())
+    with pytest.raises(RuntimeError, match='does not fit parameter'):
+        d.load_optimizer_state(bad)
+    assert float(d.arena.momentum.abs().sum()) == 0.0
+    bad2 = dict(sd, param_groups=[dict(sd['param_groups'][0], params=list(range(3)))])
+    with pytest.raises(RuntimeError, match='different model'):
+        Trainer(net()).load_optimizer_state(bad2)

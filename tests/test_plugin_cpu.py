@@ -41,6 +41,12 @@ def test_reference_build_detector_resolves_to_native_classes():
     assert not foreign and len(native) > 50, foreign[:5]
     keys = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     assert keys == ref_keys                           # reference checkpoints load by key, shapes included
+    # ... and in the reference's REGISTRATION ORDER: torch.optim.SGD's state_dict indexes parameters by their position in
+    # model.parameters(), so Trainer.load_optimizer_state can take a reference checkpoint's 'optimizer' entry only if the
+    # i-th parameter here is the i-th parameter there (engine.py)
+    ref_order = [(n, tuple(p.shape), p.requires_grad) for n, p in ref_model.named_parameters()]
+    own_order = [(n, tuple(p.shape), p.requires_grad) for n, p in model.named_parameters()]
+    assert own_order == ref_order
     # sub-builders of the reference resolve too
     from mmdet.models.builder import build_backbone, build_head
     from mmdet.core.bbox.builder import build_bbox_coder

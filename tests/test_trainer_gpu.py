@@ -1,0 +1,165 @@
+"""GPU, composite: the Trainer path that bench.py times (direct gradient sink + unpack queue + weight-gradient side stream +
+prepack + zero / scratch pools + feature hub) against plain autograd, under every A/B switch of bonai_amd/debug.py; the
+under-filled-sampler case of the speculative bbox RoIAlign; checkpoint resume against an uninterrupted run.
+Reference for what the Trainer must equal: mmcv's OptimizerHook + torch.optim.SGD as driven from mmdet/apis/train.py:84-108."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    from bonai_amd.config import Config
+    return Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+
+
+def _synth_model(cfg=None):
+    from bonai_amd.loft import build_detector
+    from oracle.synth_weights import synth_tensor
+    cfg = cfg or _cfg()
+    m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    return m.cuda().train()
+
+
+def _autograd_grads(m, data):
+    from bonai_amd.debug import DBG
+    with DBG.override(**dict({k: False for k in DBG.active()}, no_side_stream=True)):
+        m.train_step(data)['loss'].backward()
+    return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _compare(want, m, tag, tol=1e-2):
+    got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    assert set(want) <= set(got)
+    bad = []
+    for n, w in want.items():
+        d, s = (got[n] - w).norm().item(), w.norm().item()
+        if d > tol * s + 1e-7:
+            bad.append((n, d, s))
+    assert not bad, (tag, len(bad), bad[:5])
+    for n, g in got.items():
+        if n not in want:
+            assert g.abs().max().item() == 0, (tag, n)
+
+
+@pytest.fixture(scope='module')
+def first_k():
+    from bonai_amd.loft.core import RandomSampler
+    RandomSampler.choice_mode = 'first'
+    yield
+    RandomSampler.choice_mode = 'random'
+
+
+def test_every_debug_switch_alone_matches_the_default_step(first_k):
+    """One Trainer, one batch, lr = 0: the default configuration and then each switch of bonai_amd.debug.SWITCHES alone must
+    produce the gradients of plain autograd (1e-2 in norm: split-K fp32 atomics and the packed-bf16 atomics of the sparse RPN
+    scatter reorder sums from run to run).  no_block_fusion / no_linear_fn change the autograd graph, so they get their own model."""
+    from bonai_amd.debug import DBG, SWITCHES
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    data = make_batch(2, 256, 8, device='cuda')
+    want = _autograd_grads(_synth_model(), data)
+    m = _synth_model()
+    tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
+    for rep in range(2):
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+        _compare(want, m, f'default rep {rep}')
+    assert set(SWITCHES) == set(DBG.__slots__)
+    for sw in SWITCHES:
+        with DBG.override(**{sw: True}):
+            assert DBG.active() == [sw]
+            tr.train_step(data, lr=0.0)
+            torch.cuda.synchronize()
+            _compare(want, m, sw)
+    assert DBG.active() == []
+    tr.train_step(data, lr=0.0)                       # and back: the default path is intact after every detour
+    torch.cuda.synchronize()
+    _compare(want, m, 'default after the switches')
+
+
+def test_underfilled_sampler_drops_the_speculative_roialign_cleanly(first_k):
+    """with few proposals the sampler cannot fill its 1024 slots per image, the bbox features computed
+    speculatively on the worst-case list are dropped -- the fused RoIAlign backward must still launch when the THREE real lists
+    have arrived (not from a fallback flush), and the Trainer's gradients must equal autograd's."""
+    from bonai_amd import nn as F2
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    cfg = _cfg()
+    for k in ('nms_post', 'max_num'):
+        cfg.train_cfg.rpn_proposal[k] = 200           # << the RCNN sampler's num = 1024 -> M != B * num
+    data = make_batch(2, 256, 8, device='cuda')
+    want = _autograd_grads(_synth_model(cfg), data)
+    m = _synth_model(cfg)
+    tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
+    seen = []
+    flush = F2._hub_flush
+
+    def spy():
+        if F2.HUB is not None and F2.HUB.get('_pending'):
+            seen.append((F2.HUB['_seen'], F2.HUB['_expected'], len(F2.HUB['_pending'])))
+        return flush()
+    F2._hub_flush = spy
+    try:
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+    finally:
+        F2._hub_flush = flush
+    assert m.roi_head.last_stats['num_rois'] < 2 * 1024           # the case under test really is under-filled
+    assert seen == [(3, 3, 3)], seen                               # one flush, by the last of exactly three expected lists
+    _compare(want, m, 'under-filled')
+
+
+def test_resume_equals_uninterrupted(tmp_path):
+    """ADVICE r2 (engine.py): 2 steps + save + (fresh model, load, load_optimizer_state) + 2 steps == 4 uninterrupted steps,
+    with the RANDOM sampler (its draws depend on the call count that now travels in the optimizer state), momentum and weight
+    decay on.  Tolerance: the run-to-run noise of the backward's atomics through four updates."""
+    from bonai_amd import kernels as K
+    from bonai_amd.checkpoint import load_checkpoint, save_checkpoint
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft.core import RandomSampler
+    from bonai_amd.synth import make_batch
+    assert RandomSampler.choice_mode == 'random'
+    batches = [make_batch(2, 256, 8, step=s, device='cuda') for s in range(4)]
+    kw = dict(lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+
+    def run(tr, steps):
+        return [dict(tr.train_step(batches[s])['log_vars'].items()) for s in steps]
+    torch.manual_seed(11)
+    K._SAMPLE_CALLS[0] = 0
+    a = Trainer(_synth_model(), **kw)
+    logs_a = run(a, range(4))
+    torch.manual_seed(11)
+    K._SAMPLE_CALLS[0] = 0
+    b = Trainer(_synth_model(), **kw)
+    logs_b = run(b, range(2))
+    f = str(tmp_path / 'latest.pth')
+    save_checkpoint(b.model, f, optimizer_state=b.optimizer_state_dict(), meta=dict(iter=2))
+    del b
+    K._SAMPLE_CALLS[0] = 12345                                     # whatever another process would have
+    m = _synth_model()
+    c = Trainer(m, **kw)
+    ck = load_checkpoint(m, f, strict=True)
+    c.load_optimizer_state(ck['optimizer'])
+    assert c.iter == 2
+    logs_c = run(c, range(2, 4))
+    for la, lc in zip(logs_a[2:], logs_c):
+        for k in la:
+            assert abs(la[k] - lc[k]) <= 5e-3 * max(1.0, abs(la[k])), (k, la[k], lc[k])
+    for la, lb in zip(logs_a[:2], logs_b):
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    torch.cuda.synchronize()
+    pa = dict(a.model.named_parameters())
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            d, s = (p - pa[n]).norm().item(), pa[n].norm().item()
+            worst = max(worst, d / (s + 1e-12))
+            assert d <= 2e-3 * s + 1e-6, (n, d, s)
+    mo_a, mo_c = a.arena.momentum, c.arena.momentum
+    assert (mo_a - mo_c).norm().item() <= 2e-2 * mo_a.norm().item()

@@ -89,11 +89,24 @@ __device__ __forceinline__ int rot_pos(int py, int px, int P, int k) {
     return i * P + j;
 }
 
+// Which RoI a workgroup of the forward kernels serves.  Without a launch order: RoI blockIdx.x.  With one (loft_roi_order: the
+// list bucketed by (image, level, row strip of the level's map)): workgroups are dispatched round-robin over the 8 XCDs, each
+// with its own 4 MiB L2, so workgroup b takes entry (b % 8) * ceil(K / 8) + b / 8 -- every XCD walks ONE contiguous eighth of
+// the ordered list and the windows of RoIs that overlap meet in that XCD's L2 instead of being fetched from HBM once per RoI
+// (sampling order: 1.4 GB of window reads for the 8192-RoI bbox list against 0.36 GB of maps).  Grid = 8 * ceil(K / 8).
+__device__ __forceinline__ int roi_of_block(const int32_t* __restrict__ order, int K) {
+    const int b = blockIdx.x;
+    if (!order) return b < K ? b : -1;
+    const int per = (K + 7) >> 3, j = (b & 7) * per + (b >> 3);
+    return j < K ? order[j] : -1;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiLevels L, const float* __restrict__ rois, int K, int C,
-                                                            int P, int n_rot, T* __restrict__ out) {
-    const int k = blockIdx.x;
-    if (k >= K) return;
+                                                            int P, int n_rot, T* __restrict__ out,
+                                                            const int32_t* __restrict__ order) {
+    const int k = roi_of_block(order, K);
+    if (k < 0) return;
     const float* roi = rois + 5 * (size_t)k;
     const RoiGeom g = roi_geom(roi, L, P);
     const int H = L.H[g.level], W = L.W[g.level];
@@ -174,11 +187,12 @@ __device__ __forceinline__ void roi_sample_bins(const RoiGeom& g, const bf16_t* 
 }
 
 __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(RoiLevels L, const float* __restrict__ rois, int K, int C,
-                                                                int P, int n_rot, bf16_t* __restrict__ out) {
+                                                                int P, int n_rot, bf16_t* __restrict__ out,
+                                                                const int32_t* __restrict__ order) {
     __shared__ float WY[RF_MAXP][RF_MAX], WX[RF_MAXP + 2][RF_MAX];
     __shared__ int ylo[RF_MAXP], yhi[RF_MAXP], xhi[RF_MAXP];
-    const int k = blockIdx.x;
-    if (k >= K) return;
+    const int k = roi_of_block(order, K);
+    if (k < 0) return;
     const float* roi = rois + 5 * (size_t)k;
     const RoiGeom g = roi_geom(roi, L, P);
     const int H = L.H[g.level], W = L.W[g.level];
@@ -769,9 +783,65 @@ static RoiLevels make_levels(const void* const* feats, const int* H, const int* 
     return L;
 }
 
-LOFT_EXPORT int loft_roi_align_fwd_v(const void* const* feats, const int* H, const int* W, const float* scales,
-                                     int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
-                                     int P, int n_rot, void* out, int variant, void* stream) {
+// ---- launch order of a RoI list (loft_roi_order) ---------------------------------------------------------------------------
+// One workgroup: counting sort of the K RoIs by (image, pyramid level, row strip of that level's map).  The order INSIDE a bucket
+// is whatever the LDS atomics give -- it only decides which workgroup computes which RoI, every RoI's arithmetic and output row
+// are untouched, so results are bit-identical to the unordered launch.
+#define RO_BINS 2048
+__global__ __launch_bounds__(1024) void roi_order_kernel(RoiLevels L, const float* __restrict__ rois, int K, int B,
+                                                         int32_t* __restrict__ order) {
+    __shared__ int hist[RO_BINS];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x;
+    int nstrip = RO_BINS / (4 * (B > 0 ? B : 1));
+    nstrip = nstrip > 32 ? 32 : (nstrip < 1 ? 1 : nstrip);
+    auto key_of = [&](int k) {
+        const float* r = rois + 5 * (size_t)k;
+        int b = (int)r[0];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        const int lv = L.num_levels > 1 ? roi_level(r, L.num_levels, L.finest_scale) : 0;
+        const float cy = 0.5f * (r[2] + r[4]) * L.scale[lv];
+        int st = (int)(cy * (float)nstrip / (float)L.H[lv]);
+        st = st < 0 ? 0 : (st >= nstrip ? nstrip - 1 : st);
+        const int key = (b * 4 + lv) * nstrip + st;
+        return key < RO_BINS ? key : RO_BINS - 1;
+    };
+    for (int i = tid; i < RO_BINS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < K; k += 1024) atomicAdd(&hist[key_of(k)], 1);
+    __syncthreads();
+    // exclusive scan of the 2048 bins: two per thread, wave scan, then the 16 wave totals
+    const int a = hist[2 * tid], c = hist[2 * tid + 1];
+    int v = a + c;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if ((tid & 63) >= d) v += u;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = v;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    const int excl = base + v - (a + c);
+    __syncthreads();
+    hist[2 * tid] = excl;
+    hist[2 * tid + 1] = excl + a;
+    __syncthreads();
+    for (int k = tid; k < K; k += 1024) order[atomicAdd(&hist[key_of(k)], 1)] = k;
+}
+
+LOFT_EXPORT int loft_roi_order(const int* H, const float* scales, int num_levels, int finest_scale, const float* rois, int K,
+                               int B, int32_t* order, void* stream) {
+    if (K <= 0) return 0;
+    if (num_levels < 1 || num_levels > 4 || B < 1) return (int)hipErrorInvalidValue;
+    RoiLevels L = make_levels(nullptr, H, H, scales, num_levels, finest_scale);
+    hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, rois, K, B, order);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+LOFT_EXPORT int loft_roi_align_fwd_ord(const void* const* feats, const int* H, const int* W, const float* scales,
+                                       int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
+                                       int P, int n_rot, void* out, int variant, const int32_t* order, void* stream) {
     if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (K <= 0) return 0;
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4)) return (int)hipErrorInvalidValue;
@@ -779,16 +849,24 @@ LOFT_EXPORT int loft_roi_align_fwd_v(const void* const* feats, const int* H, con
     hipStream_t s = (hipStream_t)stream;
     if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_FWD_SAMPLE) return (int)hipErrorInvalidValue;
     const bool sample_form = variant == LOFT_ROI_FWD_SAMPLE;      // the sample-order kernel also for the 16-bit type (tests, A/B)
+    const dim3 grid(order ? 8 * ((K + 7) / 8) : K);
     if (dtype == LOFT_ACT16 && !sample_form)
-        hipLaunchKernelGGL(roi_align_fwd_sep_kernel, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out);
+        hipLaunchKernelGGL(roi_align_fwd_sep_kernel, grid, dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out, order);
     else if (dtype == LOFT_ACT16)
-        hipLaunchKernelGGL(roi_align_fwd_kernel<bf16_t>, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out);
+        hipLaunchKernelGGL(roi_align_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out, order);
     else if (dtype == LOFT_F32)
-        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, dim3(K), dim3(256), 0, s, L, rois, K, C, P, n_rot, (float*)out);
+        hipLaunchKernelGGL(roi_align_fwd_kernel<float>, grid, dim3(256), 0, s, L, rois, K, C, P, n_rot, (float*)out, order);
     else
         return (int)hipErrorInvalidValue;
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_roi_align_fwd_v(const void* const* feats, const int* H, const int* W, const float* scales,
+                                     int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
+                                     int P, int n_rot, void* out, int variant, void* stream) {
+    return loft_roi_align_fwd_ord(feats, H, W, scales, num_levels, finest_scale, C, dtype, rois, K, P, n_rot, out, variant, nullptr,
+                                  stream);
 }
 
 LOFT_EXPORT int loft_roi_align_fwd(const void* const* feats, const int* H, const int* W, const float* scales,

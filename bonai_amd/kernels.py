@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import lib as L
+from .debug import DBG as _DBG     # A/B switches (bonai_amd/debug.py)
 
 c_int, c_int64, c_float, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -127,6 +128,7 @@ def _level_args(feats, strides):
 # include/loft_hip.h LOFT_ROI_*: kernel selector of loft_roi_align_{fwd,bwd}_v (0 = the shipped choice); tests set these
 ROI_AUTO, ROI_FWD_SAMPLE, ROI_BWD_VALU = 0, 1, 1
 ROI_FWD_VARIANT = ROI_AUTO
+ROI_FWD_SORT_MIN = 256     # RoI lists at least this long are launched in (image, level, row strip) order (loft_roi_order)
 ROI_BWD_VARIANT = ROI_AUTO
 
 
@@ -141,8 +143,15 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
         return out
     H, W, S = _level_args(feats, strides)
     fp = L.arr(c_void_p, [f.data_ptr() for f in feats])
-    L.check(lib.loft_roi_align_fwd_v(fp, H, W, S, len(feats), int(finest_scale), C, L.dtype_code(feats[0]), L.ptr(rois),
-                                     K, int(P), int(n_rot), L.ptr(out), int(ROI_FWD_VARIANT), L.stream()), 'loft_roi_align_fwd_v')
+    order = None
+    if K >= ROI_FWD_SORT_MIN and not _DBG.no_roi_sort:
+        # launch order (image, level, row strip): one XCD walks one contiguous eighth of it, overlapping windows meet in its L2
+        order = torch.empty(K, dtype=torch.int32, device=rois.device)
+        L.check(lib.loft_roi_order(H, S, len(feats), int(finest_scale), L.ptr(rois), K, int(feats[0].shape[0]), L.ptr(order),
+                                   L.stream()), 'loft_roi_order')
+    L.check(lib.loft_roi_align_fwd_ord(fp, H, W, S, len(feats), int(finest_scale), C, L.dtype_code(feats[0]), L.ptr(rois),
+                                       K, int(P), int(n_rot), L.ptr(out), int(ROI_FWD_VARIANT), L.ptr(order), L.stream()),
+            'loft_roi_align_fwd_ord')
     return out
 
 
@@ -323,6 +332,10 @@ def zero_page(device):
     key = str(device)
     if key not in _ZERO_PAGES:
         _ZERO_PAGES[key] = torch.zeros(512, dtype=torch.uint8, device=device)
+        if torch.device(device).type == 'cuda':
+            # every stream's launches read this page from now on: it must BE zero before the first of them runs, whichever
+            # stream that is (the fill above is only ordered on the current one).  Once per process.
+            torch.cuda.current_stream().synchronize()
     return _ZERO_PAGES[key]
 
 
@@ -466,7 +479,6 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
 
 
 import os as _os
-from .debug import DBG as _DBG     # A/B switches (bonai_amd/debug.py)
 
 
 # Split-K combination of the weight gradients whose consumer is the batched unpack: False = fp32 atomics into a zeroed buffer

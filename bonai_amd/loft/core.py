@@ -54,6 +54,8 @@ class AnchorGenerator:
                 yy = sy.view(-1, 1).repeat(1, int(w)).view(-1)
                 shifts = torch.stack([xx, yy, xx, yy], dim=-1)
                 out.append((ba[None] + shifts[:, None]).view(-1, 4).to(device))
+            if torch.device(device).type == 'cuda':      # cached across streams: complete before anyone reads it (rpn._static_ready)
+                torch.cuda.current_stream().synchronize()
             self._cache[key] = out
         return self._cache[key]
 

@@ -29,6 +29,14 @@ from .core import pad_gts
 TENSOR_GATHER = False   # tests: the tensor formulation of the sampled-anchor gather instead of loft_rpn_sample_gather
 
 
+def _static_ready(device):
+    """Called once after a cached device table has been queued for construction: wait until it IS constructed.  Cached tables
+    outlive the stream that built them and are read from whichever stream the next caller runs on (the proposal chain has its own
+    stream), so 'stream-ordered' is not enough for them.  One host synchronisation per table and shape, never per step."""
+    if torch.device(device).type == 'cuda':
+        torch.cuda.current_stream().synchronize()
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256, anchor_generator=None, bbox_coder=None, reg_decoded_bbox=False,
@@ -95,6 +103,7 @@ class RPNHead(nn.Module):
             self._static[key] = dict(sizes=sizes, n_l=n_l, lvl_off=lvl_off, N=lvl_off[-1], anchors=anchors,
                                      anchors_b=anchors[None].expand(B, -1, -1).contiguous(), seg=seg,
                                      base=[b.to(device).contiguous() for b in self.anchor_generator.base_anchors])
+            _static_ready(device)
         return self._static[key]
 
     def _flatten(self, fused):
@@ -217,6 +226,7 @@ class RPNHead(nn.Module):
         nlv = len(fused)
         max_coord = cand.view(B, -1).amax(dim=1)
         key = ('nms_seg', B, tuple(topk))
+        fresh = ('lvl_ar', nlv) not in self._static or key not in self._static
         if ('lvl_ar', nlv) not in self._static:
             self._static[('lvl_ar', nlv)] = torch.arange(nlv, device=dev, dtype=torch.float32)[None]
         shift = (self._static[('lvl_ar', nlv)] * (max_coord[:, None] + 1)).reshape(-1)
@@ -224,6 +234,8 @@ class RPNHead(nn.Module):
             self._static[key] = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64,
                                              device=dev)
             self._static[('img_seg', B, C)] = torch.arange(B + 1, dtype=torch.int64, device=dev) * C
+        if fresh:
+            _static_ready(dev)
         keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk),
                                predicate=cfg.get('nms_predicate', 'device'))
         masked = torch.where(keep.view(B, C).view(torch.bool), cscore, -1.0)        # (keep is 0 / 1 bytes: a bool view, no copy)
@@ -272,6 +284,13 @@ class RPNHead(nn.Module):
         side = self._prop_stream
         with torch.no_grad():
             fused, hs = self.forward_fused(x, keep_hidden=True)
+        # The anchor tables BOTH chains read are built here, on the calling stream, before the fork.  Round 2 let the first
+        # get_bboxes_fused build them lazily -- i.e. with kernels and copies queued on the SIDE stream -- while loss_fused on the
+        # main stream read `anchors_b` in the IoU assignment with no ordering against them: on a model's first training step the
+        # assigner could see a half-written anchor table (VERDICT round 2's nondeterministic gradient mismatch of
+        # test_trainer_direct_grad_sink_matches_autograd_accumulation, rep 0).  _static_ready() additionally completes every
+        # cached table before it can be handed to another stream.
+        self._geometry(fused, fused[0].device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             props, counts = self.get_bboxes_fused([f.detach() for f in fused], img_metas, proposal_cfg)

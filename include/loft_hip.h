@@ -64,6 +64,17 @@ int loft_roi_align_bwd(void* const* grad_feats_host, const int* H_host, const in
 int loft_roi_align_fwd_v(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                          int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                          int n_rot, void* out, int variant, void* stream);
+/* Launch order for a RoI list (SingleRoIExtractor receives the sampler's list in sampling order,
+ * single_level_roi_extractor.py:53-80): order[K] int32 (device) = the RoI indices bucketed by (image, level, row strip of the
+ * level's map), one workgroup, LDS counting sort.  loft_roi_align_fwd_ord = loft_roi_align_fwd_v whose workgroups serve the
+ * RoIs in that order, one contiguous eighth of it per XCD, so overlapping windows are fetched from HBM once per XCD instead
+ * of once per RoI; order = NULL is the unordered launch.  Outputs are bit-identical either way (same arithmetic, same rows).
+ * H_host / scales_host: per-level map heights and 1/stride; B = number of images (batch indices are clamped to it). */
+int loft_roi_order(const int* H_host, const float* scales_host, int num_levels, int finest_scale, const float* rois, int K, int B,
+                   int32_t* order, void* stream);
+int loft_roi_align_fwd_ord(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
+                           int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
+                           int n_rot, void* out, int variant, const int32_t* order, void* stream);
 int loft_roi_align_bwd_v(void* const* grad_feats_host, const int* H_host, const int* W_host, const float* scales_host,
                          int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                          int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted, void* workspace,

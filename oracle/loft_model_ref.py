@@ -29,26 +29,99 @@ def _bn(x, sd, p, eps=1e-5):
     return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'], sd[p + '.weight'], sd[p + '.bias'], False, 0., eps)
 
 
+# ---- numerics mode -------------------------------------------------------------------------------------------------------
+# None (default): the reference's fp32 arithmetic, operation for operation (what tests/golden/e2e_256.npz pins).
+# torch.bfloat16 / torch.float16 ("16-bit points" mode, R50-FPN path): the SAME graph with values rounded to the 16-bit type at
+# exactly the points where the HIP training path (bonai_amd/nn.py, csrc/*.hip) holds 16-bit data:
+#   * every conv / deconv / linear operand: activations as stored (16-bit), weights AFTER folding the frozen-statistics BN
+#     (w * gamma / sqrt(var + eps), loft_fold_pack) rounded to 16 bit; accumulation, bias (= BN shift), residual add and ReLU
+#     in fp32; the result rounded to 16 bit when the layer's output tensor is 16-bit (all but the narrow heads: rpn_cls /
+#     rpn_reg, fc_cls / fc_reg, conv_logits, fc_offset, which stay fp32 like the reference's force_fp32 boundary);
+#   * the shortcut conv of a downsample block is rounded before it enters conv3's epilogue as the residual (_ResBlockFn);
+#   * the image enters the stem rounded to 16 bit (stem_mfma_kernel builds its im2col rows in the 16-bit type);
+#   * FPN top-down: each in-place sum is rounded (loft_upsample2x_add on 16-bit maps);
+#   * RoIAlign: fp32 arithmetic on the 16-bit maps, 16-bit output.
+# Losses, coders, assignment, NMS stay fp32.  The HIP kernels accumulate in another ORDER, so an output can land on the other
+# side of a rounding boundary (1 ulp = 2^-8 relative for bf16): agreement is statistical -- relative L2 error of a tensor at a
+# few 1e-3 -- not element-exact.  tests/golden/e2e_256_bf16.npz (oracle/make_bf16_golden.py) holds this mode's outputs.
+_NUM = [None]
+
+
+class numerics:
+    """``with numerics(torch.bfloat16): forward_train(...)``"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev, _NUM[0] = _NUM[0], self.dtype
+
+    def __exit__(self, *a):
+        _NUM[0] = self.prev
+
+
+def _q(x):
+    return x if _NUM[0] is None else x.to(_NUM[0]).float()
+
+
+def _layer(x, w, b=None, stride=1, pad=0, bn=None, relu=False, res=None, out16=True, transposed=False):
+    """conv (+ BN) (+ residual) (+ ReLU).  fp32 mode: the reference's op order.  16-bit mode: see above.  bn = (sd, prefix)."""
+    conv = (lambda a, ww, bb: F.conv_transpose2d(a, ww, bb, stride=stride)) if transposed else \
+        (lambda a, ww, bb: F.conv2d(a, ww, bb, stride, pad))
+    if _NUM[0] is None:
+        y = conv(x, w, b)
+        if bn is not None:
+            y = _bn(y, bn[0], bn[1])
+        if res is not None:
+            y = y + res
+        return F.relu(y) if relu else y
+    shift = b
+    if bn is not None:
+        sd, p = bn
+        scale = sd[p + '.weight'] / torch.sqrt(sd[p + '.running_var'] + 1e-5)
+        w = w * scale[:, None, None, None]
+        shift = sd[p + '.bias'] - sd[p + '.running_mean'] * scale + (0 if b is None else b * scale)
+    y = conv(_q(x), _q(w), None)
+    if shift is not None:
+        y = y + shift[None, :, None, None]
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    return _q(y) if out16 else y
+
+
+def _lin(x, w, b, relu=False, out16=True):
+    if _NUM[0] is None:
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+    y = F.linear(_q(x), _q(w), None) + b
+    if relu:
+        y = F.relu(y)
+    return _q(y) if out16 else y
+
+
 def backbone(sd, img, prefix='backbone.'):
-    x = F.relu(_bn(F.conv2d(img, sd[prefix + 'conv1.weight'], None, 2, 3), sd, prefix + 'bn1'))
+    x = _layer(img, sd[prefix + 'conv1.weight'], None, 2, 3, bn=(sd, prefix + 'bn1'), relu=True)
     x = F.max_pool2d(x, 3, 2, 1)
     outs = []
     for li, nb in enumerate(STAGE_BLOCKS):
         for bi in range(nb):
             p = f'{prefix}layer{li + 1}.{bi}.'
             stride = 2 if (bi == 0 and li > 0) else 1
-            out = F.relu(_bn(F.conv2d(x, sd[p + 'conv1.weight']), sd, p + 'bn1'))
+            out = _layer(x, sd[p + 'conv1.weight'], bn=(sd, p + 'bn1'), relu=True)
             if (p + 'conv2.conv_offset.weight') in sd:      # DCNv2 (resnet.py:171-194)
+                if _NUM[0] is not None:
+                    raise NotImplementedError('16-bit points mode: plain R50-FPN only')
                 c2 = R.mdcn_pack(out, sd[p + 'conv2.weight'], None, sd[p + 'conv2.conv_offset.weight'],
                                  sd[p + 'conv2.conv_offset.bias'], stride, 1)
+                out = F.relu(_bn(c2, sd, p + 'bn2'))
             else:
-                c2 = F.conv2d(out, sd[p + 'conv2.weight'], None, stride, 1)
-            out = F.relu(_bn(c2, sd, p + 'bn2'))
-            out = _bn(F.conv2d(out, sd[p + 'conv3.weight']), sd, p + 'bn3')
+                out = _layer(out, sd[p + 'conv2.weight'], None, stride, 1, bn=(sd, p + 'bn2'), relu=True)
             idt = x
             if (p + 'downsample.0.weight') in sd:
-                idt = _bn(F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride), sd, p + 'downsample.1')
-            x = F.relu(out + idt)
+                idt = _layer(x, sd[p + 'downsample.0.weight'], None, stride, bn=(sd, p + 'downsample.1'))
+            x = _layer(out, sd[p + 'conv3.weight'], bn=(sd, p + 'bn3'), res=idt, relu=True)
         outs.append(x)
     return outs
 
@@ -112,6 +185,8 @@ def _hr_module(sd, p, xs, num_blocks):
 
 def hrnet_backbone(sd, img, extra=HRNET_W32, prefix='backbone.'):
     """HRNet.forward (hrnet.py:480-515)."""
+    if _NUM[0] is not None:
+        raise NotImplementedError('16-bit points mode: plain R50-FPN only')
     x = F.relu(_bn(F.conv2d(img, sd[prefix + 'conv1.weight'], None, 2, 1), sd, prefix + 'bn1'))
     x = F.relu(_bn(F.conv2d(x, sd[prefix + 'conv2.weight'], None, 2, 1), sd, prefix + 'bn2'))
     for k in range(extra['stage1']['num_blocks'][0]):
@@ -158,13 +233,13 @@ def _fpn_conv(sd, p, x, pad):
     """ConvModule of the neck: plain conv, or DCNv2 when conv_cfg=dict(type='DCNv2') (fpn.py:116-132)."""
     if (p + 'conv_offset.weight') in sd:
         return R.mdcn_pack(x, sd[p + 'weight'], sd[p + 'bias'], sd[p + 'conv_offset.weight'], sd[p + 'conv_offset.bias'], 1, pad)
-    return F.conv2d(x, sd[p + 'weight'], sd[p + 'bias'], padding=pad)
+    return _layer(x, sd[p + 'weight'], sd[p + 'bias'], 1, pad)
 
 
 def fpn(sd, feats, prefix='neck.'):
     lats = [_fpn_conv(sd, f'{prefix}lateral_convs.{i}.conv.', f, 0) for i, f in enumerate(feats)]
     for i in range(len(lats) - 1, 0, -1):
-        lats[i - 1] = lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest')
+        lats[i - 1] = _q(lats[i - 1] + F.interpolate(lats[i], size=lats[i - 1].shape[2:], mode='nearest'))
     outs = [_fpn_conv(sd, f'{prefix}fpn_convs.{i}.conv.', l, 1) for i, l in enumerate(lats)]
     outs.append(F.max_pool2d(outs[-1], 1, stride=2))
     return outs
@@ -173,9 +248,9 @@ def fpn(sd, feats, prefix='neck.'):
 def rpn_forward(sd, feats, prefix='rpn_head.'):
     cls, reg = [], []
     for x in feats:
-        h = F.relu(F.conv2d(x, sd[prefix + 'rpn_conv.weight'], sd[prefix + 'rpn_conv.bias'], padding=1))
-        cls.append(F.conv2d(h, sd[prefix + 'rpn_cls.weight'], sd[prefix + 'rpn_cls.bias']))
-        reg.append(F.conv2d(h, sd[prefix + 'rpn_reg.weight'], sd[prefix + 'rpn_reg.bias']))
+        h = _layer(x, sd[prefix + 'rpn_conv.weight'], sd[prefix + 'rpn_conv.bias'], 1, 1, relu=True)
+        cls.append(_layer(h, sd[prefix + 'rpn_cls.weight'], sd[prefix + 'rpn_cls.bias'], out16=False))
+        reg.append(_layer(h, sd[prefix + 'rpn_reg.weight'], sd[prefix + 'rpn_reg.bias'], out16=False))
     return cls, reg
 
 
@@ -233,22 +308,23 @@ def rpn_proposals(cls, reg, img_shape, nms_pre=3000, nms_post=3000, nms_thr=0.7)
     return out
 
 
-def _fc(sd, p, x):
-    return F.linear(x, sd[p + '.weight'], sd[p + '.bias'])
+def _fc(sd, p, x, relu=False, out16=True):
+    """nn.Linear (+ ReLU).  out16=False: a head output (fp32 in every mode)."""
+    return _lin(x, sd[p + '.weight'], sd[p + '.bias'], relu, out16)
 
 
 def bbox_head(sd, x, prefix='roi_head.bbox_head.'):
     h = x.flatten(1)
-    h = F.relu(_fc(sd, prefix + 'shared_fcs.0', h))
-    h = F.relu(_fc(sd, prefix + 'shared_fcs.1', h))
-    return _fc(sd, prefix + 'fc_cls', h), _fc(sd, prefix + 'fc_reg', h)
+    h = _fc(sd, prefix + 'shared_fcs.0', h, relu=True)
+    h = _fc(sd, prefix + 'shared_fcs.1', h, relu=True)
+    return _fc(sd, prefix + 'fc_cls', h, out16=False), _fc(sd, prefix + 'fc_reg', h, out16=False)
 
 
 def mask_head(sd, x, prefix='roi_head.mask_head.'):
     for i in range(4):
-        x = F.relu(F.conv2d(x, sd[f'{prefix}convs.{i}.conv.weight'], sd[f'{prefix}convs.{i}.conv.bias'], padding=1))
-    x = F.relu(F.conv_transpose2d(x, sd[prefix + 'upsample.weight'], sd[prefix + 'upsample.bias'], stride=2))
-    return F.conv2d(x, sd[prefix + 'conv_logits.weight'], sd[prefix + 'conv_logits.bias'])
+        x = _layer(x, sd[f'{prefix}convs.{i}.conv.weight'], sd[f'{prefix}convs.{i}.conv.bias'], 1, 1, relu=True)
+    x = _layer(x, sd[prefix + 'upsample.weight'], sd[prefix + 'upsample.bias'], 2, 0, relu=True, transposed=True)
+    return _layer(x, sd[prefix + 'conv_logits.weight'], sd[prefix + 'conv_logits.bias'], out16=False)
 
 
 def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.'):
@@ -256,12 +332,11 @@ def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.'):
     for k in range(4):
         h = R.foa_rotate_feature(x, k)
         for i in range(num_convs):
-            h = F.relu(F.conv2d(h, sd[f'{prefix}expand_convs.{k}.{i}.weight'], sd[f'{prefix}expand_convs.{k}.{i}.bias'],
-                                padding=1))
+            h = _layer(h, sd[f'{prefix}expand_convs.{k}.{i}.weight'], sd[f'{prefix}expand_convs.{k}.{i}.bias'], 1, 1, relu=True)
         h = h.reshape(h.shape[0], -1)
-        h = F.relu(_fc(sd, prefix + 'fcs.0', h))
-        h = F.relu(_fc(sd, prefix + 'fcs.1', h))
-        outs.append(_fc(sd, prefix + 'fc_offset', h))
+        h = _fc(sd, prefix + 'fcs.0', h, relu=True)
+        h = _fc(sd, prefix + 'fcs.1', h, relu=True)
+        outs.append(_fc(sd, prefix + 'fc_offset', h, out16=False))
     return torch.cat(outs, 0)
 
 
@@ -270,11 +345,11 @@ def offset_head(sd, x, num_convs=4, num_fcs=2, prefix='roi_head.offset_head.'):
     if x.shape[0] == 0:
         return x.new_empty(0, 2)
     for i in range(num_convs):
-        x = F.relu(F.conv2d(x, sd[f'{prefix}convs.{i}.weight'], sd[f'{prefix}convs.{i}.bias'], padding=1))
+        x = _layer(x, sd[f'{prefix}convs.{i}.weight'], sd[f'{prefix}convs.{i}.bias'], 1, 1, relu=True)
     h = x.reshape(x.shape[0], -1)
     for i in range(num_fcs):
-        h = F.relu(_fc(sd, f'{prefix}fcs.{i}', h))
-    return _fc(sd, prefix + 'fc_offset', h)
+        h = _fc(sd, f'{prefix}fcs.{i}', h, relu=True)
+    return _fc(sd, prefix + 'fc_offset', h, out16=False)
 
 
 def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_offsets, choose=R.choose_first,
@@ -292,7 +367,7 @@ def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_o
                         pos_gt_bboxes=gt_bboxes[i][gi[pos] - 1], pos_gt_labels=gt_labels[i][gi[pos] - 1]))
     rois = R.bbox2roi([torch.cat([r['pos_bboxes'], r['neg_bboxes']]) for r in res])
     p4 = feats[:4]
-    cls_score, bbox_pred = bbox_head(sd, R.roi_extract(p4, rois, 7))
+    cls_score, bbox_pred = bbox_head(sd, _q(R.roi_extract(p4, rois, 7)))
     labels, lw, bt, bw = [], [], [], []
     for r in res:
         npos, nneg = r['pos_bboxes'].shape[0], r['neg_bboxes'].shape[0]
@@ -311,7 +386,7 @@ def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_o
     pred = bbox_pred.view(bbox_pred.shape[0], -1, 4)[posm, labels[posm]]
     losses['loss_bbox'] = R.l1_loss(pred, bt[posm], bw[posm], float(bt.shape[0])) if posm.any() else bbox_pred.sum() * 0
     pos_rois = R.bbox2roi([r['pos_bboxes'] for r in res])
-    mask_pred = mask_head(sd, R.roi_extract(p4, pos_rois, 14))
+    mask_pred = mask_head(sd, _q(R.roi_extract(p4, pos_rois, 14)))
     mts = []
     for i, r in enumerate(res):
         if r['pos_bboxes'].shape[0] == 0:
@@ -325,7 +400,7 @@ def roi_forward_train(sd, feats, proposals, gt_bboxes, gt_labels, gt_masks, gt_o
     mask_targets = torch.cat(mts)
     pos_labels = torch.cat([r['pos_gt_labels'] for r in res])
     losses['loss_mask'] = R.mask_bce_loss(mask_pred, mask_targets, pos_labels) if mask_pred.shape[0] else mask_pred.sum() * 0
-    offset_pred = foa_head(sd, R.roi_extract(p4, pos_rois, 7))
+    offset_pred = foa_head(sd, _q(R.roi_extract(p4, pos_rois, 7)))
     offset_targets = R.foa_offset_targets([r['pos_bboxes'] for r in res], [r['pos_gt_inds'] for r in res], gt_offsets)
     losses['loss_offset'] = 16.0 * R.smooth_l1_loss(offset_pred, offset_targets) if offset_pred.shape[0] else offset_pred.sum() * 0
     extras = dict(rois=rois, pos_rois=pos_rois, cls_score=cls_score, bbox_pred=bbox_pred, mask_pred=mask_pred,
@@ -359,7 +434,7 @@ def simple_test(sd, img, rescale=False, scale_factor=(1., 1., 1., 1.), score_thr
     props = rpn_proposals(cls, reg, (H, W, 3))[0]
     rois = R.bbox2roi([props])
     p4 = feats[:4]
-    cls_score, bbox_pred = bbox_head(sd, R.roi_extract(p4, rois, 7))
+    cls_score, bbox_pred = bbox_head(sd, _q(R.roi_extract(p4, rois, 7)))
     scores = torch.softmax(cls_score, dim=1)
     bboxes = R.delta2bbox(rois[:, 1:], bbox_pred, stds=(.1, .1, .2, .2), max_shape=(H, W, 3))
     sf = torch.tensor(scale_factor, dtype=torch.float32)
@@ -370,9 +445,9 @@ def simple_test(sd, img, rescale=False, scale_factor=(1., 1., 1., 1.), score_thr
         return det, lab, torch.zeros(0, H, W, dtype=torch.bool), torch.zeros(0, 2)
     _b = det[:, :4] * sf if rescale else det[:, :4]
     drois = R.bbox2roi([_b])
-    mp = mask_head(sd, R.roi_extract(p4, drois, 14)).sigmoid()
+    mp = mask_head(sd, _q(R.roi_extract(p4, drois, 14))).sigmoid()
     mp = mp[torch.arange(mp.shape[0]), lab][:, None]
     masks = R.paste_masks(mp, _b / sf if rescale else _b, H, W, 0.5)
-    op = foa_head(sd, R.roi_extract(p4, drois, 7))
+    op = foa_head(sd, _q(R.roi_extract(p4, drois, 7)))
     offsets = R.delta2offset(_b, R.foa_fuse(op), max_shape=[1024, 1024])
     return det, lab, masks, offsets

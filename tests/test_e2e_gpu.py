@@ -240,3 +240,77 @@ def test_odd_map_sizes_16bit_backward_agrees_with_fp32_parity_backward(size, bat
         if abs(n16 - n32) > (0.25 if g32.numel() <= 8 else 0.10) * max(n32, 1e-2):
             bad.append((n, n16, n32))
     assert not bad, bad[:8]
+
+
+def _rel_l2(got, want):
+    return float((got.float().cpu() - want).norm() / want.norm())
+
+
+def test_e2e_bf16_kernels_vs_bf16_points_oracle():
+    """the TIMED bf16 kernels bounded at model level.  The CPU oracle runs the same tile in its
+    16-bit-points mode (oracle/loft_model_ref.numerics: bf16 roundings exactly where this path holds bf16 data, fp32
+    accumulation; pinned by tests/golden/e2e_256_bf16.npz), so what is left between the two is accumulation ORDER -- a value now
+    and then lands on the other side of a bf16 rounding boundary and the flip travels on.  Bounds (relative L2 per tensor):
+    FPN maps 5e-3, head outputs on the oracle's own RoI lists 5e-3 (FOA: 14 stacked layers after RoIAlign, 1e-2), the seven
+    losses 5e-3.  For scale: the bf16 formulation itself sits ~9e-3 (maps) / 2e-2 (offsets) from the reference's fp32."""
+    from bonai_amd.synth import make_batch
+    from oracle import loft_model_ref as M
+    from oracle.synth_weights import synth_tensor
+    gd = np.load(os.path.join(GOLD, 'e2e_256_bf16.npz'))
+    size, batch, num_gt = [int(v) for v in gd['meta']]
+    m = _build()
+    sd = {k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()}
+    cpu = make_batch(batch, size, num_gt)
+    with torch.no_grad(), M.numerics(torch.bfloat16):
+        ol, ex = M.forward_train(sd, cpu['img'], cpu['gt_bboxes'], cpu['gt_labels'], cpu['gt_masks'], cpu['gt_offsets'],
+                                 return_extras=True)
+    for i in range(5):                                         # the live oracle IS the committed fixture
+        want = torch.from_numpy(gd[f'feat_{i}_sub'])
+        assert float((ex['feats'][i][:, ::8, ::2, ::2] - want).norm() / want.norm()) < 3e-3
+    data = make_batch(batch, size, num_gt, device='cuda')
+    report = {}
+    with torch.no_grad():
+        feats = m.extract_feat(data['img'])
+        for i, f in enumerate(feats):
+            report[f'feat_{i}'] = _rel_l2(f, ex['feats'][i])
+            assert report[f'feat_{i}'] < 5e-3, report
+        rh = m.roi_head
+        rois, pos_rois = ex['rois'].cuda().contiguous(), ex['pos_rois'].cuda().contiguous()
+        cls_score, bbox_pred = rh.bbox_head(rh.bbox_roi_extractor(feats[:4], rois))
+        report['cls_score'], report['bbox_pred'] = _rel_l2(cls_score, ex['cls_score']), _rel_l2(bbox_pred, ex['bbox_pred'])
+        mask_pred = rh.mask_head(rh.mask_roi_extractor(feats[:4], pos_rois))
+        report['mask_pred'] = _rel_l2(mask_pred[:, :1], ex['mask_pred'])
+        offset_pred = rh._offset_forward(feats, pos_rois)
+        report['offset_pred'] = _rel_l2(offset_pred, ex['offset_pred'])
+    print('bf16 kernels vs bf16-points oracle, relative L2:', {k: f'{v:.2e}' for k, v in report.items()})
+    assert report['cls_score'] < 5e-3 and report['bbox_pred'] < 5e-3 and report['mask_pred'] < 5e-3, report
+    assert report['offset_pred'] < 1e-2, report
+    lv = dict(m.train_step(data)['log_vars'].items())
+    same_rois = m.roi_head.last_stats['num_rois'] == ex['rois'].shape[0]
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'loss_mask', 'loss_offset', 'loss'):
+        want = float(ol[k].sum())
+        # (a proposal that flips across the NMS threshold changes the sampled set: RoI-head losses then move by a sample's
+        #  share; the RPN losses and the total do not depend on that)
+        tol = 5e-3 if (same_rois or k.startswith('loss_rpn')) else 1e-2
+        assert abs(lv[k] - want) <= tol * max(1.0, abs(want)), (k, lv[k], want, same_rois)
+
+
+def test_bf16_vs_fp32_parity_mode_at_bench_size():
+    """The same comparison once at BASELINE configs[1]'s tile size (1024 x 1024, batch 1 to keep the fp32 MFMA run short):
+    bf16 training kernels against the fp32 parity mode of the same model on the same tile -- FPN maps within 2e-2 relative L2
+    (bf16 operands through 53 convs; 256^2 tiles measure 9e-3 against the reference), RPN and total loss within 2 %."""
+    from bonai_amd.synth import make_batch
+    data = make_batch(1, 1024, 80, device='cuda')
+    m = _build()
+    with torch.no_grad():
+        f16 = [f.float() for f in m.extract_feat(data['img'])]
+        l16 = dict(m.train_step(data)['log_vars'].items())
+        m.backbone.compute_dtype = torch.float32
+        f32 = m.extract_feat(data['img'])
+        l32 = dict(m.train_step(data)['log_vars'].items())
+    rel = [float((a - b).norm() / b.norm()) for a, b in zip(f16, f32)]
+    print('bf16 vs fp32 parity mode at 1024^2, relative L2 per FPN level:', [f'{r:.2e}' for r in rel],
+          {k: (round(l16[k], 4), round(l32[k], 4)) for k in l16})
+    assert all(f.dtype == torch.float32 for f in f32) and max(rel) < 2e-2, rel
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss'):
+        assert abs(l16[k] - l32[k]) <= 2e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])

@@ -269,3 +269,37 @@ def test_roi_align_bwd_multi_matches_sum_of_lists():
             for tt, ww in zip(twice, ref):
                 scale = max(1.0, ww.abs().max().item())
                 assert (tt.float() - 2 * ww).abs().max().item() <= 3e-2 * scale
+
+
+@pytest.mark.parametrize('K_,B,P,n_rot', [(8192, 8, 7, 1), (1001, 3, 14, 1), (777, 2, 7, 4), (256, 1, 7, 1)])
+def test_roi_align_launch_order_is_a_permutation_and_changes_nothing(K_, B, P, n_rot):
+    """loft_roi_order + loft_roi_align_fwd_ord: the (image, level, row strip) launch order is a permutation
+    of the list whose buckets ascend, and the ordered launch writes bit-identical features (same arithmetic, same output rows) --
+    for K not a multiple of 8, for the four FOA rotations, for fp32 maps as well."""
+    import ctypes
+    from bonai_amd import kernels as K, lib as L
+    from bonai_amd.debug import DBG
+    rng = np.random.RandomState(K_)
+    C, size, strides = 64, 512, [4, 8, 16, 32]
+    torch.manual_seed(1)
+    rois = _rand_rois(rng, K_, B, size).cuda()
+    for dtype in (torch.bfloat16, torch.float32):
+        feats = [torch.randn(B, C, size // s, size // s, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
+                 for s in strides]
+        with DBG.override(no_roi_sort=True):
+            plain = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)
+        ordered = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)
+        assert torch.equal(plain, ordered), dtype
+    H, W, S = K._level_args(feats, strides)
+    order = torch.full((K_,), -1, dtype=torch.int32, device='cuda')
+    L.check(L.load().loft_roi_order(H, S, 4, 56, L.ptr(rois), K_, B, L.ptr(order), L.stream()), 'loft_roi_order')
+    o = order.long().cpu()
+    assert torch.equal(o.sort()[0], torch.arange(K_))
+    r = rois.cpu()[o]
+    lv = ops_ref.map_roi_levels(r)
+    nstrip = min(32, 2048 // (4 * B))
+    hs = torch.tensor([size // s for s in strides], dtype=torch.float32)
+    cy = 0.5 * (r[:, 2] + r[:, 4]) / torch.tensor(strides, dtype=torch.float32)[lv]
+    strip = (cy * nstrip / hs[lv]).floor().clamp(0, nstrip - 1).long()   # (float32 like the kernel: an RoI ON a strip edge may differ)
+    key = (r[:, 0].long() * 4 + lv) * nstrip + strip
+    assert int((key[1:] < key[:-1]).sum()) <= max(2, K_ // 500), 'buckets must ascend along the launch order'

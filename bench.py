@@ -284,7 +284,7 @@ def main():
         ach = fam[dom][0] / fam[dom][1] / 1e12
         kname = dom     # family = one C-ABI entry point (loft_conv_tap_bf16_v / loft_conv_wgrad_bf16_v) and the kernel templates it dispatches
         traffic = mfma_util = None   # from separate rocprofv3 --pmc passes of this command (tools/pmc_collect.py -> profiles/)
-        pmc = os.path.join(ROOT, 'profiles', 'round2_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'round3_pmc_traffic.json')
         if os.path.exists(pmc) and args.batch == 8 and args.size == 1024 and headline:
             ent = json.load(open(pmc)).get(kname, {})
             traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
@@ -295,9 +295,9 @@ def main():
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
                                  'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
-                                 'rocprofv3 summary of that mode: profiles/round2_bench_kernel_stats_serial.csv '
-                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round2_bench_kernel_stats.csv; traffic / '
-                                 'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/round2_pmc_traffic.json)',
+                                 'rocprofv3 summary of that mode: profiles/round3_bench_kernel_stats_serial.csv '
+                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round3_bench_kernel_stats.csv; traffic / '
+                                 'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/round3_pmc_traffic.json)',
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     if rank == 0:

@@ -101,27 +101,38 @@ def _lin(x, w, b, relu=False, out16=True):
     return _q(y) if out16 else y
 
 
-def backbone(sd, img, prefix='backbone.'):
+def stem(sd, img, prefix='backbone.'):
+    """conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 (resnet.py:623-630)."""
     x = _layer(img, sd[prefix + 'conv1.weight'], None, 2, 3, bn=(sd, prefix + 'bn1'), relu=True)
-    x = F.max_pool2d(x, 3, 2, 1)
+    return F.max_pool2d(x, 3, 2, 1)
+
+
+def res_stage(sd, x, li, prefix='backbone.'):
+    """layer{li+1}: STAGE_BLOCKS[li] bottlenecks (resnet.py:266-298)."""
+    for bi in range(STAGE_BLOCKS[li]):
+        p = f'{prefix}layer{li + 1}.{bi}.'
+        stride = 2 if (bi == 0 and li > 0) else 1
+        out = _layer(x, sd[p + 'conv1.weight'], bn=(sd, p + 'bn1'), relu=True)
+        if (p + 'conv2.conv_offset.weight') in sd:      # DCNv2 (resnet.py:171-194)
+            if _NUM[0] is not None:
+                raise NotImplementedError('16-bit points mode: plain R50-FPN only')
+            c2 = R.mdcn_pack(out, sd[p + 'conv2.weight'], None, sd[p + 'conv2.conv_offset.weight'],
+                             sd[p + 'conv2.conv_offset.bias'], stride, 1)
+            out = F.relu(_bn(c2, sd, p + 'bn2'))
+        else:
+            out = _layer(out, sd[p + 'conv2.weight'], None, stride, 1, bn=(sd, p + 'bn2'), relu=True)
+        idt = x
+        if (p + 'downsample.0.weight') in sd:
+            idt = _layer(x, sd[p + 'downsample.0.weight'], None, stride, bn=(sd, p + 'downsample.1'))
+        x = _layer(out, sd[p + 'conv3.weight'], bn=(sd, p + 'bn3'), res=idt, relu=True)
+    return x
+
+
+def backbone(sd, img, prefix='backbone.'):
+    x = stem(sd, img, prefix)
     outs = []
-    for li, nb in enumerate(STAGE_BLOCKS):
-        for bi in range(nb):
-            p = f'{prefix}layer{li + 1}.{bi}.'
-            stride = 2 if (bi == 0 and li > 0) else 1
-            out = _layer(x, sd[p + 'conv1.weight'], bn=(sd, p + 'bn1'), relu=True)
-            if (p + 'conv2.conv_offset.weight') in sd:      # DCNv2 (resnet.py:171-194)
-                if _NUM[0] is not None:
-                    raise NotImplementedError('16-bit points mode: plain R50-FPN only')
-                c2 = R.mdcn_pack(out, sd[p + 'conv2.weight'], None, sd[p + 'conv2.conv_offset.weight'],
-                                 sd[p + 'conv2.conv_offset.bias'], stride, 1)
-                out = F.relu(_bn(c2, sd, p + 'bn2'))
-            else:
-                out = _layer(out, sd[p + 'conv2.weight'], None, stride, 1, bn=(sd, p + 'bn2'), relu=True)
-            idt = x
-            if (p + 'downsample.0.weight') in sd:
-                idt = _layer(x, sd[p + 'downsample.0.weight'], None, stride, bn=(sd, p + 'downsample.1'))
-            x = _layer(out, sd[p + 'conv3.weight'], bn=(sd, p + 'bn3'), res=idt, relu=True)
+    for li in range(len(STAGE_BLOCKS)):
+        x = res_stage(sd, x, li, prefix)
         outs.append(x)
     return outs
 

@@ -106,21 +106,40 @@ def test_trainer_direct_grad_sink_matches_autograd_accumulation():
         m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
         return m.cuda().train()
     from bonai_amd.debug import DBG
-    ref = build()
-    with DBG.override(no_side_stream=True):          # reference: one stream, plain autograd accumulation
-        ref.train_step(data)['loss'].backward()
-    want = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+    def autograd_grads():
+        ref = build()
+        with DBG.override(no_side_stream=True):          # reference: one stream, plain autograd accumulation
+            ref.train_step(data)['loss'].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+    def rel(a, b):
+        return (a - b).norm().item() / (b.norm().item() + 1e-12)
+    want = autograd_grads()
+    # (diagnostic, round 3: the driver once saw an uncorrelated layer2.0.conv1 gradient here that 176 repetitions in fresh and
+    #  in suite-history processes never reproduced.  Should it come back, the message says WHICH side moved: the reference is
+    #  computed twice, and a mismatching Trainer step is repeated once.)
+    again = autograd_grads()
+    unstable = [(n, rel(again[n], w)) for n, w in want.items() if rel(again[n], w) > 1e-2]
+    assert not unstable, ('plain autograd path differs between two runs', unstable[:4])
     m = build()
     tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
     # the trainer path also runs the bbox / mask branches on the side stream (forward and backward) and deposits through the
     # unpack queue; lr = 0 keeps the weights, so every repetition must reproduce the same gradients (a stream race would not)
     for rep in range(3):
-        tr.train_step(data, lr=0.0)
+        lv = dict(tr.train_step(data, lr=0.0)['log_vars'].items())
         torch.cuda.synchronize()
         got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
         assert set(want) <= set(got)
-        for n, w in want.items():
-            assert (got[n] - w).norm().item() <= 1e-2 * w.norm().item() + 1e-7, (rep, n, (got[n] - w).norm().item(), w.norm().item())
+        bad = [(n, round(rel(got[n], w), 4)) for n, w in want.items() if (got[n] - w).norm().item() > 1e-2 * w.norm().item() + 1e-7]
+        if bad:
+            first = {n: got[n].clone() for n, _ in bad[:8]}
+            tr.train_step(data, lr=0.0)
+            torch.cuda.synchronize()
+            retry = [(n, round(rel(m.get_parameter(n).grad, want[n]), 4), round(rel(m.get_parameter(n).grad, first[n]), 4)) for n in first]
+            raise AssertionError(f'rep {rep}: {len(bad)} of {len(want)} gradients off; first {bad[:6]}; losses {lv}; '
+                                 f'the same step repeated (name, vs autograd, vs the failing step): {retry}')
         for n, g in got.items():
             if n not in want:
                 assert g.abs().max().item() == 0, n

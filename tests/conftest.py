@@ -36,3 +36,5 @@ def pytest_collection_modifyitems(config, items):
             return (2, _LAST.index(name))
         return (1, 0)
     items.sort(key=rank)          # stable: the order inside a file (and among unnamed files) is pytest's own
+    if os.environ.get('LOFT_TEST_ORDER') == 'reverse':      # (the suite must not depend on its file order)
+        items.reverse()

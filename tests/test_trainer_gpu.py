@@ -32,7 +32,9 @@ def _autograd_grads(m, data):
     return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
 
 
-def _compare(want, m, tag, tol=1e-2):
+def _compare(want, m, tag, tol=1.5e-2):
+    # (run-to-run noise of ONE configuration, 126 fresh-process runs: worst 6.4e-3, a BN gamma gradient of layer2 --
+    #  profiles/round3_probes/trainer_race.txt; a wrong path is off by O(1))
     got = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
     assert set(want) <= set(got)
     bad = []
@@ -46,7 +48,7 @@ def _compare(want, m, tag, tol=1e-2):
             assert g.abs().max().item() == 0, (tag, n)
 
 
-@pytest.fixture(scope='module')
+@pytest.fixture()
 def first_k():
     from bonai_amd.loft.core import RandomSampler
     RandomSampler.choice_mode = 'first'
@@ -117,49 +119,60 @@ def test_underfilled_sampler_drops_the_speculative_roialign_cleanly(first_k):
 def test_resume_equals_uninterrupted(tmp_path):
     """ADVICE r2 (engine.py): 2 steps + save + (fresh model, load, load_optimizer_state) + 2 steps == 4 uninterrupted steps,
     with the RANDOM sampler (its draws depend on the call count that now travels in the optimizer state), momentum and weight
-    decay on.  Tolerance: the run-to-run noise of the backward's atomics through four updates."""
+    decay on.  Compared: the logged losses of steps 3-4 and the UPDATE every parameter received over the four steps
+    (final - initial), at the run-to-run noise of the backward's atomics carried through four updates; a resume that lost the
+    momentum, the iteration or the sampler's sequence moves the update by tens of percent."""
     from bonai_amd import kernels as K
     from bonai_amd.checkpoint import load_checkpoint, save_checkpoint
     from bonai_amd.engine import Trainer
     from bonai_amd.loft.core import RandomSampler
     from bonai_amd.synth import make_batch
-    assert RandomSampler.choice_mode == 'random'
-    batches = [make_batch(2, 256, 8, step=s, device='cuda') for s in range(4)]
-    kw = dict(lr=0.02, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+    prev_mode, RandomSampler.choice_mode = RandomSampler.choice_mode, 'random'
+    try:
+        batches = [make_batch(2, 256, 8, step=s, device='cuda') for s in range(4)]
+        kw = dict(lr=2e-3, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
 
-    def run(tr, steps):
-        return [dict(tr.train_step(batches[s])['log_vars'].items()) for s in steps]
-    torch.manual_seed(11)
-    K._SAMPLE_CALLS[0] = 0
-    a = Trainer(_synth_model(), **kw)
-    logs_a = run(a, range(4))
-    torch.manual_seed(11)
-    K._SAMPLE_CALLS[0] = 0
-    b = Trainer(_synth_model(), **kw)
-    logs_b = run(b, range(2))
-    f = str(tmp_path / 'latest.pth')
-    save_checkpoint(b.model, f, optimizer_state=b.optimizer_state_dict(), meta=dict(iter=2))
-    del b
-    K._SAMPLE_CALLS[0] = 12345                                     # whatever another process would have
-    m = _synth_model()
-    c = Trainer(m, **kw)
-    ck = load_checkpoint(m, f, strict=True)
-    c.load_optimizer_state(ck['optimizer'])
-    assert c.iter == 2
-    logs_c = run(c, range(2, 4))
-    for la, lc in zip(logs_a[2:], logs_c):
-        for k in la:
-            assert abs(la[k] - lc[k]) <= 5e-3 * max(1.0, abs(la[k])), (k, la[k], lc[k])
-    for la, lb in zip(logs_a[:2], logs_b):
-        for k in la:
-            assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(la[k])), (k, la[k], lb[k])
-    torch.cuda.synchronize()
-    pa = dict(a.model.named_parameters())
-    worst = 0.0
-    for n, p in m.named_parameters():
-        if p.requires_grad:
-            d, s = (p - pa[n]).norm().item(), pa[n].norm().item()
-            worst = max(worst, d / (s + 1e-12))
-            assert d <= 2e-3 * s + 1e-6, (n, d, s)
-    mo_a, mo_c = a.arena.momentum, c.arena.momentum
-    assert (mo_a - mo_c).norm().item() <= 2e-2 * mo_a.norm().item()
+        def run(tr, steps):
+            return [dict(tr.train_step(batches[s])['log_vars'].items()) for s in steps]
+        init = {n: p.detach().clone() for n, p in _synth_model().named_parameters()}
+        torch.manual_seed(11)
+        K._SAMPLE_CALLS[0] = 0
+        a = Trainer(_synth_model(), **kw)
+        logs_a = run(a, range(4))
+        torch.manual_seed(11)
+        K._SAMPLE_CALLS[0] = 0
+        b = Trainer(_synth_model(), **kw)
+        logs_b = run(b, range(2))
+        f = str(tmp_path / 'latest.pth')
+        save_checkpoint(b.model, f, optimizer_state=b.optimizer_state_dict(), meta=dict(iter=2))
+        del b
+        K._SAMPLE_CALLS[0] = 12345                                     # whatever another process would have
+        m = _synth_model()
+        c = Trainer(m, **kw)
+        ck = load_checkpoint(m, f, strict=True)
+        c.load_optimizer_state(ck['optimizer'])
+        assert c.iter == 2 and K._SAMPLE_CALLS[0] == ck['optimizer']['sampler_calls']
+        logs_c = run(c, range(2, 4))
+        torch.cuda.synchronize()
+        for la, lc in list(zip(logs_a[:2], logs_b)) + list(zip(logs_a[2:], logs_c)):
+            for k in la:
+                assert abs(la[k] - lc[k]) <= 2e-2 * max(1.0, abs(la[k])), (k, la[k], lc[k])
+        pa = dict(a.model.named_parameters())
+        num = den = 0.0
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                ua, uc = pa[n].detach() - init[n], p.detach() - init[n]
+                num += float((ua - uc).pow(2).sum())
+                den += float(ua.pow(2).sum())
+        assert den > 0 and (num / den) ** 0.5 <= 5e-2, (num, den)      # all four steps' updates, both runs
+        mo_a, mo_c = a.arena.momentum, c.arena.momentum
+        assert (mo_a - mo_c).norm().item() <= 5e-2 * mo_a.norm().item()
+        # control: a resume WITHOUT the optimizer state is visibly different (the check above has teeth)
+        m2 = _synth_model()
+        d = Trainer(m2, **kw)
+        load_checkpoint(m2, f, strict=True)
+        run(d, range(2, 4))
+        torch.cuda.synchronize()
+        assert (mo_a - d.arena.momentum).norm().item() > 0.2 * mo_a.norm().item()
+    finally:
+        RandomSampler.choice_mode = prev_mode

@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-saturate', action='store_true', help='time the random-init RPN\'s light RoI load (~110 positives per image) '
                     'instead of the trained-RPN load (<= 256): the mode of rounds 1-2 and of the profile scripts')
+    ap.add_argument('--graph', action='store_true', help='backbone + neck forward / backward as two hipGraphs (bonai_amd/graphs.py)')
     ap.add_argument('--no-light', action='store_true', help='skip the second timed loop (value_random_init_rpn)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the cpu_baseline leg (0: min(host cores, 32))')
     return ap.parse_args()
@@ -169,7 +170,8 @@ def main():
     torch.manual_seed(0)                                   # same random-init weights on every rank
     model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
     trainer = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
-                      max_norm=cfg.optimizer_config.grad_clip.max_norm, loss_scale=(fp16 or {}).get('loss_scale', 1.0))
+                      max_norm=cfg.optimizer_config.grad_clip.max_norm, loss_scale=(fp16 or {}).get('loss_scale', 1.0),
+                      graph_features=args.graph)
     data = make_batch(args.batch, args.size, args.num_gt, rank=rank, device='cuda')
     n_pos, n_roi = [], []
     comm = None
@@ -312,6 +314,7 @@ def main():
                                         f'({"BASELINE configs[1]" if headline else args.config}), {args.num_gt} gt/img, full train step '
                                         '(fwd+losses+bwd+allreduce+clip+SGD), random-init weights' + (', RoI heads at the load of a trained RPN (first proposals = jittered gt boxes)' if saturate else ''),
                                global_batch=args.batch * world, per_gpu_batch=args.batch, parallelism=f'dp{world}',
+                               graph_features=bool(args.graph and trainer._fgraphs is not None and trainer._fgraphs.ready),
                                mean_num_pos_per_img=round(mean_pos, 1), mean_num_rois_per_img=round(mean_roi, 1),
                                algorithmic_gflop_per_img=round(f_img, 1),
                                conv_roofline_frac=round(f_img * 1e9 * value / (world * 2.5e15), 4)),

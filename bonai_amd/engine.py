@@ -106,6 +106,7 @@ class BucketedAllReduce:
             for p in arena.order:
                 p.register_post_accumulate_grad_hook(self._autograd_hook)
         self._remaining = None
+        self.capturing = False     # True while bonai_amd.graphs records a section: nothing may be released or launched from it
 
     def begin(self):
         self._remaining = [len(b['params']) for b in self.buckets]
@@ -133,13 +134,13 @@ class BucketedAllReduce:
         """autograd's post-accumulate callback.  It also runs for parameters whose Function returned None because a kernel
         deposits the gradient in the arena itself -- possibly later, at the next UnpackQueue flush: those report through the
         gradient sink (Trainer._sink -> _hook) once the deposit has been enqueued, never from here."""
-        if getattr(p, '_loft_sunk', False):
+        if getattr(p, '_loft_sunk', False) or self.capturing:
             return
         self._hook(p)
 
     def _hook(self, p):
         """Gradient of ``p`` is final for this step (autograd post-accumulate hook, or the kernels' direct arena sink)."""
-        if id(p) in self._seen:       # idempotent: a parameter must never release its bucket twice
+        if id(p) in self._seen or self.capturing:       # idempotent: a parameter must never release its bucket twice
             return
         self._seen.add(id(p))
         bi = self.param_bucket[id(p)]
@@ -200,12 +201,16 @@ def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16,
 
 class Trainer:
     def __init__(self, model, lr=0.005, momentum=0.9, weight_decay=1e-4, max_norm=35.0, bucket_bytes=25 << 20,
-                 loss_scale=1.0):
+                 loss_scale=1.0, graph_features=False):
         """loss_scale: the static scale of the reference's Fp16OptimizerHook (``fp16 = dict(loss_scale=512.)``,
         mmdet/core/fp16/hooks.py:64-96): the loss is multiplied before backward and the gradients are divided again inside
         the fused clip + SGD kernel (after the all-reduce, before the norm), exactly the hook's order.  bf16 activations have
         fp32's exponent range, so the scale is not needed for range here; it is honoured for runner parity."""
         self.model = model
+        # graph_features: backbone + neck forward and backward as two hipGraphs, recorded at the third step and replayed from
+        # then on (bonai_amd/graphs.py); fixed-size batches only.  Capture failures fall back to eager launches, loudly.
+        self.graph_features = bool(graph_features)
+        self._fgraphs = None
         self.lr, self.mu, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
         self.loss_scale = float(loss_scale)
         self.arena = FlatArena(model)
@@ -217,6 +222,25 @@ class Trainer:
         # kernels accumulate weight / BN gradients straight into the arena slots (bonai_amd.nn.GRAD_SINK); the callback
         # replaces the post-accumulate-grad hook for those parameters
         self._sink = self.reducer._hook if self.reducer.enabled else (lambda p: None)
+
+    def _graph_step_setup(self, img):
+        from .graphs import FeatureGraphs
+        fg = self._fgraphs
+        if fg is None:
+            fg = self._fgraphs = FeatureGraphs(self)
+        if not fg.ready and fg.failed is None and self.iter >= 2:
+            self.reducer.capturing = True
+            try:
+                fg.capture(img)
+            except Exception as e:      # noqa: BLE001 -- any capture refusal: stay eager, say so once
+                import warnings
+                fg.failed = f'{type(e).__name__}: {e}'
+                warnings.warn(f'hipGraph capture of backbone + neck failed, the trainer stays on eager launches: {fg.failed}',
+                              RuntimeWarning)
+            finally:
+                self.reducer.capturing = False
+        if fg.ready:
+            self.model.feat_provider = fg.provider
 
     def optimizer_state_dict(self):
         """The arena's SGD state in torch.optim.SGD.state_dict() layout (what mmcv's CheckpointHook stores under 'optimizer',
@@ -282,11 +306,16 @@ class Trainer:
             self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
         prev_hub = F2.HUB_ENABLED
         F2.HUB_ENABLED = self.arena.data.is_cuda and not DBG.no_feat_hub
+        if self.graph_features and self.arena.data.is_cuda and K.PROFILE is None and F2.PREPACK is not None \
+                and hasattr(self.model, 'extract_feat'):
+            self._graph_step_setup(data['img'])
         try:
             out = self.model.train_step(data)
         finally:
             F2.PREPACK = prev_pp
             F2.HUB_ENABLED = prev_hub
+            if self.graph_features:
+                self.model.feat_provider = None
         prev, F2.GRAD_SINK = F2.GRAD_SINK, (self._sink if self.arena.data.is_cuda and not DBG.no_grad_sink else None)
         if self.arena.data.is_cuda and not DBG.no_zero_pool:
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers

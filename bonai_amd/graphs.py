@@ -1,0 +1,126 @@
+"""hipGraph capture of the fixed-shape section of the training step: backbone + neck, forward AND backward.
+
+Why (north_star: "HIP streams and graphs instead of a tracing compiler"; VERDICT round 2, missing #4 / next #5b).  The step's
+launches are issued from Python: ~27 us of host time per launch, 19.4 ms per step for the R50 model -- 5.8 ms short of the GPU's
+25.2 ms at the random-init load -- and 65 of 71 ms for HRNet-W32 (config 5: ~2100 launches, host-bound outright).  More than half
+of those launches belong to a section whose shapes never change from step to step: image in, five FPN maps out, and on the way back
+five gradient maps in, weight gradients deposited into the trainer's flat arena.  That section is recorded ONCE into two hipGraphs
+(``torch.cuda.CUDAGraph`` is the hipGraph object on ROCm) and replayed with one host call each.  Everything that depends on the
+data -- RPN targets, proposals, the sampler's per-image counts, the RoI heads whose launch sizes follow the number of positives --
+stays on the eager path between the two replays.
+
+How it plugs in (no tracing, no second implementation): the SAME python code runs once under stream capture, so the graphs hold
+exactly the kernels of bonai_amd/nn.py with their arguments baked in:
+
+    forward graph   static_img -> extract_feat() -> static FPN maps (all activations live in the graphs' private pool)
+    backward graph  static gradient maps -> autograd of the captured forward -> kernels deposit dW / dgamma / dbeta into the
+                    arena (GRAD_SINK + UnpackQueue, flushed INSIDE the graph)
+
+and a tiny autograd node (``_BridgeFn``) hands the static maps to the eager heads and, when their gradients arrive, copies them
+into the static gradient maps and replays the backward graph.  What makes capture legal: every address the section touches is
+persistent (arena slots, the PrepackRegistry's operand buffers, frozen-layer packings cached on their parameters, the private
+pool), kernel argument structs are copied by value at launch, the descriptor tables of the batched unpack hold only such
+addresses and are uploaded once, at capture, on a stream that is not capturing (kernels.h2d / H2D_KEEP), and nothing in the
+section reads back to the host.
+
+Not captured: the per-step BN fold + operand packing (one launch, runs before the forward replay), the optimizer, the collective.
+Under data parallelism the backbone's gradient buckets are released right after the backward replay has been enqueued (the
+reducer orders its collective behind the replay with an event, as for eager launches).
+"""
+import torch
+
+from . import kernels as K
+from . import nn as F2
+
+
+class _BridgeFn(torch.autograd.Function):
+    """Eager autograd <-> the two graphs.  Inputs: a dummy leaf (so the node exists in the graph) and the static maps."""
+
+    @staticmethod
+    def forward(ctx, owner, token, *maps):
+        ctx.owner = owner
+        return tuple(m.detach() for m in maps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.owner._run_backward(grads)
+        return (None, None) + (None,) * len(grads)
+
+
+class FeatureGraphs:
+    """Owns the two graphs of one model + trainer.  ``provider(img)`` replaces ``model.extract_feat`` inside train_step."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.model = trainer.model
+        self.ready = False
+        self.failed = None            # the exception text when capture was refused: the trainer then stays on the eager path
+        self.keep = []                # device tables uploaded at capture (kernels.h2d): must outlive the graphs
+        self.token = None
+
+    # ------------------------------------------------------------------ capture
+    def capture(self, img):
+        """Record both graphs on the shapes of ``img``.  Called by the trainer in place of an eager forward once the prepack
+        registry knows every conv of the section (step >= 2).  Nothing executes during capture; the caller replays afterwards."""
+        tr, m = self.tr, self.model
+        dev = img.device
+        self.static_img = torch.empty_like(img)
+        self.static_img.copy_(img)
+        self.token = torch.zeros(1, device=dev, requires_grad=True)
+        params = [p for p in list(m.backbone.parameters()) + (list(m.neck.parameters()) if m.with_neck else []) if p.requires_grad]
+        self.params = params
+        torch.cuda.synchronize()
+        self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        prev = (F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED)
+        zp_active, sp_active = K._ZeroPool.active, K._ScratchPool.active
+        K._ZeroPool.active = K._ScratchPool.active = False      # accumulation buffers of the section: private-pool tensors, their
+        K.H2D_KEEP = self.keep                                   # fills recorded as graph nodes (the slab's offsets are per step)
+        try:
+            F2.PREPACK = tr.prepack
+            F2.HUB_ENABLED = False
+            with torch.cuda.graph(self.g_fwd, stream=stream, capture_error_mode='relaxed'):
+                feats = m.extract_feat(self.static_img)
+            feats = tuple(feats)
+            self.static_grads = tuple(torch.zeros_like(f) for f in feats)
+            F2.GRAD_SINK = lambda p: None                        # (the reducer is told after each replay, not during capture)
+            F2.WGRAD_STREAM = None                               # one stream inside the graph: the replay orders nodes by data flow
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=stream, capture_error_mode='relaxed'):
+                F2.UNPACK_Q = K.UnpackQueue(limit=48)
+                for p in params:
+                    p._loft_sunk = False
+                torch.autograd.backward(list(feats), grad_tensors=list(self.static_grads))
+                F2.UNPACK_Q.flush()
+            self.static_feats = tuple(f.detach() for f in feats)      # aliases of the static maps, cut loose from the captured graph
+        finally:
+            F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED = prev
+            K._ZeroPool.active, K._ScratchPool.active = zp_active, sp_active
+            K.H2D_KEEP = None
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self.shape = tuple(img.shape)
+        self.ready = True
+
+    # ------------------------------------------------------------------ per step
+    def provider(self, img):
+        """extract_feat of the step: upload into the static image, replay the forward graph, hand the maps to autograd."""
+        if tuple(img.shape) != self.shape or img.dtype != self.static_img.dtype:
+            raise K.L.LoftHipError(f'FeatureGraphs were captured for images {self.shape}, got {tuple(img.shape)}: '
+                                   'capture is per shape (Trainer(graph_features=True) expects fixed-size batches)')
+        self.static_img.copy_(img)
+        self.g_fwd.replay()
+        return _BridgeFn.apply(self, self.token, *self.static_feats)
+
+    def _run_backward(self, grads):
+        for s, g in zip(self.static_grads, grads):
+            if g is None:
+                s.zero_()
+            else:
+                s.copy_(g)
+        self.g_bwd.replay()
+        sink = F2.GRAD_SINK
+        if sink is not None:              # data parallelism: these parameters' gradients are final for the step (enqueued)
+            for p in self.params:
+                p._loft_sunk = True
+                sink(p)

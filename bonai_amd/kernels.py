@@ -26,7 +26,23 @@ def h2d(values, dtype, device):
     t = torch.from_numpy(values).to(dtype) if isinstance(values, np.ndarray) else torch.tensor(values, dtype=dtype)
     if torch.device(device).type != 'cuda':
         return t.to(device)
+    if H2D_KEEP is not None:
+        # hipGraph capture (bonai_amd/graphs.py): a table uploaded inside a captured section holds addresses that are static
+        # for the graph's lifetime, so it is uploaded ONCE, now, on a stream that is not capturing (no memcpy node, no pinned
+        # buffer the replay would read again), and kept alive by the graph's owner.
+        global _H2D_STREAM
+        if _H2D_STREAM is None:
+            _H2D_STREAM = torch.cuda.Stream()
+        with torch.cuda.stream(_H2D_STREAM):
+            d = t.to(device)
+        _H2D_STREAM.synchronize()
+        H2D_KEEP.append(d)
+        return d
     return t.pin_memory().to(device, non_blocking=True)
+
+
+H2D_KEEP = None       # a list while bonai_amd.graphs.FeatureGraphs.capture() records a section
+_H2D_STREAM = None
 
 
 class _ZeroPool:
@@ -128,7 +144,12 @@ def _level_args(feats, strides):
 # include/loft_hip.h LOFT_ROI_*: kernel selector of loft_roi_align_{fwd,bwd}_v (0 = the shipped choice); tests set these
 ROI_AUTO, ROI_FWD_SAMPLE, ROI_BWD_VALU = 0, 1, 1
 ROI_FWD_VARIANT = ROI_AUTO
-ROI_FWD_SORT_MIN = 256     # RoI lists at least this long are launched in (image, level, row strip) order (loft_roi_order)
+# RoI lists at least this long are launched in (image, level, row strip) order (loft_roi_order); None = list order (shipped).
+# Measured round 3 (rocprofv3, bench step at 256 positives / image, same box): roi_align_fwd_sep_kernel 243.7 us per launch
+# ordered against 248.3 us in list order (-2 %), plus 14 us for the ordering launch in front of it; step 37.70-37.96 ms ordered
+# against 37.61-37.82 ms: the forward is bound by its per-RoI chain of dependent L2 round trips, not by where the windows come
+# from, so fetching them from HBM once per XCD instead of once per RoI buys nothing.  Kept selectable and tested, not shipped.
+ROI_FWD_SORT_MIN = None
 ROI_BWD_VARIANT = ROI_AUTO
 
 
@@ -144,7 +165,7 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
     H, W, S = _level_args(feats, strides)
     fp = L.arr(c_void_p, [f.data_ptr() for f in feats])
     order = None
-    if K >= ROI_FWD_SORT_MIN and not _DBG.no_roi_sort:
+    if ROI_FWD_SORT_MIN is not None and K >= ROI_FWD_SORT_MIN and not _DBG.no_roi_sort:
         # launch order (image, level, row strip): one XCD walks one contiguous eighth of it, overlapping windows meet in its L2
         order = torch.empty(K, dtype=torch.int32, device=rois.device)
         L.check(lib.loft_roi_order(H, S, len(feats), int(finest_scale), L.ptr(rois), K, int(feats[0].shape[0]), L.ptr(order),

@@ -81,7 +81,11 @@ class LOFT(nn.Module):
         if self.with_roi_head:
             self.roi_head.init_weights(pretrained)
 
+    feat_provider = None      # the running Trainer's bonai_amd.graphs.FeatureGraphs.provider (hipGraph replay of this function)
+
     def extract_feat(self, img):
+        if self.feat_provider is not None and torch.is_grad_enabled():
+            return self.feat_provider(img)
         x = self.backbone(img)
         if self.with_neck:
             x = self.neck(x)

@@ -286,9 +286,14 @@ def test_roi_align_launch_order_is_a_permutation_and_changes_nothing(K_, B, P, n
     for dtype in (torch.bfloat16, torch.float32):
         feats = [torch.randn(B, C, size // s, size // s, device='cuda').to(dtype).contiguous(memory_format=torch.channels_last)
                  for s in strides]
-        with DBG.override(no_roi_sort=True):
-            plain = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)
-        ordered = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)
+        plain = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)          # (shipped: list order)
+        prev, K.ROI_FWD_SORT_MIN = K.ROI_FWD_SORT_MIN, 256
+        try:
+            ordered = K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot)
+            with DBG.override(no_roi_sort=True):
+                assert torch.equal(plain, K.roi_align_fwd(feats, rois, P, strides, n_rot=n_rot))
+        finally:
+            K.ROI_FWD_SORT_MIN = prev
         assert torch.equal(plain, ordered), dtype
     H, W, S = K._level_args(feats, strides)
     order = torch.full((K_,), -1, dtype=torch.int32, device='cuda')

@@ -176,3 +176,30 @@ def test_resume_equals_uninterrupted(tmp_path):
         assert (mo_a - d.arena.momentum).norm().item() > 0.2 * mo_a.norm().item()
     finally:
         RandomSampler.choice_mode = prev_mode
+
+
+def test_graph_features_match_eager(first_k):
+    """bonai_amd/graphs.py: backbone + neck forward and backward recorded into two hipGraphs at the trainer's third step and
+    replayed from then on.  With lr = 0 every step must reproduce plain autograd's gradients -- the two eager steps before the
+    capture, the step that captures, and the replays after it -- and a changed image must change the features (the replay reads
+    the static input buffer, not a stale copy)."""
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    data = make_batch(2, 256, 8, device='cuda')
+    want = _autograd_grads(_synth_model(), data)
+    m = _synth_model()
+    tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0, graph_features=True)
+    for step in range(5):
+        lv = dict(tr.train_step(data, lr=0.0)['log_vars'].items())
+        torch.cuda.synchronize()
+        assert tr._fgraphs is not None and tr._fgraphs.failed is None, tr._fgraphs.failed
+        assert tr._fgraphs.ready == (step >= 2)
+        _compare(want, m, f'graph step {step}')
+    other = make_batch(2, 256, 8, step=3, device='cuda')
+    want2 = _autograd_grads(_synth_model(), other)
+    tr.train_step(other, lr=0.0)
+    torch.cuda.synchronize()
+    _compare(want2, m, 'graph replay on another batch')
+    assert m.feat_provider is None                              # only set inside train_step
+    with pytest.raises(Exception, match='captured for images'):
+        tr.train_step(make_batch(2, 320, 8, device='cuda'), lr=0.0)

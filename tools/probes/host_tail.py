@@ -16,7 +16,8 @@ if cfg.get('fp16'):
     L.set_act16(torch.float16)
 torch.manual_seed(0)
 m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-tr = Trainer(m, lr=0.005, loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0))
+graph = len(sys.argv) > 3 and sys.argv[3] == 'graph'
+tr = Trainer(m, lr=0.005, loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0), graph_features=graph)
 data = make_batch(8, size, 80 if size >= 512 else 8, device='cuda')
 for _ in range(5):
     tr.train_step(data)
@@ -27,10 +28,10 @@ for it in range(6):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f'size {size}: host {1e3 * (t1 - t0):6.1f} ms   GPU tail {1e3 * (t2 - t1):6.1f} ms   step {1e3 * (t2 - t0):6.1f} ms')
+    print(f'size {size}{" graph" if graph else ""}: host {1e3 * (t1 - t0):6.1f} ms   GPU tail {1e3 * (t2 - t1):6.1f} ms   step {1e3 * (t2 - t0):6.1f} ms')
 # back-to-back (no sync between steps): the steady-state rate
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for it in range(10):
     tr.train_step(data)
 torch.cuda.synchronize()
-print(f'size {size}: back-to-back {1e2 * (time.perf_counter() - t0):6.1f} ms/step')
+print(f'size {size}{" graph" if graph else ""}: back-to-back {1e2 * (time.perf_counter() - t0):6.1f} ms/step')

@@ -247,3 +247,65 @@ def test_optimizer_state_round_trip_and_loud_mismatch(tmp_path):
     bad2 = dict(sd, param_groups=[dict(sd['param_groups'][0], params=list(range(3)))])
     with pytest.raises(RuntimeError, match='different model'):
         Trainer(net()).load_optimizer_state(bad2)
+
+
+def test_bonai_dataset_from_annotation_files(tmp_path):
+    """bonai_amd/dataset.py (VERDICT r2 missing #6): COCO-style BONAI annotation files + PNG tiles on disk -> samples with the
+    reference's semantics: images without usable annotations are filtered (bonai.py:85-100), values come from the pinned
+    parser, a direction LIST is resolved once per pipeline (transforms.py:371-372), flipped samples follow the flip rules, the
+    per-epoch index lists of the ranks are disjoint, equally long and cover the dataset (DistributedGroupSampler contract)."""
+    import json
+    from PIL import Image
+    from bonai_amd.data import flip_bboxes, flip_offsets, parse_bonai_annotations
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.synth import synth_bonai_anns
+    size = 1024
+    rng = np.random.RandomState(0)
+    images, annotations, aid = [], [], 0
+    for i in range(5):
+        name = f'tile_{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name)
+        images.append(dict(id=100 + i, file_name=name, width=size, height=size))
+        anns = synth_bonai_anns(seed=i, size=size) if i not in (1, 3) else []
+        if i == 3:                                      # only a crowd annotation: filtered like an empty image
+            anns = synth_bonai_anns(seed=9, n=12, size=size)[2:3]
+        for a in anns:
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=100 + i))
+    small = dict(id=999, file_name='small.png', width=16, height=16)
+    images.append(small)
+    annotations.append(dict(synth_bonai_anns(seed=3, size=size)[0], id=aid + 1, image_id=999))
+    f = tmp_path / 'bonai_test_trainval.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building'), dict(id=7, name='other')]),
+              open(f, 'w'))
+    ds = BonaiDataset(str(f), str(tmp_path), bbox_type='building', mask_type='roof', flip_ratio=0.0)
+    assert len(ds) == 3 and [d['id'] for d in ds.data_infos] == [100, 102, 104]
+    s = ds[1]
+    want = parse_bonai_annotations(dict(width=size, height=size, filename='tile_2.png'), synth_bonai_anns(seed=2, size=size),
+                                   bbox_type='building')
+    assert np.array_equal(s['gt_bboxes'], want['bboxes']) and np.array_equal(s['gt_offsets'], want['offsets'])
+    assert s['gt_polygons'] == want['masks'] and 'gt_masks' not in s and s['gt_labels'].dtype == np.int64
+    png = np.asarray(Image.open(tmp_path / 'tile_2.png').convert('RGB'))
+    assert s['img'].shape == (size, size, 3) and np.array_equal(s['img'][:, :, ::-1], png)          # BGR like mmcv.imread
+    # flips: probability 1, direction list resolved once
+    dsf = BonaiDataset(str(f), str(tmp_path), bbox_type='building', flip_ratio=1.0, flip_direction=['horizontal', 'vertical'], seed=5)
+    d = dsf.flip_direction
+    assert d in ('horizontal', 'vertical')
+    for k in range(3):
+        sf = dsf[k]
+        base = ds[k]
+        assert sf['flip'] and sf['flip_direction'] == d and sf['mask_flips'] == (d,)
+        assert np.array_equal(sf['gt_bboxes'], flip_bboxes(base['gt_bboxes'], (size, size), d))
+        assert np.array_equal(sf['gt_offsets'], flip_offsets(base['gt_offsets'], d))
+        assert np.array_equal(sf['img'], np.flip(base['img'], axis=1 if d == 'horizontal' else 0))
+    # sharding
+    idx = [ds.epoch_indices(3, 2, rank=r, world=2, seed=1) for r in range(2)]
+    assert len(idx[0]) == len(idx[1]) == 2 and set(idx[0] + idx[1]) == {0, 1, 2}
+    assert ds.epoch_indices(3, 2, 0, 2, seed=1) == idx[0] and ds.epoch_indices(4, 2, 0, 2, seed=1) != idx[0] or len(ds) < 3
+    # test mode keeps every image; another tile size is refused on the training path
+    assert len(BonaiDataset(str(f), str(tmp_path), test_mode=True)) == 6
+    images[0]['width'] = images[0]['height'] = 512
+    Image.fromarray(np.zeros((512, 512, 3), np.uint8)).save(tmp_path / 'tile_0.png')
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    with pytest.raises(NotImplementedError):
+        BonaiDataset(str(f), str(tmp_path), flip_ratio=0.0)[0]

@@ -4,9 +4,10 @@
     python tools/train.py configs/loft_foa/loft_foa_r50_fpn_2x_bonai.py [--work-dir D] [--launcher pytorch]
                           [--options k=v ...] [--iters N] [--synthetic]
 
-The BONAI data pipeline is outside the hot-path scope; `--synthetic` (the default, and the
-only source available offline) feeds seeded 1024x1024 tiles with the reference's batch-dict keys.  Logging mirrors
-TextLoggerHook's key set (default_runtime.py:3-8).
+Data: when the annotation files of ``cfg.data.train`` exist, batches come from them (bonai_amd/dataset.py: the reference's
+BONAI dataset + train pipeline semantics, polygons rasterised and images normalised on the device), sharded over the ranks like
+DistributedGroupSampler; otherwise -- offline, as in this image -- or with ``--synthetic``, seeded 1024x1024 tiles with the
+reference's batch-dict keys.  Logging mirrors TextLoggerHook's key set (default_runtime.py:3-8).
 """
 import argparse
 import os
@@ -31,7 +32,8 @@ def main():
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--local_rank', type=int, default=0)
     ap.add_argument('--iters', type=int, default=50)
-    ap.add_argument('--synthetic', action='store_true', default=True)
+    ap.add_argument('--synthetic', action='store_true', help='seeded synthetic tiles even when the dataset files are present')
+    ap.add_argument('--graph', action='store_true', help='backbone + neck forward / backward as two hipGraphs (bonai_amd/graphs.py)')
     args = ap.parse_args()
     from bonai_amd.config import Config
     from bonai_amd.engine import Trainer, step_lr
@@ -58,7 +60,7 @@ def main():
         load_checkpoint(model, args.load_from, strict=False)
     tr = Trainer(model, lr=cfg.optimizer.lr, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
                  max_norm=cfg.optimizer_config.grad_clip.max_norm,
-                 loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0))
+                 loss_scale=(cfg.get('fp16') or {}).get('loss_scale', 1.0), graph_features=args.graph)
     start_iter = 0
     if args.resume_from:                                   # mmcv runner.resume: weights + optimizer state + iter / epoch
         ckpt = load_checkpoint(model, args.resume_from, strict=True)
@@ -69,9 +71,34 @@ def main():
     interval = cfg.log_config.get('interval', 10)
     ipe = args.iters_per_epoch or max(args.iters, 1)
     sched = {k: cfg.lr_config[k] for k in ('warmup_iters', 'warmup_ratio', 'step') if k in cfg.lr_config}
+    dataset = None
+    tcfg = cfg.data.get('train') if cfg.get('data') else None
+    if tcfg is not None and not args.synthetic:
+        files = [tcfg['ann_file']] if isinstance(tcfg['ann_file'], str) else list(tcfg['ann_file'])
+        if files and all(os.path.exists(f) for f in files):
+            from bonai_amd.dataset import BonaiDataset
+            flip = next((p for p in tcfg.get('pipeline', []) if p.get('type') == 'RandomFlip'), {})
+            dataset = BonaiDataset(tcfg['ann_file'], tcfg.get('img_prefix', ''), bbox_type=tcfg.get('bbox_type', 'roof'),
+                                   mask_type=tcfg.get('mask_type', 'roof'), flip_ratio=flip.get('flip_ratio', 0.0) or 0.0,
+                                   flip_direction=flip.get('direction', 'horizontal'), seed=args.seed + rank)
+            ipe = args.iters_per_epoch or max(1, len(dataset.epoch_indices(0, bs, rank, world)) // bs)
+        elif rank == 0:
+            print(f'dataset files of cfg.data.train not found ({files[:1]}...): synthetic tiles', flush=True)
+
+    def stream():
+        if dataset is None:
+            for it in range(start_iter, args.iters):
+                yield it, make_batch(bs, 1024, 80, rank=rank, step=it, device='cuda')
+            return
+        it = start_iter
+        while it < args.iters:
+            for data in dataset.batches(it // ipe, bs, rank, world, seed=args.seed):
+                if it >= args.iters:
+                    return
+                yield it, data
+                it += 1
     t0 = time.time()
-    for it in range(start_iter, args.iters):
-        data = make_batch(bs, 1024, 80, rank=rank, step=it, device='cuda')
+    for it, data in stream():
         out = tr.train_step(data, lr=step_lr(cfg.optimizer.lr, it, it // ipe, **sched))
         if rank == 0 and (it + 1) % interval == 0:
             torch.cuda.synchronize()

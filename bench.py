@@ -291,10 +291,24 @@ def main():
             ent = json.load(open(pmc)).get(kname, {})
             traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
             mfma_util = round(ent['mfma_util'], 4) if 'mfma_util' in ent else None
+        rocprof = None     # the same family in the committed rocprofv3 --stats summary of this command (serialised mode)
+        csvf = os.path.join(ROOT, 'profiles', 'round3_bench_kernel_stats_serial.csv')
+        if os.path.exists(csvf) and args.batch == 8 and args.size == 1024 and headline and saturate:
+            import csv
+            subs = {'conv_tap': ('conv_tap_kernel', 'conv_tap_pipe_kernel'),
+                    'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv_wgrad64_kernel')}[dom]
+            rows = [r for r in csv.DictReader(open(csvf)) if any(sub + '<' in r['Name'] or sub + '(' in r['Name'] for sub in subs)]
+            nsteps = 27        # the summary's run: 5 warm-up + 20 timed + 2 instrumented steps (bench.py defaults)
+            t_ns, calls = sum(float(r['TotalDurationNs']) for r in rows), sum(int(r['Calls']) for r in rows)
+            if calls:
+                rocprof = dict(ms_per_step=round(t_ns / nsteps / 1e6, 2), launches_per_step=round(calls / nsteps, 1),
+                               avg_launch_us=round(t_ns / calls / 1e3, 1),
+                               frac=round(fam[dom][0] / 2 / (t_ns / nsteps * 1e-9) / 2.5e15, 4),
+                               source='profiles/round3_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
         roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates (loft_conv_tap_bf16_v)',
                                               'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
-                        launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1),
+                        launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1), rocprof=rocprof,
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
                                  'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
                                  'rocprofv3 summary of that mode: profiles/round3_bench_kernel_stats_serial.csv '

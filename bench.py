@@ -140,6 +140,21 @@ def offset_epe_vs_ref():
             ev = offset_error_vector(off_ref[:100][ok].numpy(), offs[arg[ok]].numpy())
             n = int(ok.sum())
         out[mode] = dict(aEPE=round(float(ev['aEPE']), 6), max_EPE=round(float(ev['max_EPE']), 6), pairs=n)
+        # The same model on the REFERENCE's boxes: every one of its detections paired, no matching involved -- what is left is
+        # the numeric distance of the feature maps + FOA head alone (the IoU pairing above mixes it with the
+        # detector's own box jitter, which on random name-seeded weights re-orders soft-NMS).  rel = EPE / |reference offset|.
+        with torch.no_grad():
+            feats = m.extract_feat(data['img'])
+            rb = want[:, :4].cuda().contiguous()
+            rois = torch.cat([rb.new_zeros(rb.shape[0], 1), rb], 1).contiguous()
+            op = m.roi_head._offset_forward(feats, rois)
+            o2 = m.roi_head.offset_head.get_offsets(op, rb, None, False)
+        epe = np.sqrt(((np.asarray(o2) - off_ref.numpy()) ** 2).sum(1))
+        mag = np.sqrt((off_ref.numpy() ** 2).sum(1))
+        out[mode]['on_reference_boxes'] = dict(aEPE=round(float(epe.mean()), 6), max_EPE=round(float(epe.max()), 6),
+                                               pairs=int(epe.shape[0]), mean_ref_offset=round(float(mag.mean()), 4),
+                                               rel_aEPE=round(float((epe / np.maximum(mag, 1e-6)).mean()), 6),
+                                               rel_median=round(float(np.median(epe / np.maximum(mag, 1e-6))), 6))
     return out
 
 

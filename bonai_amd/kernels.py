@@ -693,14 +693,20 @@ def stem7x7_bn_relu(img, w, scale, shift, out_dtype=None):
     return out
 
 
-def stem7x7_mfma(img, w, scale, shift):
-    """MFMA stem: img fp32 NCHW [B,3,H,W], w fp32 [64,3,7,7], folded BN scale/shift -> bf16 channels_last [B,64,H/2,W/2]."""
-    lib = L.load()
-    L.dev_check(img, w, scale, shift)
-    img = img.float().contiguous()
-    wp = torch.zeros(64, 192, dtype=L.act16(), device=img.device)
+def stem7x7_pack(w, scale, shift):
+    """-> (wp 16-bit [64,192]: w * BN scale, k = c*49 + r*7 + s zero-padded to 192; bias fp32 [64] = BN shift)."""
+    wp = torch.zeros(64, 192, dtype=L.act16(), device=w.device)
     wp[:, :147] = (w.float() * scale.float()[:, None, None, None]).reshape(64, 147).to(L.act16())
-    bias = shift.float().contiguous()
+    return wp, shift.float().contiguous()
+
+
+def stem7x7_mfma(img, w, scale, shift, packed=None):
+    """MFMA stem: img fp32 NCHW [B,3,H,W], w fp32 [64,3,7,7], folded BN scale/shift -> bf16 channels_last [B,64,H/2,W/2].
+    packed = stem7x7_pack(...) of a frozen stem (cached by the caller): no packing launches."""
+    lib = L.load()
+    L.dev_check(img, w)
+    img = img.float().contiguous()
+    wp, bias = packed if packed is not None else stem7x7_pack(w, scale, shift)
     B, _, H, W = img.shape
     out = empty_nhwc(B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1, L.act16(), img.device)
     L.check(lib.loft_stem7x7_mfma(L.ptr(img), L.ptr(wp), L.ptr(bias), L.ptr(out), B, H, W, L.stream()),

@@ -198,11 +198,21 @@ class ResNet(nn.Module):
     def forward(self, img):
         """img fp32 NCHW [B,3,H,W] -> tuple of bf16 NHWC-in-memory maps (C2..C5)."""
         with torch.no_grad():                               # frozen stem (frozen_stages >= 0, enforced in _freeze_stages)
-            scale, shift = self.bn1.fold()
             if getattr(self, 'compute_dtype', None) == torch.float32:   # fp32 parity mode (else: the library's 16-bit type)
+                scale, shift = self.bn1.fold()
                 x = K.stem7x7_bn_relu(img, self.conv1.weight, scale, shift, out_dtype=torch.float32)
             else:
-                x = K.stem7x7_mfma(img, self.conv1.weight, scale, shift)
+                # frozen stem: BN fold + 16-bit packing once per weight version (nine small launches per step otherwise),
+                # cached on the parameter like every frozen layer's operands (nn._pack_cache_*)
+                bn = self.bn1
+                srcs = (self.conv1.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                key = ('stem', K.L.act16())
+                packed = F2._pack_cache_get(key, srcs) if all(F2._cacheable(t) for t in srcs[:3]) else None
+                if packed is None:
+                    packed = K.stem7x7_pack(self.conv1.weight, *bn.fold())
+                    if all(F2._cacheable(t) for t in srcs[:3]):
+                        F2._pack_cache_put(key, srcs, packed)
+                x = K.stem7x7_mfma(img, self.conv1.weight, None, None, packed=packed)
             x = K.maxpool3x3s2(x)
         outs = []
         for i, name in enumerate(self.res_layers):

@@ -224,12 +224,12 @@ def test_loss_decreases_on_a_fixed_batch():
     cfg = _cfg()
     torch.manual_seed(0)
     m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
-    tr = Trainer(m, lr=0.02, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
+    tr = Trainer(m, lr=0.002, momentum=cfg.optimizer.momentum, weight_decay=cfg.optimizer.weight_decay,
                  max_norm=cfg.optimizer_config.grad_clip.max_norm)
     data = make_batch(2, 256, 8, device='cuda')
     logs = []
     for it in range(40):
-        out = tr.train_step(data, lr=step_lr(0.02, it, 0, warmup_iters=10, warmup_ratio=0.001))
+        out = tr.train_step(data, lr=step_lr(0.002, it, 0, warmup_iters=10, warmup_ratio=0.001))
         logs.append(dict(out['log_vars'].items()))
     first = {k: sum(l[k] for l in logs[:4]) / 4 for k in logs[0]}
     last = {k: sum(l[k] for l in logs[-4:]) / 4 for k in logs[0]}
@@ -239,3 +239,56 @@ def test_loss_decreases_on_a_fixed_batch():
     for k in ('loss_rpn_cls', 'loss_cls', 'loss_mask', 'loss_offset'):
         assert last[k] < first[k], (k, first[k], last[k])
     assert torch.isfinite(tr.arena.data).all()
+
+
+def test_training_trajectory_vs_cpu_oracle(first_k):
+    """Runner parity against the reference's recipe itself: the CPU oracle (fp32, oracle/loft_model_ref.forward_train under
+    torch autograd) is trained for 5 steps with what mmcv's OptimizerHook + torch.optim.SGD do (apis/train.py:84-108:
+    clip_grad_norm_(35) then SGD(momentum 0.9, weight_decay 1e-4); frozen stem / layer1, frozen BN statistics) and the HIP
+    Trainer (bf16 kernels, fused clip + SGD over the flat arena) runs the same 5 steps on the same batch: the loss trajectories
+    must agree step by step (the single-step bf16 tolerances of test_e2e_gpu.py, 2-5 % per loss) and the parameter UPDATES after 5 steps must
+    point the same way (cosine > 0.97 for the layers checked, update norms within 10 %)."""
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    from oracle import loft_model_ref as M
+    from oracle.synth_weights import synth_tensor
+    steps, lr = 5, 5e-4     # (at 2e-3 the name-seeded weights overshoot -- total loss 11.6 -> 124.7 -> 72.0 -> 6.7 -> 39.5 -- and
+                            #  BOTH paths follow that same trajectory within 3 %; the committed test uses a calmer rate)
+    m = _synth_model()
+    init = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+    trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+    sd = {k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()}
+    for n in trainable:
+        sd[n] = sd[n].clone().requires_grad_(True)
+    opt = torch.optim.SGD([sd[n] for n in trainable], lr=lr, momentum=0.9, weight_decay=1e-4)
+    cpu = make_batch(2, 256, 8)
+    ref_logs = []
+    for _ in range(steps):
+        opt.zero_grad()
+        losses = M.forward_train(sd, cpu['img'], cpu['gt_bboxes'], cpu['gt_labels'], cpu['gt_masks'], cpu['gt_offsets'])
+        losses['loss'].backward()
+        torch.nn.utils.clip_grad_norm_([sd[n] for n in trainable if sd[n].grad is not None], 35.0)
+        opt.step()
+        ref_logs.append({k: float(v.sum()) for k, v in losses.items()})
+    tr = Trainer(m, lr=lr, momentum=0.9, weight_decay=1e-4, max_norm=35.0)
+    data = make_batch(2, 256, 8, device='cuda')
+    logs = [dict(tr.train_step(data)['log_vars'].items()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    # per-loss tolerances of the single-step bf16 comparison (tests/test_e2e_gpu.py), widened by a quarter for steps 2-5
+    tol = dict(loss_rpn_cls=0.02, loss_rpn_bbox=0.05, loss_cls=0.03, loss_bbox=0.05, loss_mask=0.03, loss_offset=0.05, loss=0.05)
+    print('loss trajectory HIP / oracle:', [(round(a['loss'], 3), round(b['loss'], 3)) for a, b in zip(logs, ref_logs)])
+    for i, (a, b) in enumerate(zip(logs, ref_logs)):
+        for k, t in tol.items():
+            assert abs(a[k] - b[k]) <= (t if i == 0 else 1.25 * t) * max(1.0, abs(b[k])), (i, k, a[k], b[k])
+    now = dict(m.named_parameters())
+    report = {}
+    for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer3.1.bn2.weight',
+              'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_conv.weight', 'roi_head.bbox_head.shared_fcs.0.weight',
+              'roi_head.mask_head.convs.3.conv.weight', 'roi_head.offset_head.expand_convs.2.5.weight',
+              'roi_head.offset_head.fcs.1.weight', 'roi_head.offset_head.fc_offset.bias'):
+        ua = (now[n].detach().cpu() - init[n]).flatten()
+        ub = (sd[n].detach() - init[n]).flatten()
+        cos = float(torch.dot(ua, ub) / (ua.norm() * ub.norm() + 1e-30))
+        report[n] = (round(cos, 4), round(float(ua.norm() / (ub.norm() + 1e-30)), 4))
+        assert cos > 0.97 and 0.9 < float(ua.norm() / (ub.norm() + 1e-30)) < 1.1, (n, report[n])
+    print('update after 5 steps, HIP vs CPU oracle (cosine, norm ratio):', report)

@@ -14,7 +14,7 @@ os.chdir(ROOT)
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
-    if os.environ.get('RACE_OLD_NN'):
+    if os.environ.get('RACE_OLD_NN'):      # needs:  git show c4f7e1c:bonai_amd/nn.py > tools/probes/_abl/nn_r2.py  (not tracked)
         import importlib.util
         import bonai_amd
         spec = importlib.util.spec_from_file_location('bonai_amd.nn', os.path.join(ROOT, 'tools', 'probes', '_abl', 'nn_r2.py'))

@@ -17,7 +17,7 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     prior = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # random-init models built, run and freed first (allocator history)
-    if os.environ.get('RACE_OLD_NN'):      # the round-2 bonai_amd/nn.py (process-global _PACK_CACHE) under the current tree
+    if os.environ.get('RACE_OLD_NN'):      # needs:  git show c4f7e1c:bonai_amd/nn.py > tools/probes/_abl/nn_r2.py  (not tracked)      # the round-2 bonai_amd/nn.py (process-global _PACK_CACHE) under the current tree
         import importlib.util
         import bonai_amd
         spec = importlib.util.spec_from_file_location('bonai_amd.nn', os.path.join(ROOT, 'tools', 'probes', '_abl', 'nn_r2.py'))

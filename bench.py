@@ -298,6 +298,10 @@ def main():
                       f'us={v[1] / v[2] * 1e6:6.1f}  TF={v[0] / v[1] / 1e12:7.1f}  TB/s>={byt / v[1] / 1e12:5.2f}', file=sys.stderr)
         K.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
+        # operands-once bytes of the dominant family's launches (input + output maps, 16-bit; weights and residuals not counted):
+        # the figure `traffic` (HBM bytes per launch from the PMC passes) is to be read against
+        alg_bytes = sum(2.0 * t[0] * t[1] * t[2] * t[3] * (t[4] * t[7] * t[7] / max(1, t[8] * t[8]) + t[5]) * v[2]
+                        for (name, t), v in shapes.items() if name == dom) / max(1, fam[dom][2])
         ach = fam[dom][0] / fam[dom][1] / 1e12
         kname = dom     # family = one C-ABI entry point (loft_conv_tap_bf16_v / loft_conv_wgrad_bf16_v) and the kernel templates it dispatches
         traffic = mfma_util = None   # from separate rocprofv3 --pmc passes of this command (tools/pmc_collect.py -> profiles/)
@@ -324,6 +328,7 @@ def main():
                                               'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1), rocprof=rocprof,
+                        algorithmic_bytes_per_launch=round(alg_bytes),
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
                                  'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
                                  'rocprofv3 summary of that mode: profiles/round3_bench_kernel_stats_serial.csv '

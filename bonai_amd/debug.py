@@ -35,7 +35,9 @@ SWITCHES = {
     'no_linear_fn': 'Linear layers through the generic conv node',
     'wgrad_no_patch': 'the tap weight-gradient kernel for 64-channel high-resolution layers (no patch kernel)',
     'roi_fp32_bwd': 'RoIAlign backward into fp32 maps + a cast',
-    'no_roi_sort': 'RoIAlign forward workgroups in list (sampling) order instead of the (image, level, row strip) launch order',
+    'roi_sort': 'RoIAlign forward workgroups in (image, level, row strip) launch order for lists of >= 256 RoIs (loft_roi_order; '
+                'measured neutral on the step, not shipped)',
+    'no_roi_sort': 'list (sampling) order even where kernels.ROI_FWD_SORT_MIN asks for the launch order',
     'narrow_mfma_bwd': 'narrow (<= 8 output) heads backward as padded MFMA GEMMs',
 }
 

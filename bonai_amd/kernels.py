@@ -165,7 +165,8 @@ def roi_align_fwd(feats, rois, P, strides, finest_scale=56, n_rot=1):
     H, W, S = _level_args(feats, strides)
     fp = L.arr(c_void_p, [f.data_ptr() for f in feats])
     order = None
-    if ROI_FWD_SORT_MIN is not None and K >= ROI_FWD_SORT_MIN and not _DBG.no_roi_sort:
+    sort_min = ROI_FWD_SORT_MIN if ROI_FWD_SORT_MIN is not None else (256 if _DBG.roi_sort else None)
+    if sort_min is not None and K >= sort_min and not _DBG.no_roi_sort:
         # launch order (image, level, row strip): one XCD walks one contiguous eighth of it, overlapping windows meet in its L2
         order = torch.empty(K, dtype=torch.int32, device=rois.device)
         L.check(lib.loft_roi_order(H, S, len(feats), int(finest_scale), L.ptr(rois), K, int(feats[0].shape[0]), L.ptr(order),

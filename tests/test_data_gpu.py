@@ -116,3 +116,56 @@ def test_flip_of_polygon_samples_equals_bitmap_flip():
         flip_sample(dict(base), 'horizontal')
     with pytest.raises(ValueError):
         flip_sample(s_poly, 'diagonal')
+
+
+def test_dataset_files_to_training_step(tmp_path):
+    """bonai_amd/dataset.py end to end on the device: annotation file + PNG tiles on disk -> BonaiDataset.batches() (filter, parser,
+    flip, polygons rasterised and images normalised on the GPU) -> a Trainer step.  The flipped batch's masks equal the host
+    pipeline's (rasterise on the host, flip the bitmap), and it is the mirror image of the unflipped batch (masks, image, boxes, offsets)."""
+    import json
+    import os
+    from PIL import Image
+    from bonai_amd.config import Config
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import synth_bonai_anns
+    size = 1024
+    rng = np.random.RandomState(0)
+    images, annotations, aid = [], [], 0
+    for i in range(2):
+        name = f'tile_{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name)
+        images.append(dict(id=10 + i, file_name=name, width=size, height=size))
+        for a in synth_bonai_anns(seed=i, size=size):
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=10 + i))
+    f = tmp_path / 'ann.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    per_ratio = {}
+    for ratio in (0.0, 1.0):
+        dev_ds = BonaiDataset(str(f), str(tmp_path), bbox_type='roof', flip_ratio=ratio, flip_direction='horizontal', seed=1)
+        host_ds = BonaiDataset(str(f), str(tmp_path), bbox_type='roof', flip_ratio=ratio, flip_direction='horizontal', seed=1,
+                               rasterise_on_device=False)
+        bd = next(dev_ds.batches(0, 2, shuffle=False))
+        bh = next(host_ds.batches(0, 2, shuffle=False))
+        for k in ('img',):
+            assert torch.equal(bd[k], bh[k])
+        for i in range(2):
+            assert torch.equal(bd['gt_masks'][i], bh['gt_masks'][i]) and torch.equal(bd['gt_bboxes'][i], bh['gt_bboxes'][i])
+            assert torch.equal(bd['gt_offsets'][i], bh['gt_offsets'][i]) and bd['img_metas'][i]['flip'] == (ratio == 1.0)
+        per_ratio[ratio] = bd
+    for i in range(2):                                          # the flipped batch is the mirror image of the unflipped one
+        assert torch.equal(per_ratio[1.0]['gt_masks'][i], per_ratio[0.0]['gt_masks'][i].flip(-1))
+        assert torch.equal(per_ratio[1.0]['img'][i], per_ratio[0.0]['img'][i].flip(-1))
+        b0, b1 = per_ratio[0.0]['gt_bboxes'][i], per_ratio[1.0]['gt_bboxes'][i]
+        assert torch.allclose(b1[:, 0], size - b0[:, 2]) and torch.allclose(b1[:, 2], size - b0[:, 0]) and torch.equal(b1[:, 1], b0[:, 1])
+        o0, o1 = per_ratio[0.0]['gt_offsets'][i], per_ratio[1.0]['gt_offsets'][i]
+        assert torch.equal(o1[:, 0], -o0[:, 0]) and torch.equal(o1[:, 1], o0[:, 1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    torch.manual_seed(0)
+    m = build_detector(dict(cfg.model, pretrained=None), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+    tr = Trainer(m, lr=1e-3)
+    lv = dict(tr.train_step(bd)['log_vars'].items())
+    assert all(np.isfinite(v) for v in lv.values()) and lv['loss_mask'] > 0 and lv['loss_offset'] > 0

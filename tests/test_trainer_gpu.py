@@ -274,12 +274,12 @@ def test_training_trajectory_vs_cpu_oracle(first_k):
     data = make_batch(2, 256, 8, device='cuda')
     logs = [dict(tr.train_step(data)['log_vars'].items()) for _ in range(steps)]
     torch.cuda.synchronize()
-    # per-loss tolerances of the single-step bf16 comparison (tests/test_e2e_gpu.py), widened by a quarter for steps 2-5
+    # per-loss tolerances of the single-step bf16 comparison (tests/test_e2e_gpu.py), widened by half for steps 2-5
     tol = dict(loss_rpn_cls=0.02, loss_rpn_bbox=0.05, loss_cls=0.03, loss_bbox=0.05, loss_mask=0.03, loss_offset=0.05, loss=0.05)
     print('loss trajectory HIP / oracle:', [(round(a['loss'], 3), round(b['loss'], 3)) for a, b in zip(logs, ref_logs)])
     for i, (a, b) in enumerate(zip(logs, ref_logs)):
         for k, t in tol.items():
-            assert abs(a[k] - b[k]) <= (t if i == 0 else 1.25 * t) * max(1.0, abs(b[k])), (i, k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= (t if i == 0 else 1.5 * t) * max(1.0, abs(b[k])), (i, k, a[k], b[k])
     now = dict(m.named_parameters())
     report = {}
     for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer3.1.bn2.weight',

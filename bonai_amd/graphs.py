@@ -73,20 +73,36 @@ class FeatureGraphs:
         self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         stream = torch.cuda.Stream()
         stream.wait_stream(torch.cuda.current_stream())
-        prev = (F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED)
-        zp_active, sp_active = K._ZeroPool.active, K._ScratchPool.active
-        K._ZeroPool.active = K._ScratchPool.active = False      # accumulation buffers of the section: private-pool tensors, their
-        K.H2D_KEEP = self.keep                                   # fills recorded as graph nodes (the slab's offsets are per step)
+        from .loft import hrnet as H
+        prev = (F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED, H.BRANCH_STREAMS)
+        zp, sp = K._ZeroPool, K._ScratchPool
+        zp_state, sp_state = (zp.buf, zp.off, zp.need, zp.active), (sp.buf, sp.off, sp.need, sp.active)
+        zero_need = max(int(zp.need), int(zp.buf.numel()) if zp.buf is not None else 0)     # >= what the section's backward asks for
+        sp.active = False
+        zp.active = False
+        K.H2D_KEEP = self.keep
+        # forks inside the graphs: HRNet's branches and the weight-gradient launches keep their own streams (parallel branches of
+        # the captured graph; every fork is joined before the capture ends: HRModule joins its branches, the final UnpackQueue
+        # flush waits for every weight-gradient launch)
+        self.side = [torch.cuda.Stream() for _ in range(4)]
         try:
             F2.PREPACK = tr.prepack
             F2.HUB_ENABLED = False
+            H.BRANCH_STREAMS = self.side[:3]
             with torch.cuda.graph(self.g_fwd, stream=stream, capture_error_mode='relaxed'):
                 feats = m.extract_feat(self.static_img)
             feats = tuple(feats)
             self.static_grads = tuple(torch.zeros_like(f) for f in feats)
             F2.GRAD_SINK = lambda p: None                        # (the reducer is told after each replay, not during capture)
-            F2.WGRAD_STREAM = None                               # one stream inside the graph: the replay orders nodes by data flow
+            F2.WGRAD_STREAM = self.side[3]
             with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), stream=stream, capture_error_mode='relaxed'):
+                if zero_need > 0:
+                    # the section's accumulation buffers: ONE slab of the graphs' private pool, zeroed by one node per replay
+                    # (bump offsets are identical in every replay: the same launches in the same order)
+                    zp.buf = torch.empty(int(zero_need * 1.05) + 1024, dtype=torch.float32, device=dev)
+                    zp.buf.zero_()
+                    zp.off, zp.need, zp.active = 0, 0, True
+                    self.keep.append(zp.buf)
                 F2.UNPACK_Q = K.UnpackQueue(limit=48)
                 for p in params:
                     p._loft_sunk = False
@@ -94,8 +110,8 @@ class FeatureGraphs:
                 F2.UNPACK_Q.flush()
             self.static_feats = tuple(f.detach() for f in feats)      # aliases of the static maps, cut loose from the captured graph
         finally:
-            F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED = prev
-            K._ZeroPool.active, K._ScratchPool.active = zp_active, sp_active
+            F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED, H.BRANCH_STREAMS = prev
+            (zp.buf, zp.off, zp.need, zp.active), (sp.buf, sp.off, sp.need, sp.active) = zp_state, sp_state
             K.H2D_KEEP = None
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()

@@ -22,6 +22,7 @@ from .backbone import Bottleneck, ConvW, FrozenStatBN
 from .builder import BACKBONES, NECKS
 
 PAD = 64      # narrowest channel count carried in memory
+BRANCH_STREAMS = None     # list of >= 3 torch.cuda.Stream: HRModule branches 1.. on their own streams (see HRModule._run_branches)
 
 
 def _p(c):
@@ -128,10 +129,32 @@ class HRModule(nn.Module):
             fuse.append(nn.ModuleList(row))
         return nn.ModuleList(fuse)
 
+    def _run_branches(self, x):
+        """The branches of a module are independent chains of small launches (hrnet.py:177-183 runs them one after the other):
+        with BRANCH_STREAMS set (hipGraph capture: bonai_amd/graphs.py; tests) branch i > 0 runs on its own HIP stream, forked
+        from and joined to the calling stream -- in a captured graph that makes them parallel branches, and autograd replays the
+        backward on the same streams."""
+        streams = BRANCH_STREAMS
+        if not streams or not x[0].is_cuda or len(streams) < self.num_branches - 1:
+            return [self.branches[i](x[i]) for i in range(self.num_branches)]
+        main = torch.cuda.current_stream()
+        ys = [None] * self.num_branches
+        for i in range(1, self.num_branches):
+            s = streams[i - 1]
+            s.wait_stream(main)
+            x[i].record_stream(s)
+            with torch.cuda.stream(s):
+                ys[i] = self.branches[i](x[i])
+        ys[0] = self.branches[0](x[0])
+        for i in range(1, self.num_branches):
+            main.wait_stream(streams[i - 1])
+            ys[i].record_stream(main)
+        return ys
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        x = self._run_branches(list(x))
         out = []
         for i in range(len(self.fuse_layers)):
             terms, shifts = [], []

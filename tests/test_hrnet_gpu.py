@@ -165,3 +165,49 @@ def test_config5_train_step_runs():
     for n, p in m.named_parameters():
         if n.startswith('backbone'):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_hrnet_branch_streams_and_graph_replay():
+    """HRModule branches on their own HIP streams (loft.hrnet.BRANCH_STREAMS) reproduce the single-stream forward and backward
+    bit for bit where sums are ordered (features) and within atomics noise (gradients); and the whole backbone + HRFPN section
+    replayed from hipGraphs (Trainer(graph_features=True): branch streams and the weight-gradient stream forked inside the
+    capture, one zeroed slab for the accumulation buffers) gives the eager Trainer's gradients."""
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft import hrnet as H
+    from bonai_amd.loft.core import RandomSampler
+    from bonai_amd.synth import make_batch
+    RandomSampler.choice_mode = 'first'
+    try:
+        data = make_batch(2, 256, 6, device='cuda')
+        m = _build()
+        with torch.no_grad():
+            ref = [f.clone() for f in m.extract_feat(data['img'])]
+        H.BRANCH_STREAMS = [torch.cuda.Stream() for _ in range(3)]
+        try:
+            with torch.no_grad():
+                got = m.extract_feat(data['img'])
+            torch.cuda.synchronize()
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+        finally:
+            H.BRANCH_STREAMS = None
+        eager = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
+        eager.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+        want = {n: p.grad.clone() for n, p in m.named_parameters() if p.requires_grad}
+        m2 = _build()
+        tr = Trainer(m2, lr=0.0, momentum=0.0, weight_decay=0.0, graph_features=True)
+        for step in range(4):
+            tr.train_step(data, lr=0.0)
+            torch.cuda.synchronize()
+            assert tr._fgraphs.failed is None, tr._fgraphs.failed
+            bad = []
+            for n, p in m2.named_parameters():
+                if p.requires_grad:
+                    d, s = (p.grad - want[n]).norm().item(), want[n].norm().item()
+                    if d > 2e-2 * s + 1e-6:
+                        bad.append((n, d, s))
+            assert not bad, (step, len(bad), bad[:4])
+        assert tr._fgraphs.ready and H.BRANCH_STREAMS is None
+    finally:
+        RandomSampler.choice_mode = 'random'

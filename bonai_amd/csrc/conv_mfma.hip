@@ -444,7 +444,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_STREAM64N || (variant & ~0x1ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM64N || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -551,6 +551,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.trace = (variant & 0x1000) ? const_cast<float*>(bias) : nullptr;      // experiment bits 12-15 (conv_pipe.hip VAR); TRACE
         if (a.trace) a.bias = nullptr;                                          // borrows the bias pointer for its buffer
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
+        a.krot = (variant & LOFT_CONV_FLAG_KROT) && !a.tap_major ? 1 : 0;
         return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : 1, (variant >> 12) & 0xf,
                                          k == LOFT_CONV_STREAM128 ? 2 : ((k == LOFT_CONV_STREAM64 || k == LOFT_CONV_STREAM64N) ? 1 : 4),
                                          k == LOFT_CONV_STREAM64N ? 1 : 0, s);

@@ -209,7 +209,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
     constexpr bool TRACE = VAR & 1, NOPRIO = !ABL && (VAR & 2), OLDORDER = !ABL && (VAR & 4);
     constexpr bool NOGLDS = ABL && ((VAR >> 1) & 3) == 0, NOREADS = ABL && ((VAR >> 1) & 3) == 1, NOMFMA = ABL && ((VAR >> 1) & 3) == 2,
-                   NOSEL = ABL && ((VAR >> 1) & 3) == 3;
+                   NOSEL = false;                      // (sub-code 3 used to skip the zero-page select: faults on padded maps; retired)
+    // VAR 14 (round 3): the copy volume of a SHARED HALO PATCH, timing only -- the activation copies of a 64-channel chunk are
+    // issued for its first tap alone (one tile's worth of rows, where a patch would stage 18 x 18 = 1.27 tiles), the weight copies
+    // for every tap as before.  An upper bound on what any patch scheme can return.
+    constexpr bool HALOX = ABL && ((VAR >> 1) & 3) == 3;
     // Stage ring.  The 256-pixel tile double-buffers (4 x 32 KiB).  The 128- / 64-pixel tiles (layer3 / layer4: few workgroups, one per
     // CU, K-tiles of only 256-512 MFMA cycles) take THREE stages: a K-tile's copies are requested two tiles ahead and retired
     // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
@@ -342,12 +346,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         nk = __popc(tmask) * kchunks;
     }
     // ---- wave-uniform state of the K-tile being STAGED: tap, channel offset, the tap's source / weight offsets
-    int st_t = 0, st_c = 0;
+    int st_t = 0, st_c = a.krot ? (V % kchunks) * BK : 0;        // (krot: this workgroup's first channel chunk)
     while (st_t < a.T - 1 && !((tmask >> st_t) & 1u)) ++st_t;
     long st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
     const bf16_t* st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
     // (stream mode: the weight pieces are issued one K-tile ahead of the activation pieces -> their own tap / channel state)
-    int sw_t = st_t, sw_c = 0;
+    int sw_t = st_t, sw_c = st_c;
     // K order.  Chunk-major (default): for every 64-channel chunk, all taps.  The three dx taps of an input row -- and the rows a
     // tile shares with its neighbours -- then re-read the same 128-byte segments within a few K-tiles, while they are still in
     // the XCD's L2; in tap-major order (a.tap_major: the lock-step kernels' order, bit-identical sums) a re-read comes kchunks
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         } else {
             sw_t = next_tap(sw_t);
-            if (sw_t >= a.T) { sw_t = first_t; sw_c += BK; }
+            if (sw_t >= a.T) { sw_t = first_t; sw_c += BK; if (sw_c == a.Cin) sw_c = 0; }      // (wraps under krot; nk ends the loop)
             st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
         }
     };
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         } else {
             st_t = next_tap(st_t);
-            if (st_t >= a.T) { st_t = first_t; st_c += BK; }
+            if (st_t >= a.T) { st_t = first_t; st_c += BK; if (st_c == a.Cin) st_c = 0; }
             st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
         }
     };
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         } else {
             st_t = next_tap(st_t);
-            if (st_t >= a.T) { st_t = first_t; st_c += BK; }
+            if (st_t >= a.T) { st_t = first_t; st_c += BK; if (st_c == a.Cin) st_c = 0; }
             st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
             st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, st_t);
         }
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     auto issue_x = [&](auto halfc, auto bufc) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
+        if constexpr (HALOX) { if (in_loop && st_t != first_t) return; }
         if constexpr (2 * H >= NI) return;                        // (128- / 64-pixel tiles: the second half does not exist)
         const long aoff = st_aoff + st_c;
 #pragma unroll
@@ -860,6 +865,7 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         case 8: PIPE_LAUNCH(1, 8); break;
         case 10: PIPE_LAUNCH(1, 10); break;
         case 12: PIPE_LAUNCH(1, 12); break;
+        case 14: PIPE_LAUNCH(1, 14); break;
         default: return (int)hipErrorInvalidValue;
         }
     } else {

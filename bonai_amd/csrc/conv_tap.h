@@ -33,6 +33,8 @@ struct ConvArgs {
     void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
     unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
     int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
+    int krot;        // conv_pipe.hip, chunk-major order: workgroup V starts at channel chunk (V % krot_n) and wraps -- at any instant the
+                     // workgroups of the chip read DIFFERENT weight tiles instead of all 256 CUs fetching the same 32 KiB
     unsigned gxy_mul, gxy_sh, gx_mul, gx_sh, gy_mul, gy_sh;   // conv_pipe.hip: exact division by grid.x * grid.y, grid.x, grid.y
     int pointwise;   // conv_pipe.hip: one tap at offset 0, unit strides, input map = output map: row m reads input pixel m
     // conv_pipe.hip, pixel-major rows in RoI BLOCKS: row m -> segment m / pm_S (pm_S rows = the RoIs of one block at one pixel

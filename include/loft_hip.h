@@ -165,6 +165,7 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400
 #define LOFT_CONV_FLAG_TAP_MAJOR 0x800   /* pipelined kernels: K order (tap, channel chunk) -- the lock-step kernels' order -- instead of (chunk, tap) */
+#define LOFT_CONV_FLAG_KROT 0x20000   /* pipelined kernels, chunk-major order: rotate the channel-chunk order per workgroup (see ConvArgs::krot) */
 #define LOFT_CONV_FLAG_NO_ROI_BLOCKS 0x10000   /* pipelined kernels on RoI maps: position-major rows over all RoIs instead of blocks of ~256 RoIs */
 int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual, const void* relu_mask,
                          void* out,

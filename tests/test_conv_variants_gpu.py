@@ -149,7 +149,8 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         outs = []
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_T256, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR,
                   K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM64 | K.CONV_FLAG_TAP_MAJOR,
-                  K.CONV_STREAM64N | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128):
+                  K.CONV_STREAM64N | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128,
+                  K.CONV_STREAM256 | K.CONV_FLAG_KROT, K.CONV_STREAM128 | K.CONV_FLAG_KROT, K.CONV_STREAM64 | K.CONV_FLAG_KROT):
             K.CONV_VARIANT = v
             try:
                 # (the pipelined kernels serve bf16 outputs; fp32 / accumulating launches stay on the lockstep ones)
@@ -165,7 +166,8 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         for o in outs[1:7]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)
-        for o in outs[7:]:          # chunk-major K order: a different fp32 summation order, then one bf16 rounding
+        for o in outs[7:]:          # chunk-major K order (and its per-workgroup chunk rotation, LOFT_CONV_FLAG_KROT): a different
+                                    # fp32 summation order, then one bf16 rounding
             for got, want in zip(o, outs[0]):
                 if want is None:
                     assert got is None

@@ -214,6 +214,9 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // issued for its first tap alone (one tile's worth of rows, where a patch would stage 18 x 18 = 1.27 tiles), the weight copies
     // for every tap as before.  An upper bound on what any patch scheme can return.
     constexpr bool HALOX = ABL && ((VAR >> 1) & 3) == 3;
+    // VAR 4 in the stream schedule (round 3, timing only): per K-tile only ONE wave of every SIMD issues global->LDS copies -- waves
+    // 0-3 in even tiles, 4-7 in odd ones -- and it issues twice as many (its own pieces twice: same instruction count and bytes per CU)
+    constexpr bool ALTCOPY = MODE == 1 && VAR == 4;
     // Stage ring.  The 256-pixel tile double-buffers (4 x 32 KiB).  The 128- / 64-pixel tiles (layer3 / layer4: few workgroups, one per
     // CU, K-tiles of only 256-512 MFMA cycles) take THREE stages: a K-tile's copies are requested two tiles ahead and retired
     // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
@@ -609,9 +612,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             using s1_t = std::integral_constant<int, 12 * B + 2>;
             using s2_t = std::integral_constant<int, 12 * B + 4>;
             using s3_t = std::integral_constant<int, 12 * B + 8>;
+            const bool copier = !ALTCOPY || (wave >> 2) == B;
             substep(fa, fb, bufc, k1_t{}, true,
-                    [&] { if (has1) issue_x(c0_t{}, other_t{}); },
-                    [&] { if (has1) { issue_x(c1_t{}, other_t{}); advance_x(); } }, s0_t{});
+                    [&] { if (has1 && copier) { issue_x(c0_t{}, other_t{}); if constexpr (ALTCOPY) issue_x(c0_t{}, other_t{}); } },
+                    [&] { if (has1) { if (copier) { issue_x(c1_t{}, other_t{}); if constexpr (ALTCOPY) issue_x(c1_t{}, other_t{}); } advance_x(); } }, s0_t{});
             // ---- ks1, ks2
             substep(fb, fa, bufc, k2_t{}, true, nop, nop, s1_t{});
             substep(fa, fb, bufc, k3_t{}, true, nop, nop, s2_t{});
@@ -624,8 +628,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
             // ---- ks3: MFMA fb, read F(t+1,0) -> fa from buffer 1-B, issue W(t+2) -> buffer B
             substep(fb, fa, other_t{}, k0_t{}, has1,
-                    [&] { if (has2) issue_w(c0_t{}, bufc); },
-                    [&] { if (has2) { issue_w(c1_t{}, bufc); advance_w(); } }, s3_t{});
+                    [&] { if (has2 && copier) { issue_w(c0_t{}, bufc); if constexpr (ALTCOPY) issue_w(c0_t{}, bufc); } },
+                    [&] { if (has2) { if (copier) { issue_w(c1_t{}, bufc); if constexpr (ALTCOPY) issue_w(c1_t{}, bufc); } advance_w(); } }, s3_t{});
             STREAM_STAMP(12 * B + 10);
             ++cur_t;
             if constexpr (TRACE) {
@@ -862,6 +866,7 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         case 1: PIPE_LAUNCH(1, 1); break;
         case 2: PIPE_LAUNCH(1, 2); break;      // direct (unstaged) epilogue
         case 3: PIPE_LAUNCH(1, 3); break;
+        case 4: PIPE_LAUNCH(1, 4); break;
         case 8: PIPE_LAUNCH(1, 8); break;
         case 10: PIPE_LAUNCH(1, 10); break;
         case 12: PIPE_LAUNCH(1, 12); break;

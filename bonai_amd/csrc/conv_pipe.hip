@@ -462,6 +462,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
 
     if constexpr (MODE == 1) {
+        // Static priority for the younger half (round 3): waves 4-7 are dispatched second and lose every VALU / LDS arbitration
+        // against their SIMD partner by age -- in the barrier-level trace they reach the K-tile's barrier ~580 cycles after waves
+        // 0-3.  One s_setprio for the whole loop (no per-segment flips; MI355X_MICROARCH.md "Two waves per SIMD", item 4):
+        // +0.6 .. +2.4 % on every shape of tools/pipe_trace.py, same box (profiles/round3_probes/stream_ablations.txt).
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
         // ================= stream schedule =================
         // Per K-tile t (buffer B = t&1), 16-channel sub-steps ks = 0..3; fragment set F(t,ks) = 2 weight + 4 activation
         // ds_read_b128.  Two register sets alternate (ks even -> fa, odd -> fb); the reads of a sub-step are issued ONE SUB-STEP
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         }
         }
         if constexpr (TRACE) kst2 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (VAR & 2)
             conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
                                          a.pixmajor != 0);

@@ -280,10 +280,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
         }
         WG_SUBSTEP(fb, fa, 1 - B, 0, has1, if (has2) issue_g(s + 2, bufc, c0_t{}), if (has2) issue_g(s + 2, bufc, c2_t{}));
     };
+    // static priority for the younger half of the workgroup over the whole K loop (see conv_pipe.hip, round 3)
+    if ((threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
     for (int s = 0; s < nsteps; s += 2) {
         step(c0_t{}, s, s + 1 < nsteps, s + 2 < nsteps);
         if (s + 1 < nsteps) step(c1_t{}, s + 1, s + 2 < nsteps, s + 3 < nsteps);
     }
+    __builtin_amdgcn_s_setprio(0);
 
     if (do_db && (lane & 31) == 0) {
         float* db = a.db + (long)grp * a.Cout;

@@ -37,7 +37,7 @@ CLASSES = ('building',)
 class BonaiDataset:
     def __init__(self, ann_file, img_prefix='', classes=None, test_mode=False, filter_empty_gt=True, bbox_type='roof',
                  mask_type='roof', offset_coordinate='rectangle', resolution=0.6, ignore_buildings=True, flip_ratio=0.5,
-                 flip_direction=('horizontal', 'vertical'), img_scale=(1024, 1024), seed=0, rasterise_on_device=True):
+                 flip_direction=('horizontal', 'vertical'), img_scale=(1024, 1024), seed=0, host_rasteriser=None):
         ann_files = [ann_file] if isinstance(ann_file, str) else list(ann_file)
         prefixes = [img_prefix] * len(ann_files) if isinstance(img_prefix, str) else list(img_prefix)
         if len(prefixes) != len(ann_files):
@@ -47,7 +47,9 @@ class BonaiDataset:
         self.kw = dict(bbox_type=bbox_type, mask_type=mask_type, offset_coordinate=offset_coordinate, resolution=resolution,
                        ignore_buildings=ignore_buildings)
         self.flip_ratio, self.img_scale = flip_ratio, tuple(img_scale)
-        self.rasterise_on_device = rasterise_on_device
+        # host_rasteriser(polygons_of_one_instance, h, w) -> uint8 [h, w]: a caller-supplied host rasteriser (the tests pass the
+        # oracle's); None (the product): polygons travel to the device and kernels.poly2mask rasterises them there
+        self.host_rasteriser = host_rasteriser
         self.rng = np.random.RandomState(seed)
         if isinstance(flip_direction, str):
             self.flip_direction = flip_direction
@@ -120,11 +122,10 @@ class BonaiDataset:
                                       'tiles as they are (Resize / Pad of bonai_instance.py:11,14 are identities there)')
         sample = dict(img=img, filename=info['filename'], gt_bboxes=ann['bboxes'], gt_labels=ann['labels'],
                       gt_offsets=ann['offsets'])
-        if self.rasterise_on_device:
+        if self.host_rasteriser is None:
             sample['gt_polygons'] = ann['masks']
         else:
-            from oracle import ops_ref as R                             # (host rasterisation exists for tests only)
-            sample['gt_masks'] = np.stack([R.poly2mask(m, h, w) for m in ann['masks']])
+            sample['gt_masks'] = np.stack([self.host_rasteriser(m, h, w) for m in ann['masks']])
         if self.flip_ratio and self.rng.rand() < self.flip_ratio:
             sample = flip_sample(sample, self.flip_direction)
         return sample

@@ -1,13 +1,14 @@
-"""The driver's failing situation, reproduced in ONE process: the GPU test files that precede tests/test_edge_gpu.py in
+"""TEST INFRASTRUCTURE (a stress form of a GPU test; imports the oracle's name-seeded weights like the test it repeats).
+The driver's failing situation, reproduced in ONE process: the GPU test files that precede tests/test_edge_gpu.py in
 alphabetical order run first (pytest.main, in-process: allocator history, stream pool, library state as on the driver's box),
 then the body of test_trainer_direct_grad_sink_matches_autograd_accumulation is repeated N times with diagnostics.
-    python tools/probes/suite_then_race.py [N] [--no-history]        (RACE_OLD_NN=1: round-2 bonai_amd/nn.py)"""
+    python tests/stress/suite_then_race.py [N] [--no-history]        (RACE_OLD_NN=1: round-2 bonai_amd/nn.py)"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 

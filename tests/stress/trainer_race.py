@@ -1,15 +1,16 @@
-"""Stress form of tests/test_edge_gpu.py::test_trainer_direct_grad_sink_matches_autograd_accumulation:
+"""TEST INFRASTRUCTURE (a stress form of a GPU test; imports the oracle's name-seeded weights like the test it repeats).
+Stress form of tests/test_edge_gpu.py::test_trainer_direct_grad_sink_matches_autograd_accumulation:
 ONE fresh process = the reference gradients (plain autograd, one stream) and `reps` Trainer steps (gradient sink + unpack queue +
 weight-gradient side stream + prepack + zero / scratch pools -- what bench.py times) on the same batch; prints one line
     RESULT <ok|BAD> switches=<LOFT_NO_* set> worst=<param> rel=<|got-want|/|want|> nbad=<#params over 1e-2> loss_ref=.. loss_tr=..
-The driver script tools/probes/trainer_race.sh runs it N times per switch, several processes at once (their kernels interleave on
+The driver script tests/stress/trainer_race.sh runs it N times per switch, several processes at once (their kernels interleave on
 the one GPU, which moves every launch's timing), and tabulates."""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/stress/ -> repo root
 sys.path.insert(0, ROOT)
 
 

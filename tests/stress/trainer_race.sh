@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/probes/trainer_race.sh [runs-per-switch] [parallel] -> gpurun_out/trainer_race.txt (table) + trainer_race_raw.txt
+# tests/stress/trainer_race.sh [runs-per-switch] [parallel] -> gpurun_out/trainer_race.txt (table) + trainer_race_raw.txt
 N=${1:-30}; P=${2:-3}
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
@@ -8,7 +8,7 @@ for sw in RACE_OLD_NN - LOFT_NO_WGRAD_STREAM LOFT_NO_ZERO_POOL LOFT_NO_PREPACK L
   for ((i = 0; i < N; i += P)); do
     for ((j = 0; j < P && i + j < N; j++)); do
       ( if [ "$sw" != "-" ]; then export $sw=1; fi
-        timeout 300 python tools/probes/trainer_race.py 3 256 $(( (i + j) % 3 )) 2>&1 | grep RESULT || echo "RESULT CRASH switches=$sw" ) >> $RAW &
+        timeout 300 python tests/stress/trainer_race.py 3 256 $(( (i + j) % 3 )) 2>&1 | grep RESULT || echo "RESULT CRASH switches=$sw" ) >> $RAW &
     done
     wait
   done

@@ -146,7 +146,7 @@ def test_dataset_files_to_training_step(tmp_path):
     for ratio in (0.0, 1.0):
         dev_ds = BonaiDataset(str(f), str(tmp_path), bbox_type='roof', flip_ratio=ratio, flip_direction='horizontal', seed=1)
         host_ds = BonaiDataset(str(f), str(tmp_path), bbox_type='roof', flip_ratio=ratio, flip_direction='horizontal', seed=1,
-                               rasterise_on_device=False)
+                               host_rasteriser=R.poly2mask)
         bd = next(dev_ds.batches(0, 2, shuffle=False))
         bh = next(host_ds.batches(0, 2, shuffle=False))
         for k in ('img',):

@@ -877,6 +877,8 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         case 10: PIPE_LAUNCH(1, 10); break;
         case 12: PIPE_LAUNCH(1, 12); break;
         case 14: PIPE_LAUNCH(1, 14); break;
+        case 9: PIPE_LAUNCH(1, 9); break;       // TRACE + no copies
+        case 15: PIPE_LAUNCH(1, 15); break;     // TRACE + halo-volume copies
         default: return (int)hipErrorInvalidValue;
         }
     } else {

@@ -55,7 +55,7 @@ def main():
         x = torch.randn(B, Cin, H, W, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
         wp = K.pack_w_fwd(torch.randn(Cout, Cin, R, R, device='cuda') * 0.02)[None]
         tr = torch.zeros(2 * 8 * 64, dtype=torch.int64, device='cuda')
-        K.CONV_VARIANT = K.CONV_STREAM256 | (1 << 12)
+        K.CONV_VARIANT = K.CONV_STREAM256 | (int(os.environ.get('STREAM_TRACE_VAR', '1')) << 12)
         K.conv2d_fwd(x, wp, tr.view(torch.float32), R, R, st, pad, groups=G)
         K.CONV_VARIANT = K.CONV_AUTO
         torch.cuda.synchronize()

@@ -211,6 +211,7 @@ class Trainer:
         # then on (bonai_amd/graphs.py); fixed-size batches only.  Capture failures fall back to eager launches, loudly.
         self.graph_features = bool(graph_features)
         self._fgraphs = None
+        self._steps_run = 0          # steps THIS trainer has run (a resumed trainer starts at iter > 0 with an empty prepack registry)
         self.lr, self.mu, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
         self.loss_scale = float(loss_scale)
         self.arena = FlatArena(model)
@@ -228,7 +229,7 @@ class Trainer:
         fg = self._fgraphs
         if fg is None:
             fg = self._fgraphs = FeatureGraphs(self)
-        if not fg.ready and fg.failed is None and self.iter >= 2:
+        if not fg.ready and fg.failed is None and self._steps_run >= 2 and self.prepack.order:
             self.reducer.capturing = True
             try:
                 fg.capture(img)
@@ -343,4 +344,5 @@ class Trainer:
         K.sgd_momentum_(self.arena.data, self.arena.grad, self.arena.momentum, self.gnorm_sq, self.max_norm,
                         self.lr if lr is None else lr, self.mu, self.wd, grad_scale=1.0 / (self.world * self.loss_scale))
         self.iter += 1
+        self._steps_run += 1
         return out

@@ -20,8 +20,12 @@ class AnchorGenerator:
                  scales_per_octave=None, centers=None, center_offset=0.):
         if scales is None or octave_base_scale is not None or centers is not None or center_offset != 0. or not scale_major:
             raise NotImplementedError('only the (scales, ratios, strides) form used by configs/loft_foa')
-        self.strides = [int(s) for s in strides]
-        self.base_sizes = list(self.strides) if base_sizes is None else list(base_sizes)
+        # anchor_generator.py:72-76: a stride is an int or an (x, y) pair; base size = the smaller of the pair
+        self.stride_pairs = [(int(s), int(s)) if not isinstance(s, (tuple, list)) else (int(s[0]), int(s[1])) for s in strides]
+        self.strides = [sx if sx == sy else (sx, sy) for sx, sy in self.stride_pairs]
+        self.base_sizes = [min(p) for p in self.stride_pairs] if base_sizes is None else list(base_sizes)
+        if len(self.base_sizes) != len(self.strides):
+            raise ValueError(f'The number of strides should be the same as base sizes, got {self.strides} and {self.base_sizes}')
         self.scales = torch.tensor(scales, dtype=torch.float32)
         self.ratios = torch.tensor(ratios, dtype=torch.float32)
         self.base_anchors = [self._base(b) for b in self.base_sizes]
@@ -47,9 +51,11 @@ class AnchorGenerator:
         key = (tuple(tuple(int(v) for v in s) for s in featmap_sizes), str(device))
         if key not in self._cache:
             out = []
-            for (h, w), s, ba in zip(featmap_sizes, self.strides, self.base_anchors):
-                sx = torch.arange(0, int(w), dtype=torch.float32) * s
-                sy = torch.arange(0, int(h), dtype=torch.float32) * s
+            if len(featmap_sizes) != self.num_levels:
+                raise ValueError(f'{len(featmap_sizes)} feature maps for {self.num_levels} anchor levels')
+            for (h, w), (stx, sty), ba in zip(featmap_sizes, self.stride_pairs, self.base_anchors):
+                sx = torch.arange(0, int(w), dtype=torch.float32) * stx
+                sy = torch.arange(0, int(h), dtype=torch.float32) * sty
                 xx = sx.repeat(int(h))
                 yy = sy.view(-1, 1).repeat(1, int(w)).view(-1)
                 shifts = torch.stack([xx, yy, xx, yy], dim=-1)

@@ -45,6 +45,8 @@ class RPNHead(nn.Module):
         self.in_channels, self.feat_channels = in_channels, feat_channels
         self.anchor_generator = build_anchor_generator(anchor_generator)
         self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        if any(isinstance(s, tuple) for s in self.anchor_generator.strides):
+            raise NotImplementedError('RPNHead decodes with square strides (loft_rpn_decode); got ' + str(self.anchor_generator.strides))
         self.bbox_coder = build_bbox_coder(bbox_coder or dict(type='DeltaXYWHBBoxCoder'))
         self.loss_cls = build_loss(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
         self.loss_bbox = build_loss(loss_bbox or dict(type='L1Loss', loss_weight=1.0))

@@ -497,3 +497,22 @@ def test_fused_roi_backward_matches_per_extractor_passes():
     ref, got = run(False), run(True)
     assert torch.isfinite(got).all()
     assert (got - ref).norm().item() <= 1e-2 * ref.norm().item(), ((got - ref).norm().item(), ref.norm().item())
+
+
+def test_product_anchor_generator_device_tables_vs_reference_fixture(golden_dir):
+    """a6: the anchor tables the RPN head decodes from ON THE DEVICE (AnchorGenerator.grid_anchors(device='cuda') and the
+    base-anchor tables handed to loft_rpn_decode) are bit-identical to mmdet's own generator (anchor_generator.py:142-265)."""
+    import os
+    from bonai_amd.loft.builder import build_anchor_generator
+    g = np.load(os.path.join(golden_dir, 'core_ops.npz'))
+    ag = build_anchor_generator(dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64]))
+    sizes = [tuple(int(v) for v in s) for s in g['anchor_sizes']]
+    got = ag.grid_anchors(sizes, device='cuda')
+    for i, a in enumerate(got):
+        assert a.is_cuda and torch.equal(a.cpu(), torch.from_numpy(g[f'anchors_{i}'])), i
+    assert ag.grid_anchors(sizes, device='cuda') is got                 # cached per (sizes, device)
+    # the decode kernel rebuilds anchor k of cell (y, x) as base[k] + (x, y, x, y) * stride: same fp32 values as the table
+    for (h, w), s, ba, tab in zip(sizes, ag.strides, ag.base_anchors, got):
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+        sh = torch.stack([xs, ys, xs, ys], -1).view(-1, 1, 4) * s
+        assert torch.equal((ba[None] + sh).view(-1, 4), tab.cpu())

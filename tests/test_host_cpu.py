@@ -309,3 +309,30 @@ def test_bonai_dataset_from_annotation_files(tmp_path):
     json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
     with pytest.raises(NotImplementedError):
         BonaiDataset(str(f), str(tmp_path), flip_ratio=0.0)[0]
+
+
+# ---- a6: the PRODUCT AnchorGenerator (bonai_amd/loft/core.py) against the reference-made fixture and the reference's known answers
+
+def test_product_anchor_generator_vs_reference_fixture_and_known_answers():
+    import numpy as np
+    from bonai_amd.loft.core import AnchorGenerator
+    from bonai_amd.loft.builder import build_anchor_generator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'core_ops.npz'))
+    # configs/_base_/models/bonai/loft_foa_r50_fpn.py rpn_head.anchor_generator, through the registry like the reference builds it
+    ag = build_anchor_generator(dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64]))
+    sizes = [tuple(int(v) for v in s) for s in g['anchor_sizes']]
+    got = ag.grid_anchors(sizes, device='cpu')
+    assert len(got) == len(sizes) and ag.num_levels == 5 and ag.num_base_anchors == [3] * 5
+    for i, a in enumerate(got):
+        assert torch.equal(a, torch.from_numpy(g[f'anchors_{i}'])), i              # bit-exact vs mmdet's own generator
+    # tests/test_anchor.py:22-40 (reference): square and (x, y) strides
+    a = AnchorGenerator([10], [1.], [1.], [10]).grid_anchors([(2, 2)], device='cpu')[0]
+    assert torch.equal(a, torch.tensor([[-5., -5., 5., 5.], [5., -5., 15., 5.], [-5., 5., 5., 15.], [5., 5., 15., 15.]]))
+    a = AnchorGenerator([(10, 20)], [1.], [1.], [10]).grid_anchors([(2, 2)], device='cpu')[0]
+    assert torch.equal(a, torch.tensor([[-5., -5., 5., 5.], [5., -5., 15., 5.], [-5., 15., 5., 25.], [5., 15., 15., 25.]]))
+    # anchor_generator.py:39-55 doctest
+    a = AnchorGenerator([16, 32], [1.], [1.]).grid_anchors([(2, 2), (1, 1)], device='cpu')
+    assert torch.equal(a[0], torch.tensor([[-8., -8., 8., 8.], [8., -8., 24., 8.], [-8., 8., 8., 24.], [8., 8., 24., 24.]]))
+    assert torch.equal(a[1], torch.tensor([[-16., -16., 16., 16.]]))
+    with pytest.raises(ValueError):
+        ag.grid_anchors(sizes[:2], device='cpu')

@@ -77,6 +77,67 @@ __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const b
     return base + out_g + opix * a.Cout + n0;
 }
 
+// Wave-uniform description of where the rows of ONE tile live in an NHWC map (round 4).  The per-row decode above costs three
+// multiply-high divisions and a chain of 64-bit multiplies per row AND -- what the barrier-level trace of round 4 showed to be the
+// real price -- a dozen kernarg (SMEM) reloads per row, each behind its own s_waitcnt lgkmcnt(0): hipcc does not keep ~15 ConvArgs
+// scalars live across the K loop, so the 16 row stores of the epilogue ran ~120 instructions and 6-9 scalar-memory round trips
+// apiece (10.9k of a tile's 147k cycles on the FOA maps, 8.7k more in the set-up).  Both layouts the RoI heads and the backbone
+// use are piecewise LINEAR in the tile row r:
+//   pixel-major RoI blocks: rows [0, rs1) are RoIs b00, b00+1, .. at pixel position pos0, rows [rs1, BM) RoIs b10, .. at pos1
+//                           (a tile spans at most two segments because pm_S >= 256 >= BM) -- element offset = off_k + idx * stride
+//                           with stride = (map pixels) * channels;
+//   dense maps (output pixel index == m): one segment, stride = channels.
+// Six scalars per tile, computed once on the scalar unit; a row costs a compare, two selects and one 64-bit multiply-add.
+struct TileRows {
+    int lin;                 // 0: neither layout (strided / offset outputs): the per-row decode above
+    int rs1, nv0, nv1;       // first row of the second segment (>= BM: none); valid rows per segment
+    long off0, off1, stride; // element offsets
+};
+__device__ __forceinline__ int pipe_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// pixel-major tile -> its two segments: first RoI and pixel position of each
+__device__ __forceinline__ void pipe_pm_tile(const ConvArgs& a, int m0, int& rs1, int& b00, int& b10, int& pos0, int& pos1) {
+    const int seg0 = fastdiv(m0, a.pms_mul, a.pms_sh), blk0 = fastdiv(seg0, a.pmp_mul, a.pmp_sh);
+    pos0 = seg0 - blk0 * a.pm_P;
+    const int r0 = m0 - seg0 * a.pm_S;
+    b00 = blk0 * a.pm_S + r0;
+    rs1 = a.pm_S - r0;
+    const bool wrap = pos0 + 1 == a.pm_P;
+    pos1 = wrap ? 0 : pos0 + 1;
+    b10 = (wrap ? blk0 + 1 : blk0) * a.pm_S;
+}
+// rows of the tile in a map of [B][H][W][C] whose pixel (oy, ox) of output position `pos` is (oy * st + o_y, ox * st + o_x)
+template <int BM>
+__device__ __forceinline__ TileRows pipe_tile_rows(const ConvArgs& a, int m0, bool dense, int H, int W, int C, int st, int o_y, int o_x) {
+    TileRows t;
+    t.lin = 1; t.rs1 = BM; t.nv1 = 0; t.off1 = 0;
+    if (a.pixmajor) {
+        int rs1, b00, b10, pos0, pos1;
+        pipe_pm_tile(a, m0, rs1, b00, b10, pos0, pos1);
+        const int oy0 = fastdiv(pos0, a.ow_mul, a.ow_sh), ox0 = pos0 - oy0 * a.OW;
+        const int oy1 = fastdiv(pos1, a.ow_mul, a.ow_sh), ox1 = pos1 - oy1 * a.OW;
+        const int rows = pipe_clamp(a.M - m0, 0, BM);
+        t.rs1 = rs1 < BM ? rs1 : BM;
+        t.nv0 = pipe_clamp(a.B - b00, 0, t.rs1 < rows ? t.rs1 : rows);
+        t.nv1 = pipe_clamp(a.B - b10, 0, rows - t.rs1 > 0 ? rows - t.rs1 : 0);
+        t.off0 = (((long)b00 * H + oy0 * st + o_y) * W + ox0 * st + o_x) * C;
+        t.off1 = (((long)b10 * H + oy1 * st + o_y) * W + ox1 * st + o_x) * C;
+        t.stride = (long)H * W * C;
+    } else if (dense) {
+        t.nv0 = pipe_clamp(a.M - m0, 0, BM);
+        t.off0 = (long)m0 * C;
+        t.stride = C;
+    } else {
+        t.lin = 0; t.nv0 = 0; t.stride = 0; t.off0 = 0;
+    }
+    return t;
+}
+__device__ __forceinline__ long pipe_row_off(const TileRows& t, int r, bool& ok) {
+    const bool k = r >= t.rs1;
+    const int idx = k ? r - t.rs1 : r;
+    ok = idx < (k ? t.nv1 : t.nv0);
+    return (k ? t.off1 : t.off0) + (long)idx * t.stride;
+}
+
 // bias (+ residual) + ReLU -> bf16 -> LDS -> whole rows out; the ReLU-backward mask (data-gradient launches) is applied in the
 // copy-out pass on the packed bf16 values against 16-byte mask loads with the address pattern of the stores -- the accumulators
 // are dead by then.  RES: the residual tile (bottleneck shortcut, resnet.py:294-296; shortcut gradient of a fused block) comes in
@@ -84,29 +145,38 @@ __device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const b
 // the result in place.
 // NW = 32-cout blocks per wave: 2 -> 256 couts per tile (512-byte rows, 32 chunks), 1 -> 128 couts (256-byte rows, 16 chunks).
 template <int MJ, int NW>
-__device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int ohw, int wave, int lane,
-                                              char* lds) {
+__device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const TileRows& tr, const bf16_t* t, long out_g, int m0, int n0, int ohw,
+                                              int wave, int lane, char* lds) {
     constexpr int RW = 8 * MJ;                    // tile rows copied by one wave (8 waves cover 64 MJ rows)
     constexpr int CPR = 16 * NW, RPI = 64 / CPR;  // 16-byte chunks per row; rows per wave-level copy
+    const bf16_t* tb = t + out_g + n0;
 #pragma unroll 1
     for (int it = 0; it < RW / RPI; ++it) {
         const int r = wave * RW + it * RPI + lane / CPR;
         const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));   // the LDS image of a glds is lane-linear: swizzle the SOURCE chunk
-        const int m = m0 + r;
         const bf16_t* p = a.zero_page;
-        if (m < a.M) {
-            const bf16_t* rp = pipe_row_ptr(a, t, out_g, m, n0, ohw);
-            if (rp) p = rp + c * 8;
+        if (tr.lin) {
+            bool ok;
+            const long off = pipe_row_off(tr, r, ok);
+            if (ok) p = tb + off + c * 8;
+        } else {
+            const int m = m0 + r;
+            if (m < a.M) {
+                const bf16_t* rp = pipe_row_ptr(a, t, out_g, m, n0, ohw);
+                if (rp) p = rp + c * 8;
+            }
         }
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + (wave * RW + it * RPI) * (CPR * 16)), 16, 0, 0);
     }
 }
 
 template <bool RES, int MJ, int NW, typename StampFn>
-__device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (&acc)[2][4], char* lds, int g, int m0, int n0, int wave,
-                                                     int lane, int ohw, StampFn&& kstamp) {
+__device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const TileRows& tr, f32x16 (&acc)[2][4], char* lds, int g, int m0,
+                                                     int n0, int wave, int lane, int ohw, StampFn&& kstamp) {
     constexpr int RW = 8 * MJ;
     constexpr int CPR = 16 * NW, ROWB = CPR * 16, RPI = 64 / CPR;      // chunks per row, bytes per row, rows per wave-level access
+    // (ConvArgs block 2 in one go: see the set-up)
+    asm volatile("" :: "s"(a.bias), "s"(a.residual), "s"(a.mask), "s"(a.out_gs), "s"(a.bias_gs), "s"(a.relu), "s"(a.out), "s"(a.zero_page));
     const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
     const long out_g = (long)g * a.out_gs;
     // (no bias: read zeros -- a branch around the adds makes hipcc keep two copies of the 128 accumulator registers)
@@ -124,7 +194,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     __syncthreads();                                   // every wave is done with the K loop's fragments
     kstamp(44);
     if constexpr (RES) {
-        pipe_stage_in<MJ, NW>(a, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
+        pipe_stage_in<MJ, NW>(a, tr, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -155,34 +225,71 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, f32x16 (
     // LDS -> HBM, whole rows.  All 16 row reads first (the accumulators are dead: 64 free registers), then the stores: one
     // lgkmcnt wait for the whole tile instead of a read -> wait -> store chain per row pair.
     const bf16_t* mask = a.mask;
-    const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m: no decode
-    uint4 rowv[RW / RPI];
+    const bf16_t* ob = reinterpret_cast<const bf16_t*>(a.out) + out_g + n0;
+    // keep a bf16 lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
+    auto sel = [](unsigned vv, unsigned mm) {
+        const unsigned lo16 = ((mm & 0x8000u) == 0u && (mm & 0x7fffu) != 0u) ? 0xffffu : 0u;
+        const unsigned hi16 = ((mm & 0x80000000u) == 0u && (mm & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+        return vv & (lo16 | hi16);
+    };
+    if (tr.lin) {
+        // Linear rows: no decode and no kernarg reload per row; a row's address is one of two scalar bases + a 32-bit element
+        // offset.  With a mask (data-gradient launches) the mask rows of HALF a tile are requested together before the first is
+        // used: the per-row form chained 16 dependent L2 round trips per thread.
+        constexpr int NR = RW / RPI, HALF = NR >= 8 ? NR / 2 : NR;
+        const bf16_t* ob0 = ob + tr.off0;
+        const bf16_t* ob1 = ob + tr.off1;
+        const long md = mask ? mask - reinterpret_cast<const bf16_t*>(a.out) : 0;
+        const int stride = (int)tr.stride;              // (< 2^31 / BM: map pixels <= 1024 x channels <= 2048, or channels alone)
 #pragma unroll
-    for (int it = 0; it < RW / RPI; ++it) {
-        const int r = wave * RW + it * RPI + lane / CPR;
-        rowv[it] = *reinterpret_cast<const uint4*>(lds + r * ROWB + (lane & (CPR - 1)) * 16);
-    }
+        for (int h = 0; h < NR; h += HALF) {
+            uint4 rowv[HALF];
+            int eo[HALF];
+            unsigned kbits = 0u;
 #pragma unroll
-    for (int it = 0; it < RW / RPI; ++it) {
-        const int r = wave * RW + it * RPI + lane / CPR;
-        const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));
-        const int m = m0 + r;
-        const bf16_t* rp = m >= a.M ? nullptr : (dense ? reinterpret_cast<const bf16_t*>(a.out) + out_g + (long)m * a.Cout + n0
-                                                       : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw));
-        if (rp) {
-            uint4 v = rowv[it];
-            const bf16_t* p = rp + c * 8;
-            if (mask) {
-                const uint4 mk = *reinterpret_cast<const uint4*>(mask + (p - reinterpret_cast<const bf16_t*>(a.out)));
-                // keep a bf16 lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
-                auto sel = [](unsigned vv, unsigned mm) {
-                    const unsigned lo16 = ((mm & 0x8000u) == 0u && (mm & 0x7fffu) != 0u) ? 0xffffu : 0u;
-                    const unsigned hi16 = ((mm & 0x80000000u) == 0u && (mm & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
-                    return vv & (lo16 | hi16);
-                };
-                v.x = sel(v.x, mk.x); v.y = sel(v.y, mk.y); v.z = sel(v.z, mk.z); v.w = sel(v.w, mk.w);
+            for (int j = 0; j < HALF; ++j) {
+                const int r = wave * RW + (h + j) * RPI + lane / CPR;
+                rowv[j] = *reinterpret_cast<const uint4*>(lds + r * ROWB + (lane & (CPR - 1)) * 16);
+                const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));
+                const bool k = r >= tr.rs1;
+                const int idx = k ? r - tr.rs1 : r;
+                eo[j] = idx < (k ? tr.nv1 : tr.nv0) ? idx * stride + c * 8 : -1;
+                kbits |= k ? (1u << j) : 0u;
             }
-            *reinterpret_cast<uint4*>(const_cast<bf16_t*>(p)) = v;
+            if (mask) {
+                uint4 mk[HALF];
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) {
+                    mk[j] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+                    if (eo[j] >= 0) mk[j] = *reinterpret_cast<const uint4*>(((kbits >> j) & 1u ? ob1 : ob0) + eo[j] + md);
+                }
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) {
+                    rowv[j].x = sel(rowv[j].x, mk[j].x); rowv[j].y = sel(rowv[j].y, mk[j].y);
+                    rowv[j].z = sel(rowv[j].z, mk[j].z); rowv[j].w = sel(rowv[j].w, mk[j].w);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                if (eo[j] >= 0) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(((kbits >> j) & 1u ? ob1 : ob0) + eo[j])) = rowv[j];
+        }
+    } else {
+        // strided / offset outputs (parity-class launches of strided data gradients, the mask head's 2x2 deconvolution): per-row decode
+#pragma unroll 1
+        for (int it = 0; it < RW / RPI; ++it) {
+            const int r = wave * RW + it * RPI + lane / CPR;
+            const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));
+            const int m = m0 + r;
+            const bf16_t* rp = m >= a.M ? nullptr : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw);
+            if (rp) {
+                uint4 v = *reinterpret_cast<const uint4*>(lds + r * ROWB + (lane & (CPR - 1)) * 16);
+                const bf16_t* p = rp + c * 8;
+                if (mask) {
+                    const uint4 mk = *reinterpret_cast<const uint4*>(mask + (p - reinterpret_cast<const bf16_t*>(a.out)));
+                    v.x = sel(v.x, mk.x); v.y = sel(v.y, mk.y); v.z = sel(v.z, mk.z); v.w = sel(v.w, mk.w);
+                }
+                *reinterpret_cast<uint4*>(const_cast<bf16_t*>(p)) = v;
+            }
         }
     }
     kstamp(48);
@@ -238,6 +345,13 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         }
     };
     if constexpr (TRACE && MODE == 1) kst0 = __builtin_amdgcn_s_memtime();
+    // every scalar of the set-up requested NOW, in a handful of wide loads behind one wait (ConvArgs block 1)
+    // (ONE statement per ~20 operands: separate asm statements are ordered among themselves and each would wait for its own load)
+    asm volatile("" :: "s"(a.src), "s"(a.wgt), "s"(a.zero_page), "s"(a.out), "s"(a.src_gs), "s"(a.wgt_gs), "s"(a.gxy_mul), "s"(a.gxy_sh),
+                 "s"(a.gx_mul), "s"(a.gx_sh), "s"(a.gy_mul), "s"(a.gy_sh), "s"(a.nfast), "s"(a.pixmajor), "s"(a.pointwise), "s"(a.T),
+                 "s"(a.B), "s"(a.IH), "s"(a.IW), "s"(a.Cin), "s"(a.Cout), "s"(a.OH), "s"(a.OW), "s"(a.M), "s"(a.ss), "s"(a.pm_S),
+                 "s"(a.pm_P), "s"(a.pms_mul), "s"(a.pms_sh));
+    asm volatile("" :: "s"(a.pmp_mul), "s"(a.pmp_sh), "s"(a.ohw_mul), "s"(a.ohw_sh), "s"(a.ow_mul), "s"(a.ow_sh), "s"(a.tap_major), "s"(a.krot));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,6 +388,40 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const bf16_t* a_ptr[4];
     unsigned a_mask[4];
     int a_iy[4], a_ix[4];
+    unsigned tmask = 0xffffffffu;       // taps any row of the tile needs (pixel-major tiles skip the others)
+    if (a.pixmajor) {
+        // pixel-major rows (RoI maps): the tile's rows are linear in the row index within each of its (at most two) segments,
+        // and the tap masks are functions of the segment's pixel position only -- everything but one select + multiply-add per
+        // staged row runs on the scalar unit (TileRows above; pix_ok guarantees ss == os == 1)
+        int rs1, b00, b10, pos0, pos1;
+        pipe_pm_tile(a, m0, rs1, b00, b10, pos0, pos1);
+        const int oy0 = fastdiv(pos0, a.ow_mul, a.ow_sh), ox0 = pos0 - oy0 * a.OW;
+        const int oy1 = fastdiv(pos1, a.ow_mul, a.ow_sh), ox1 = pos1 - oy1 * a.OW;
+        unsigned mk0 = 0u, mk1 = 0u;
+        for (int t = 0; t < a.T; ++t) {
+            const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+            const int iy0_ = oy0 * a.ss + dy, ix0_ = ox0 * a.ss + dx, iy1_ = oy1 * a.ss + dy, ix1_ = ox1 * a.ss + dx;
+            mk0 |= ((iy0_ >= 0) & (iy0_ < a.IH) & (ix0_ >= 0) & (ix0_ < a.IW)) ? (1u << t) : 0u;
+            mk1 |= ((iy1_ >= 0) & (iy1_ < a.IH) & (ix1_ >= 0) & (ix1_ < a.IW)) ? (1u << t) : 0u;
+        }
+        const int rows = pipe_clamp(a.M - m0, 0, BM);
+        const int nv0 = pipe_clamp(a.B - b00, 0, rs1 < rows ? rs1 : rows);
+        const int nv1 = pipe_clamp(a.B - b10, 0, rows - rs1 > 0 ? rows - rs1 : 0);
+        const long in0 = ((long)(b00 * a.IH + oy0 * a.ss) * a.IW + ox0 * a.ss) * a.Cin;
+        const long in1 = ((long)(b10 * a.IH + oy1 * a.ss) * a.IW + ox1 * a.ss) * a.Cin;
+        const long istr = (long)a.IH * a.IW * a.Cin;
+        tmask = (nv0 > 0 ? mk0 : 0u) | (nv1 > 0 ? mk1 : 0u);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * 64 + srow;
+            const bool k = row >= rs1;
+            const int idx = k ? row - rs1 : row;
+            const bool ok = idx < (k ? nv1 : nv0);
+            a_ptr[i] = ok ? src + ((k ? in1 : in0) + (long)idx * istr + swz(row, lchunk) * 8) : src;
+            a_mask[i] = ok ? (k ? mk1 : mk0) : 0u;
+            a_iy[i] = 0; a_ix[i] = 0;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = i * 64 + srow;
@@ -281,7 +429,6 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         a_ptr[i] = src;
         a_mask[i] = 0u;
         a_iy[i] = -(1 << 20); a_ix[i] = -(1 << 20);
-        int b = a.B, rem = 0;
         if (a.pointwise) {                       // input pixel index = m: no decode, the one tap is always inside the map
             if (m < a.M) {
                 a_iy[i] = 0; a_ix[i] = 0;
@@ -290,37 +437,15 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
             continue;
         }
-        if (m < a.M) pipe_row_decode(a, m, ohw, b, rem);
-        if (b < a.B) {
+        if (m < a.M) {
+            const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
             const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
             a_iy[i] = oy * a.ss; a_ix[i] = ox * a.ss;
             a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + swz(row, lchunk) * 8);
         }
     }
     kstamp(41);
-    if (a.pixmajor) {
-        // pixel-major rows: m = position * B + RoI with B >= 256, so the 256 rows of a tile sit on at most TWO pixel positions
-        // and the tap masks are functions of the position only: two wave-uniform (scalar) passes over the taps instead of a
-        // per-lane loop of T x 4 rows (3-4k cycles per workgroup on the 7x7 / 14x14 RoI maps)
-        // (blocked order: "position" = segment m / pm_S, its pixel = segment % pm_P; a tile still spans at most two segments)
-        const int seg0 = fastdiv(m0, a.pms_mul, a.pms_sh);
-        const int rem0 = seg0 - fastdiv(seg0, a.pmp_mul, a.pmp_sh) * a.pm_P;
-        unsigned mk0 = 0u, mk1 = 0u;
-        const int oy0 = fastdiv(rem0, a.ow_mul, a.ow_sh), ox0 = rem0 - oy0 * a.OW;
-        const int rem1 = rem0 + 1 == a.pm_P ? 0 : rem0 + 1;
-        const int oy1 = fastdiv(rem1, a.ow_mul, a.ow_sh), ox1 = rem1 - oy1 * a.OW;
-        for (int t = 0; t < a.T; ++t) {
-            const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
-            const int iy0_ = oy0 * a.ss + dy, ix0_ = ox0 * a.ss + dx, iy1_ = oy1 * a.ss + dy, ix1_ = ox1 * a.ss + dx;
-            mk0 |= ((iy0_ >= 0) & (iy0_ < a.IH) & (ix0_ >= 0) & (ix0_ < a.IW)) ? (1u << t) : 0u;
-            mk1 |= ((iy1_ >= 0) & (iy1_ < a.IH) & (ix1_ >= 0) & (ix1_ < a.IW)) ? (1u << t) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int m = m0 + i * 64 + srow;
-            if (a_iy[i] >= 0) a_mask[i] = (fastdiv(m, a.pms_mul, a.pms_sh) == seg0) ? mk0 : mk1;      // (padding rows keep mask 0)
-        }
-    } else if (!a.pointwise) {
+    if (!a.pointwise) {
         for (int t = 0; t < a.T; ++t) {
             const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
 #pragma unroll
@@ -330,24 +455,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         }
     }
-    kstamp(42);
-    // pixel-major tiles (RoI maps): taps that leave the map for every row of the tile are skipped (see conv_mfma.hip)
-    unsigned tmask = 0xffffffffu;
-    int nk = a.T * kchunks;
-    if (a.pixmajor) {
-        unsigned* wor = reinterpret_cast<unsigned*>(lds + LDSZ - 64);   // inside X buf1's last row: first overwritten in slot 4
-        unsigned mm = a_mask[0];
-        if constexpr (NI >= 2) mm |= a_mask[1];
-        if constexpr (NI == 4) mm |= a_mask[2] | a_mask[3];
-        for (int o = 32; o > 0; o >>= 1) mm |= (unsigned)__shfl_xor((int)mm, o, 64);
-        if (lane == 0) wor[wave] = mm;
-        __syncthreads();
-        tmask = 0u;
-#pragma unroll
-        for (int w2 = 0; w2 < 8; ++w2) tmask |= wor[w2];
-        tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)tmask);
-        nk = __popc(tmask) * kchunks;
     }
+    kstamp(42);
+    int nk = a.T * kchunks;
+    if (a.pixmajor) nk = __popc(tmask) * kchunks;
     // ---- wave-uniform state of the K-tile being STAGED: tap, channel offset, the tap's source / weight offsets
     int st_t = 0, st_c = a.krot ? (V % kchunks) * BK : 0;        // (krot: this workgroup's first channel chunk)
     while (st_t < a.T - 1 && !((tmask >> st_t) & 1u)) ++st_t;
@@ -663,8 +774,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         if constexpr (VAR & 2)
             conv_epilogue<2, 4, 128, 64>(a, acc, g, m0, n0, wave >> 2, wave & 3, lane & 31, lane >> 5, ohw, nullptr, nullptr, nullptr,
                                          a.pixmajor != 0);
-        else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-        else pipe_epilogue_staged<false, MJ, NW>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else {
+            const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m
+            const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
+            if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        }
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long kst3 = __builtin_amdgcn_s_memtime();
@@ -842,8 +957,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
     if (wm == 0) PIPE_BARRIER();          // barrier counts of the two groups match again
 
-    if (a.residual) pipe_epilogue_staged<true, 4, 2>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-    else pipe_epilogue_staged<false, 4, 2>(a, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    {
+        const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;
+        const TileRows otr = pipe_tile_rows<256>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
+        if (a.residual) pipe_epilogue_staged<true, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        else pipe_epilogue_staged<false, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+    }
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.

@@ -12,31 +12,23 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 #define BK 64
 
 struct ConvArgs {
+    // ---- block 1 (44 dwords): every scalar the pipelined kernels' set-up reads, CONTIGUOUS and in first-use order so that they
+    // arrive in a few wide s_loads issued together at kernel entry (round 4: scattered over the struct they came in ~25 dependent
+    // scalar-memory round trips, most of the 8.7k-cycle set-up of a 147k-cycle tile)
     const bf16_t* src;
     const bf16_t* wgt;
-    const float* bias;
-    const bf16_t* residual;
-    const bf16_t* mask;      // optional: zero the result where mask <= 0 (ReLU backward of the tensor this gradient is for)
-    void* out;
     const bf16_t* zero_page;
-    int B, IH, IW, Cin, Cout;
-    int OH, OW, OHf, OWf;
-    int os, oo_y, oo_x, ss;
-    int T;
-    int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
-    int relu, out_f32, accumulate;
-    long src_gs, wgt_gs, out_gs, bias_gs;
-    int M;
-    int pixmajor;            // FAST kernels on small RoI maps: tile rows enumerate (pixel, RoI) instead of (RoI, pixel) -- see below
-    int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
-    int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
-    void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
-    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh, b_mul, b_sh;   // exact division by OH*OW, OW, B via multiply-high (host-computed)
-    int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
-    int krot;        // conv_pipe.hip, chunk-major order: workgroup V starts at channel chunk (V % krot_n) and wraps -- at any instant the
-                     // workgroups of the chip read DIFFERENT weight tiles instead of all 256 CUs fetching the same 32 KiB
+    void* out;
+    long src_gs, wgt_gs;
     unsigned gxy_mul, gxy_sh, gx_mul, gx_sh, gy_mul, gy_sh;   // conv_pipe.hip: exact division by grid.x * grid.y, grid.x, grid.y
+    int nfast;               // tile order: channel tiles of one pixel tile adjacent (the pixel tile is read from HBM once)
+    int pixmajor;            // FAST kernels on small RoI maps: tile rows enumerate (pixel, RoI) instead of (RoI, pixel) -- see below
     int pointwise;   // conv_pipe.hip: one tap at offset 0, unit strides, input map = output map: row m reads input pixel m
+    int T;
+    int B, IH, IW, Cin, Cout;
+    int OH, OW;
+    int M;
+    int ss;
     // conv_pipe.hip, pixel-major rows in RoI BLOCKS: row m -> segment m / pm_S (pm_S rows = the RoIs of one block at one pixel
     // position), block = segment / pm_P, position = segment % pm_P, RoI = block * pm_S + m % pm_S (rows with RoI >= B are
     // padding: pm_S = ceil(B / number of blocks) >= 256).  The 49 / 196 positions of a block's RoIs are then CONSECUTIVE tiles --
@@ -45,6 +37,23 @@ struct ConvArgs {
     // concurrently running tile shared (fetch 4.1x the input, tools/pmc_traffic_shapes.sh).  M counts the padded rows.
     int pm_S, pm_P;
     unsigned pms_mul, pms_sh, pmp_mul, pmp_sh;
+    unsigned ohw_mul, ohw_sh, ow_mul, ow_sh;   // exact division by OH*OW, OW via multiply-high (host-computed)
+    int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
+    int krot;        // conv_pipe.hip, chunk-major order: workgroup V starts at channel chunk (V % krot_n) and wraps -- at any instant the
+                     // workgroups of the chip read DIFFERENT weight tiles instead of all 256 CUs fetching the same 32 KiB
+    // ---- block 2: the epilogue's scalars
+    const float* bias;
+    const bf16_t* residual;
+    const bf16_t* mask;      // optional: zero the result where mask <= 0 (ReLU backward of the tensor this gradient is for)
+    long out_gs, bias_gs;
+    int OHf, OWf;
+    int os, oo_y, oo_x;
+    int relu, out_f32, accumulate;
+    int staged_out;          // 128x128 kernel, dense bf16 output: collect the tile in LDS and store it row-contiguously
+    unsigned b_mul, b_sh;    // exact division by B
+    void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
+    // ---- block 3: per-tap tables (read by lanes, once)
+    int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
 };
 
 // n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)

@@ -116,3 +116,103 @@ def test_bucket_layout_covers_the_arena_and_tapers_at_the_end():
     # a model too small for a taper keeps the plain greedy layout
     small = BucketedAllReduce(FlatArena(nn.Sequential(nn.Linear(64, 64), nn.Linear(64, 64))), bucket_bytes=cap)
     assert len(small.buckets) == 1 and small.buckets[0]['end'] == 2 * (64 * 64 + 64)
+
+
+# ---- world 8 (the node size the driver scales to): bucket ORDER under rank-dependent graphs ------------------------------------
+class _Branchy(torch.nn.Module):
+    """A trunk and four heads; which heads take part in a rank's loss depends on the rank -- what a rank without positive RoIs
+    does to the mask / FOA branches (roi head: no positives -> no mask / offset loss; mmdet/models/roi_heads/loft_roi_head.py)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = nn.Sequential(nn.Linear(16, 96), nn.ReLU(), nn.Linear(96, 96), nn.ReLU())
+        self.heads = nn.ModuleList([nn.Sequential(nn.Linear(96, 64), nn.ReLU(), nn.Linear(64, 8)) for _ in range(4)])
+
+    def forward(self, x, use):
+        f = self.trunk(x)
+        return sum(self.heads[i](f).pow(2).sum() * (i + 1) for i in use)
+
+
+def _heads_of(rank, step):
+    # rank 0: every head; rank 3: none at all (its backward never reaches any head); others: rank- and step-dependent subsets,
+    # enumerated in rank-dependent ORDER so that the heads' gradients are produced in different sequences on different ranks
+    if rank == 0:
+        return [0, 1, 2, 3]
+    if rank == 3:
+        return []
+    sel = [i for i in range(4) if ((rank * 5 + step * 3 + i) % 3) != 0]
+    return sel[::-1] if rank % 2 else sel
+
+
+def _worker8(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from bonai_amd.engine import BucketedAllReduce, FlatArena
+        torch.manual_seed(0)
+        model = _Branchy()
+        arena = FlatArena(model)
+        red = BucketedAllReduce(arena, bucket_bytes=8192)
+        assert red.enabled and len(red.buckets) >= 6
+        launched = []
+        orig = red._launch
+        red._launch = lambda bi: (launched.append(bi), orig(bi))[1]
+        for step in range(3):
+            use = _heads_of(rank, step)
+            x = torch.randn(4, 16, generator=torch.Generator().manual_seed(1000 * step + rank))
+            arena.grad.zero_()
+            arena.rebind_grads()
+            launched.clear()
+            red.begin()
+            loss = model(x, use) if use else model.trunk(x).sum() * 0.0 + model.trunk[0].weight.sum() * 0.0
+            loss.backward()
+            red.finish()
+            # every rank issued every bucket exactly once, in index order (the collectives pair up by construction)
+            assert launched == list(range(len(red.buckets))), launched
+            ref = torch.zeros_like(arena.grad)
+            for r in range(world):
+                m2 = _Branchy()
+                m2.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+                u2 = _heads_of(r, step)
+                if not u2:
+                    continue
+                xr = torch.randn(4, 16, generator=torch.Generator().manual_seed(1000 * step + r))
+                m2(xr, u2).backward()
+                for p, p2 in zip(arena.order, reversed(list(m2.parameters()))):
+                    if p2.grad is not None:
+                        o = arena.offsets[id(p)]
+                        ref[o:o + p.numel()] += p2.grad.reshape(-1)
+            assert torch.allclose(arena.grad, ref, rtol=1e-4, atol=1e-4), float((arena.grad - ref).abs().max())
+            # bit-identical on every rank (all-reduce result), so the SGD that follows keeps the replicas identical
+            mine = arena.grad.clone()
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            assert all(torch.equal(gathered[0], t) for t in gathered)
+            with torch.no_grad():
+                arena.data -= 1e-3 * arena.grad / world
+        q.put((rank, 'ok'))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_allreduce_gloo_world8_rank_dependent_graphs():
+    """eight ranks whose autograd graphs differ (heads missing on some ranks, one rank with no head at
+    all, heads finishing in different orders): every rank launches every bucket once, in index order, so the collectives pair up;
+    sums equal the sum of the ranks' local gradients; replicas stay bit-identical over three steps."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}: {msg}'

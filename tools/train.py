@@ -19,6 +19,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+def parse_option(opt):
+    """'key=value' -> (key, value): Python literals (numbers, tuples, lists, True/False/None, quoted strings) through
+    ast.literal_eval -- never eval() --, anything else stays the string it is (mmcv DictAction's behaviour for plain words)."""
+    import ast
+    if '=' not in opt:
+        raise ValueError(f'--options takes key=value pairs, got {opt!r}')
+    k, v = opt.split('=', 1)
+    try:
+        return k, ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return k, v
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('config')
@@ -41,8 +54,7 @@ def main():
     from bonai_amd.synth import make_batch
     cfg = Config.fromfile(args.config)
     if args.options:
-        cfg.merge_from_dict({k: eval(v) if v.replace('.', '', 1).lstrip('-').isdigit() else v
-                             for k, v in (o.split('=', 1) for o in args.options)})
+        cfg.merge_from_dict(dict(parse_option(o) for o in args.options))
     rank, world = 0, 1
     if args.launcher == 'pytorch':
         rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -78,9 +90,11 @@ def main():
         if files and all(os.path.exists(f) for f in files):
             from bonai_amd.dataset import BonaiDataset
             flip = next((p for p in tcfg.get('pipeline', []) if p.get('type') == 'RandomFlip'), {})
+            extra = {k: tcfg[k] for k in ('offset_coordinate', 'resolution', 'ignore_buildings', 'filter_empty_gt', 'classes')
+                     if k in tcfg}                     # (bonai.py:18-35: the dataset's own keyword arguments)
             dataset = BonaiDataset(tcfg['ann_file'], tcfg.get('img_prefix', ''), bbox_type=tcfg.get('bbox_type', 'roof'),
                                    mask_type=tcfg.get('mask_type', 'roof'), flip_ratio=flip.get('flip_ratio', 0.0) or 0.0,
-                                   flip_direction=flip.get('direction', 'horizontal'), seed=args.seed + rank)
+                                   flip_direction=flip.get('direction', 'horizontal'), seed=args.seed + rank, **extra)
             ipe = args.iters_per_epoch or max(1, len(dataset.epoch_indices(0, bs, rank, world)) // bs)
         elif rank == 0:
             print(f'dataset files of cfg.data.train not found ({files[:1]}...): synthetic tiles', flush=True)

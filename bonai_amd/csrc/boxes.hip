@@ -620,6 +620,45 @@ LOFT_EXPORT int loft_mask_paste(const float* logits, const float* boxes, int N, 
     return 0;
 }
 
+// ---- footprint = roof mask translated by the predicted offset (inference / evaluation) -----------------------------------------
+// BONAI's offset is the footprint -> roof vector (tools/bonai/bonai_evaluation.py:41 offset_model='footprint2roof'; the annotation's
+// 'offset' field, mmdet/datasets/bonai.py:184-196): footprint(y, x) = roof(y + oy, x + ox) with the offset rounded to whole pixels
+// (round half away from zero, like numpy's / C's lround on the values the evaluation reads back), zero outside the image.  bstool
+// translates the roof POLYGON by -offset and rasterises; on the bitmaps simple_test returns the translation is this shift.
+// in / out uint8 [N, H, W]; offsets fp32 [N, 2] = (dx, dy).  16 output bytes per thread, byte-exact against the numpy shift oracle.
+__global__ void mask_translate_kernel(const uint8_t* __restrict__ in, const float* __restrict__ offsets, int N, int H, int W,
+                                      uint8_t* __restrict__ out) {
+    const int n = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (x0 >= W) return;
+    const float fx = offsets[2 * n], fy = offsets[2 * n + 1];
+    const int ox = (int)lroundf(fx), oy = (int)lroundf(fy);
+    const int sy = y + oy;
+    const uint8_t* src = in + ((long)n * H + sy) * W;
+    uint8_t* dst = out + ((long)n * H + y) * W + x0;
+    const bool row_ok = sy >= 0 && sy < H;
+    if (row_ok && x0 + ox >= 0 && x0 + 15 + ox < W && x0 + 15 < W && ((W | (x0 + ox)) & 3) == 0 && (((size_t)dst) & 15) == 0) {
+        // whole 16-byte run inside the row, source dword-aligned: four dword loads, one 16-byte store
+        const unsigned* sp = reinterpret_cast<const unsigned*>(src + x0 + ox);
+        uint4 v;
+        v.x = sp[0]; v.y = sp[1]; v.z = sp[2]; v.w = sp[3];
+        *reinterpret_cast<uint4*>(dst) = v;
+        return;
+    }
+    for (int i = 0; i < 16 && x0 + i < W; ++i) {
+        const int sx = x0 + i + ox;
+        dst[i] = (row_ok && sx >= 0 && sx < W) ? src[sx] : (uint8_t)0;
+    }
+}
+LOFT_EXPORT int loft_mask_translate(const uint8_t* masks, const float* offsets, int N, int H, int W, uint8_t* out, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    if (masks == out) return (int)hipErrorInvalidValue;
+    dim3 grid(loft_cdiv(loft_cdiv(W, 16), 64), H, N);
+    hipLaunchKernelGGL(mask_translate_kernel, grid, dim3(64), 0, (hipStream_t)stream, masks, offsets, N, H, W, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- RandomSampler on the device
 // mmdet/core/bbox/samplers/random_sampler.py:31-75 + base_sampler.py:34-101 for a whole batch in one launch: per image, up to
 // max_pos of the positives (gt_inds > 0) and then num - #sampled_pos of the negatives (gt_inds == 0), each a uniformly random

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                  "s"(a.gx_mul), "s"(a.gx_sh), "s"(a.gy_mul), "s"(a.gy_sh), "s"(a.nfast), "s"(a.pixmajor), "s"(a.pointwise), "s"(a.T),
                  "s"(a.B), "s"(a.IH), "s"(a.IW), "s"(a.Cin), "s"(a.Cout), "s"(a.OH), "s"(a.OW), "s"(a.M), "s"(a.ss), "s"(a.pm_S),
                  "s"(a.pm_P), "s"(a.pms_mul), "s"(a.pms_sh));
-    asm volatile("" :: "s"(a.pmp_mul), "s"(a.pmp_sh), "s"(a.ohw_mul), "s"(a.ohw_sh), "s"(a.ow_mul), "s"(a.ow_sh), "s"(a.tap_major), "s"(a.krot));
+    asm volatile("" :: "s"(a.pmp_mul), "s"(a.pmp_sh), "s"(a.ohw_mul), "s"(a.ohw_sh), "s"(a.ow_mul), "s"(a.ow_sh), "s"(a.tap_major), "s"(a.krot),
+                 "s"(a.dy_pk), "s"(a.dx_pk), "s"(a.wt_pk), "s"(a.pk_ok));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -379,7 +380,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // and inside the K loop it would make hipcc wait lgkmcnt(0), i.e. for every fragment read in flight.
     int tab_dy = 0, tab_dx = 0, tab_a = 0, tab_w = 0;
     if (a.pointwise) tab_w = a.wt[0] * a.Cout * a.Cin;          // (1x1 / FC: no per-lane table loads; offsets are zero)
-    else if (lane < a.T) {
+    else if (a.pk_ok) {
+        const int sh = (lane & 15) * 4;
+        tab_dy = (int)((a.dy_pk >> sh) & 15ull) - 8; tab_dx = (int)((a.dx_pk >> sh) & 15ull) - 8;
+        tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
+        tab_w = (int)((a.wt_pk >> sh) & 15ull) * a.Cout * a.Cin;
+    } else if (lane < a.T) {
         tab_dy = a.dy[lane]; tab_dx = a.dx[lane];
         tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
         tab_w = a.wt[lane] * a.Cout * a.Cin;
@@ -549,20 +555,23 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     using c0_t = std::integral_constant<int, 0>;
     using c1_t = std::integral_constant<int, 1>;
 
+    // Accumulator zeroing (128 v_mov per wave: ~1k cycles of a SIMD's VALU for its two waves) and the fragment base addresses are
+    // issued AFTER the first K-tile's copies have been requested (late_init below): they run under that fetch's latency instead
+    // of in front of it.
     f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 31, fq = lane >> 5;
     // fragment bases per 16-channel sub-step ks (the swizzle depends on ks); buffer / 32-row block offsets are ds_read immediates
     const char* wb[4];
     const char* xb[4];
-    {
+    auto late_init = [&]() {
+        PIPE_SB();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int rw = wn * (32 * NW) + frow, rx = wm * (32 * MJ) + frow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -570,7 +579,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
             xb[ks] = lds + PXO + rx * 128 + swz(rx, q) * 16;
         }
-    }
+        PIPE_SB();
+    };
 
     if constexpr (MODE == 1) {
         // Static priority for the younger half (round 3): waves 4-7 are dispatched second and lose every VALU / LDS arbitration
@@ -669,8 +679,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                 issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
                 issue_x(c0_t{}, c1_t{}); issue_x(c1_t{}, c1_t{});
                 advance_w(); advance_x();
+                late_init();
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXW) : "memory");
             } else {
+                late_init();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             PIPE_BARRIER();
@@ -708,9 +720,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             advance_w(); advance_x();
             issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
             advance_w();
+            late_init();
             if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but W(1)'s copies has landed
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
+            late_init();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         PIPE_BARRIER();
@@ -798,8 +812,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     if (nk > 1) {
         advance();
         issue_w(c0_t{}, c1_t{});
+        late_init();
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
+        late_init();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PIPE_BARRIER();
@@ -976,6 +992,14 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
     fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);
     a.pointwise = a.T == 1 && a.dy[0] == 0 && a.dx[0] == 0 && a.ss == 1 && !a.pixmajor && a.IH == a.OH && a.IW == a.OW;
+    a.dy_pk = a.dx_pk = a.wt_pk = 0ull;
+    a.pk_ok = 1;
+    for (int t = 0; t < a.T; ++t) {
+        if (a.dy[t] < -8 || a.dy[t] > 7 || a.dx[t] < -8 || a.dx[t] > 7 || a.wt[t] < 0 || a.wt[t] > 15) { a.pk_ok = 0; break; }
+        a.dy_pk |= (unsigned long long)(a.dy[t] + 8) << (4 * t);
+        a.dx_pk |= (unsigned long long)(a.dx[t] + 8) << (4 * t);
+        a.wt_pk |= (unsigned long long)a.wt[t] << (4 * t);
+    }
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
     if (nw == 1 && mj == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 1>), grid, dim3(512), 0, s, a);

@@ -41,6 +41,11 @@ struct ConvArgs {
     int tap_major;   // conv_pipe.hip: K order (tap, chunk) instead of (chunk, tap); see the kernel
     int krot;        // conv_pipe.hip, chunk-major order: workgroup V starts at channel chunk (V % krot_n) and wraps -- at any instant the
                      // workgroups of the chip read DIFFERENT weight tiles instead of all 256 CUs fetching the same 32 KiB
+    // conv_pipe.hip: the tap tables as 4-bit fields of three 64-bit scalars (tap t: bits 4t..4t+3; dy + 8, dx + 8, wt), valid when
+    // pk_ok (every |dy|, |dx| <= 7 -- always, for the 3x3 / strided-parity tap sets of this model): lane t unpacks its entry with
+    // two VALU ops instead of loading it from the kernarg segment (a vector-memory round trip in the middle of the set-up)
+    unsigned long long dy_pk, dx_pk, wt_pk;
+    int pk_ok;
     // ---- block 2: the epilogue's scalars
     const float* bias;
     const bf16_t* residual;

@@ -154,14 +154,18 @@ def _masks_of(s, dev):
     return torch.from_numpy(np.ascontiguousarray(s['gt_masks'], dtype=np.uint8)).to(dev)
 
 
-def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True):
+def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True, staged=None):
     """Collate + DefaultFormatBundle + Normalize, on the device: list of samples (img uint8/float HxWx3 BGR, gt_* numpy) ->
     the batch dict of forward_train.  Images are stacked (same size: BONAI tiles are 1024x1024), normalised on the GPU;
+    ``staged``: the images as one uint8 [n,H,W,3] host tensor (BonaiDataset's pinned staging ring; sample['img'] are views of it).
     masks go up once as uint8 [K,H,W] tensors -- or, when a sample carries ``gt_polygons`` (per instance a list of flat polygons: the
     annotation's ``masks`` entry, bonai.py:186-199) instead of ``gt_masks``, only the vertices go up and the bitmaps are rasterised on the
     device (kernels.poly2mask = LoadAnnotations._poly2mask, loading.py:301-326): no K x 1024^2 host bitmaps, no upload."""
     dev = torch.device(device)
-    imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(s['img'])) for s in samples]).to(dev)
+    if staged is not None:       # uint8 [n, H, W, 3] holding the samples' images already (a pinned staging slot): one async upload
+        imgs = staged.to(dev, non_blocking=True)
+    else:
+        imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(s['img'])) for s in samples]).to(dev)
     x = imgs.float()
     if to_rgb:
         x = x.flip(-1)

@@ -21,6 +21,13 @@ What is mirrored, with the reference's semantics:
 Image decoding uses PIL (cv2 / mmcv are not in this image); ``mmcv.imread`` returns BGR, so the RGB decode is reversed to BGR and
 ``to_device_batch(to_rgb=True)`` converts it back exactly as Normalize does.
 
+Feeding the step (round 4): ``batches(..., prefetch=N)`` decodes on a pool of host threads (PIL releases the GIL while it
+inflates a tile), writes the decoded tiles straight into a ring of PINNED staging buffers and uploads + normalises + rasterises
+on a side HIP stream, N batches ahead of the training step -- the reference's ``workers_per_gpu`` DataLoader processes
+(mmdet/datasets/builder.py:58-136) as threads of the one process that owns the GPU.  Every random decision (flip draw,
+``_rand_another`` replacement) is taken by the single producer thread in sample order, so the stream of batches is identical to
+the synchronous loader's for the same seed.
+
 Data parallelism: ``epoch_indices`` is DistributedGroupSampler's contract (datasets/builder.py:107-110): every rank gets a disjoint,
 equally long slice of a per-epoch permutation seeded identically on all ranks.
 """
@@ -57,7 +64,7 @@ class BonaiDataset:
             self.flip_direction = str(self.rng.choice(list(flip_direction)))
         if self.flip_direction not in ('horizontal', 'vertical'):
             raise ValueError(f"Invalid flipping direction '{self.flip_direction}'")
-        self.data_infos, self.anns = [], []
+        self.data_infos, self.anns, self.cat_ids = [], [], None
         for f, prefix in zip(ann_files, prefixes):
             self._load(f, prefix)
         if not test_mode:
@@ -74,6 +81,10 @@ class BonaiDataset:
         cat_ids = [c['id'] for c in coco.get('categories', []) if c['name'] in self.classes]
         if not cat_ids:
             raise ValueError(f'{ann_file}: no category named {self.classes}')
+        if getattr(self, 'cat_ids', None) is not None and list(self.cat_ids) != cat_ids:
+            # (the reference builds one dataset PER annotation file and concatenates them, each with its own category map;
+            #  one shared map is only right when the files agree -- BONAI's do: a single 'building' category)
+            raise ValueError(f'{ann_file}: category ids {cat_ids} differ from the previous files\' {list(self.cat_ids)}')
         self.cat_ids = cat_ids
         self.cat2label = {c: i for i, c in enumerate(cat_ids)}
         by_img = {}
@@ -110,7 +121,9 @@ class BonaiDataset:
         rgb = np.asarray(Image.open(path).convert('RGB'))
         return np.ascontiguousarray(rgb[:, :, ::-1])                    # BGR, as mmcv.imread / cv2 deliver it
 
-    def prepare_train_img(self, idx):
+    def prepare_train_img(self, idx, flip_draw=None, img_out=None):
+        """One training sample.  flip_draw: the uniform draw that decides the flip (None: drawn here from self.rng);
+        img_out: optional uint8 [H, W, 3] array (a pinned staging slot) the final image is written into."""
         info = self.data_infos[idx]
         ann = self.get_ann_info(idx)
         if ann['bboxes'].shape[0] == 0:                                 # custom.py:188-191: no gt after parsing -> another sample
@@ -126,20 +139,28 @@ class BonaiDataset:
             sample['gt_polygons'] = ann['masks']
         else:
             sample['gt_masks'] = np.stack([self.host_rasteriser(m, h, w) for m in ann['masks']])
-        if self.flip_ratio and self.rng.rand() < self.flip_ratio:
+        if self.flip_ratio and (self.rng.rand() if flip_draw is None else flip_draw) < self.flip_ratio:
             sample = flip_sample(sample, self.flip_direction)
+        if img_out is not None:
+            np.copyto(img_out, sample['img'])
+            sample['img'] = img_out
         return sample
+
+    def resolve(self, idx):
+        """The random decisions of one training sample, in the reference's order: while the sample has no ground truth after
+        parsing, another one of its aspect-ratio group (custom.py:170-191); then the flip draw (transforms.py:379-391).
+        -> (index actually used, uniform draw for the flip)."""
+        while self.get_ann_info(idx)['bboxes'].shape[0] == 0:
+            pool = np.where(self.flag == self.flag[idx])[0]
+            idx = int(self.rng.choice(pool))
+        return idx, (float(self.rng.rand()) if self.flip_ratio else 1.0)
 
     def __getitem__(self, idx):
         if self.test_mode:
             info = self.data_infos[idx]
             return dict(img=self._read_image(info), filename=info['filename'])
-        while True:
-            s = self.prepare_train_img(idx)
-            if s is not None:
-                return s
-            pool = np.where(self.flag == self.flag[idx])[0]
-            idx = int(self.rng.choice(pool))
+        idx, draw = self.resolve(idx)
+        return self.prepare_train_img(idx, flip_draw=draw)
 
     # ------------------------------------------------------------------ batches
     def epoch_indices(self, epoch, samples_per_gpu, rank=0, world=1, shuffle=True, seed=0):
@@ -149,11 +170,120 @@ class BonaiDataset:
         order = np.random.RandomState(seed + epoch).permutation(n) if shuffle else np.arange(n)
         per_rank = -(-n // (world * samples_per_gpu)) * samples_per_gpu
         total = per_rank * world
-        order = np.concatenate([order, order[:total - n]]) if total > n else order
+        if total > n:
+            # (wrap as often as needed: a small dataset with many ranks / a large batch needs more than one extra pass;
+            #  order[:total - n] alone came up short there and left ranks with unequal slices -- a deadlock at the all-reduce)
+            order = np.resize(order, total)
         return order[rank * per_rank:(rank + 1) * per_rank].tolist()
 
-    def batches(self, epoch, samples_per_gpu, rank=0, world=1, shuffle=True, seed=0, device='cuda'):
-        """Device batches of one epoch for this rank (img, img_metas, gt_bboxes, gt_labels, gt_masks, gt_offsets)."""
+    def batches(self, epoch, samples_per_gpu, rank=0, world=1, shuffle=True, seed=0, device='cuda', prefetch=0, workers=8):
+        """Device batches of one epoch for this rank (img, img_metas, gt_bboxes, gt_labels, gt_masks, gt_offsets).
+        prefetch = 0: decode + upload synchronously in the caller's thread and stream; prefetch = N > 0: N batches ahead on
+        ``workers`` decoder threads, pinned staging and a side stream (see the module docstring) -- same batches, same order."""
         idx = self.epoch_indices(epoch, samples_per_gpu, rank, world, shuffle, seed)
-        for i in range(0, len(idx), samples_per_gpu):
-            yield to_device_batch([self[j] for j in idx[i:i + samples_per_gpu]], device=device)
+        groups = [idx[i:i + samples_per_gpu] for i in range(0, len(idx), samples_per_gpu)]
+        if prefetch <= 0 or self.test_mode:
+            for g in groups:
+                yield to_device_batch([self[j] for j in g], device=device)
+            return
+        yield from _Prefetcher(self, groups, device, depth=prefetch, workers=workers)
+
+    def test_batches(self, device='cuda'):
+        """Test mode, samples_per_gpu = 1 (mmdet/apis/test.py:26 with the test pipeline of bonai_instance.py:18-31: one scale,
+        no flip): yields (idx, dict(img=[tensor 1x3xHxW], img_metas=[[meta]])) in dataset order."""
+        for i in range(len(self)):
+            info = self.data_infos[i]
+            b = to_device_batch([dict(img=self._read_image(info), filename=info['filename'], gt_bboxes=np.zeros((0, 4), np.float32),
+                                      gt_labels=np.zeros((0,), np.int64), gt_masks=np.zeros((0, 1, 1), np.uint8),
+                                      gt_offsets=np.zeros((0, 2), np.float32))], device=device)
+            yield i, dict(img=[b['img']], img_metas=[b['img_metas']])
+
+
+class _Prefetcher:
+    """Iterator over device batches produced ``depth`` batches ahead of the consumer (BonaiDataset.batches)."""
+
+    def __init__(self, ds, groups, device, depth=2, workers=8):
+        import queue
+        import threading
+        import torch
+        self.ds, self.groups, self.device, self.depth = ds, groups, torch.device(device), max(1, int(depth))
+        self.cuda = self.device.type == 'cuda'
+        self.q = queue.Queue(maxsize=self.depth)
+        self.stop = threading.Event()
+        self.workers = max(1, int(workers))
+        bs = max(len(g) for g in groups) if groups else 0
+        w, h = ds.img_scale
+        # ring of staging buffers: depth in the queue + one being filled + one the consumer's upload may still read
+        self.slots = []
+        for _ in range(self.depth + 2):
+            t = torch.empty((bs, h, w, 3), dtype=torch.uint8)
+            self.slots.append(t.pin_memory() if self.cuda else t)
+        self.slot_free = [None] * len(self.slots)         # event after which a slot's upload has completed
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.thread = threading.Thread(target=self._produce, name='bonai-prefetch', daemon=True)
+        self.thread.start()
+
+    def _produce(self):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            with ThreadPoolExecutor(self.workers, thread_name_prefix='bonai-decode') as pool:
+                for bi, g in enumerate(self.groups):
+                    if self.stop.is_set():
+                        return
+                    k = bi % len(self.slots)
+                    if self.slot_free[k] is not None:
+                        self.slot_free[k].synchronize()            # the upload that last read this slot has finished
+                    buf = self.slots[k].numpy()
+                    # every random decision in THIS thread, in the synchronous loader's order -- per sample: replacements of a
+                    # sample without ground truth (custom.py:188-191), then its flip draw -- so both loaders emit the same stream
+                    futs = []
+                    for i, j in enumerate(g):
+                        j, draw = self.ds.resolve(j)
+                        futs.append(pool.submit(self.ds.prepare_train_img, j, draw, buf[i]))
+                    samples = [f.result() for f in futs]
+                    if self.cuda:
+                        with torch.cuda.stream(self.side):
+                            batch = to_device_batch(samples, device=self.device, staged=self.slots[k][:len(g)])
+                            ev = torch.cuda.Event()
+                            ev.record(self.side)
+                        self.slot_free[k] = ev
+                    else:
+                        batch, ev = to_device_batch(samples, device=self.device), None
+                    while not self.stop.is_set():
+                        try:
+                            self.q.put((batch, ev), timeout=0.1)
+                            break
+                        except Exception:
+                            continue
+            self.q.put((None, None))
+        except BaseException as e:      # noqa -- surfaced in the consumer
+            self.q.put((e, None))
+
+    def __iter__(self):
+        import torch
+        try:
+            while True:
+                batch, ev = self.q.get()
+                if batch is None:
+                    return
+                if isinstance(batch, BaseException):
+                    raise batch
+                if ev is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ev)
+                    for v in batch.values():                       # allocated on the side stream, consumed on this one
+                        for t in (v if isinstance(v, (list, tuple)) else [v]):
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(cur)
+                yield batch
+        finally:
+            self.stop.set()
+            while self.thread.is_alive():                          # unblock a producer waiting on a full queue
+                try:
+                    self.q.get_nowait()
+                except Exception:
+                    pass
+                self.thread.join(0.05)

@@ -967,6 +967,21 @@ def mask_paste(logits, boxes, img_h, img_w, thr=0.5):
     return out
 
 
+def mask_translate(masks, offsets):
+    """Footprints from roofs: masks uint8/bool [N,H,W], offsets fp32 [N,2] = (dx, dy) footprint -> roof (the model's offset
+    output) -> uint8 [N,H,W] with out[n, y, x] = masks[n, y + round(dy), x + round(dx)], zero outside the image."""
+    lib = L.load()
+    L.dev_check(masks, offsets)
+    m = masks.to(torch.uint8).contiguous()
+    o = offsets.float().contiguous()
+    if m.dim() != 3 or o.shape != (m.shape[0], 2):
+        raise L.LoftHipError(f'mask_translate: masks [N,H,W] and offsets [N,2] expected, got {tuple(m.shape)} and {tuple(o.shape)}')
+    out = torch.empty_like(m)
+    L.check(lib.loft_mask_translate(L.ptr(m), L.ptr(o), m.shape[0], m.shape[1], m.shape[2], L.ptr(out), L.stream()),
+            'loft_mask_translate')
+    return out
+
+
 # ------------------------------------------------------------------ sparse RPN backward helpers
 
 def _sparse_levels(maps):

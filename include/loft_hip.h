@@ -344,6 +344,11 @@ int loft_soft_nms(const float* boxes, const float* scores, int64_t n, float iou_
                   void* workspace, float* dets, int64_t* inds, int* n_out, void* stream);
 int loft_mask_paste(const float* logits, const float* boxes, int N, int S, int img_h, int img_w, float thr, uint8_t* out,
                     void* stream);
+/* loft_mask_translate: footprint bitmaps from roof bitmaps and predicted offsets -- what the reference's evaluation does on polygons
+ * through the external bstool package (tools/bonai/bonai_evaluation.py:64-91 BSPklParser(..., offset_model='footprint2roof'):
+ * footprint = roof translated by -offset; offsets are the third element of the result tuples of mmdet/apis/test.py:53-72).
+ * masks uint8 [N,H,W], offsets fp32 [N,2] = (dx, dy) in pixels -> out[n, y, x] = masks[n, y + round(dy), x + round(dx)] (0 outside). */
+int loft_mask_translate(const uint8_t* masks, const float* offsets, int N, int H, int W, uint8_t* out, void* stream);
 
 /* ---- sparse backward of the RPN head -------------------------------------------------------------
  * The RPN losses (anchor_head.py:429-497, rpn_head.py:56-80) read the head outputs only at the sampled anchors (<= 256 per

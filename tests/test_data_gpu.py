@@ -169,3 +169,76 @@ def test_dataset_files_to_training_step(tmp_path):
     tr = Trainer(m, lr=1e-3)
     lv = dict(tr.train_step(bd)['log_vars'].items())
     assert all(np.isfinite(v) for v in lv.values()) and lv['loss_mask'] > 0 and lv['loss_offset'] > 0
+
+
+def test_prefetching_loader_feeds_the_step(tmp_path):
+    """f2: the prefetching loader (decoder threads -> pinned staging ring -> side-stream upload, normalise and
+    polygon rasterisation) hands the Trainer the same device batches as the synchronous one, on its own sustains well above the
+    step's consumption, and a training loop fed by it runs at the speed of the same loop fed with resident batches."""
+    import json
+    import os
+    import time
+    from PIL import Image
+    from bonai_amd.config import Config
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.engine import Trainer
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import synth_bonai_anns
+    size, n_tiles, bs = 1024, 32, 8
+    rng = np.random.RandomState(0)
+    images, annotations, aid = [], [], 0
+    base = (rng.randint(0, 255, (size // 8, size // 8, 3)).astype(np.uint8)).repeat(8, 0).repeat(8, 1)   # compressible, like real tiles
+    for i in range(n_tiles):
+        name = f'tile_{i}.png'
+        Image.fromarray(np.roll(base, 17 * i, axis=1)).save(tmp_path / name, compress_level=3)
+        images.append(dict(id=10 + i, file_name=name, width=size, height=size))
+        for a in synth_bonai_anns(seed=i, n=40, size=size):
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=10 + i))
+    f = tmp_path / 'ann.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    mk = lambda: BonaiDataset(str(f), str(tmp_path), flip_ratio=0.5, flip_direction='vertical', seed=2)
+    a, b = mk(), mk()
+    sync = list(a.batches(0, bs, seed=7))
+    pre = list(b.batches(0, bs, seed=7, prefetch=2))
+    torch.cuda.synchronize()
+    assert len(sync) == len(pre) == n_tiles // bs
+    for x, y in zip(sync, pre):
+        assert torch.equal(x['img'], y['img'])
+        for k in ('gt_bboxes', 'gt_labels', 'gt_offsets', 'gt_masks'):
+            assert all(torch.equal(p, q) for p, q in zip(x[k], y[k])), k
+        assert [m['flip'] for m in x['img_metas']] == [m['flip'] for m in y['img_metas']]
+    # loader alone
+    t0 = time.time()
+    n = 0
+    for ep in range(3):
+        for batch in b.batches(ep, bs, seed=7, prefetch=3, workers=min(16, os.cpu_count() or 8)):
+            n += batch['img'].shape[0]
+    torch.cuda.synchronize()
+    rate = n / (time.time() - t0)
+    print(f'prefetching loader alone: {rate:.0f} img/s')
+    assert rate >= 250, rate
+    # fed training loop vs resident batches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    torch.manual_seed(0)
+    m = build_detector(dict(cfg.model, pretrained=None), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+    tr = Trainer(m, lr=1e-4)
+    for batch in sync[:3]:
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+
+    def run(it):
+        torch.cuda.synchronize()
+        t = time.time()
+        k = 0
+        for batch in it:
+            tr.train_step(batch)
+            k += 1
+        torch.cuda.synchronize()
+        return (time.time() - t) / k
+    resident = min(run(sync * 2) for _ in range(2))
+    fed = min(run(batch for ep in range(2) for batch in b.batches(ep, bs, seed=7, prefetch=3, workers=min(16, os.cpu_count() or 8)))
+              for _ in range(2))
+    print(f'step fed by the loader {fed * 1e3:.1f} ms, by resident batches {resident * 1e3:.1f} ms')
+    assert fed <= resident * 1.10 + 1e-3, (fed, resident)

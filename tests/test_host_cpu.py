@@ -336,3 +336,55 @@ def test_product_anchor_generator_vs_reference_fixture_and_known_answers():
     assert torch.equal(a[1], torch.tensor([[-16., -16., 16., 16.]]))
     with pytest.raises(ValueError):
         ag.grid_anchors(sizes[:2], device='cpu')
+
+
+def test_prefetching_loader_emits_the_synchronous_loaders_stream(tmp_path):
+    """f2: BonaiDataset.batches(prefetch=N) -- decoder threads, staging ring, producer thread -- yields the
+    same batches in the same order as the synchronous path for the same seed, including flip draws and the replacement of a
+    sample that has no ground truth after parsing; an abandoned iterator shuts its producer down.  Also the sampler padding
+    for a dataset smaller than world x batch (every rank must get an equally long slice)."""
+    import json
+    import threading
+    from PIL import Image
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.synth import synth_bonai_anns
+    size = 1024
+    rng = np.random.RandomState(1)
+    images, annotations, aid = [], [], 0
+    for i in range(7):
+        name = f't{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name, compress_level=1)
+        images.append(dict(id=i + 1, file_name=name, width=size, height=size))
+        for a in (synth_bonai_anns(seed=i, size=size) if i != 2 else []):           # tile 2: no annotation -> replaced
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=i + 1))
+    f = tmp_path / 'ann.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    raster = lambda polys, h, w: np.zeros((h, w), np.uint8)       # (bitmaps are not what this test is about)
+    mk = lambda: BonaiDataset(str(f), str(tmp_path), filter_empty_gt=False, flip_ratio=0.5, flip_direction='horizontal', seed=3,
+                              host_rasteriser=raster)
+    a, b = mk(), mk()
+    assert len(a) == 7
+    n_threads = threading.active_count()
+    for epoch in range(2):
+        sync = list(a.batches(epoch, 2, device='cpu', seed=5))
+        pre = list(b.batches(epoch, 2, device='cpu', seed=5, prefetch=2, workers=3))
+        assert len(sync) == len(pre) == 4
+        for x, y in zip(sync, pre):
+            assert torch.equal(x['img'], y['img'])
+            assert [m['filename'] for m in x['img_metas']] == [m['filename'] for m in y['img_metas']]
+            assert [m['flip'] for m in x['img_metas']] == [m['flip'] for m in y['img_metas']]
+            for k in ('gt_bboxes', 'gt_labels', 'gt_offsets'):
+                assert all(torch.equal(p, q) for p, q in zip(x[k], y[k]))
+            assert all(m['filename'] != 't2.png' for m in x['img_metas'])
+    it = iter(b.batches(0, 2, device='cpu', seed=5, prefetch=2))
+    next(it)
+    it.close()                                                     # consumer walks away: the producer thread must end
+    deadline = __import__('time').time() + 10
+    while threading.active_count() > n_threads and __import__('time').time() < deadline:
+        __import__('time').sleep(0.05)
+    assert threading.active_count() <= n_threads
+    # sampler padding: 7 samples over 8 ranks x 2 per GPU -> every rank 2 indices, all valid
+    sl = [a.epoch_indices(0, 2, rank=r, world=8, seed=1) for r in range(8)]
+    assert all(len(s) == 2 for s in sl) and all(0 <= i < 7 for s in sl for i in s)
+    assert set(i for s in sl for i in s) == set(range(7))

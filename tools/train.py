@@ -46,6 +46,7 @@ def main():
     ap.add_argument('--local_rank', type=int, default=0)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--synthetic', action='store_true', help='seeded synthetic tiles even when the dataset files are present')
+    ap.add_argument('--prefetch', type=int, default=2, help='dataset batches decoded / uploaded ahead of the step (0: synchronous loader)')
     ap.add_argument('--graph', action='store_true', help='backbone + neck forward / backward as two hipGraphs (bonai_amd/graphs.py)')
     args = ap.parse_args()
     from bonai_amd.config import Config
@@ -106,7 +107,8 @@ def main():
             return
         it = start_iter
         while it < args.iters:
-            for data in dataset.batches(it // ipe, bs, rank, world, seed=args.seed):
+            for data in dataset.batches(it // ipe, bs, rank, world, seed=args.seed, prefetch=args.prefetch,
+                                        workers=cfg.data.get('workers_per_gpu', 2) * 4):
                 if it >= args.iters:
                     return
                 yield it, data

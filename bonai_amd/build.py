@@ -62,5 +62,18 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and headers -- what a committed profile under profiles/ was measured
+    on.  bench.py quotes a profile file only when the hash recorded in it equals the running tree's (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files.append(os.path.join(os.path.dirname(CSRC), '..', 'include', 'loft_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))

@@ -598,6 +598,11 @@ class LoftRoIHead(nn.Module):
                     segm_results[int(dl[i])].append(im[i])
         offset_pred = self._offset_forward(x, det_rois)
         offset_results = self.offset_head.get_offsets(offset_pred, _bboxes.contiguous(), scale_factor, rescale)
+        if cfg.get('keep_device_masks', False):
+            # tools/test.py --eval: the pasted roof bitmaps stay on the device for bonai_amd.evaluation (footprints by
+            # kernels.mask_translate, IoU pairing) -- next to, not instead of, the result tuple
+            self.last_device_masks = pasted if self.with_mask else None
+            self.last_dets, self.last_det_labels = db, dl              # detection order = the order of the bitmaps and offsets
         return bbox_results, segm_results, offset_results
 
     def forward_dummy(self, x, proposals):

@@ -57,7 +57,9 @@ def main():
                 a.setdefault(c, [0.0, set()])
                 a[c][0] += float(r.get('Counter_Value', 0.0))
                 a[c][1].add(r.get('Dispatch_Id'))
-    out = {'_how': __doc__.strip().split('\n\n')[0], '_args': extra}
+    sys.path.insert(0, ROOT)
+    from bonai_amd.build import source_hash
+    out = {'_how': __doc__.strip().split('\n\n')[0], '_args': extra, '_source_hash': source_hash()}
     for fam, a in agg.items():
         n = max((len(v[1]) for v in a.values()), default=0)
         e = dict(launches=n)

@@ -178,6 +178,15 @@ def main():
     from bonai_amd.loft import build_detector
     from bonai_amd.synth import make_batch
     K.L.load()
+    if os.environ.get('LOFT_BENCH_ROLES'):      # A/B only: route launches to the role-split stream kernel ('mask' | 'roi' | 'all')
+        which = os.environ['LOFT_BENCH_ROLES']
+
+        def pick(G, B, OH, OW, Cin, Cout, T, ss, os_):
+            big = Cout % 256 == 0 and -(-B * OH * OW // 256) * (Cout // 256) * G >= 192 and T * Cin >= 512
+            roi = big and B >= 256 and T > 1 and OH * OW <= 1024
+            ok = roi and OH * OW >= 100 if which == 'mask' else (roi if which == 'roi' else big)
+            return K.CONV_ROLES256 if ok else K.CONV_AUTO
+        K.CONV_VARIANT = pick
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', args.config))
     fp16 = cfg.get('fp16')                                 # the reference's fp16 recipe (config 5): binary16 build of the library
     if fp16:
@@ -237,7 +246,7 @@ def main():
     # run at ~40 % load.  Here the first proposals of every image are replaced by jittered copies of its gt boxes (IoU > 0.5: what
     # a trained RPN produces), everything else is unchanged; nothing is skipped -- the RPN still runs its full proposal chain.
     # `value_random_init_rpn` is the second timed loop without the replacement (rounds 1-2 reported that one as `value`).
-    saturate = (not args.no_saturate) and headline
+    saturate = not args.no_saturate                       # (every config of BASELINE.json: the side configs' lines are at the trained-RPN load too)
     light = None
     orig_ft = model.rpn_head.forward_train
     if saturate:

@@ -308,6 +308,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
 // is not a multiple of 256) -- one weight fragment per sub-step, 256-byte output rows in the staged epilogue.
 template <int MODE, int VAR, int MJ = 4, int NW = 2>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
+    static_assert(MODE <= 2, "MODE 0 phase, 1 stream, 2 role-split stream");
     static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
     static_assert(NW == 2 || (NW == 1 && MODE == 1 && !(VAR & 2)), "the 128-cout tile exists for the stream schedule");
     constexpr int BN = 128 * NW;
@@ -329,9 +330,15 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // with a counted vmcnt, because an L2 round trip is longer than one of their K-tiles (two stages left them latency-bound at
     // 20-35 % of the MFMA rate).  Weights 3 x NW x 16 KiB, activations 3 x MJ x 8 KiB behind them; also the 128-cout tile (NW = 1).
     constexpr int NS = (MODE == 1 && VAR == 0 && !(MJ == 4 && NW == 2)) ? 3 : 2;
-    constexpr int PBW = NS == 3 ? NW * 16384 : PBUF, PBX = NS == 3 ? MJ * 8192 : PBUF;
-    constexpr int PXO = NS == 3 ? 3 * PBW : PX_OFF;
-    constexpr int LDSZ = NS == 3 ? 3 * PBW + 3 * PBX : PLDS;
+    // MODE 2 ("roles", round 4; see the schedule below): THREE weight stages + two activation stages = all 160 KiB of the CU
+    constexpr bool ROLES = MODE == 2;
+    static_assert(!ROLES || (MJ == 4 && NW == 2 && VAR == 0), "the role-split schedule exists for the 256 x 256 tile");
+    constexpr int PBW = ROLES ? PBUF : (NS == 3 ? NW * 16384 : PBUF), PBX = ROLES ? PBUF : (NS == 3 ? MJ * 8192 : PBUF);
+    constexpr int PXO = ROLES ? 3 * PBUF : (NS == 3 ? 3 * PBW : PX_OFF);
+    constexpr int LDSZ = ROLES ? 5 * PBUF : (NS == 3 ? 3 * PBW + 3 * PBX : PLDS);
+    // rows a thread holds staging pointers for: its own four (i = 0..3 -> tile row i*64 + wave*8 + lrow) and, in the role-split
+    // schedule, the four of its SIMD partner (wave ^ 4), whose activation pieces the copier wave issues as well
+    constexpr int NI2 = ROLES ? 2 * NI : NI;
     __shared__ __attribute__((aligned(16))) char lds[LDSZ];
     unsigned long long kst0 = 0ull, kst1 = 0ull, kst2 = 0ull;
     const int trace_b0 = gridDim.x > 1100 ? 1024 : 0;        // TRACE: a workgroup of a later round (steady state) when there is one
@@ -391,9 +398,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         tab_w = a.wt[lane] * a.Cout * a.Cin;
     }
     kstamp(40);
-    const bf16_t* a_ptr[4];
-    unsigned a_mask[4];
-    int a_iy[4], a_ix[4];
+    const bf16_t* a_ptr[NI2];
+    unsigned a_mask[NI2];
+    int a_iy[NI2], a_ix[NI2];
+    auto tile_row = [&](int i) { return (i % NI) * 64 + (i < NI ? wave : (wave ^ 4)) * 8 + lrow; };
     unsigned tmask = 0xffffffffu;       // taps any row of the tile needs (pixel-major tiles skip the others)
     if (a.pixmajor) {
         // pixel-major rows (RoI maps): the tile's rows are linear in the row index within each of its (at most two) segments,
@@ -418,8 +426,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         const long istr = (long)a.IH * a.IW * a.Cin;
         tmask = (nv0 > 0 ? mk0 : 0u) | (nv1 > 0 ? mk1 : 0u);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = i * 64 + srow;
+        for (int i = 0; i < NI2; ++i) {
+            const int row = tile_row(i);
             const bool k = row >= rs1;
             const int idx = k ? row - rs1 : row;
             const bool ok = idx < (k ? nv1 : nv0);
@@ -429,8 +437,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         }
     } else {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = i * 64 + srow;
+    for (int i = 0; i < NI2; ++i) {
+        const int row = tile_row(i);
         const int m = m0 + row;
         a_ptr[i] = src;
         a_mask[i] = 0u;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         for (int t = 0; t < a.T; ++t) {
             const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < NI2; ++i) {
                 const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
                 a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
             }
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
         if constexpr (2 * H >= 2 * NW) return;                    // (128-cout tile: the second half does not exist)
-        const bf16_t* wt = st_w + (MODE == 1 ? sw_c : st_c) + b_off0;
+        const bf16_t* wt = st_w + (MODE >= 1 ? sw_c : st_c) + b_off0;
 #pragma unroll
         for (int i = 2 * H; i < 2 * H + 2; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(wt + (long)i * b_step),
@@ -582,6 +590,174 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         PIPE_SB();
     };
 
+    if constexpr (MODE == 2) {
+        // ================= role-split stream schedule (round 4) =================
+        // What the barrier-level traces of the stream schedule say (profiles/round3_probes/stream_ablations.txt, round4_probes/
+        // tile_overhead.txt): a sub-step without copies runs both waves of a SIMD at the full matrix rate (8 MFMAs in ~290 cycles for
+        // the leading wave, ~600 for the pair = the pipe's 512), a sub-step in which BOTH waves issue four global->LDS copies takes
+        // ~1050 cycles for the same 512 cycles of MFMA work: a wave blocked in vector-memory issue (the CU's copy path takes ~30
+        // cycles per 1 KiB piece with four SIMDs feeding it) cannot issue its MFMAs, and its partner is blocked at the same moment.
+        // Here the two waves of a SIMD never issue copies at the same time:
+        //   waves 0-3 ("X role") issue ALL activation pieces of the tile -- their own rows and their partner's -- in the FIRST half of
+        //             a K-tile interval (sub-steps ks3 of the previous tile and ks0),
+        //   waves 4-7 ("W role") issue ALL weight pieces in the SECOND half (ks1, ks2),
+        // so whichever wave is held up in the copy path, the other one of that SIMD has a full half-tile of MFMAs to feed the pipe
+        // with.  The weight pieces then land one whole K-tile later than they do in the stream schedule, which takes a THIRD weight
+        // stage: LDS = [W0][W1][W2][X0][X1] = 5 x 32 KiB, all of the CU's 160 KiB (one workgroup per CU anyway).
+        // Per K-tile t (X stage t & 1, W stage t % 3), same fragment pipeline as the stream schedule:
+        //   ks0: MFMA fa | read F(t,1) | X role: X(t+1) second half (rows 128..255: own + partner pieces) -> X stage 1 - (t&1)
+        //   ks1: MFMA fb | read F(t,2) | W role: W(t+2) first half  -> W stage (t+2) % 3   (stage of W(t-1): free since SYNC(t-1))
+        //   ks2: MFMA fa | read F(t,3) | W role: W(t+2) second half
+        //   SYNC(t): X role vmcnt(0) [X(t+1) landed]; W role vmcnt(8) [everything but the W(t+2) pieces just issued, i.e. W(t+1),
+        //            has landed]; lgkmcnt(0); s_barrier
+        //   ks3: MFMA fb | read F(t+1,0) | X role: X(t+2) first half -> X stage t & 1 (free behind SYNC(t))
+        // RAW: X(t+1) complete at SYNC(t) by the X waves' vmcnt(0) + barrier; W(t+1) was issued during tile t-1 and is complete at
+        // SYNC(t) by the W waves' counted wait + barrier; both are first read in ks3(t).  WAR: X stage t&1 is rewritten from ks3(t),
+        // behind SYNC(t) (last read F(t,3) in ks2(t), complete at the lgkmcnt(0) of SYNC(t)); W stage of W(t-1) from ks1(t), behind
+        // SYNC(t-1).
+        const bool xrole = wave < 4;
+        const int pw = wave ^ 4;                                         // the SIMD partner (dispatch order 0->2->1->3 twice)
+        const int srow_p = pw * 8 + lrow;
+        const int b_off0_p = (n0 + srow_p) * a.Cin + swz(srow_p, lchunk) * 8;
+        bf16x8 fa[6], fb[6];
+        using k0_t = std::integral_constant<int, 0>;
+        using k1_t = std::integral_constant<int, 1>;
+        using k2_t = std::integral_constant<int, 2>;
+        using k3_t = std::integral_constant<int, 3>;
+        using k4_t = std::integral_constant<int, 4>;
+        using k6_t = std::integral_constant<int, 6>;
+        auto rdf = [&](bf16x8 (&f)[6], int woff, auto xbufc, auto ksc, auto firstc, auto lastc) {   // fragments [first, last) of F(., KS)
+            constexpr int XB = decltype(xbufc)::value, KS = decltype(ksc)::value, F0 = decltype(firstc)::value, F1 = decltype(lastc)::value;
+#pragma unroll
+            for (int I = F0; I < F1; ++I) {
+                if (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + woff + I * 4096);
+                else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + XB * PBX + (I - 2) * 4096);
+            }
+        };
+        auto mmj = [&](bf16x8 (&f)[6], auto jc) {
+            constexpr int J = decltype(jc)::value;
+            acc[0][J] = LOFT_MFMA_32x32x16(f[0], f[2 + J], acc[0][J]);
+            acc[1][J] = LOFT_MFMA_32x32x16(f[1], f[2 + J], acc[1][J]);
+        };
+        // activation pieces of tile rows i*64 + [wave*8, +8) and i*64 + [partner*8, +8): this wave's row i AND its partner's
+        auto issue_xi = [&](auto ic, auto xbufc) {
+            constexpr int i = decltype(ic)::value, XB = decltype(xbufc)::value;
+            const long aoff = st_aoff + st_c;
+            const bf16_t* p0 = ((a_mask[i] >> st_t) & 1u) ? a_ptr[i] + aoff : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p0, (lds_ptr_t)(lds + PXO + XB * PBX + (i * 64 + wave * 8) * 128), 16, 0, 0);
+            const bf16_t* p1 = ((a_mask[NI + i] >> st_t) & 1u) ? a_ptr[NI + i] + aoff : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p1, (lds_ptr_t)(lds + PXO + XB * PBX + (i * 64 + pw * 8) * 128), 16, 0, 0);
+        };
+        // weight pieces of rows (couts) i*64 + [wave*8, +8) and the partner's, into the stage at byte offset woff
+        auto issue_wi = [&](auto ic, int woff) {
+            constexpr int i = decltype(ic)::value;
+            const bf16_t* wt = st_w + sw_c;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_off0 + (long)i * b_step),
+                                             (lds_ptr_t)(lds + PW_OFF + woff + (i * 64 + wave * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + b_off0_p + (long)i * b_step),
+                                             (lds_ptr_t)(lds + PW_OFF + woff + (i * 64 + pw * 8) * 128), 16, 0, 0);
+        };
+        // ---- prologue (every wave its own pieces, as in the stream schedule): W(0), X(0), W(1); X role: first half of X(1)
+        issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
+        issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
+        if (nk > 1) {
+            advance_w(); advance_x();
+            issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
+            advance_w();
+            if (xrole) {
+                issue_xi(k0_t{}, c1_t{}); issue_xi(k1_t{}, c1_t{});
+                late_init();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // in flight: W(1) (4 pieces) + the first half of X(1) (4)
+            } else {
+                late_init();
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // in flight: W(1)
+            }
+        } else {
+            late_init();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PIPE_BARRIER();
+        in_loop = true;
+        int w_cur = 0, w_nxt = PBW, w_fill = 2 * PBW;                    // byte offsets of the stages of W(t), W(t+1), W(t+2)
+        rdf(fa, w_cur, c0_t{}, k0_t{}, k0_t{}, k6_t{});
+        // one sub-step: 8 MFMAs on `cur`, the 6 reads of `nxt`, and `copies` (four global->LDS pieces or nothing) pinned between
+        // the MFMA pairs
+        auto sub = [&](bf16x8 (&cur)[6], bf16x8 (&nxt)[6], int woff, auto xbufc, auto ksc, bool do_read, auto&& copies0, auto&& copies1) {
+            PIPE_SB();
+            mmj(cur, k0_t{});
+            PIPE_SB();
+            if (do_read) rdf(nxt, woff, xbufc, ksc, k0_t{}, k2_t{});
+            PIPE_SB();
+            mmj(cur, k1_t{});
+            if (do_read) rdf(nxt, woff, xbufc, ksc, k2_t{}, k4_t{});
+            copies0();
+            PIPE_SB();
+            mmj(cur, k2_t{});
+            if (do_read) rdf(nxt, woff, xbufc, ksc, k4_t{}, k6_t{});
+            PIPE_SB();
+            mmj(cur, k3_t{});
+            copies1();
+            PIPE_SB();
+        };
+        auto nop = [] {};
+        // the two roles run the same fragment / MFMA stream and differ only in where their copies sit: two loop bodies, selected
+        // once per workgroup half (wave-uniform branch; both execute exactly one barrier per K-tile)
+        auto rtile = [&](auto rolec, auto xbufc, bool has1, bool has2) {
+            constexpr bool XR = decltype(rolec)::value != 0;
+            constexpr int XB = decltype(xbufc)::value;
+            using xo_t = std::integral_constant<int, 1 - XB>;
+            // ks0: X role issues the second half of X(t+1)
+            if constexpr (XR)
+                sub(fa, fb, w_cur, xbufc, k1_t{}, true, [&] { if (has1) issue_xi(k2_t{}, xo_t{}); },
+                    [&] { if (has1) { issue_xi(k3_t{}, xo_t{}); advance_x(); } });
+            else
+                sub(fa, fb, w_cur, xbufc, k1_t{}, true, nop, nop);
+            // ks1, ks2: W role issues W(t+2)
+            if constexpr (XR) {
+                sub(fb, fa, w_cur, xbufc, k2_t{}, true, nop, nop);
+                sub(fa, fb, w_cur, xbufc, k3_t{}, true, nop, nop);
+            } else {
+                sub(fb, fa, w_cur, xbufc, k2_t{}, true, [&] { if (has2) issue_wi(k0_t{}, w_fill); }, [&] { if (has2) issue_wi(k1_t{}, w_fill); });
+                sub(fa, fb, w_cur, xbufc, k3_t{}, true, [&] { if (has2) issue_wi(k2_t{}, w_fill); },
+                    [&] { if (has2) { issue_wi(k3_t{}, w_fill); advance_w(); } });
+            }
+            if (has1) {
+                if constexpr (XR) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else {
+                    if (has2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                PIPE_BARRIER();
+            }
+            // ks3: read F(t+1,0); X role issues the first half of X(t+2) into the stage tile t just released
+            if constexpr (XR)
+                sub(fb, fa, w_nxt, xo_t{}, k0_t{}, has1, [&] { if (has2) issue_xi(k0_t{}, xbufc); }, [&] { if (has2) issue_xi(k1_t{}, xbufc); });
+            else
+                sub(fb, fa, w_nxt, xo_t{}, k0_t{}, has1, nop, nop);
+            const int w_old = w_cur;
+            w_cur = w_nxt; w_nxt = w_fill; w_fill = w_old;
+        };
+        using xr_t = std::integral_constant<int, 1>;
+        using wr_t = std::integral_constant<int, 0>;
+        if (xrole) {
+            for (int t = 0; t < nk; t += 2) {
+                rtile(xr_t{}, c0_t{}, t + 1 < nk, t + 2 < nk);
+                if (t + 1 < nk) rtile(xr_t{}, c1_t{}, t + 2 < nk, t + 3 < nk);
+            }
+        } else {
+            for (int t = 0; t < nk; t += 2) {
+                rtile(wr_t{}, c0_t{}, t + 1 < nk, t + 2 < nk);
+                if (t + 1 < nk) rtile(wr_t{}, c1_t{}, t + 2 < nk, t + 3 < nk);
+            }
+        }
+        {
+            const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;
+            const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
+            if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        }
+        return;
+    }
     if constexpr (MODE == 1) {
         // Static priority for the younger half (round 3): waves 4-7 are dispatched second and lose every VALU / LDS arbitration
         // against their SIMD partner by age -- in the barrier-level trace they reach the K-tile's barrier ~580 cycles after waves
@@ -985,6 +1161,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s) {
     ConvArgs a = a_in;
     if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
+    if (mode == 2 && (a.Cout % 256 || nw_force == 1)) return (int)hipErrorInvalidValue;
     const int nw = nw_force == 1 ? 1 : (a.Cout % 256 == 0 ? 2 : 1);       // 128-cout tiles: Cout = 128 (mod 256), or by choice with 64-pixel tiles
     if (nw == 1 && !(mode == 1 && var == 0 && (mj == 4 || mj == 1) && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
     dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / (128 * nw), groups);
@@ -1009,6 +1186,9 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2>), grid, dim3(512), 0, s, a);
     } else if (mode == 1 && mj == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1>), grid, dim3(512), 0, s, a);
+    } else if (mode == 2) {
+        if (var != 0) return (int)hipErrorInvalidValue;
+        PIPE_LAUNCH(2, 0);
     } else if (mode == 1) {
         switch (var) {
         case 0: PIPE_LAUNCH(1, 0); break;

@@ -116,7 +116,7 @@ def flip_offsets(offsets, direction):
     return off
 
 
-def flip_sample(sample, direction='horizontal'):
+def flip_sample(sample, direction='horizontal', defer_image=False):
     """One training sample (img HxWx3, gt_bboxes, gt_masks [K,H,W] u8 -- or gt_polygons --, gt_offsets) flipped as
     RandomFlip.__call__ does (transforms.py:406-456).
 
@@ -130,7 +130,10 @@ def flip_sample(sample, direction='horizontal'):
     h, w = sample['img'].shape[:2]
     ax = 1 if direction == 'horizontal' else 0
     out = dict(sample)
-    out['img'] = np.flip(sample['img'], axis=ax).copy()
+    if defer_image:          # the prefetching loader: the image is mirrored on the device after the upload (to_device_batch)
+        out['img_flip'] = tuple(sample.get('img_flip', ())) + (direction,)
+    else:
+        out['img'] = np.flip(sample['img'], axis=ax).copy()
     out['gt_bboxes'] = flip_bboxes(sample['gt_bboxes'], (h, w), direction)
     if sample.get('gt_masks') is not None:
         out['gt_masks'] = np.flip(sample['gt_masks'], axis=ax + 1).copy()
@@ -167,8 +170,18 @@ def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=
     else:
         imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(s['img'])) for s in samples]).to(dev)
     x = imgs.float()
-    if to_rgb:
-        x = x.flip(-1)
+    rgb = [bool(s.get('img_rgb', False)) for s in samples]         # decoded straight to RGB: Normalize's reversal already done
+    if to_rgb and not all(rgb):
+        if any(rgb):
+            keep = torch.tensor(rgb, device=dev).view(-1, 1, 1, 1)
+            x = torch.where(keep, x, x.flip(-1))
+        else:
+            x = x.flip(-1)
+    elif not to_rgb and any(rgb):
+        raise ValueError('samples decoded to RGB need to_rgb=True (the configured Normalize of bonai_instance.py:3-4)')
+    for i, s in enumerate(samples):                                  # RandomFlip's image mirror, deferred by the loader
+        for d in s.get('img_flip', ()):
+            x[i] = x[i].flip(1 if d == 'horizontal' else 0)
     x = (x - torch.tensor(mean, device=dev)) / torch.tensor(std, device=dev)
     img = x.permute(0, 3, 1, 2).contiguous()
     metas = []

@@ -229,6 +229,9 @@ class Trainer:
         fg = self._fgraphs
         if fg is None:
             fg = self._fgraphs = FeatureGraphs(self)
+        if fg.ready and fg.validate() is not None:
+            import warnings
+            warnings.warn(f'hipGraphs of backbone + neck dropped and recaptured: {fg.stale}', RuntimeWarning)
         if not fg.ready and fg.failed is None and self._steps_run >= 2 and self.prepack.order:
             self.reducer.capturing = True
             try:

@@ -56,6 +56,9 @@ class FeatureGraphs:
         self.ready = False
         self.failed = None            # the exception text when capture was refused: the trainer then stays on the eager path
         self.keep = []                # device tables uploaded at capture (kernels.h2d): must outlive the graphs
+        self.pack_deps = []           # (signature, source tensors, packing) of every frozen-layer packing the graphs read
+        self.prepack_sig = None       # identity of the PrepackRegistry operand buffers the graphs read
+        self.stale = None             # why the last set of graphs was dropped (recaptured at the next step)
         self.token = None
 
     # ------------------------------------------------------------------ capture
@@ -81,6 +84,7 @@ class FeatureGraphs:
         sp.active = False
         zp.active = False
         K.H2D_KEEP = self.keep
+        prev_trace, F2.PACK_TRACE = F2.PACK_TRACE, []
         # forks inside the graphs: HRNet's branches and the weight-gradient launches keep their own streams (parallel branches of
         # the captured graph; every fork is joined before the capture ends: HRModule joins its branches, the final UnpackQueue
         # flush waits for every weight-gradient launch)
@@ -113,10 +117,40 @@ class FeatureGraphs:
             F2.GRAD_SINK, F2.UNPACK_Q, F2.WGRAD_STREAM, F2.PREPACK, F2.HUB_ENABLED, H.BRANCH_STREAMS = prev
             (zp.buf, zp.off, zp.need, zp.active), (sp.buf, sp.off, sp.need, sp.active) = zp_state, sp_state
             K.H2D_KEEP = None
+            trace, F2.PACK_TRACE = F2.PACK_TRACE, prev_trace
+        # Addresses the graphs do not own: the frozen layers' packings live in a cache on their Parameters and the
+        # trainable layers' operands in the PrepackRegistry.  The graphs hold a reference to every such buffer (it cannot be freed
+        # and handed to someone else under a live graph) and remember what it was computed from; provider() drops the graphs when
+        # a source changed (load_state_dict / load_checkpoint mid-run, .data re-assignment) or the registry re-allocated.
+        self.pack_deps = trace
+        self.keep.extend(v for _, _, v in trace)
+        self.prepack_sig = self._prepack_signature()
+        self.keep.extend(t for grp in tr.prepack.jobs.values() for t in (grp['wp'], grp['wpt'], grp['bias']) if t is not None)
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         self.shape = tuple(img.shape)
         self.ready = True
+
+    def _prepack_signature(self):
+        reg = self.tr.prepack
+        return tuple((k, grp['wp'].data_ptr(), 0 if grp['wpt'] is None else grp['wpt'].data_ptr(), grp['bias'].data_ptr())
+                     for k, grp in ((k, reg.jobs[k]) for k in reg.order))
+
+    def validate(self):
+        """-> None when every address baked into the graphs still holds what the graphs expect, else the reason (the graphs are
+        then dropped: ``ready`` False, recaptured by the trainer at the next step)."""
+        why = None
+        for sig, tensors, _ in self.pack_deps:
+            if not F2._pack_sig_valid(sig, tensors):
+                why = 'a frozen layer\'s weights changed after capture (load_state_dict / load_checkpoint / .data re-assignment)'
+                break
+        if why is None and self._prepack_signature()[:len(self.prepack_sig)] != self.prepack_sig:
+            why = 'the PrepackRegistry re-allocated an operand buffer the graphs read'
+        if why is not None:
+            self.ready, self.stale = False, why
+            self.g_fwd = self.g_bwd = None
+            self.keep, self.pack_deps = [], []
+        return why
 
     # ------------------------------------------------------------------ per step
     def provider(self, img):

@@ -125,11 +125,31 @@ def _pack_sig_valid(sig, tensors):
     return True
 
 
+# A hipGraph that was captured while these packings were in use has their device ADDRESSES baked in (bonai_amd/graphs.py): while
+# PACK_TRACE is a list (set by FeatureGraphs.capture), every packing handed out is recorded there with the tensors it was
+# computed from and their signature; the graphs keep the packings alive and re-validate the signatures before every replay.
+PACK_TRACE = None
+
+
+class _PackCache(dict):
+    """The per-parameter cache.  Its entries hold weak references (not picklable): pickling / deep-copying a Parameter that has
+    run a forward -- torch.save(model), a model handed to mp.spawn -- must not fail on them, so the cache
+    reduces to an EMPTY cache; it is a cache."""
+
+    def __reduce__(self):
+        return (_PackCache, ())
+
+    def __deepcopy__(self, memo):
+        return _PackCache()
+
+
 def _pack_cache_get(sub, tensors):
     """Cached packing for the frozen tensors ``tensors`` (tensors[0] = the first weight = the owner) under sub-key ``sub``."""
     d = _base_of(tensors[0]).__dict__.get('_loft_packs')
     e = d.get(sub) if d else None
     if e is not None and _pack_sig_valid(e[0], tensors):
+        if PACK_TRACE is not None:
+            PACK_TRACE.append((e[0], list(tensors), e[1]))
         return e[1]
     return None
 
@@ -138,14 +158,18 @@ def _pack_cache_put(sub, tensors, value):
     owner = _base_of(tensors[0])
     d = owner.__dict__.get('_loft_packs')
     if d is None:
-        d = owner._loft_packs = {}
+        d = owner._loft_packs = _PackCache()
     if len(d) >= 8 and sub not in d:     # (dtype, padding, dgrad) variants of ONE conv: bounded; stale variants go first
-        d.clear()
-    d[sub] = (_pack_sig(tensors), value)
+        d.clear()                        # (a live graph keeps its own references to the packings it replays: see PACK_TRACE)
+    sig = _pack_sig(tensors)
+    d[sub] = (sig, value)
+    if PACK_TRACE is not None:
+        PACK_TRACE.append((sig, list(tensors), value))
 
 
 def clear_pack_cache(module):
-    """Drop every cached packing of ``module``'s parameters (frees their device memory; nothing needs this for correctness)."""
+    """Drop every cached packing of ``module``'s parameters (frees their device memory; nothing needs this for correctness:
+    a captured graph holds its own references and notices at its next replay that the cache no longer vouches for them)."""
     for p in module.parameters():
         p.__dict__.pop('_loft_packs', None)
 

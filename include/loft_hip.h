@@ -161,6 +161,7 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
 #define LOFT_CONV_STREAM128 10    /* the same stream kernel on 128-pixel x 256-cout tiles (launches with too few 256-pixel tiles) */
 #define LOFT_CONV_STREAM64 11     /* ... on 64-pixel x 256-cout tiles (layer4's 32 x 32 maps) */
 #define LOFT_CONV_STREAM64N 12    /* ... on 64-pixel x 128-cout tiles (256-channel convs on 32 x 32 maps: FPN P5, the RPN conv on it) */
+#define LOFT_CONV_ROLES256 13     /* 256x256x64, role-split stream: waves 0-3 issue every activation copy, waves 4-7 every weight copy (three weight stages) */
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400

@@ -149,7 +149,8 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
         outs = []
         for v in (K.CONV_T256_FAST, K.CONV_PIPE256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_T256, K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR,
                   K.CONV_STREAM128 | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM64 | K.CONV_FLAG_TAP_MAJOR,
-                  K.CONV_STREAM64N | K.CONV_FLAG_TAP_MAJOR, K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128,
+                  K.CONV_STREAM64N | K.CONV_FLAG_TAP_MAJOR, K.CONV_ROLES256 | K.CONV_FLAG_TAP_MAJOR, K.CONV_ROLES256,
+                  K.CONV_STREAM256, K.CONV_PIPE256, K.CONV_STREAM128,
                   K.CONV_STREAM256 | K.CONV_FLAG_KROT, K.CONV_STREAM128 | K.CONV_FLAG_KROT, K.CONV_STREAM64 | K.CONV_FLAG_KROT):
             K.CONV_VARIANT = v
             try:
@@ -163,10 +164,10 @@ def test_pipe256_bit_identical_to_lockstep_kernel():
             finally:
                 K.CONV_VARIANT = K.CONV_AUTO
             outs.append((o16, gm, o16p, o16r, grm))
-        for o in outs[1:7]:
+        for o in outs[1:8]:
             for got, want in zip(o, outs[0]):
                 assert (got is None and want is None) or torch.equal(got, want), (B, Cin, Cout, H, W, R)
-        for o in outs[7:]:          # chunk-major K order (and its per-workgroup chunk rotation, LOFT_CONV_FLAG_KROT): a different
+        for o in outs[8:]:          # chunk-major K order (and its per-workgroup chunk rotation, LOFT_CONV_FLAG_KROT): a different
                                     # fp32 summation order, then one bf16 rounding
             for got, want in zip(o, outs[0]):
                 if want is None:
@@ -312,3 +313,32 @@ def test_stream_kernel_128_cout_tiles_bit_identical_to_lockstep_128():
                 K.CONV_VARIANT = K.CONV_AUTO
         for got, want in zip(outs[1], outs[0]):
             assert torch.equal(got, want), (B, Cin, Cout, H, W, R)
+
+
+def test_role_split_schedule_bit_identical_to_stream_schedule_at_bench_size():
+    """conv_tap_pipe_kernel<2,...> (round 4: waves 0-3 issue every activation copy, waves 4-7 every weight copy, three weight
+    stages) computes the same sums in the same order as the stream schedule it is derived from: forward (bias + ReLU, residual) and
+    data gradient (ReLU mask) of the launches it serves at the bench's sizes -- FOA (4 groups, pixel-major, tiles with skipped
+    taps), mask head (14 x 14), FPN P2 3x3, an FC, one- and two-K-tile launches -- torch.equal."""
+    from bonai_amd import kernels as K
+    for (G, B, Cin, Cout, H, W, R, pad) in [(4, 2048, 256, 256, 7, 7, 3, 1), (1, 2048, 256, 256, 14, 14, 3, 1), (1, 8, 256, 256, 256, 256, 3, 1),
+                                           (1, 8192, 1024, 1024, 1, 1, 1, 0), (1, 8, 64, 256, 256, 256, 1, 0), (1, 8, 128, 512, 128, 128, 1, 0),
+                                           (1, 777, 256, 256, 7, 7, 3, 1), (1, 8, 256, 256, 64, 64, 3, 1)]:
+        x, w, bias = _mk(G, B, Cin, Cout, H, W, R, seed=B + Cin)
+        wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
+        wpt = torch.stack([K.pack_w_dgrad(w[i]) for i in range(G)])
+        res = _cl(torch.randn(G * B, Cout, H, W, device='cuda').bfloat16())
+        outs = []
+        for v in (K.CONV_STREAM256, K.CONV_ROLES256):
+            K.CONV_VARIANT = v
+            try:
+                o = [K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, groups=G),
+                     K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, residual=res, groups=G)]
+                if Cin % 256 == 0:
+                    o.append(K.conv2d_dgrad(res, wpt, (H, W), R, R, 1, pad, mask=x, groups=G))
+            finally:
+                K.CONV_VARIANT = K.CONV_AUTO
+            outs.append(o)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_), (G, B, Cin, Cout, H, W, R)

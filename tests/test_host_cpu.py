@@ -368,7 +368,7 @@ def test_prefetching_loader_emits_the_synchronous_loaders_stream(tmp_path):
     n_threads = threading.active_count()
     for epoch in range(2):
         sync = list(a.batches(epoch, 2, device='cpu', seed=5))
-        pre = list(b.batches(epoch, 2, device='cpu', seed=5, prefetch=2, workers=3))
+        pre = list(b.batches(epoch, 2, device='cpu', seed=5, prefetch=2, workers=3, processes=bool(epoch)))   # threads, then processes
         assert len(sync) == len(pre) == 4
         for x, y in zip(sync, pre):
             assert torch.equal(x['img'], y['img'])
@@ -388,3 +388,26 @@ def test_prefetching_loader_emits_the_synchronous_loaders_stream(tmp_path):
     sl = [a.epoch_indices(0, 2, rank=r, world=8, seed=1) for r in range(8)]
     assert all(len(s) == 2 for s in sl) and all(0 <= i < 7 for s in sl for i in s)
     assert set(i for s in sl for i in s) == set(range(7))
+
+
+def test_evaluation_pairing_rule_and_scores():
+    """bonai_amd/evaluation.py against the reference's formulas (tools/bonai/bonai_evaluation.py:461-475, 375-389): iou =
+    inter / (area_pred + area_gt - inter + 1), every pair >= 0.5 counts (not one-to-one), FN / FP = unpaired."""
+    from bonai_amd.evaluation import f1_scores, pair_by_iou, summarize
+    inter = np.array([[90., 0., 0.], [60., 55., 0.], [0., 0., 10.], [0., 0., 0.]])      # [pred, gt]
+    ap, ag = np.array([100., 110., 100., 50.]), np.array([100., 100., 100.])
+    p = pair_by_iou(inter, ap, ag)
+    want = inter / (ap[:, None] + ag[None, :] - inter + 1.0)
+    assert np.allclose(p['iou'], want)
+    assert list(zip(p['pred_TP'], p['gt_TP'])) == [(0, 0)]                 # 90/111 = .81; 60/151, 55/156, 10/191 below .5
+    assert p['gt_FN'] == [1, 2] and p['pred_FP'] == [1, 2, 3]
+    inter2 = np.array([[80., 0.], [75., 0.]])
+    p2 = pair_by_iou(inter2, np.array([100., 100.]), np.array([100., 50.]))
+    assert p2['gt_TP'] == [0, 0] and p2['pred_TP'] == [0, 1]              # one gt in two pairs: TP counts pairs, like the reference
+    s = f1_scores(3, 1, 2)
+    assert abs(s['Precision'] - 0.6) < 1e-12 and abs(s['Recall'] - 0.75) < 1e-12 and abs(s['F1_score'] - 2 * 0.6 * 0.75 / 1.35) < 1e-12
+    recs = [dict(roof=p, footprint=p2, gt_offsets=np.array([[3., 4.]]), pred_offsets=np.array([[0., 0.]]))]
+    out = summarize(recs)
+    assert out['roof']['TP'] == 1 and out['roof']['FN'] == 2 and out['roof']['FP'] == 3
+    assert out['footprint']['TP'] == 2 and out['offset']['aEPE'] == 5.0 and out['offset']['pairs'] == 1
+    assert np.isnan(summarize([])['roof']['F1_score'])

@@ -145,3 +145,106 @@ def test_simple_test_rle_masks_equal_bitmaps():
     for r, b in list(zip(segm_rle[0], segm_bitmap[0]))[:200]:
         assert r['size'] == [256, 256] and isinstance(r['counts'], bytes)
         assert np.array_equal(RL.rle_decode(r), b)
+
+
+def test_mask_translate_bit_exact_vs_numpy_shift_oracle():
+    """f3: footprint = roof bitmap translated by -offset (kernels.mask_translate, boxes.hip) against oracle.ops_ref.translate_masks:
+    every rounding case (halves round away from zero), shifts that leave the image, widths that are no multiple of 16 or 4."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(0)
+    for (n, h, w) in ((7, 37, 53), (5, 64, 128), (3, 130, 1024), (2, 33, 20)):
+        m = (rng.rand(n, h, w) > 0.6).astype(np.uint8)
+        offs = rng.uniform(-1.2 * w, 1.2 * w, (n, 2)).astype(np.float32)
+        offs[0] = (0.5, -0.5); offs[1] = (-1.5, 2.5)
+        if n > 2:
+            offs[2] = (16.0, 0.0)
+        if n > 3:
+            offs[3] = (4.49999, -3.50001)
+        if n > 4:
+            offs[4] = (0.0, float(h))          # shifted out completely
+        got = K.mask_translate(torch.from_numpy(m).cuda(), torch.from_numpy(offs).cuda()).cpu().numpy()
+        assert np.array_equal(got, R.translate_masks(m, offs)), (n, h, w)
+    assert K.mask_translate(torch.zeros(0, 8, 8, dtype=torch.uint8, device='cuda'), torch.zeros(0, 2, device='cuda')).shape == (0, 8, 8)
+
+
+def test_dataset_evaluation_on_annotation_files(tmp_path):
+    """f3 end to end: tools/test.py's dataset path on a tmp-path BONAI file set -- results in the reference's pickle layout (RLE
+    masks in detection order), the evaluation's pairing rule (tools/bonai/bonai_evaluation.py:461-475) and statistics.  Ground
+    truth fed back as predictions scores F1 = 1 on roofs and footprints and aEPE = 0; predictions moved off their buildings
+    score 0; the HIP model's own detections run through the same code."""
+    import json
+    import sys
+    from PIL import Image
+    from bonai_amd import evaluation as E, kernels as K
+    from bonai_amd.config import Config
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.loft import build_detector
+    from bonai_amd.rle import rle_decode
+    from oracle.synth_weights import synth_tensor
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import test as T           # tools/test.py
+    size = 1024
+    rng = np.random.RandomState(0)
+    images, annotations, aid = [], [], 0
+    for i in range(3):
+        name = f'tile_{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name, compress_level=1)
+        images.append(dict(id=10 + i, file_name=name, width=size, height=size))
+        k = 0
+        while k < 12:                                   # well-separated axis-aligned buildings with in-image footprints
+            w, h = rng.uniform(40, 120, 2)
+            x, y = rng.uniform(60, size - 200, 2)
+            ox, oy = rng.uniform(-30, 30, 2)
+            box = [x, y, x + w, y + h]
+            if any(not (box[2] + 40 < b[0] or b[2] + 40 < box[0] or box[3] + 40 < b[1] or b[3] + 40 < box[1])
+                   for b in (a['_box'] for a in annotations if a['image_id'] == 10 + i)):
+                continue
+            aid += 1
+            k += 1
+            annotations.append(dict(id=aid, image_id=10 + i, category_id=1, iscrowd=0, area=float(w * h), _box=box,
+                                    bbox=[float(x), float(y), float(w), float(h)], roof_bbox=[float(x), float(y), float(w), float(h)],
+                                    building_bbox=[float(x - 30), float(y - 30), float(w + 60), float(h + 60)],
+                                    footprint_bbox=[float(x - ox), float(y - oy), float(w), float(h)],
+                                    segmentation=[[float(v) for v in (x, y, x + w, y, x + w, y + h, x, y + h)]],
+                                    footprint_mask=[float(v) for v in (x - ox, y - oy, x + w - ox, y - oy, x + w - ox, y + h - oy, x - ox, y + h - oy)],
+                                    offset=[float(ox), float(oy)], building_height=10.0))
+    f = tmp_path / 'bonai_test.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    ds = BonaiDataset(str(f), str(tmp_path), test_mode=True)
+    assert len(ds) == 3
+    # (1) ground truth as predictions
+    recs = []
+    for i in range(len(ds)):
+        ann = ds.get_ann_info(i)
+        roofs = K.poly2mask(ann['roof_masks'], size, size)
+        boxes = np.concatenate([ann['bboxes'], np.ones((len(ann['bboxes']), 1), np.float32)], 1)
+        recs.append(E.evaluate_image(roofs, boxes, ann['offsets'], ann))
+    s = E.summarize(recs)
+    assert s['roof']['F1_score'] == 1.0 and s['roof']['TP'] == 36 and s['roof']['FN'] == 0 and s['roof']['FP'] == 0
+    assert s['footprint']['F1_score'] == 1.0 and s['footprint']['TP'] == 36
+    assert s['offset']['pairs'] == 36 and s['offset']['aEPE'] < 1e-6 and s['offset']['aAE'] < 1e-6
+    # wrong offsets: footprints leave their buildings -> no footprint pair, roofs unaffected; a score / area filter drops predictions
+    ann = ds.get_ann_info(0)
+    roofs = K.poly2mask(ann['roof_masks'], size, size)
+    boxes = np.concatenate([ann['bboxes'], np.ones((12, 1), np.float32)], 1)
+    r = E.evaluate_image(roofs, boxes, ann['offsets'] + 400.0, ann)
+    assert len(r['roof']['gt_TP']) == 12 and len(r['footprint']['gt_TP']) == 0 and len(r['footprint']['pred_FP']) == 12
+    boxes[:5, 4] = 0.1
+    assert E.evaluate_image(roofs, boxes, ann['offsets'], ann)['num_pred'] == 7
+    assert E.evaluate_image(roofs, boxes, ann['offsets'], ann, min_area=1e9)['num_pred'] == 0
+    # (2) the HIP model through tools/test.py's loop
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    m = m.cuda().eval()
+    results, records = T.run_dataset(m, ds, evaluate=True, eval_kw=dict(score_thr=0.0, min_area=0), log=lambda *_: None)
+    assert len(results) == 3 and len(records) == 3
+    for (bbox_res, segm, offs), rec in zip(results, records):
+        n = bbox_res[0].shape[0]
+        assert len(segm[0]) == n and np.asarray(offs).reshape(-1, 2).shape[0] == n and rec['num_pred'] == n and rec['num_gt'] == 12
+    (bbox_res, segm, offs) = results[-1]
+    if bbox_res[0].shape[0]:                            # the RLE of the pickle is the device bitmap the evaluation saw
+        dm = rle_decode(segm[0][0])
+        assert np.array_equal(np.asarray(dm, bool), m.roi_head.last_device_masks[0].bool().cpu().numpy())
+    out = E.summarize(records)
+    assert set(out) == {'roof', 'footprint', 'offset'} and out['roof']['TP'] + out['roof']['FN'] >= 36

@@ -292,3 +292,65 @@ def test_training_trajectory_vs_cpu_oracle(first_k):
         report[n] = (round(cos, 4), round(float(ua.norm() / (ub.norm() + 1e-30)), 4))
         assert cos > 0.97 and 0.9 < float(ua.norm() / (ub.norm() + 1e-30)) < 1.1, (n, report[n])
     print('update after 5 steps, HIP vs CPU oracle (cosine, norm ratio):', report)
+
+
+def test_graph_replay_follows_the_optimizer_and_survives_reloaded_frozen_weights(first_k):
+    """(a) with lr > 0 and momentum the replayed graphs must read the weights the SGD kernel just wrote (operand
+    packings re-made every step into the buffers whose addresses the graphs hold) -- five optimisation steps under
+    graph_features=True against the same five steps on eager launches: same loss trajectory, same parameter updates; (b) a
+    FROZEN weight replaced after capture (load_state_dict mid-run: its cached packing, whose address is baked into the graphs,
+    is stale) is noticed before the next replay -- the graphs are dropped with a warning and recaptured, and the step's
+    gradients equal plain autograd's on the new weights; (c) a model that has run can be pickled (pack cache entries hold weak
+    references)."""
+    import copy
+    import pickle
+    import warnings
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    data = make_batch(2, 256, 8, device='cuda')
+    logs, finals = {}, {}
+    for mode in ('eager', 'graph'):
+        m = _synth_model()
+        init = {n: p.detach().clone() for n, p in m.named_parameters()}
+        tr = Trainer(m, lr=5e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0, graph_features=(mode == 'graph'))
+        logs[mode] = [dict(tr.train_step(data)['log_vars'].items()) for _ in range(5)]
+        torch.cuda.synchronize()
+        if mode == 'graph':
+            assert tr._fgraphs.ready and tr._fgraphs.failed is None and tr._fgraphs.pack_deps, tr._fgraphs.failed
+        finals[mode] = {n: (p.detach() - init[n]).flatten() for n, p in m.named_parameters() if p.requires_grad}
+    for i, (a, b) in enumerate(zip(logs['eager'], logs['graph'])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 0.03 * max(1.0, abs(a[k])), (i, k, a[k], b[k])
+    for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer3.1.bn2.weight',
+              'neck.fpn_convs.0.conv.weight', 'neck.lateral_convs.2.conv.weight'):
+        ua, ub = finals['eager'][n], finals['graph'][n]
+        cos = float(torch.dot(ua, ub) / (ua.norm() * ub.norm() + 1e-30))
+        assert cos > 0.98 and 0.93 < float(ua.norm() / (ub.norm() + 1e-30)) < 1.07, (n, cos)
+    # (b) lr = 0 from here on; replace a frozen stem / layer1 weight in place of the captured one
+    m = _synth_model()
+    tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0, graph_features=True)
+    for _ in range(3):
+        tr.train_step(data, lr=0.0)
+    assert tr._fgraphs.ready
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad and n.startswith('backbone.layer1') and n.endswith('conv2.weight')]
+    assert frozen
+    sd[frozen[0]] = sd[frozen[0]] * 1.5
+    m.load_state_dict(sd)
+    ref = _synth_model()
+    ref.load_state_dict(sd)
+    want = _autograd_grads(ref, data)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+    assert any('dropped and recaptured' in str(x.message) for x in w), [str(x.message) for x in w]
+    assert tr._fgraphs.ready and tr._fgraphs.stale is not None
+    _compare(want, m, 'after the frozen weight changed under a live graph')
+    tr.train_step(data, lr=0.0)                                    # and the recaptured graphs replay
+    torch.cuda.synchronize()
+    _compare(want, m, 'replay of the recaptured graphs')
+    # (c)
+    blob = pickle.dumps(m.backbone.conv1)
+    assert pickle.loads(blob).weight.shape == m.backbone.conv1.weight.shape
+    copy.deepcopy(m.backbone.layer1)

@@ -211,6 +211,76 @@ class BonaiDataset:
             return
         yield from _Prefetcher(self, groups, device, depth=prefetch, workers=workers, processes=processes)
 
+    # ---- decoder processes and their staging block live as long as the dataset (forking a process that has a HIP context mapped
+    # costs ~0.1 s per worker: paid once, not per epoch)
+    def _decoder_pool(self, workers):
+        pool = getattr(self, '_pool', None)
+        if pool is None or self._pool_workers != workers:
+            if pool is not None:
+                pool.shutdown(wait=True, cancel_futures=True)
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            self._pool = ProcessPoolExecutor(workers, mp_context=mp.get_context('fork'))
+            self._pool_workers = workers
+            list(self._pool.map(_worker_ready, range(workers)))          # fork them all now
+        return self._pool
+
+    def _staging_block(self, nslots, bs, h, w, cuda):
+        import torch
+        st = getattr(self, '_staging', None)
+        if st is not None and st['shape'] == (nslots, bs, h, w) and st['cuda'] == cuda:
+            return st
+        self._release_staging()
+        from multiprocessing import shared_memory
+        shm = shared_memory.SharedMemory(create=True, size=nslots * bs * h * w * 3)
+        whole = torch.from_numpy(np.ndarray((nslots, bs, h, w, 3), dtype=np.uint8, buffer=shm.buf))
+        registered = None
+        if cuda:
+            try:                                            # pinned in place: the H2D copy of a slot is one asynchronous DMA
+                if int(torch.cuda.cudart().cudaHostRegister(whole.data_ptr(), whole.numel(), 0)) == 0:
+                    registered = whole.data_ptr()
+            except Exception:                               # noqa -- unpinned staging still works (the copy is then synchronous)
+                registered = None
+        self._staging = dict(shm=shm, whole=whole, registered=registered, shape=(nslots, bs, h, w), cuda=cuda)
+        return self._staging
+
+    def _release_staging(self):
+        st = getattr(self, '_staging', None)
+        if st is None:
+            return
+        import torch
+        if st['cuda']:
+            torch.cuda.synchronize()
+            if st['registered'] is not None:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(st['registered'])
+                except Exception:                           # noqa
+                    pass
+        st['whole'] = None
+        try:
+            st['shm'].close()
+        except BufferError:
+            pass
+        try:
+            st['shm'].unlink()
+        except FileNotFoundError:
+            pass
+        self._staging = None
+
+    def close(self):
+        """Stop the decoder processes and free the staging block (also done when the dataset is collected)."""
+        pool = getattr(self, '_pool', None)
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+            self._pool = None
+        self._release_staging()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # noqa
+            pass
+
     def test_batches(self, device='cuda'):
         """Test mode, samples_per_gpu = 1 (mmdet/apis/test.py:26 with the test pipeline of bonai_instance.py:18-31: one scale,
         no flip): yields (idx, dict(img=[tensor 1x3xHxW], img_metas=[[meta]])) in dataset order."""
@@ -223,6 +293,12 @@ class BonaiDataset:
 
 
 _SHM_CACHE = {}
+
+
+def _worker_ready(i):
+    import time
+    time.sleep(0.05)          # (keeps the first `workers` tasks on distinct processes: every worker is forked at pool creation)
+    return i
 
 
 def decode_tile_into(path, shm_name, offset, h, w):
@@ -271,21 +347,13 @@ class _Prefetcher:
         bs = max(len(g) for g in groups) if groups else 0
         w, h = ds.img_scale
         # ring of staging buffers: depth in the queue + one being filled + one the consumer's upload may still read
-        self.slots, self.shm, self.registered = [], None, None
+        self.slots, self.shm = [], None
         nslots = self.depth + 2
         if self.processes and bs:
-            from multiprocessing import shared_memory
-            self.slot_bytes = bs * h * w * 3
-            self.shm = shared_memory.SharedMemory(create=True, size=nslots * self.slot_bytes)
-            whole = torch.from_numpy(np.ndarray((nslots, bs, h, w, 3), dtype=np.uint8, buffer=self.shm.buf))
-            if self.cuda:
-                try:                                        # pinned in place: the H2D copy of a slot is one asynchronous DMA
-                    rt = torch.cuda.cudart()
-                    if int(rt.cudaHostRegister(whole.data_ptr(), whole.numel(), 0)) == 0:
-                        self.registered = whole.data_ptr()
-                except Exception:                           # noqa -- unpinned staging still works (the copy is then synchronous)
-                    self.registered = None
-            self.slots = [whole[k] for k in range(nslots)]
+            st = ds._staging_block(nslots, bs, h, w, self.cuda)
+            self.shm, self.slot_bytes = st['shm'], bs * h * w * 3
+            self.slots = [st['whole'][k] for k in range(nslots)]
+            self.pool = ds._decoder_pool(self.workers)
         else:
             for _ in range(nslots):
                 t = torch.empty((bs, h, w, 3), dtype=torch.uint8)
@@ -301,12 +369,8 @@ class _Prefetcher:
         try:
             if self.cuda:
                 torch.cuda.set_device(self.device)
-            if self.processes:
-                import multiprocessing as mp
-                from concurrent.futures import ProcessPoolExecutor
-                pool_cm = ProcessPoolExecutor(self.workers, mp_context=mp.get_context('fork'))
-            else:
-                pool_cm = ThreadPoolExecutor(self.workers, thread_name_prefix='bonai-decode')
+            import contextlib
+            pool_cm = contextlib.nullcontext(self.pool) if self.processes else ThreadPoolExecutor(self.workers, thread_name_prefix='bonai-decode')
             with pool_cm as pool:
                 for bi, g in enumerate(self.groups):
                     if self.stop.is_set():
@@ -382,22 +446,6 @@ class _Prefetcher:
 
     def _release(self):
         import torch
-        if self.shm is not None:
-            if self.cuda:
-                torch.cuda.synchronize(self.device)                # no upload may still be reading the block
-            if self.registered is not None:
-                try:
-                    torch.cuda.cudart().cudaHostUnregister(self.registered)
-                except Exception:                                  # noqa
-                    pass
-                self.registered = None
-            self.slots = []
-            try:
-                self.shm.close()
-            except BufferError:                                    # a view of the block is still referenced somewhere: leave it to gc
-                pass
-            try:
-                self.shm.unlink()
-            except FileNotFoundError:
-                pass
-            self.shm = None
+        if self.cuda:
+            torch.cuda.synchronize(self.device)                    # no upload may still be reading the staging ring
+        self.slots = []

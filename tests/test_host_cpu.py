@@ -380,6 +380,7 @@ def test_prefetching_loader_emits_the_synchronous_loaders_stream(tmp_path):
     it = iter(b.batches(0, 2, device='cpu', seed=5, prefetch=2))
     next(it)
     it.close()                                                     # consumer walks away: the producer thread must end
+    b.close()                                                      # (and the dataset's decoder processes + their manager threads)
     deadline = __import__('time').time() + 10
     while threading.active_count() > n_threads and __import__('time').time() < deadline:
         __import__('time').sleep(0.05)

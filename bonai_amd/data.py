@@ -150,7 +150,7 @@ def _masks_of(s, dev):
     if 'gt_polygons' in s and s.get('gt_masks') is None:
         from . import kernels as K
         h, w = s['img'].shape[:2]
-        m = K.poly2mask(s['gt_polygons'], h, w, device=dev)
+        m = K.poly2mask(s.get('gt_polygons_packed') or s['gt_polygons'], h, w, device=dev)
         for d in s.get('mask_flips', ()):                   # flip_sample on a polygon sample: the bitmap is mirrored, as the
             m = m.flip(2 if d == 'horizontal' else 1)       # reference's RandomFlip does after LoadAnnotations rasterised it
         return m.contiguous()
@@ -191,8 +191,60 @@ def to_device_batch(samples, device='cuda', mean=(123.675, 116.28, 103.53), std=
                           scale_factor=np.array([1., 1., 1., 1.], dtype=np.float32), flip=bool(s.get('flip', False)),
                           flip_direction=s.get('flip_direction'),
                           img_norm_cfg=dict(mean=np.array(mean, np.float32), std=np.array(std, np.float32), to_rgb=to_rgb)))
+    if dev.type == 'cuda' and staged is not None:
+        # the loader's path: every small array of the batch (boxes, labels, offsets, polygon vertices and their offset tables)
+        # in ONE pinned buffer and ONE asynchronous copy -- 48 pageable synchronous copies of a few hundred bytes each were
+        # 5 of the 6 ms this function held the interpreter lock next to the training loop
+        return dict(img=img, img_metas=metas, **_small_arrays_one_copy(samples, dev))
     return dict(img=img, img_metas=metas,
                 gt_bboxes=[torch.from_numpy(np.asarray(s['gt_bboxes'], np.float32)).to(dev) for s in samples],
                 gt_labels=[torch.from_numpy(np.asarray(s['gt_labels'], np.int64)).to(dev) for s in samples],
                 gt_masks=[_masks_of(s, dev) for s in samples],
                 gt_offsets=[torch.from_numpy(np.asarray(s['gt_offsets'], np.float32).reshape(-1, 2)).to(dev) for s in samples])
+
+
+def _small_arrays_one_copy(samples, dev):
+    from . import kernels as K
+    arrs, slots = [], []          # (numpy array) and (sample index, field)
+    packs = []
+    for i, s in enumerate(samples):
+        arrs += [np.ascontiguousarray(s['gt_bboxes'], np.float32), np.ascontiguousarray(s['gt_labels'], np.int64),
+                 np.ascontiguousarray(np.asarray(s['gt_offsets'], np.float32).reshape(-1, 2))]
+        slots += [(i, 'gt_bboxes'), (i, 'gt_labels'), (i, 'gt_offsets')]
+        pk = None
+        if 'gt_polygons' in s and s.get('gt_masks') is None:
+            pk = s.get('gt_polygons_packed') or K.pack_polygons(s['gt_polygons'])
+            arrs += [pk.xy, pk.poff, pk.ioff]
+            slots += [(i, '_xy'), (i, '_poff'), (i, '_ioff')]
+        packs.append(pk)
+    offs, total = [], 0
+    for a in arrs:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, o in zip(arrs, offs):
+        if a.nbytes:
+            hv[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    devb = host.to(dev, non_blocking=True)
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64}
+    out = dict(gt_bboxes=[None] * len(samples), gt_labels=[None] * len(samples), gt_offsets=[None] * len(samples))
+    aux = [dict() for _ in samples]
+    for a, o, (i, name) in zip(arrs, offs, slots):
+        t = devb[o:o + a.nbytes].view(tdt[a.dtype]).view(a.shape)
+        if name[0] == '_':
+            aux[i][name] = t
+        else:
+            out[name][i] = t
+    masks = []
+    for i, s in enumerate(samples):
+        if packs[i] is None:
+            masks.append(_masks_of(s, dev))
+            continue
+        h, w = s['img'].shape[:2]
+        m = K.poly2mask_device(aux[i]['_xy'], aux[i]['_poff'], aux[i]['_ioff'], packs[i].n, h, w, packs[i].maxv)
+        for d in s.get('mask_flips', ()):
+            m = m.flip(2 if d == 'horizontal' else 1)
+        masks.append(m.contiguous())
+    out['gt_masks'] = masks
+    return out

@@ -162,6 +162,12 @@ class BonaiDataset:
             sample['img_rgb'] = True
         if self.host_rasteriser is None:
             sample['gt_polygons'] = ann['masks']
+            if img_out is not None:                 # the prefetching loader: vertex arrays for loft_poly2mask, packed once per image
+                pk = ann.get('_packed')
+                if pk is None:
+                    from .kernels import pack_polygons
+                    pk = ann['_packed'] = pack_polygons(ann['masks'])
+                sample['gt_polygons_packed'] = pk
         else:
             sample['gt_masks'] = np.stack([self.host_rasteriser(m, h, w) for m in ann['masks']])
         if self.flip_ratio and (self.rng.rand() if flip_draw is None else flip_draw) < self.flip_ratio:
@@ -313,6 +319,11 @@ def decode_tile_into(path, shm_name, offset, h, w):
                 v.close()
             _SHM_CACHE.clear()
         shm = _SHM_CACHE[shm_name] = shared_memory.SharedMemory(name=shm_name)
+        try:        # the parent owns the block: an attaching process must not report it to the resource tracker as its own leak
+            from multiprocessing import resource_tracker
+            resource_tracker.unregister(shm._name, 'shared_memory')
+        except Exception:       # noqa
+            pass
     im = Image.open(path)
     if im.mode != 'RGB':
         im = im.convert('RGB')

@@ -863,12 +863,41 @@ def poly2mask(instances, H, W, device='cuda'):
     """instances: list (one per instance) of lists of polygons, each polygon a flat [x0, y0, x1, y1, ...] sequence (the BONAI
     ``segmentation`` / ``[footprint_mask]`` fields) -> uint8 [K, H, W] device tensor.  LoadAnnotations._poly2mask
     (datasets/pipelines/loading.py:301-326) for every instance of a tile in ONE launch; only the vertices cross PCIe."""
-    import numpy as np
     lib = L.load()
-    K_ = len(instances)
+    pk = instances if isinstance(instances, PackedPolygons) else pack_polygons(instances)
+    K_ = pk.n
     out = torch.empty(K_, H, W, dtype=torch.uint8, device=device)
     if K_ == 0:
         return out
+    xy = torch.from_numpy(pk.xy).to(device)
+    poff_t = torch.from_numpy(pk.poff).to(device)
+    ioff_t = torch.from_numpy(pk.ioff).to(device)
+    L.check(lib.loft_poly2mask(L.ptr(xy), L.ptr(poff_t), L.ptr(ioff_t), K_, H, W, int(pk.maxv), L.ptr(out), L.stream()), 'loft_poly2mask')
+    return out
+
+
+def poly2mask_device(xy, poff, ioff, n, H, W, maxv):
+    """loft_poly2mask on tables that are already on the device (fp64 [V,2], int64 offsets): the loader uploads them together with
+    the batch's other small arrays in one copy."""
+    lib = L.load()
+    L.dev_check(xy, poff, ioff)
+    out = torch.empty(n, H, W, dtype=torch.uint8, device=xy.device)
+    if n:
+        L.check(lib.loft_poly2mask(L.ptr(xy), L.ptr(poff), L.ptr(ioff), n, H, W, int(maxv), L.ptr(out), L.stream()), 'loft_poly2mask')
+    return out
+
+
+class PackedPolygons:
+    """The host arrays loft_poly2mask reads (vertices fp64 [V,2], polygon offsets, instance offsets): built once per annotation
+    (pack_polygons) and reusable -- the loader caches it per image instead of re-walking ~100 python lists every epoch."""
+    __slots__ = ('xy', 'poff', 'ioff', 'maxv', 'n')
+
+    def __init__(self, xy, poff, ioff, maxv, n):
+        self.xy, self.poff, self.ioff, self.maxv, self.n = xy, poff, ioff, maxv, n
+
+
+def pack_polygons(instances):
+    import numpy as np
     pts, poff, ioff = [], [0], [0]
     for inst in instances:
         for poly in inst:
@@ -877,11 +906,8 @@ def poly2mask(instances, H, W, device='cuda'):
             poff.append(poff[-1] + a.shape[0])
         ioff.append(len(poff) - 1)
     maxv = max((b - a for a, b in zip(poff[:-1], poff[1:])), default=0)
-    xy = torch.from_numpy(np.concatenate(pts, 0) if pts else np.zeros((0, 2))).to(device)
-    poff_t = torch.tensor(poff, dtype=torch.int64, device=device)
-    ioff_t = torch.tensor(ioff, dtype=torch.int64, device=device)
-    L.check(lib.loft_poly2mask(L.ptr(xy), L.ptr(poff_t), L.ptr(ioff_t), K_, H, W, int(maxv), L.ptr(out), L.stream()), 'loft_poly2mask')
-    return out
+    xy = np.ascontiguousarray(np.concatenate(pts, 0) if pts else np.zeros((0, 2)), dtype=np.float64)
+    return PackedPolygons(xy, np.asarray(poff, np.int64), np.asarray(ioff, np.int64), int(maxv), len(instances))
 
 
 def mask_target(masks_u8, boxes, gt_idx, S=28):

@@ -270,7 +270,15 @@ def main():
             props[:, :njit] = jit
             return losses, (props, counts.clamp(min=njit))
         model.rpn_head.forward_train = saturated
+    if comm is not None and trainer.reducer.on_gpu:
+        trainer.reducer.measure = True
     value, ms_step, mean_pos, mean_roi = timed(0)
+    if comm is not None and trainer.reducer.on_gpu:
+        # gradient all-reduce time the backward pass did not hide, mean over this rank's steps of the primary timed loop
+        # (includes its warm-up steps); rank 0's view -- every rank waits for the same collectives
+        ex = trainer.reducer.exposed_ms()
+        comm['exposed_ms'] = None if ex is None else round(ex, 3)
+        trainer.reducer.measure = False
     elapsed = ms_step * args.steps / 1e3
     if saturate and not args.no_light:
         model.rpn_head.forward_train = orig_ft

@@ -43,26 +43,32 @@
 // into LDS, 4 waves, swizzled as conv_epilogue expects.
 __device__ __forceinline__ void conv_stage_tile(const ConvArgs& a, const bf16_t* t, long out_g, int m0, int n0, int wave, int lane,
                                                 char* dst) {
+    int aM = a.M, aCout = a.Cout;
+    const bf16_t* zp = a.zero_page;
+    LOFT_KEEP_S(aM); LOFT_KEEP_S(aCout);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 16 + wave * 4 + (lane >> 4);
         const int lc = (lane & 15) ^ (row & 15);
         const int m = m0 + row, n = n0 + lc * 8;
-        const bf16_t* p = (m < a.M && n < a.Cout) ? t + out_g + (long)m * a.Cout + n : a.zero_page;
+        const bf16_t* p = (m < aM && n < aCout) ? t + out_g + (long)m * aCout + n : zp;
         __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(dst + (it * 16 + wave * 4) * 256), 16, 0, 0);
     }
 }
 
 // The reverse: the finished [128][128] bf16 tile from LDS to the (dense) output, 16 bytes per lane, 16 lanes per 256-byte row.
 __device__ __forceinline__ void conv_unstage_tile(const ConvArgs& a, long out_g, int m0, int n0, int wave, int lane, const char* srct) {
+    int aM = a.M, aCout = a.Cout;
+    void* aout = a.out;
+    LOFT_KEEP_S(aM); LOFT_KEEP_S(aCout);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 16 + wave * 4 + (lane >> 4);
         const int lc = (lane & 15) ^ (row & 15);
         const int m = m0 + row, n = n0 + lc * 8;
-        if (m < a.M && n < a.Cout) {
+        if (m < aM && n < aCout) {
             const uint4 v = *reinterpret_cast<const uint4*>(srct + row * 256 + (lane & 15) * 16);
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.out) + out_g + (long)m * a.Cout + n) = v;
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(aout) + out_g + (long)m * aCout + n) = v;
         }
     }
 }

@@ -61,6 +61,12 @@ struct ConvArgs {
     int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
 };
 
+// A kernarg scalar made OPAQUE to the compiler at this point: hipcc treats ConvArgs fields as rematerialisable loads and re-fetches
+// them from scalar memory (s_load + s_waitcnt lgkmcnt(0), ~100-200 cycles each) inside unrolled row loops instead of keeping them
+// in SGPRs -- the epilogues' row stores ran 6-9 such round trips apiece (round 4, ISA of conv_tap_kernel / conv_tap_pipe_kernel).
+// After LOFT_KEEP_S(x) the value lives in a register the compiler cannot re-derive from memory.
+#define LOFT_KEEP_S(x) asm volatile("" : "+s"(x))
+
 // n / d for 0 <= n < 2^31 with (mul, sh) = fastdiv_setup(d): q = (umulhi(n, mul) + n) >> sh  (Granlund-Montgomery)
 __device__ __forceinline__ int fastdiv(int n, unsigned mul, unsigned sh) {
     return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> sh);
@@ -98,20 +104,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
     //  64-byte runs -- 8 % slower end to end: store width per lane matters more than run contiguity, L2 merges the lines.)
     const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
     const long out_g = (long)g * a.out_gs;
+    // every scalar of the row / store loops in registers the compiler cannot re-fetch from the kernarg segment (LOFT_KEEP_S)
+    int aM = a.M, aB = a.B, aOW = a.OW, aOHf = a.OHf, aOWf = a.OWf, aos = a.os, aoy = a.oo_y, aox = a.oo_x, aCout = a.Cout;
+    int arelu = a.relu, af32 = a.out_f32, aacc = a.accumulate;
+    const bf16_t* ares = a.residual;
+    const bf16_t* amask = a.mask;
+    void* aout = a.out;
+    LOFT_KEEP_S(aM); LOFT_KEEP_S(aB); LOFT_KEEP_S(aOW); LOFT_KEEP_S(aOHf); LOFT_KEEP_S(aOWf); LOFT_KEEP_S(aos); LOFT_KEEP_S(aoy);
+    LOFT_KEEP_S(aox); LOFT_KEEP_S(aCout); LOFT_KEEP_S(arelu); LOFT_KEEP_S(af32); LOFT_KEEP_S(aacc); LOFT_KEEP_S(ares);
+    LOFT_KEEP_S(amask); LOFT_KEEP_S(aout);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * WM + j * 32 + frow;
-        if (m >= a.M) continue;
+        if (m >= aM) continue;
         int b, rem;
-        if (pixmajor) { rem = m / a.B; b = m - rem * a.B; } else { b = m / ohw; rem = m - b * ohw; }
-        const int oy = rem / a.OW, ox = rem - oy * a.OW;
-        const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+        if (pixmajor) { rem = m / aB; b = m - rem * aB; } else { b = m / ohw; rem = m - b * ohw; }
+        const int oy = rem / aOW, ox = rem - oy * aOW;
+        const long opix = ((long)b * aOHf + oy * aos + aoy) * aOWf + ox * aos + aox;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int n = n0 + wn * WN + i * 32 + 8 * gq + 4 * fq;
-                if (n >= a.Cout) continue;
+                if (n >= aCout) continue;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
@@ -119,32 +134,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     const float4 bv = *reinterpret_cast<const float4*>(bias + n);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                const long o = out_g + opix * a.Cout + n;
+                const long o = out_g + opix * aCout + n;
                 const int trow = wm * WM + j * 32 + frow;                      // position inside a staged 128x128 tile
                 const int tcol = (((wn * WN + i * 32 + 8 * gq) >> 3) ^ (trow & 15)) * 16 + 8 * fq;
-                if (a.residual) {
+                if (ares) {
                     float rv[4];
                     if (res_t) ld4(reinterpret_cast<const bf16_t*>(res_t + trow * 256 + tcol), rv);
-                    else ld4(a.residual + o, rv);
+                    else ld4(ares + o, rv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rv[e];
                 }
-                if (a.relu) {
+                if (arelu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (a.mask) {
+                if (amask) {
                     float mv[4];
                     if (mask_t) ld4(reinterpret_cast<const bf16_t*>(mask_t + trow * 256 + tcol), mv);
-                    else ld4(a.mask + o, mv);
+                    else ld4(amask + o, mv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
                 }
                 if (out_t) {              // bf16 tile collected in LDS (same swizzle), written out by conv_unstage_tile
                     st4(reinterpret_cast<bf16_t*>(out_t + trow * 256 + tcol), v);
-                } else if (a.out_f32) {
-                    float* op = reinterpret_cast<float*>(a.out) + o;
-                    if (a.accumulate) {
+                } else if (af32) {
+                    float* op = reinterpret_cast<float*>(aout) + o;
+                    if (aacc) {
                         float ov[4];
                         ld4(op, ov);
 #pragma unroll
@@ -152,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     }
                     st4(op, v);
                 } else {
-                    st4(reinterpret_cast<bf16_t*>(a.out) + o, v);
+                    st4(reinterpret_cast<bf16_t*>(aout) + o, v);
                 }
             }
         }

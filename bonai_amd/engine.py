@@ -106,6 +106,7 @@ class BucketedAllReduce:
             for p in arena.order:
                 p.register_post_accumulate_grad_hook(self._autograd_hook)
         self._remaining = None
+        self.measure, self.exposed = False, []      # bench.py: record (backward end, last collective end) event pairs per step
         self.capturing = False     # True while bonai_amd.graphs records a section: nothing may be released or launched from it
 
     def begin(self):
@@ -176,16 +177,33 @@ class BucketedAllReduce:
             self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
 
     def finish(self):
-        """Make the main stream wait for every outstanding collective (no host sync)."""
+        """Make the main stream wait for every outstanding collective (no host sync).  With ``measure`` set, two events bracket
+        what the step could not hide: the end of backward on the main stream and the end of the last collective on the side
+        stream (``exposed_ms()`` after a synchronisation)."""
         if not self.enabled:
             return
         while self._next < len(self.buckets):   # buckets holding parameters that got no gradient this step
             self._launch(self._next)
             self._next += 1
+        if self.on_gpu and self.measure:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         for w in self.works:
             w.wait()
         if self.on_gpu:
+            if self.measure:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(self.stream)
+                self.exposed.append((e0, e1))
             torch.cuda.current_stream().wait_stream(self.stream)
+
+    def exposed_ms(self):
+        """Mean over the measured steps of max(0, end of the last gradient collective - end of backward): the all-reduce time the
+        backward pass did not cover.  Call after torch.cuda.synchronize(); clears the record."""
+        ev, self.exposed = self.exposed, []
+        if not ev:
+            return None
+        return sum(max(0.0, a.elapsed_time(b)) for a, b in ev) / len(ev)
 
 
 def step_lr(base_lr, it, epoch, warmup_iters=300, warmup_ratio=0.001, steps=(16, 22), gamma=0.1, step=None):

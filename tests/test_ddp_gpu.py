@@ -199,3 +199,26 @@ def test_bench_launch_contract_two_ranks():
     assert j['config']['global_batch'] == 4 and j['config']['parallelism'] == 'dp2' and j['value'] > 0
     assert 'roofline' in j and 'cpu_baseline' not in j
     assert j['comm']['rccl_ranks_seen'] == 2 and j['comm']['buckets'] >= 8 and j['comm']['bucket_mib'] <= 52
+    assert 'exposed_ms' in j['comm']
+
+
+@pytest.mark.timeout(1500)
+def test_bench_launch_contract_eight_ranks():
+    """the driver's N = 8 command line on this 1-GPU box -- eight ranks sharing the device over gloo at a
+    tiny size: the rendezvous, the reducer's bucket order under eight autograd threads' worth of rank skew, the max-over-ranks
+    timing and the single JSON line with the whole-job value all run before the driver's first real 8-GPU launch does."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, LOFT_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+           '--batch', '1', '--size', '256', '--num-gt', '8', '--no-light', '--no-roofline']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 8 and j['scaling'] == 'weak' and j['steps'] == 2 and j['warmup'] == 1
+    assert j['config']['global_batch'] == 8 and j['config']['parallelism'] == 'dp8' and j['value'] > 0
+    assert j['comm']['rccl_ranks_seen'] == 8 and 'cpu_baseline' not in j and j.get('value_fp32_parity') is None

@@ -333,6 +333,125 @@ __device__ __forceinline__ int block_exscan(int v, int* total, int* wsum /*[16]*
     return base + inc - v;
 }
 
+// ---------------------------------------------------------------- segmented top-k (in-house; round 4)
+// What the training step needs from `scores.sort(descending=True)` + `[:nms_pre]` (rpn_head.py:129-136) and from the final
+// `dets[:nms_post]` (rpn_head.py:166-168) is only the FIRST k entries of each segment's stable descending order -- 3000 of up to
+// 196 608 anchors per (image, level), 1000-2000 of 12 768 candidates per image.  One workgroup per segment, no library:
+//   1. radix SELECT of the k-th largest key: three histogram passes (11 + 11 + 10 bits of the order-preserving key image) in LDS;
+//   2. one pass appends every key above that threshold -- and the threshold's own ties -- to an LDS candidate list (<= 4096 x 8 B);
+//      ties that straddle position k are taken in INDEX order (an ordered chunked scan; only on that rare path), which is what a
+//      stable sort followed by [:k] keeps;
+//   3. bitonic sort of the candidates on (key descending, index ascending), written to the head of the segment's output range.
+// Bit-identical to the first k entries of loft_segmented_sort_desc (tests/test_roi_nms_gpu.py); entries past k are not written.
+#define TOPK_MAX 4096
+__device__ __forceinline__ unsigned topk_ord(float f) {
+    unsigned u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;                                     // -0.0 == +0.0 must tie
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);                // larger value <-> larger unsigned
+}
+__global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __restrict__ keys, const int32_t* __restrict__ vals_in,
+                                                               const int64_t* __restrict__ seg_off, int k,
+                                                               float* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long cand[TOPK_MAX];
+    __shared__ int wsum[SNMS_THREADS / 64];
+    __shared__ unsigned s_bin, s_need, s_cnt;
+    const int tid = threadIdx.x;
+    const long s0 = seg_off[blockIdx.x], s1 = seg_off[blockIdx.x + 1];
+    const int len = (int)(s1 - s0);
+    const int kk = k < len ? k : len;
+    if (kk <= 0) return;
+    const float* kp = keys + s0;
+    unsigned T = 0u, need = (unsigned)kk, total_eq = 0u;
+    if (kk < len) {
+        unsigned prefix = 0u, pmask = 0u;
+        const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const int sh = shifts[pass], nb = 1 << nbits[pass];
+            for (int b = tid; b < 2048; b += SNMS_THREADS) hist[b] = 0u;
+            __syncthreads();
+            for (int i = tid; i < len; i += SNMS_THREADS) {
+                const unsigned o = topk_ord(kp[i]);
+                if ((o & pmask) == prefix) atomicAdd(&hist[(o >> sh) & (unsigned)(nb - 1)], 1u);
+            }
+            __syncthreads();
+            // bins in DESCENDING order, two per thread: the bin where the running count first reaches `need`
+            int tot;
+            const int b0 = nb - 1 - 2 * tid, b1 = nb - 2 - 2 * tid;
+            const unsigned h0 = b0 >= 0 ? hist[b0] : 0u, h1 = b1 >= 0 ? hist[b1] : 0u;
+            const unsigned before = (unsigned)block_exscan((int)(h0 + h1), &tot, wsum);
+            if (before < need && need <= before + h0) { s_bin = (unsigned)b0; s_need = need - before; s_cnt = h0; }
+            else if (before + h0 < need && need <= before + h0 + h1) { s_bin = (unsigned)b1; s_need = need - before - h0; s_cnt = h1; }
+            __syncthreads();
+            prefix |= s_bin << sh;
+            pmask |= (unsigned)(nb - 1) << sh;
+            need = s_need;
+            total_eq = s_cnt;
+            __syncthreads();
+        }
+        T = prefix;
+    }
+    // ---- candidates: everything above T in any order; T's ties in any order when all of them are taken, else by index
+    const unsigned n_gt = (unsigned)kk - (kk < len ? need : 0u);
+    auto compose = [](unsigned o, int i) { return ((unsigned long long)(~o) << 32) | (unsigned)i; };
+    if (tid == 0) s_cnt = 0u;
+    __syncthreads();
+    if (kk == len) {
+        for (int i = tid; i < len; i += SNMS_THREADS) cand[i] = compose(topk_ord(kp[i]), i);
+    } else if (total_eq == need) {
+        for (int i = tid; i < len; i += SNMS_THREADS) {
+            const unsigned o = topk_ord(kp[i]);
+            if (o >= T) cand[atomicAdd(&s_cnt, 1u)] = compose(o, i);
+        }
+    } else {
+        unsigned eq_base = 0u;
+        for (int c0 = 0; c0 < len; c0 += SNMS_THREADS) {
+            const int i = c0 + tid;
+            const unsigned o = i < len ? topk_ord(kp[i]) : 0u;
+            const bool in = i < len;
+            if (in && o > T) cand[atomicAdd(&s_cnt, 1u)] = compose(o, i);
+            const int fe = (in && o == T) ? 1 : 0;
+            int te;
+            const unsigned pe = (unsigned)block_exscan(fe, &te, wsum);
+            if (fe && eq_base + pe < need) cand[n_gt + eq_base + pe] = compose(o, i);
+            eq_base += (unsigned)te;
+        }
+    }
+    int P = 1;
+    while (P < kk) P <<= 1;
+    __syncthreads();
+    for (int i = kk + tid; i < P; i += SNMS_THREADS) cand[i] = ~0ull;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += SNMS_THREADS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned long long a = cand[lo], b = cand[hi];
+                const bool up = (lo & k2) == 0;
+                if ((a > b) == up) { cand[lo] = b; cand[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < kk; r += SNMS_THREADS) {
+        const unsigned long long c = cand[r];
+        const int i = (int)(unsigned)(c & 0xffffffffull);
+        const unsigned o = ~(unsigned)(c >> 32);
+        const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+        keys_out[s0 + r] = __uint_as_float(u);
+        vals_out[s0 + r] = vals_in ? vals_in[s0 + i] : (int32_t)(s0 + i);
+    }
+}
+LOFT_EXPORT int loft_segmented_topk_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out,
+                                         int num_segments, const int64_t* seg_offsets_dev, int k, void* stream) {
+    if (k < 1 || k > TOPK_MAX) return (int)hipErrorInvalidValue;
+    if (num_segments <= 0) return 0;
+    hipLaunchKernelGGL(seg_topk_kernel, dim3(num_segments), dim3(SNMS_THREADS), 0, (hipStream_t)stream, keys_in, vals_in,
+                       seg_offsets_dev, k, keys_out, vals_out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ __launch_bounds__(SNMS_THREADS) void soft_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                int n, float iou_thr, float sigma, float min_score, int method,
                                                                SnmsState s, float* __restrict__ dets, int64_t* __restrict__ inds,

@@ -313,6 +313,30 @@ def segmented_sort_desc(keys, seg_offsets, values=None):
     return ko, vo
 
 
+TOPK_MAX = 4096     # nms.hip TOPK_MAX: candidates of one segment sorted in one workgroup's LDS
+
+
+def segmented_topk_desc(keys, seg_offsets, k, values=None):
+    """The first k entries of each segment's stable descending order, in the layout of segmented_sort_desc (entry r of segment s at
+    seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  k <= TOPK_MAX: in-house select + LDS sort
+    (loft_segmented_topk_desc); larger k: the full sort."""
+    if k > TOPK_MAX:
+        return segmented_sort_desc(keys, seg_offsets, values)
+    lib = L.load()
+    L.dev_check(keys, seg_offsets)
+    keys = keys.float().contiguous()
+    S = seg_offsets.numel() - 1
+    ko = torch.empty_like(keys)
+    vo = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+    if keys.numel() == 0 or S <= 0:
+        return ko, vo
+    if values is not None:
+        values = values.to(torch.int32).contiguous()
+    L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), S, L.ptr(seg_offsets), int(k), L.stream()),
+            'loft_segmented_topk_desc')
+    return ko, vo
+
+
 def nms(boxes, scores, iou_thr, predicate='device'):
     """mmcv.ops.nms contract: -> (dets [M,5], keep [M] int64 in score-descending order)."""
     n = boxes.shape[0]

@@ -119,6 +119,13 @@ int loft_nms_segmented_pred(const float* boxes, const int64_t* seg_offsets, cons
 int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out,
                              int64_t num_items, int num_segments, const int64_t* seg_offsets, void* workspace,
                              int64_t* workspace_bytes, void* stream);
+/* loft_segmented_topk_desc: the first k (<= 4096) entries of every segment's STABLE descending order -- all the training step reads
+ * of `scores.sort(descending=True)[:nms_pre]` per (image, level) (rpn_head.py:129-136) and of the post-NMS `dets[:nms_post]`
+ * (rpn_head.py:166-168).  In-house radix select + LDS bitonic sort, one workgroup per segment, no workspace.  Outputs have the
+ * layout of loft_segmented_sort_desc (entry r of segment s at seg_offsets[s] + r); entries r >= min(k, segment length) are NOT
+ * written.  vals_in may be NULL (values = global element indices). */
+int loft_segmented_topk_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out, int num_segments,
+                             const int64_t* seg_offsets_dev, int k, void* stream);
 
 /* ---- dense contractions on MFMA -----------------------------------------------------------
  * loft_conv_tap_bf16: im2col-free NHWC convolution / linear layer, bf16 operands, fp32 accumulate.

@@ -163,6 +163,47 @@ def test_sort_stability():
         assert torch.equal(vs[a:b].cpu().long(), want)
 
 
+@pytest.mark.parametrize('k', [1, 768, 1000, 3000, 4096])
+def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
+    """loft_segmented_topk_desc (in-house radix select + LDS bitonic sort; the RPN's `sort(descending)[:nms_pre]` and the post-NMS
+    `[:nms_post]`): for every segment the first min(k, length) keys AND indices equal the stable descending sort's -- heavy ties
+    (keys quantised to one decimal: thousands of equal keys straddling position k), +0.0 / -0.0, segments of length 0, 1, < k,
+    = k, the 3 x 256^2 anchors of a P2 level, an all-equal segment, suppressed (-1) tails as after NMS."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(k)
+    lens = [0, 1, 5, 768, 3000, 3072, 12768, 196608, 4096, 9000, 50000]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    n = int(off[-1])
+    keys = np.round(rng.randn(n), 1).astype(np.float32)
+    keys[off[8]:off[9]] = 0.25                                           # all equal
+    seg9 = keys[off[9]:off[10]]
+    seg9[rng.rand(seg9.size) < 0.9] = -1.0                               # mostly suppressed, like the masked post-NMS scores
+    keys[off[10]:off[10] + 100] = -0.0
+    keys[off[10] + 100:off[10] + 200] = 0.0
+    fine = rng.rand(lens[6]).astype(np.float32)                          # a segment without ties
+    keys[off[6]:off[7]] = fine
+    kt = torch.from_numpy(keys)
+    ks, vs = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k)
+    ks, vs = ks.cpu(), vs.cpu().long()
+    for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
+        kk = min(k, b - a)
+        if kk == 0:
+            continue
+        canon = torch.where(kt[a:b] == 0, torch.zeros(()), kt[a:b])        # the sort treats -0.0 as +0.0 (and returns +0.0)
+        order = torch.sort(canon, descending=True, stable=True)[1][:kk]
+        assert torch.equal(vs[a:a + kk], order + a), (a, b, kk)
+        assert torch.equal(ks[a:a + kk], canon[order]), (a, b, kk)
+    # with explicit values, and the k > 4096 fallback = the full sort
+    vals = torch.arange(n, dtype=torch.int32).flip(0).contiguous()
+    ks2, vs2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, values=vals.cuda())
+    a, b = int(off[6]), int(off[7])
+    kk = min(k, b - a)
+    assert torch.equal(vs2[a:a + kk].cpu().long(), vals[vs[a:a + kk]].long())
+    fk, fv = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), 5000)
+    sk, sv = K.segmented_sort_desc(kt.cuda(), torch.from_numpy(off).cuda())
+    assert torch.equal(fk, sk) and torch.equal(fv, sv)
+
+
 @pytest.mark.parametrize('P,n_rot', [(7, 1), (14, 1), (7, 4)])
 def test_roi_align_bwd_mfma_matches_scalar_form(P, n_rot):
     """The matrix-core backward (bf16 maps, C = 256: the training path) against the scalar fp32 form that is pinned to the

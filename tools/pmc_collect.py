@@ -26,6 +26,9 @@ FAMILIES.update({k: [k] for k in [
     'narrow_head_bwd_kernel', 'random_sample_kernel', 'fold_pack_multi_kernel', 'fold_unpack_bwd_multi_kernel',
     'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
     'fuse_sum_relu_kernel', 'stem_mfma_kernel']})
+# per template instance of the weight-gradient stream kernel (0 generic taps, 1 RoI maps, 2 dense 1x1 / FC, 3 stride-1 same-size taps)
+EXACT = {f'conv_wgrad_stream_kernel<{i}>': f'conv_wgrad_stream_kernel<{i}>' for i in range(4)}
+EXACT.update({'conv_tap_pipe_kernel<1, 0, 4, 2>': 'conv_tap_pipe_kernel<1, 0, 4, 2>'})
 PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE'])]
 
 
@@ -51,7 +54,9 @@ def main():
     for tag, counters in PASSES:
         for r in run_pass(tag, counters, extra):
             name = r.get('Kernel_Name', '')
-            for fam in (f for f, subs in FAMILIES.items() if any(sub + '<' in name or sub + '(' in name or name.endswith(sub) for sub in subs)):
+            fams = [f for f, subs in FAMILIES.items() if any(sub + '<' in name or sub + '(' in name or name.endswith(sub) for sub in subs)]
+            fams += [f for f, sub in EXACT.items() if sub in name]
+            for fam in fams:
                 a = agg.setdefault(fam, {})
                 c = r.get('Counter_Name')
                 a.setdefault(c, [0.0, set()])

@@ -248,3 +248,50 @@ def test_dataset_evaluation_on_annotation_files(tmp_path):
         assert np.array_equal(np.asarray(dm, bool), m.roi_head.last_device_masks[0].bool().cpu().numpy())
     out = E.summarize(records)
     assert set(out) == {'roof', 'footprint', 'offset'} and out['roof']['TP'] + out['roof']['FN'] >= 36
+
+
+def test_tools_test_py_command_line_on_annotation_files(tmp_path):
+    """The reference's argv surface end to end (tools/test.py:17-67): `tools/test.py CONFIG CKPT --out R.pkl --eval --ann-file F
+    --img-prefix D` as a subprocess -- reference-format checkpoint in, results pickle in single_gpu_test's layout out, the
+    evaluation summary printed as JSON."""
+    import json
+    import pickle
+    import subprocess
+    import sys
+    from PIL import Image
+    from bonai_amd.checkpoint import save_checkpoint
+    from bonai_amd.config import Config
+    from bonai_amd.loft import build_detector
+    from bonai_amd.synth import synth_bonai_anns
+    from oracle.synth_weights import synth_tensor
+    size = 1024
+    rng = np.random.RandomState(4)
+    images, annotations, aid = [], [], 0
+    for i in range(2):
+        name = f'tile_{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name, compress_level=1)
+        images.append(dict(id=7 + i, file_name=name, width=size, height=size))
+        for a in synth_bonai_anns(seed=i, size=size):
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=7 + i))
+    f = tmp_path / 'bonai_test.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    cfgf = os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py')
+    cfg = Config.fromfile(cfgf)
+    m = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    m.load_state_dict({k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()})
+    ck = tmp_path / 'ckpt.pth'
+    save_checkpoint(m, str(ck))
+    out = tmp_path / 'results.pkl'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfgf, str(ck), '--out', str(out), '--eval',
+                        '--ann-file', str(f), '--img-prefix', str(tmp_path), '--score-thr', '0.0', '--min-area', '0'],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = pickle.load(open(out, 'rb'))
+    assert len(res) == 2
+    for bbox_res, segm, offs in res:
+        n = bbox_res[0].shape[0]
+        assert bbox_res[0].shape[1] == 5 and len(segm[0]) == n and np.asarray(offs).reshape(-1, 2).shape[0] == n
+        assert all(isinstance(s_, dict) and s_['size'] == [size, size] for s_ in segm[0])
+    summary = json.loads(r.stdout[r.stdout.index('{'):])
+    assert set(summary) == {'roof', 'footprint', 'offset'} and summary['roof']['TP'] + summary['roof']['FN'] > 0

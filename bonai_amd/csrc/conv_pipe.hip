@@ -491,33 +491,42 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         while (t < a.T && !((tmask >> t) & 1u)) ++t;
         return t;
     };
-    auto advance_w = [&]() {
-        if (a.tap_major) {
-            sw_c += BK;
-            if (sw_c == a.Cin) {
-                sw_c = 0;
-                sw_t = next_tap(sw_t);
-                if (sw_t < a.T) st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
-            }
-        } else {
-            sw_t = next_tap(sw_t);
-            if (sw_t >= a.T) { sw_t = first_t; sw_c += BK; if (sw_c == a.Cin) sw_c = 0; }      // (wraps under krot; nk ends the loop)
-            st_w = wgt + (long)__builtin_amdgcn_readlane(tab_w, sw_t);
+    // The K-tile sequence of the stream schedules WITHOUT control flow (round 4).  The ISA of the loop body showed the tap / chunk
+    // bookkeeping -- "next tap that some row of this tile needs", wrap to the next channel chunk, table look-ups -- as ~100 scalar
+    // instructions with two nested search loops and a dozen taken branches, sitting between the MFMA pairs of the two copy
+    // sub-steps of EVERY K-tile, in both waves of a SIMD at the same moment.  Here the taps the tile needs are compacted ONCE into
+    // lanes 0..nv-1 (vt_a / vt_w: activation / weight element offsets, vt_m: the tap's bit in the row masks) and a step is an
+    // increment, a compare and four s_cselect.
+    int vt_a = 0, vt_w = 0, vt_m = 0, nv = 0;
+    for (int t = 0; t < a.T; ++t) {
+        if ((tmask >> t) & 1u) {
+            const int ta = __builtin_amdgcn_readlane(tab_a, t), tw = __builtin_amdgcn_readlane(tab_w, t);
+            vt_a = lane == nv ? ta : vt_a;
+            vt_w = lane == nv ? tw : vt_w;
+            vt_m = lane == nv ? t : vt_m;
+            ++nv;
         }
+    }
+    if (a.pointwise) { vt_w = tab_w; nv = 1; }                  // (tab_w is uniform there, tab_a / the mask bit are 0)
+    int xj = 0, wj = 0;                                          // positions in the compact list of the tiles being staged
+    auto seq_step = [&](int& j, int& c) {
+        const int jn = j + 1, cn = c + BK;
+        const bool wj_ = jn >= nv, wc_ = cn == a.Cin;
+        // chunk-major: next tap, wrapping to the next chunk (which itself wraps under krot); tap-major: next chunk, wrapping to the next tap
+        const int j_cm = wj_ ? 0 : jn, c_cm = wj_ ? (wc_ ? 0 : cn) : c;
+        const int j_tm = wc_ ? jn : j, c_tm = wc_ ? 0 : cn;
+        j = a.tap_major ? j_tm : j_cm;
+        c = a.tap_major ? c_tm : c_cm;
+    };
+    auto advance_w = [&]() {
+        seq_step(wj, sw_c);
+        sw_t = __builtin_amdgcn_readlane(vt_m, wj);
+        st_w = wgt + (long)__builtin_amdgcn_readlane(vt_w, wj);
     };
     auto advance_x = [&]() {
-        if (a.tap_major) {
-            st_c += BK;
-            if (st_c == a.Cin) {
-                st_c = 0;
-                st_t = next_tap(st_t);
-                if (st_t < a.T) st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
-            }
-        } else {
-            st_t = next_tap(st_t);
-            if (st_t >= a.T) { st_t = first_t; st_c += BK; if (st_c == a.Cin) st_c = 0; }
-            st_aoff = (long)__builtin_amdgcn_readlane(tab_a, st_t);
-        }
+        seq_step(xj, st_c);
+        st_t = __builtin_amdgcn_readlane(vt_m, xj);
+        st_aoff = (long)__builtin_amdgcn_readlane(vt_a, xj);
     };
     auto advance = [&]() {
         if (a.tap_major) {
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         auto nop = [] {};
         // the two roles run the same fragment / MFMA stream and differ only in where their copies sit: two loop bodies, selected
         // once per workgroup half (wave-uniform branch; both execute exactly one barrier per K-tile)
-        auto rtile = [&](auto rolec, auto xbufc, bool has1, bool has2) {
+        auto rtile = [&](auto rolec, auto xbufc, auto has1, auto has2) {
             constexpr bool XR = decltype(rolec)::value != 0;
             constexpr int XB = decltype(xbufc)::value;
             using xo_t = std::integral_constant<int, 1 - XB>;
@@ -740,12 +749,22 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         using xr_t = std::integral_constant<int, 1>;
         using wr_t = std::integral_constant<int, 0>;
         if (xrole) {
-            for (int t = 0; t < nk; t += 2) {
+            int t = 0;
+            for (; t + 3 < nk; t += 2) {
+                rtile(xr_t{}, c0_t{}, std::true_type{}, std::true_type{});
+                rtile(xr_t{}, c1_t{}, std::true_type{}, std::true_type{});
+            }
+            for (; t < nk; t += 2) {
                 rtile(xr_t{}, c0_t{}, t + 1 < nk, t + 2 < nk);
                 if (t + 1 < nk) rtile(xr_t{}, c1_t{}, t + 2 < nk, t + 3 < nk);
             }
         } else {
-            for (int t = 0; t < nk; t += 2) {
+            int t = 0;
+            for (; t + 3 < nk; t += 2) {
+                rtile(wr_t{}, c0_t{}, std::true_type{}, std::true_type{});
+                rtile(wr_t{}, c1_t{}, std::true_type{}, std::true_type{});
+            }
+            for (; t < nk; t += 2) {
                 rtile(wr_t{}, c0_t{}, t + 1 < nk, t + 2 < nk);
                 if (t + 1 < nk) rtile(wr_t{}, c1_t{}, t + 2 < nk, t + 3 < nk);
             }
@@ -910,7 +929,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             rd1(fa, c0_t{}, k0_t{}, k0_t{}); rd1(fa, c0_t{}, k0_t{}, k1_t{}); rd1(fa, c0_t{}, k0_t{}, k2_t{});
             rd1(fa, c0_t{}, k0_t{}, k3_t{}); rd1(fa, c0_t{}, k0_t{}, i4_t{}); rd1(fa, c0_t{}, k0_t{}, i5_t{});
         }
-        auto stile = [&](auto bufc, bool has1, bool has2) {
+        // has1 / has2 (K-tiles t+1 / t+2 exist): std::true_type in the steady-state loop -- the conditions fold away --, bool in the tail
+        auto stile = [&](auto bufc, auto has1, auto has2) {
             constexpr int B = decltype(bufc)::value;
             using other_t = std::integral_constant<int, 1 - B>;
             // ---- ks0: MFMA fa, read F(t,1) -> fb, issue X(t+1) -> buffer 1-B
@@ -954,9 +974,18 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         };
         if constexpr (TRACE) kst1 = __builtin_amdgcn_s_memtime();
-        for (int t = 0; t < nk; t += 2) {
-            stile(c0_t{}, t + 1 < nk, t + 2 < nk);
-            if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+        {
+            int t = 0;
+            if constexpr (!TRACE) {
+                for (; t + 3 < nk; t += 2) {          // steady state: both tiles of the pair have two successors
+                    stile(c0_t{}, std::true_type{}, std::true_type{});
+                    stile(c1_t{}, std::true_type{}, std::true_type{});
+                }
+            }
+            for (; t < nk; t += 2) {
+                stile(c0_t{}, t + 1 < nk, t + 2 < nk);
+                if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+            }
         }
         }
         if constexpr (TRACE) kst2 = __builtin_amdgcn_s_memtime();

@@ -1101,6 +1101,7 @@ LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* 
                                            void* stream) {
     if (T < 1 || T > 9 || Cout > 64 || Cin > 64 || (Cin % 8) || (Cout % 8) || groups < 1 || !workspace) return (int)hipErrorInvalidValue;
     WgradArgs a;
+    a.pm_inc_ok = 0;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = H; a.GW = W; a.Cout = Cout; a.XH = H; a.XW = W; a.Cin = Cin; a.OH = H; a.OW = W;
     a.gos = 1; a.ss = 1; a.T = T;
@@ -1152,6 +1153,7 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     if (nslots_out) *nslots_out = 0;
     if (mode == 2 && !slots_ok) return (int)hipErrorInvalidValue;
     WgradArgs a;
+    a.pm_inc_ok = 0;
     a.partial = mode == 2; a.nslots = 1; a.split_stride = (long)T * Cout * Cin;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = GH; a.GW = GW; a.Cout = Cout; a.XH = XH; a.XW = XW; a.Cin = Cin; a.OH = OH; a.OW = OW;
@@ -1253,6 +1255,7 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
                 }
             }
             fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
+            a.pm_inc_ok = ((long)groups * B * GH * GW * Cout < 0x7fffffffL && (long)groups * B * XH * XW * Cin < 0x7fffffffL) ? 1 : 0;
             int maxns = 0;
             bool every = true;
             for (int t = 0; t < T; ++t) {

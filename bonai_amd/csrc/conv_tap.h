@@ -213,6 +213,7 @@ struct WgradArgs {
     // that.  The last split of a tap with fewer than nslots splits also zero-fills that tap's remaining slots.
     int partial, nslots;
     long split_stride;
+    int pm_inc_ok;  // conv_wgrad_pipe.hip: G and X hold fewer than 2^31 elements each (32-bit running offsets in the incremental PM decode)
     int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
     unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
 };

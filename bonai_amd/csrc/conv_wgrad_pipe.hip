@@ -36,7 +36,8 @@ constexpr int WG_OFF = 0, WX_OFF = 65536, WBUF = 32768, WLDS = 131072;
 // pixel m, X row = pixel m + dy * W + dx inside the map, (oy, ox) of a thread's four rows carried from K-step to K-step).
 template <int MODE>
 __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs a) {
-    constexpr bool PM = MODE == 1, DENSE = MODE == 2, SAME = MODE == 3;
+    // (MODE 4: PM with the per-row decode -- splits of fewer than 64 RoIs, or tensors too large for 32-bit running offsets)
+    constexpr bool PM = MODE == 1 || MODE == 4, PMINC = MODE == 1, DENSE = MODE == 2, SAME = MODE == 3;
     __shared__ __attribute__((aligned(16))) char lds[WLDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,9 +82,58 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
             s_ox[i] = rem - s_oy[i] * a.OW;
         }
     }
+    // PM, incremental (round 4): the ISA of the K loop showed the per-row decode below -- two multiply-high divisions and two chains
+    // of 64-bit multiplies per staged row, 32 quarter-rate v_mul_lo_u32 + 8 v_mul_hi_u32 + 16 64-bit multiply-adds per wave and
+    // K-step -- as ~1400 cycles of VALU issue per wave against 1152 of MFMA, for BOTH waves of a SIMD: the RoI-map launches were
+    // VALU-bound on their own addressing.  A thread's row i advances by 64 reduction rows per K-step; with >= 64 RoIs per split
+    // that is 64 RoIs further at the same position or, once, a wrap to the next position of the tap's rectangle (next column, or
+    // first column of the next map row): its G / X element offsets move by one of three wave-uniform increments.  State per row:
+    // the reduction index, the RoI offset inside the split, the column inside the rectangle, the two offsets.  No multiplies.
+    // (32-bit element offsets: the host enables the incremental form only when both tensors have fewer than 2^31 elements)
+    const int pm_B = a.B;
+    const bf16_t* zpage = a.zero_page;
+    constexpr bool pm_inc = PMINC;          // (the host launches MODE 1 only when every split holds >= 64 RoIs and pm_inc_ok)
+    int pm_r[4] = {0, 0, 0, 0}, pm_rx[4] = {0, 0, 0, 0}, pm_og[4] = {0, 0, 0, 0}, pm_ox[4] = {0, 0, 0, 0};
+    int ig_step = 0, ig_col = 0, ig_row = 0, ix_step = 0, ix_col = 0, ix_row = 0, v_rb = 0, v_rw = 1;
+    if constexpr (PMINC) {
+        {
+            const int sg = a.GH * a.GW * a.Cout, sx = a.XH * a.XW * a.Cin;
+            // increments of a row's element offsets per K-step: +64 RoIs; on a position wrap additionally (-RoIs of the split, next
+            // column); on a wrap at the rectangle's last column additionally (first column of the next map row instead)
+            ig_step = 64 * sg; ig_col = a.Cout - pm_rb * sg; ig_row = (a.GW - pm_rw) * a.Cout;
+            ix_step = 64 * sx; ix_col = a.Cin - pm_rb * sx; ix_row = (a.XW - pm_rw) * a.Cin;
+            v_rb = pm_rb; v_rw = pm_rw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mbeg + i * 16 + srow;
+                const int p = fastdiv(m, rb_mul, rb_sh), r = m - p * pm_rb;
+                const int ry = fastdiv(p, pm_mul, pm_sh), rx = p - ry * pm_rw;
+                const int b = pm_b0 + r, oy = pm_y0 + ry, ox = pm_x0 + rx;
+                pm_r[i] = r; pm_rx[i] = rx;
+                pm_og[i] = ((b * a.GH + oy + goy) * a.GW + ox + gox) * a.Cout + n0 + schunk * 8;
+                pm_ox[i] = ((b * a.XH + oy + dy) * a.XW + ox + dx) * a.Cin + c0 + schunk * 8;
+            }
+        }
+    }
     // decode pixel m of the reduction range once: G pointer (or the zero page), X pointer (or the zero page)
     auto decode = [&](int m, const bf16_t*& pg, const bf16_t*& px, int i) {
-        pg = a.zero_page; px = a.zero_page;
+        pg = zpage; px = zpage;
+        if constexpr (PMINC) {
+            {                      // (row i is decoded exactly once per K-step, in step order: prologue steps 0 and 1, then s + 2)
+                const bool ok = (m < mend) & (pm_b0 + pm_r[i] < pm_B);
+                if (ok) { pg = G + pm_og[i]; px = X + pm_ox[i]; }
+                const int r2 = pm_r[i] + 64, rx2 = pm_rx[i] + 1;
+                const bool w = r2 >= v_rb, wr = w & (rx2 == v_rw);
+                pm_r[i] = w ? r2 - v_rb : r2;
+                pm_rx[i] = w ? (wr ? 0 : rx2) : pm_rx[i];
+                // (sums of masked terms, not nested selects: hipcc turns a nested ?: on wave-uniform values into control flow and
+                //  then keeps the closure's state in scratch)
+                pm_og[i] += ig_step + (w ? ig_col : 0) + (wr ? ig_row : 0);
+                pm_ox[i] += ix_step + (w ? ix_col : 0) + (wr ? ix_row : 0);
+                return;
+            }
+        } else {                   // (discarded for the incremental instance: its closure must not reference the kernarg struct --
+                                   //  hipcc otherwise copies all of WgradArgs to scratch and indexes the per-tap tables there)
         if constexpr (DENSE) {
             if (m < mend) {
                 pg = G + (long)m * a.Cout + n0 + schunk * 8;
@@ -124,6 +174,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
                     px = X + ((long)(b * a.XH + iy) * a.XW + ix) * a.Cin + c0 + schunk * 8;
                 }
             }
+        }
         }
     };
     // issue the G rows i0, i0+1 of K-step `step` into buffer B and remember their X pointers
@@ -325,7 +376,10 @@ int loft_launch_conv_wgrad_stream(const WgradArgs& a, dim3 grid, bool pm, hipStr
     bool same = samesize && a.OW >= 64;
     for (int t = 0; t < a.T; ++t) same = same && a.goy[t] == 0 && a.gox[t] == 0;
     const bool dense = samesize && a.T == 1 && a.goy[0] == 0 && a.gox[0] == 0 && a.dy[0] == 0 && a.dx[0] == 0;
-    if (pm) hipLaunchKernelGGL(conv_wgrad_stream_kernel<1>, grid, dim3(512), 0, s, a);
+    bool inc = pm && a.pm_inc_ok;
+    for (int t = 0; t < a.T && inc; ++t) inc = a.pm_blk0[t + 1] == a.pm_blk0[t] || a.pm_pps[t] >= 64;
+    if (pm && inc) hipLaunchKernelGGL(conv_wgrad_stream_kernel<1>, grid, dim3(512), 0, s, a);
+    else if (pm) hipLaunchKernelGGL(conv_wgrad_stream_kernel<4>, grid, dim3(512), 0, s, a);
     else if (dense) hipLaunchKernelGGL(conv_wgrad_stream_kernel<2>, grid, dim3(512), 0, s, a);
     else if (same) hipLaunchKernelGGL(conv_wgrad_stream_kernel<3>, grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_stream_kernel<0>, grid, dim3(512), 0, s, a);

@@ -40,7 +40,12 @@ def main():
             S = (B + nb - 1) // nb
             tiles = G * ((nb * P * P * S + 255) // 256)
             gflop = 2.0 * G * B * P * P * 256 * 256 * 9 / 1e9
-            print(f'{name:10s} {B:6d} {tiles:6d} {tiles / 256:7.3f} {ms * 1e3:8.1f} {gflop / ms:8.1f} {ms * 1e3 / (tiles / 256):9.2f}', flush=True)
+            line = f'{name:10s} {B:6d} {tiles:6d} {tiles / 256:7.3f} {ms * 1e3:8.1f} {gflop / ms:8.1f} {ms * 1e3 / (tiles / 256):9.2f}'
+            if os.environ.get('WGRAD'):          # the weight-gradient launch of the same layer (RoI-map instance of the stream kernel)
+                g = torch.randn_like(x)
+                wms = min(timeit(lambda: K.conv2d_wgrad(g, x, 3, 3, 1, 1, groups=G)) for _ in range(3))
+                line += f'   wgrad {wms * 1e3:8.1f} us {gflop / wms:8.1f} TF'
+            print(line, flush=True)
 
 
 if __name__ == '__main__':

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     //   ks1: MFMA fb | read F(s,2) -> fa        ks2: MFMA fa | read F(s,3) -> fb
     //   SYNC(s): vmcnt(0) (G(s+1), X(s+1) landed), lgkmcnt(0) (this wave's reads of buffer B are complete), barrier
     //   ks3: MFMA fb | read F(s+1,0) -> fa from buffer 1-B | decode + issue G(s+2) -> buffer B (free behind SYNC(s))
-    auto step = [&](auto bufc, int s, bool has1, bool has2) {
+    auto step = [&](auto bufc, int s, auto has1, auto has2) {     // (has1 / has2: std::true_type in the steady-state loop, bool in the tail)
         constexpr int B = decltype(bufc)::value;
         using other_t = std::integral_constant<int, 1 - B>;
         WG_SUBSTEP(fa, fb, B, 1, true, if (has1) issue_x(other_t{}, c0_t{}), if (has1) issue_x(other_t{}, c2_t{}));
@@ -333,9 +333,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     };
     // static priority for the younger half of the workgroup over the whole K loop (see conv_pipe.hip, round 3)
     if ((threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
-    for (int s = 0; s < nsteps; s += 2) {
-        step(c0_t{}, s, s + 1 < nsteps, s + 2 < nsteps);
-        if (s + 1 < nsteps) step(c1_t{}, s + 1, s + 2 < nsteps, s + 3 < nsteps);
+    {
+        int s = 0;
+        for (; s + 3 < nsteps; s += 2) {           // steady state: both K-steps of the pair have two successors
+            step(c0_t{}, s, std::true_type{}, std::true_type{});
+            step(c1_t{}, s + 1, std::true_type{}, std::true_type{});
+        }
+        for (; s < nsteps; s += 2) {
+            step(c0_t{}, s, s + 1 < nsteps, s + 2 < nsteps);
+            if (s + 1 < nsteps) step(c1_t{}, s + 1, s + 2 < nsteps, s + 3 < nsteps);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
 

@@ -274,13 +274,27 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
                 if (eo[j] >= 0) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(((kbits >> j) & 1u ? ob1 : ob0) + eo[j])) = rowv[j];
         }
     } else {
-        // strided / offset outputs (parity-class launches of strided data gradients, the mask head's 2x2 deconvolution): per-row decode
+        // strided / offset outputs (parity-class launches of strided data gradients, the mask head's 2x2 deconvolution): rows are
+        // linear only within one map row, so every row is decoded -- with the decode's scalars held in registers (LOFT_KEEP_S:
+        // the loop otherwise re-fetches a dozen kernarg fields per row)
+        int aM = a.M, aB = a.B, aOW = a.OW, aOHf = a.OHf, aOWf = a.OWf, aos = a.os, aoy = a.oo_y, aox = a.oo_x, aCout = a.Cout;
+        unsigned m1 = a.ohw_mul, s1 = a.ohw_sh, m2 = a.ow_mul, s2 = a.ow_sh;
+        LOFT_KEEP_S(aM); LOFT_KEEP_S(aB); LOFT_KEEP_S(aOW); LOFT_KEEP_S(aOHf); LOFT_KEEP_S(aOWf); LOFT_KEEP_S(aos); LOFT_KEEP_S(aoy);
+        LOFT_KEEP_S(aox); LOFT_KEEP_S(aCout); LOFT_KEEP_S(m1); LOFT_KEEP_S(s1); LOFT_KEEP_S(m2); LOFT_KEEP_S(s2);
+        const bool pmaj = a.pixmajor != 0;
 #pragma unroll 1
         for (int it = 0; it < RW / RPI; ++it) {
             const int r = wave * RW + it * RPI + lane / CPR;
             const int c = (lane & (CPR - 1)) ^ (r & (CPR - 1));
             const int m = m0 + r;
-            const bf16_t* rp = m >= a.M ? nullptr : pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw);
+            const bf16_t* rp = nullptr;
+            if (pmaj) {
+                if (m < aM) rp = pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw);
+            } else if (m < aM) {
+                const int b = fastdiv(m, m1, s1), rem = m - b * ohw;
+                const int oy = fastdiv(rem, m2, s2), ox = rem - oy * aOW;
+                if (b < aB) rp = ob + (((long)b * aOHf + oy * aos + aoy) * aOWf + ox * aos + aox) * aCout;
+            }
             if (rp) {
                 uint4 v = *reinterpret_cast<const uint4*>(lds + r * ROWB + (lane & (CPR - 1)) * 16);
                 const bf16_t* p = rp + c * 8;
@@ -884,7 +898,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             in_loop = true;
             rd1(fa, c0_t{}, k0_t{}, k0_t{}); rd1(fa, c0_t{}, k0_t{}, k1_t{}); rd1(fa, c0_t{}, k0_t{}, k2_t{});
             rd1(fa, c0_t{}, k0_t{}, k3_t{}); rd1(fa, c0_t{}, k0_t{}, i4_t{}); rd1(fa, c0_t{}, k0_t{}, i5_t{});
-            auto rtile = [&](auto bufc, bool has1, bool has2) {
+            auto rtile = [&](auto bufc, auto has1, auto has2) {
                 constexpr int B = decltype(bufc)::value;
                 using next_t = std::integral_constant<int, (B + 1) % 3>;
                 using tgt_t = std::integral_constant<int, (B + 2) % 3>;
@@ -902,7 +916,13 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                 }
                 substep(fb, fa, next_t{}, k0_t{}, has1, nop, nop, z_t{});
             };
-            for (int t = 0; t < nk; t += 3) {
+            int t = 0;
+            for (; t + 4 < nk; t += 3) {               // steady state: all three tiles of the round have two successors
+                rtile(c0_t{}, std::true_type{}, std::true_type{});
+                rtile(c1_t{}, std::true_type{}, std::true_type{});
+                rtile(c2_t{}, std::true_type{}, std::true_type{});
+            }
+            for (; t < nk; t += 3) {
                 rtile(c0_t{}, t + 1 < nk, t + 2 < nk);
                 if (t + 1 < nk) rtile(c1_t{}, t + 2 < nk, t + 3 < nk);
                 if (t + 2 < nk) rtile(c2_t{}, t + 3 < nk, t + 4 < nk);

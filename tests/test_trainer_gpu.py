@@ -363,3 +363,29 @@ def test_graph_replay_follows_the_optimizer_and_survives_reloaded_frozen_weights
     blob = pickle.dumps(m.backbone.conv1)
     assert pickle.loads(blob).weight.shape == m.backbone.conv1.weight.shape
     copy.deepcopy(m.backbone.layer1)
+
+
+@pytest.mark.parametrize('cfg_name', ['loft_foa_r50_fpn_mdconv_c3-c5_2x_bonai.py', 'loft_foa_hrnetv2p_w32_2x_bonai.py'])
+def test_graph_replay_follows_the_optimizer_side_configs(cfg_name, first_k):
+    """the lr > 0 replay check on the other two backbones -- DCNv2 (config 4: the deformable sampler's workspace and
+    offset convs inside the captured section) and HRNet-W32 + HRFPN (config 5, bf16 here: branch streams forked inside the graph).
+    Four optimisation steps under graph_features=True against the same steps on eager launches: same loss trajectory, and the
+    replays see the weights the SGD kernel wrote (the trajectory moves)."""
+    from bonai_amd.config import Config
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', cfg_name))
+    data = make_batch(2, 256, 8, device='cuda')
+    logs = {}
+    for mode in ('eager', 'graph'):
+        m = _synth_model(cfg)
+        tr = Trainer(m, lr=5e-4, momentum=0.9, weight_decay=1e-4, max_norm=35.0, graph_features=(mode == 'graph'))
+        logs[mode] = [dict(tr.train_step(data)['log_vars'].items()) for _ in range(4)]
+        torch.cuda.synchronize()
+        if mode == 'graph':
+            assert tr._fgraphs.ready and tr._fgraphs.failed is None, tr._fgraphs.failed
+    print(cfg_name, 'loss trajectory eager / graph:', [(round(a['loss'], 3), round(b['loss'], 3)) for a, b in zip(logs['eager'], logs['graph'])])
+    for i, (a, b) in enumerate(zip(logs['eager'], logs['graph'])):
+        assert all(v == v and abs(v) < 1e6 for v in b.values())
+        assert abs(a['loss'] - b['loss']) <= 0.08 * max(1.0, abs(a['loss'])), (i, a['loss'], b['loss'])
+    assert abs(logs['graph'][3]['loss'] - logs['graph'][2]['loss']) > 1e-3 * logs['graph'][2]['loss']

@@ -316,11 +316,16 @@ def segmented_sort_desc(keys, seg_offsets, values=None):
 TOPK_MAX = 4096     # nms.hip TOPK_MAX: candidates of one segment sorted in one workgroup's LDS
 
 
-def segmented_topk_desc(keys, seg_offsets, k, values=None):
+TOPK_MAX_SEGMENT = 32768   # one workgroup streams a whole segment four times: measured (tools/probes/topk_time.py) 33 us against the
+                           # full sort's 63 us for 8 x 12 768 keys, but 330 us against 220 us for 8 x (196 608 + ...) anchors
+
+
+def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None):
     """The first k entries of each segment's stable descending order, in the layout of segmented_sort_desc (entry r of segment s at
-    seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  k <= TOPK_MAX: in-house select + LDS sort
-    (loft_segmented_topk_desc); larger k: the full sort."""
-    if k > TOPK_MAX:
+    seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  k <= TOPK_MAX and segments of at most
+    TOPK_MAX_SEGMENT keys (``max_segment``: the caller's host-side bound; None = unknown): in-house select + LDS sort
+    (loft_segmented_topk_desc); otherwise the full sort (same head, every rank written)."""
+    if k > TOPK_MAX or max_segment is None or max_segment > TOPK_MAX_SEGMENT:
         return segmented_sort_desc(keys, seg_offsets, values)
     lib = L.load()
     L.dev_check(keys, seg_offsets)

@@ -213,9 +213,9 @@ class RPNHead(nn.Module):
         for f, off in zip(fused, geo['lvl_off']):
             K.rpn_scores(f, A, N, off, keys)
         topk = [min(cfg.nms_pre, n) if cfg.nms_pre > 0 else n for n in geo['n_l']]
-        # only the first topk[l] entries of every (image, level) segment are read below: select + sort those (in-house, one
-        # workgroup per segment) instead of sorting all 8 x 261 888 anchors; nms_pre <= 0 / > 4096 falls back to the full sort
-        skeys, sidx = K.segmented_topk_desc(keys, geo['seg'], max(topk))
+        # only the first topk[l] entries of every (image, level) segment are read below; the in-house select + sort takes segments up
+        # to 32 768 keys (one workgroup each) -- the 3 x 256^2 anchors of a P2 level go through the full sort
+        skeys, sidx = K.segmented_topk_desc(keys, geo['seg'], max(topk), max_segment=max(geo['n_l']))
         coff = [0]
         for t in topk:
             coff.append(coff[-1] + t)
@@ -245,7 +245,7 @@ class RPNHead(nn.Module):
         masked = torch.where(keep.view(B, C).view(torch.bool), cscore, -1.0)        # (keep is 0 / 1 bytes: a bool view, no copy)
         post = min(cfg.nms_post, cfg.max_num) if cfg.get('max_num', 0) > 0 else cfg.nms_post
         post = min(post, C)
-        fs, fi = K.segmented_topk_desc(masked.reshape(-1), self._static[('img_seg', B, C)], post)
+        fs, fi = K.segmented_topk_desc(masked.reshape(-1), self._static[('img_seg', B, C)], post, max_segment=C)
         fs = fs.view(B, C)[:, :post]
         fi = fi.view(B, C)[:, :post].long()
         boxes = cand.view(-1, 4)[fi.reshape(-1)].view(B, post, 4)

@@ -183,7 +183,8 @@ def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
     fine = rng.rand(lens[6]).astype(np.float32)                          # a segment without ties
     keys[off[6]:off[7]] = fine
     kt = torch.from_numpy(keys)
-    ks, vs = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k)
+    K.TOPK_MAX_SEGMENT, keep = 1 << 30, K.TOPK_MAX_SEGMENT          # (every segment through the in-house kernel, also the 196 608-key one)
+    ks, vs = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, max_segment=max(lens))
     ks, vs = ks.cpu(), vs.cpu().long()
     for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
         kk = min(k, b - a)
@@ -195,11 +196,12 @@ def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
         assert torch.equal(ks[a:a + kk], canon[order]), (a, b, kk)
     # with explicit values, and the k > 4096 fallback = the full sort
     vals = torch.arange(n, dtype=torch.int32).flip(0).contiguous()
-    ks2, vs2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, values=vals.cuda())
+    ks2, vs2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, values=vals.cuda(), max_segment=max(lens))
+    K.TOPK_MAX_SEGMENT = keep
     a, b = int(off[6]), int(off[7])
     kk = min(k, b - a)
     assert torch.equal(vs2[a:a + kk].cpu().long(), vals[vs[a:a + kk]].long())
-    fk, fv = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), 5000)
+    fk, fv = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), 5000, max_segment=max(lens))
     sk, sv = K.segmented_sort_desc(kt.cuda(), torch.from_numpy(off).cuda())
     assert torch.equal(fk, sk) and torch.equal(fv, sv)
 

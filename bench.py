@@ -178,6 +178,9 @@ def main():
     from bonai_amd.loft import build_detector
     from bonai_amd.synth import make_batch
     K.L.load()
+    if os.environ.get('LOFT_BENCH_SLOTS'):      # A/B only: split-K slots (plain stores summed by the unpack) instead of fp32 atomics
+        which_s = os.environ['LOFT_BENCH_SLOTS']
+        K.WGRAD_SLOTS = (lambda G, B, OH, OW, Cin, Cout, T, ss, gos: B >= 1024 and OH * OW <= 196 and T > 1) if which_s == 'roi' else True
     if os.environ.get('LOFT_BENCH_ROLES'):      # A/B only: route launches to the role-split stream kernel ('mask' | 'roi' | 'all')
         which = os.environ['LOFT_BENCH_ROLES']
 

@@ -320,14 +320,49 @@ TOPK_MAX_SEGMENT = 32768   # one workgroup streams a whole segment four times: m
                            # full sort's 63 us for 8 x 12 768 keys, but 330 us against 220 us for 8 x (196 608 + ...) anchors
 
 
-def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None):
+_TOPK_TABLES = {}
+
+
+def _topk_two_stage_tables(seg_lengths, k, device):
+    """Static tables of the two-stage selection for segments longer than TOPK_MAX_SEGMENT: every segment is cut into sub-ranges of at
+    most `sub` keys (a multiple of 4: 16-byte loads) such that sub-ranges x k candidates fit one workgroup's walk again.
+    -> (sub_off, sub_out, cand_off, seg_start, n_cand) device int64 tables, or None when even that does not fit."""
+    key = (tuple(int(n) for n in seg_lengths), int(k), str(device))
+    if key in _TOPK_TABLES:
+        return _TOPK_TABLES[key]
+    pmax = TOPK_MAX_SEGMENT // k
+    longest = max(seg_lengths) if seg_lengths else 0
+    sub = -(-longest // max(pmax, 1))
+    sub = (sub + 3) // 4 * 4
+    tabs = None
+    if pmax >= 2 and 0 < sub <= TOPK_MAX_SEGMENT:
+        sub_off, sub_out, cand_off, seg_start = [0], [], [0], []
+        pos = 0
+        for n in seg_lengths:
+            seg_start.append(pos)
+            c = cand_off[-1]
+            for a in range(0, n, sub):
+                ln = min(sub, n - a)
+                sub_out.append(c)
+                c += min(k, ln)
+                sub_off.append(pos + a + ln)
+            cand_off.append(c)
+            pos += n
+        t = lambda v: h2d(v, torch.int64, device)
+        tabs = (t(sub_off), t(sub_out), t(cand_off), t(seg_start), cand_off[-1], len(sub_out))
+    _TOPK_TABLES[key] = tabs
+    return tabs
+
+
+def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None, seg_lengths=None):
     """The first k entries of each segment's stable descending order, in the layout of segmented_sort_desc (entry r of segment s at
-    seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  k <= TOPK_MAX and segments of at most
-    TOPK_MAX_SEGMENT keys (``max_segment``: the caller's host-side bound; None = unknown): in-house select + LDS sort
-    (loft_segmented_topk_desc); otherwise the full sort (same head, every rank written)."""
-    if k > TOPK_MAX or max_segment is None or max_segment > TOPK_MAX_SEGMENT:
-        return segmented_sort_desc(keys, seg_offsets, values)
+    seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  In-house radix select + LDS bitonic sort
+    (loft_segmented_topk_desc), one workgroup per segment, for k <= TOPK_MAX and segments of at most TOPK_MAX_SEGMENT keys
+    (``max_segment``: the caller's host-side bound); longer segments with host-known lengths (``seg_lengths``) in TWO stages -- top-k
+    of every sub-range into a compact candidate list, top-k of the candidates back into place; otherwise the full library sort."""
     lib = L.load()
+    if k > TOPK_MAX or max_segment is None or (max_segment > TOPK_MAX_SEGMENT and (seg_lengths is None or values is not None)):
+        return segmented_sort_desc(keys, seg_offsets, values)
     L.dev_check(keys, seg_offsets)
     keys = keys.float().contiguous()
     S = seg_offsets.numel() - 1
@@ -335,10 +370,22 @@ def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None):
     vo = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
     if keys.numel() == 0 or S <= 0:
         return ko, vo
+    if max_segment > TOPK_MAX_SEGMENT:
+        tabs = _topk_two_stage_tables(seg_lengths, k, keys.device)
+        if tabs is None or len(seg_lengths) != S:
+            return segmented_sort_desc(keys, seg_offsets, values)
+        sub_off, sub_out, cand_off, seg_start, n_cand, n_sub = tabs
+        ck = torch.empty(n_cand, dtype=torch.float32, device=keys.device)
+        cv = torch.empty(n_cand, dtype=torch.int32, device=keys.device)
+        L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ck), c_void_p(0), L.ptr(cv), n_sub, L.ptr(sub_off), int(k), L.ptr(sub_out),
+                                             L.stream()), 'loft_segmented_topk_desc(stage 1)')
+        L.check(lib.loft_segmented_topk_desc(L.ptr(ck), L.ptr(ko), L.ptr(cv), L.ptr(vo), S, L.ptr(cand_off), int(k), L.ptr(seg_start),
+                                             L.stream()), 'loft_segmented_topk_desc(stage 2)')
+        return ko, vo
     if values is not None:
         values = values.to(torch.int32).contiguous()
-    L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), S, L.ptr(seg_offsets), int(k), L.stream()),
-            'loft_segmented_topk_desc')
+    L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), S, L.ptr(seg_offsets), int(k), c_void_p(0),
+                                         L.stream()), 'loft_segmented_topk_desc')
     return ko, vo
 
 

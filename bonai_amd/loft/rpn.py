@@ -213,9 +213,9 @@ class RPNHead(nn.Module):
         for f, off in zip(fused, geo['lvl_off']):
             K.rpn_scores(f, A, N, off, keys)
         topk = [min(cfg.nms_pre, n) if cfg.nms_pre > 0 else n for n in geo['n_l']]
-        # only the first topk[l] entries of every (image, level) segment are read below; the in-house select + sort takes segments up
-        # to 32 768 keys (one workgroup each) -- the 3 x 256^2 anchors of a P2 level go through the full sort
-        skeys, sidx = K.segmented_topk_desc(keys, geo['seg'], max(topk), max_segment=max(geo['n_l']))
+        # only the first topk[l] entries of every (image, level) segment are read below: in-house select + sort, one workgroup per
+        # segment up to 32 768 keys; the 3 x 256^2 anchors of a P2 level in two stages (top-k of ten sub-ranges, then of their candidates)
+        skeys, sidx = K.segmented_topk_desc(keys, geo['seg'], max(topk), max_segment=max(geo['n_l']), seg_lengths=list(geo['n_l']) * B)
         coff = [0]
         for t in topk:
             coff.append(coff[-1] + t)

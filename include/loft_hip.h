@@ -123,9 +123,10 @@ int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_
  * of `scores.sort(descending=True)[:nms_pre]` per (image, level) (rpn_head.py:129-136) and of the post-NMS `dets[:nms_post]`
  * (rpn_head.py:166-168).  In-house radix select + LDS bitonic sort, one workgroup per segment, no workspace.  Outputs have the
  * layout of loft_segmented_sort_desc (entry r of segment s at seg_offsets[s] + r); entries r >= min(k, segment length) are NOT
- * written.  vals_in may be NULL (values = global element indices). */
+ * written.  vals_in may be NULL (values = global element indices).  out_offsets_dev (optional, device int64 [num_segments]): segment s
+ * writes its head at out_offsets[s] instead of seg_offsets[s] (two-stage selection of long segments). */
 int loft_segmented_topk_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out, int num_segments,
-                             const int64_t* seg_offsets_dev, int k, void* stream);
+                             const int64_t* seg_offsets_dev, int k, const int64_t* out_offsets_dev, void* stream);
 
 /* ---- dense contractions on MFMA -----------------------------------------------------------
  * loft_conv_tap_bf16: im2col-free NHWC convolution / linear layer, bf16 operands, fp32 accumulate.

@@ -204,6 +204,14 @@ def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
     fk, fv = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), 5000, max_segment=max(lens))
     sk, sv = K.segmented_sort_desc(kt.cuda(), torch.from_numpy(off).cuda())
     assert torch.equal(fk, sk) and torch.equal(fv, sv)
+    # the TWO-STAGE form the RPN uses for segments past TOPK_MAX_SEGMENT (sub-range top-k -> candidates -> top-k): same heads
+    if k > 1:
+        assert K._topk_two_stage_tables(lens, k, 'cuda') is not None
+        k2, v2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, max_segment=max(lens), seg_lengths=lens)
+        k2, v2 = k2.cpu(), v2.cpu().long()
+        for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
+            kk = min(k, b - a)
+            assert torch.equal(v2[a:a + kk], vs[a:a + kk]) and torch.equal(k2[a:a + kk], ks[a:a + kk]), (a, b, kk)
 
 
 @pytest.mark.parametrize('P,n_rot', [(7, 1), (14, 1), (7, 4)])

@@ -28,13 +28,17 @@ def main():
             off.append(off[-1] + n)
     seg = torch.tensor(off, dtype=torch.int64, device='cuda')
     keys = torch.rand(B * N, device='cuda').sigmoid()
-    print(f'anchors: top-3000 of {B} x {lv}:  topk {timeit(lambda: K.segmented_topk_desc(keys, seg, 3000)):7.1f} us   full sort '
+    two = timeit(lambda: K.segmented_topk_desc(keys, seg, 3000, max_segment=max(lv), seg_lengths=lv * B))
+    K.TOPK_MAX_SEGMENT, keep = 1 << 30, K.TOPK_MAX_SEGMENT
+    one = timeit(lambda: K.segmented_topk_desc(keys, seg, 3000, max_segment=max(lv)))
+    K.TOPK_MAX_SEGMENT = keep
+    print(f'anchors: top-3000 of {B} x {lv}:  two-stage {two:7.1f} us   one workgroup per segment {one:7.1f} us   full sort '
           f'{timeit(lambda: K.segmented_sort_desc(keys, seg)):7.1f} us')
     C = 12768
     seg2 = torch.arange(B + 1, dtype=torch.int64, device='cuda') * C
     k2 = torch.rand(B * C, device='cuda')
     k2[torch.rand(B * C, device='cuda') < 0.8] = -1.0
-    print(f'post-NMS: top-1000 of {B} x {C}:  topk {timeit(lambda: K.segmented_topk_desc(k2, seg2, 1000)):7.1f} us   full sort '
+    print(f'post-NMS: top-1000 of {B} x {C}:  topk {timeit(lambda: K.segmented_topk_desc(k2, seg2, 1000, max_segment=C)):7.1f} us   full sort '
           f'{timeit(lambda: K.segmented_sort_desc(k2, seg2)):7.1f} us')
 
 

@@ -15,6 +15,7 @@
 //                    (mmdet/core/mask/mask_target.py:33-62, structures.py:261-291) -- replaces the
 //                    GPU->CPU->GPU round trip
 #include "loft_common.h"
+#include <algorithm>
 #include "../../include/loft_hip.h"
 
 __device__ __forceinline__ float iou_pair(const float4 g, const float4 b) {
@@ -279,6 +280,158 @@ LOFT_EXPORT int loft_rpn_decode(const float* head, const int32_t* sorted_idx, in
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(loft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, head, sorted_idx, B, H, W,
                        Cp, A, (long)img_stride, (long)lvl_off, topk, base_anchors, stride, c, fabsf(logf(wh_ratio_clip)), max_h,
                        max_w, (long)cand_stride, (long)cand_off, out_boxes);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same two steps for ALL pyramid levels in one launch each (the training step's proposal chain: five + five launches of
+// 5 us on a chain every RoI-head launch waits for), plus what followed them as separate small launches: the decode also writes the
+// candidates' scores in the candidate layout and the per-image maximum coordinate batched_nms shifts the levels by
+// (mmcv batched_nms: boxes + idx * (boxes.max() + 1)); the scores launch resets that maximum.
+#define RPN_MAX_LEVELS 8
+struct RpnLvl { const float* head; const float* base; int H, W, topk, stride; long lvl_off, cand_off; };
+struct RpnLvls { int n; RpnLvl l[RPN_MAX_LEVELS]; };
+
+__global__ void rpn_scores_levels_kernel(const RpnLvls lv, int B, int Cp, int A, long img_stride, float* __restrict__ keys,
+                                         float* __restrict__ img_max) {
+    const RpnLvl& L = lv.l[blockIdx.y];
+    const int HW = L.H * L.W;
+    const long n = (long)B * HW * A;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (img_max != nullptr && blockIdx.y == 0 && i < B) img_max[i] = -INFINITY;
+    if (i >= n) return;
+    const int a = (int)(i % A);
+    const long p = i / A;
+    const int pos = (int)(p % HW);
+    const int b = (int)(p / HW);
+    const float x = L.head[((long)b * HW + pos) * Cp + a];
+    keys[(long)b * img_stride + L.lvl_off + (long)pos * A + a] = 1.f / (1.f + expf(-x));
+}
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {       // any sign; *addr starts at -inf
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+__global__ void rpn_decode_levels_kernel(const RpnLvls lv, const int32_t* __restrict__ sorted_idx, const float* __restrict__ sorted_keys,
+                                         int B, int Cp, int A, long img_stride, Coder4 c, float max_ratio, float max_h, float max_w,
+                                         long cand_stride, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                         float* __restrict__ img_max) {
+    const RpnLvl& L = lv.l[blockIdx.y];
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const bool in = i < (long)B * L.topk;
+    int b = -1;
+    float m = -INFINITY;
+    if (in) {
+        const int r = (int)(i % L.topk);
+        b = (int)(i / L.topk);
+        const long src = (long)b * img_stride + L.lvl_off + r;
+        const int idx = sorted_idx[src] - (int)L.lvl_off - (int)((long)b * img_stride);
+        const int a = idx % A, pos = idx / A;
+        const int y = pos / L.W, x = pos - y * L.W;
+        const float sx = (float)(x * L.stride), sy = (float)(y * L.stride);
+        float4 anc;
+        anc.x = L.base[a * 4 + 0] + sx; anc.y = L.base[a * 4 + 1] + sy;
+        anc.z = L.base[a * 4 + 2] + sx; anc.w = L.base[a * 4 + 3] + sy;
+        const float* d = L.head + ((long)b * L.H * L.W + pos) * Cp + A + a * 4;
+        const float4 box = decode_box(anc, d[0], d[1], d[2], d[3], c.means, c.stds, max_ratio, max_h, max_w);
+        const long dst = (long)b * cand_stride + L.cand_off + r;
+        reinterpret_cast<float4*>(out_boxes)[dst] = box;
+        if (out_scores != nullptr) out_scores[dst] = sorted_keys[src];
+        m = fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w));
+    }
+    if (img_max == nullptr) return;
+    // one atomic per wave when the wave sits inside one image (all but the waves that straddle an image boundary)
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    if (__all(b == b0 || !in) && b0 >= 0) {
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) atomic_max_float(img_max + b0, m);
+    } else if (in) {
+        atomic_max_float(img_max + b, m);
+    }
+}
+
+static int rpn_levels_fill(RpnLvls& lv, const void* const* heads, const void* const* bases, const int* H, const int* W,
+                           const int* topk, const int* stride, const int64_t* lvl_off, const int64_t* cand_off, int levels) {
+    if (levels < 1 || levels > RPN_MAX_LEVELS) return (int)hipErrorInvalidValue;
+    lv.n = levels;
+    for (int l = 0; l < levels; ++l) {
+        lv.l[l].head = (const float*)heads[l];
+        lv.l[l].base = bases ? (const float*)bases[l] : nullptr;
+        lv.l[l].H = H[l]; lv.l[l].W = W[l];
+        lv.l[l].topk = topk ? topk[l] : 0;
+        lv.l[l].stride = stride ? stride[l] : 0;
+        lv.l[l].lvl_off = (long)lvl_off[l];
+        lv.l[l].cand_off = cand_off ? (long)cand_off[l] : 0l;
+    }
+    return 0;
+}
+
+LOFT_EXPORT int loft_rpn_scores_levels(const void* const* heads_host, const int* H_host, const int* W_host,
+                                       const int64_t* lvl_off_host, int levels, int B, int Cp, int A, int64_t img_stride,
+                                       float* keys, float* img_max, void* stream) {
+    RpnLvls lv;
+    if (int e = rpn_levels_fill(lv, heads_host, nullptr, H_host, W_host, nullptr, nullptr, lvl_off_host, nullptr, levels)) return e;
+    long nmax = B;
+    for (int l = 0; l < levels; ++l) nmax = std::max(nmax, (long)B * H_host[l] * W_host[l] * A);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(rpn_scores_levels_kernel, dim3(loft_cdiv(nmax, 256), levels), dim3(256), 0, (hipStream_t)stream, lv, B, Cp, A,
+                       (long)img_stride, keys, img_max);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+LOFT_EXPORT int loft_rpn_decode_levels(const void* const* heads_host, const void* const* base_anchors_host, const int* H_host,
+                                       const int* W_host, const int* topk_host, const int* stride_host, const int64_t* lvl_off_host,
+                                       const int64_t* cand_off_host, int levels, const int32_t* sorted_idx, const float* sorted_keys,
+                                       int B, int Cp, int A, int64_t img_stride, const float* means_host, const float* stds_host,
+                                       float wh_ratio_clip, float max_h, float max_w, int64_t cand_stride, float* out_boxes,
+                                       float* out_scores, float* img_max, void* stream) {
+    RpnLvls lv;
+    if (int e = rpn_levels_fill(lv, heads_host, base_anchors_host, H_host, W_host, topk_host, stride_host, lvl_off_host, cand_off_host,
+                                levels)) return e;
+    long nmax = 0;
+    for (int l = 0; l < levels; ++l) nmax = std::max(nmax, (long)B * topk_host[l]);
+    if (nmax <= 0) return 0;
+    Coder4 c;
+    for (int i = 0; i < 4; ++i) { c.means[i] = means_host[i]; c.stds[i] = stds_host[i]; }
+    hipLaunchKernelGGL(rpn_decode_levels_kernel, dim3(loft_cdiv(nmax, 256), levels), dim3(256), 0, (hipStream_t)stream, lv, sorted_idx,
+                       sorted_keys, B, Cp, A, (long)img_stride, c, fabsf(logf(wh_ratio_clip)), max_h, max_w, (long)cand_stride,
+                       out_boxes, out_scores, img_max);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// The end of the proposal chain (rpn_head.py:169-171 `dets[:cfg.nms_post]` per image + what the RoI head wants of it): the first
+// `post` entries of every image's score-sorted survivor list -> props [B][post][5] (box, score; rows past the survivors zero)
+// and counts [B].  top_scores / top_idx are loft_segmented_topk_desc's outputs over segments of `seg_stride` candidates
+// (suppressed candidates carry -1); top_idx indexes cand_boxes [B * seg_stride][4].  One workgroup per image.
+__global__ __launch_bounds__(256) void rpn_finalize_kernel(const float* __restrict__ top_scores, const int32_t* __restrict__ top_idx,
+                                                           const float* __restrict__ cand_boxes, long seg_stride, int post,
+                                                           float* __restrict__ props, int64_t* __restrict__ counts) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int cnt = 0;
+    for (int r = tid; r < post; r += 256) {
+        const float sc = top_scores[(long)b * seg_stride + r];
+        const bool valid = sc >= 0.f;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) box = reinterpret_cast<const float4*>(cand_boxes)[top_idx[(long)b * seg_stride + r]];
+        float* o = props + ((long)b * post + r) * 5;
+        o[0] = box.x; o[1] = box.y; o[2] = box.z; o[3] = box.w; o[4] = valid ? sc : 0.f;
+        cnt += valid ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) counts[b] = (int64_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+LOFT_EXPORT int loft_rpn_finalize(const float* top_scores, const int32_t* top_idx, const float* cand_boxes, int B,
+                                  int64_t seg_stride, int post, float* props, int64_t* counts, void* stream) {
+    if (B <= 0) return 0;
+    if (post < 0 || post > seg_stride) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rpn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, top_scores, top_idx, cand_boxes,
+                       (long)seg_stride, post, props, counts);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

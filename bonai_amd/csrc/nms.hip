@@ -7,12 +7,13 @@
 // the N x N suppression matrix is block diagonal and is only ever built per segment.
 //
 //  (1) nms_mask_kernel : one 64-lane wavefront per 64x64 tile of the upper triangle; lane t owns
-//      row box r*64+t and emits ONE 64-bit word -- the wave64 width IS the bitmask word width,
-//      so there is no cross-lane packing step.  Column boxes are staged once in LDS.
+//      COLUMN box c*64+t and emits ONE 64-bit word (which row boxes of the tile suppress it) -- the
+//      wave64 width IS the bitmask word width, so there is no cross-lane packing step.  Row boxes
+//      are staged once in LDS.
 //  (2) nms_scan_kernel : one wavefront per segment walks the 64-box chunks in order; the
-//      in-chunk dependency chain is resolved in scalar registers with v_readlane (no memory),
-//      then the rows of the kept boxes (one row per lane, loaded ahead of the scalar loop) are
-//      OR-reduced across the wave into the lane-distributed "removed" bitmap.
+//      in-chunk dependency chain is resolved in scalar registers with v_readlane (no memory) and
+//      only for boxes that have a candidate suppressor inside their chunk; the kept set is then
+//      applied to the later chunks' tiles lane-locally (column-form tiles: no cross-lane reduction).
 //
 // Integer / bit-exact path.  The suppression predicate is the division-free form of the
 // mmcv-1.0.5 device kernel (inter > thr * union) and this file is compiled with
@@ -49,31 +50,42 @@ __device__ __forceinline__ float4 load_box(const float* boxes, long i, float shi
     return b;
 }
 
+// Layout of the suppression matrix: 64 x 64 bit tiles, COLUMN form.  Tile (rt, ct) of a segment is 64 consecutive words; word t
+// belongs to COLUMN box ct*64+t and bit j says "row box rt*64+j suppresses it".  Tile-row rt of segment s starts at word
+// (nms_tile_row0(o_s, s) + rt) * max_words * 64: floor(o_s / 64) + s never overlaps the previous segment's last, partial tile-row.
+// The scan then needs, per chunk of 64 row boxes, ONE coalesced 512-byte load per later chunk and (word & kept) != 0 per lane --
+// no cross-lane reduction (the row form needed a 64-lane OR-reduce-scatter of 48 words per chunk through the LDS crossbar).
+__device__ __forceinline__ long nms_tile_row0(long o, int seg) { return (o >> 6) + seg; }
+
 // grid: (col_tile, row_tile, segment); block: 64 threads (one wave).
 template <int PRED>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ seg_off,
                                                       const float* __restrict__ seg_shift, float thr, int max_words,
-                                                      unsigned long long* __restrict__ mask) {
+                                                      unsigned long long* __restrict__ mask, const float* __restrict__ img_max,
+                                                      int levels) {
     const int seg = blockIdx.z, rt = blockIdx.y, ct = blockIdx.x;
     if (ct < rt) return;  // lower triangle never read
     const long o = seg_off[seg];
     const int n = (int)(seg_off[seg + 1] - o);
     if (rt * 64 >= n || ct * 64 >= n) return;
-    const float shift = seg_shift ? seg_shift[seg] : 0.f;
-    __shared__ float4 cb[64];
+    // batched_nms's shift: given per segment, or derived here as level * (the image's largest coordinate + 1) -- segment s is level
+    // s % levels of image s / levels (same two fp32 operations as the tensor expression; -ffp-contract=off)
+    const float shift = seg_shift ? seg_shift[seg] : (img_max ? (float)(seg % levels) * (img_max[seg / levels] + 1.f) : 0.f);
+    __shared__ float4 rb[64];
     const int t = threadIdx.x;
-    const int cj = ct * 64 + t;
-    if (cj < n) cb[t] = load_box(boxes, o + cj, shift);
-    __syncthreads();
     const int ri = rt * 64 + t;
-    if (ri >= n) return;
-    const float4 a = load_box(boxes, o + ri, shift);
-    const int ncol = min(64, n - ct * 64);
+    if (ri < n) rb[t] = load_box(boxes, o + ri, shift);
+    __syncthreads();
+    const int cj = ct * 64 + t;
     unsigned long long m = 0ull;
-    const int start = (rt == ct) ? t + 1 : 0;
-    for (int j = start; j < ncol; ++j)
-        if (iou_gt<PRED>(a, cb[j], thr)) m |= (1ull << j);
-    mask[(size_t)(o + ri) * max_words + ct] = m;
+    if (cj < n) {
+        const float4 b = load_box(boxes, o + cj, shift);
+        const int nrow = min(64, n - rt * 64);
+        const int end = (rt == ct) ? min(t, nrow) : nrow;          // diagonal tile: only the rows above the column
+        for (int j = 0; j < end; ++j)
+            if (iou_gt<PRED>(rb[j], b, thr)) m |= (1ull << j);
+    }
+    mask[((size_t)(nms_tile_row0(o, seg) + rt) * max_words + ct) * 64 + t] = m;
 }
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
@@ -82,47 +94,85 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ unsigned long long shfl_xor64(unsigned long long v, int d) {
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xffffffffull), d, 64);
-    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), d, 64);
-    return ((unsigned long long)hi << 32) | lo;
+// grid: (segments); block: 64 threads (one wave).  Lane j stands for box c*64+j of the current chunk c AND keeps, as bit w of
+// R[w >> 6], whether box w*64+j of chunk w is already suppressed.  Per chunk:
+//   * rem_c = ballot(bit c of R); the in-chunk chain runs in scalar registers on the diagonal tile (column form: word j = the
+//     earlier boxes of the chunk that suppress box j) and visits only boxes that HAVE such a candidate: a box nothing in its chunk
+//     overlaps is kept iff it is alive.  (The first forms walked every kept box, ~100 cycles each for a lone wave: 2.7 us per
+//     chunk, 241 us per launch on the proposal chain every RoI-head launch waits for.)
+//   * for every later chunk w: R bit w |= (tile(c, w) word & kept) != 0 -- one coalesced load (requested a chunk ahead into the
+//     other of two register sets; unconditional, so the compiler can count them in s_waitcnt) and six VALU instructions.
+template <bool ONE>       // ONE: at most 64 chunks (4096 boxes) -- R is one word per lane, no slot select anywhere
+__device__ __forceinline__ void nms_scan_body(const unsigned long long* __restrict__ mask, long o, int n, int seg, int max_words,
+                                              uint8_t* __restrict__ keep) {
+    const int lane = threadIdx.x;
+    const int nwords = (n + 63) >> 6;
+    constexpr int PF = 48;                 // tiles held in registers per chunk (segments up to 3136 boxes fully)
+    constexpr int NR = ONE ? 1 : NMS_MAX_WORDS_PER_LANE;
+    unsigned long long R[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) R[q] = 0ull;
+    const unsigned long long* seg_tiles = mask + (size_t)nms_tile_row0(o, seg) * max_words * 64;
+
+    // Plain loads off a wave-uniform tile-row pointer (scalar base + lane offset; no per-load predicate or select: a first version
+    // with `need ? tile : base` per load compiled to ~20 instructions and an SGPR spill per tile).  Tiles past the segment's last
+    // chunk are READ all the same -- inside the workspace (its size includes PF tiles of slack), unwritten or another segment's --
+    // and only ever set R bits of chunks >= nwords, which nothing reads.
+    auto fetch = [&](int c, unsigned long long (&T)[PF], unsigned long long& diag) {
+        const int cc = min(c, nwords - 1);
+        const unsigned long long* trow = seg_tiles + ((size_t)cc * max_words + cc) * 64;   // tile (cc, cc)
+        diag = trow[lane];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) T[k] = trow[(k + 1) * 64 + lane];
+    };
+    auto mark = [&](int w, unsigned long long t, unsigned long long kept) {
+        const unsigned long long bit = (t & kept) != 0ull ? (1ull << (w & 63)) : 0ull;
+        if constexpr (ONE) {
+            R[0] |= bit;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) R[q] |= (q == (w >> 6)) ? bit : 0ull;
+        }
+    };
+    auto process = [&](int c, unsigned long long (&T)[PF], unsigned long long diag) {
+        const int row = c * 64 + lane;
+        unsigned long long r = R[0];
+        if constexpr (!ONE) {
+#pragma unroll
+            for (int q = 1; q < NR; ++q) r = (q == (c >> 6)) ? R[q] : r;
+        }
+        const unsigned long long rem_c = __ballot((r >> (c & 63)) & 1ull);
+        const int nvalid = min(64, n - c * 64);
+        const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        const unsigned long long alive = ~rem_c & valid;
+        unsigned long long kept = alive;
+        unsigned long long todo = __ballot(diag != 0ull) & alive;      // boxes with an in-chunk candidate suppressor
+        while (todo) {  // wave-uniform scalar loop, ascending: every earlier box's fate is final when box b is looked at
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if (readlane64(diag, b) & kept) kept &= ~(1ull << b);
+        }
+        if (row < n) keep[o + row] = (uint8_t)((kept >> lane) & 1ull);
+        if (c + 1 >= nwords) return;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            if (c + 1 + k >= nwords) break;                            // wave-uniform
+            mark(c + 1 + k, T[k], kept);
+        }
+        for (int w = c + 1 + PF; w < nwords; ++w)                      // segments beyond 3136 boxes: the remaining tiles, loaded here
+            mark(w, seg_tiles[((size_t)c * max_words + w) * 64 + lane], kept);
+    };
+    unsigned long long T0[PF], T1[PF], d0, d1;
+    fetch(0, T0, d0);
+    for (int c = 0; c < nwords; c += 2) {
+        fetch(c + 1, T1, d1);
+        process(c, T0, d0);
+        if (c + 1 >= nwords) break;
+        fetch(c + 2, T0, d0);
+        process(c + 1, T1, d1);
+    }
 }
 
-// OR-reduce-scatter of 16 words per lane over the 64 lanes (recursive halving on lane bits 0..3, then two full exchanges):
-// on return EVERY lane holds the OR over all lanes of word (lane & 15): 15 + 2 64-bit exchanges instead of 16 x 6.
-__device__ __forceinline__ unsigned long long or_reduce_scatter16(const unsigned long long (&x)[16], int lane) {
-    unsigned long long y[8], z[4], u[2];
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {     // keep the words whose index bit 0 equals lane bit 0
-        const unsigned long long mine = b0 ? x[2 * j + 1] : x[2 * j], send = b0 ? x[2 * j] : x[2 * j + 1];
-        y[j] = mine | shfl_xor64(send, 1);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned long long mine = b1 ? y[2 * j + 1] : y[2 * j], send = b1 ? y[2 * j] : y[2 * j + 1];
-        z[j] = mine | shfl_xor64(send, 2);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const unsigned long long mine = b2 ? z[2 * j + 1] : z[2 * j], send = b2 ? z[2 * j] : z[2 * j + 1];
-        u[j] = mine | shfl_xor64(send, 4);
-    }
-    unsigned long long v = (b3 ? u[1] : u[0]) | shfl_xor64(b3 ? u[0] : u[1], 8);
-    v |= shfl_xor64(v, 16);
-    v |= shfl_xor64(v, 32);
-    return v;
-}
-
-// grid: (segments); block: 64 threads (one wave).  Per 64-box chunk c:
-//   * lane t loads ITS row (box c*64+t): the diagonal word and, in 16-word (128-byte) batches, the words right of it -- all
-//     loads are independent and issued BEFORE the chunk's scalar keep loop, so the loop hides their latency (the first form of
-//     this kernel loaded one row per KEPT box inside a dependent loop: ~0.25 us of exposed latency per kept box, 0.87 ms for
-//     the 3000-box RPN segments of a batch);
-//   * the in-chunk chain is resolved with v_readlane on the diagonal word (no memory);
-//   * rows of suppressed boxes are zeroed and each batch is OR-reduced across lanes with or_reduce_scatter16, which leaves
-//     word w in the lanes with (lane & 15) == (w & 15): exactly where the lane-distributed "removed" bitmap keeps it
-//     (word w in lane w & 63, slot w >> 6).
 __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                       const int64_t* __restrict__ seg_off, int max_words,
                                                       uint8_t* __restrict__ keep) {
@@ -130,102 +180,53 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     const long o = seg_off[seg];
     const int n = (int)(seg_off[seg + 1] - o);
     if (n <= 0) return;
-    const int lane = threadIdx.x;
-    const int nwords = (n + 63) >> 6;
-    const int nbatch = (nwords + 15) >> 4;
-    constexpr int PF = 3;                  // batches loaded ahead of the keep loop (covers segments up to 3072 boxes fully)
-    unsigned long long removed[NMS_MAX_WORDS_PER_LANE];
-#pragma unroll
-    for (int q = 0; q < NMS_MAX_WORDS_PER_LANE; ++q) removed[q] = 0ull;
-
-    auto load_batch = [&](const unsigned long long* rp, int wb, int c, unsigned long long (&x)[16]) {
-        // words [wb*16, wb*16+16) of this lane's row; only words > c and < nwords were written by nms_mask_kernel
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int w = wb * 16 + k;
-            x[k] = (rp != nullptr && w > c && w < nwords) ? rp[w] : 0ull;
-        }
-    };
-    auto deposit = [&](unsigned long long v, int wb) {
-        if ((lane >> 4) == (wb & 3)) {
-#pragma unroll
-            for (int q = 0; q < NMS_MAX_WORDS_PER_LANE; ++q)
-                if (q == (wb >> 2)) removed[q] |= v;
-        }
-    };
-
-    unsigned long long diag_next = lane < n ? mask[(size_t)(o + lane) * max_words] : 0ull;
-    for (int c = 0; c < nwords; ++c) {
-        const int row = c * 64 + lane;
-        const unsigned long long* rp = row < n ? mask + (size_t)(o + row) * max_words : nullptr;
-        const unsigned long long diag = diag_next;
-        diag_next = (row + 64 < n) ? mask[(size_t)(o + row + 64) * max_words + c + 1] : 0ull;   // next chunk's diagonal word
-        const int wb0 = (c + 1) >> 4;
-        unsigned long long x[PF][16];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) load_batch(wb0 + p < nbatch ? rp : nullptr, wb0 + p, c, x[p]);
-        // removed word of chunk c lives in lane (c & 63), slot (c >> 6)
-        unsigned long long mine = 0ull;
-#pragma unroll
-        for (int q = 0; q < NMS_MAX_WORDS_PER_LANE; ++q)
-            if (q == (c >> 6)) mine = removed[q];
-        const unsigned long long rem_c = readlane64(mine, c & 63);
-        const int nvalid = min(64, n - c * 64);
-        const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-        unsigned long long alive = ~rem_c & valid, kept = 0ull;
-        while (alive) {  // wave-uniform scalar loop
-            const int b = __builtin_ctzll(alive);
-            kept |= (1ull << b);
-            alive &= ~readlane64(diag, b);
-            alive &= ~(1ull << b);
-        }
-        const bool i_am_kept = (kept >> lane) & 1ull;
-        if (row < n) keep[o + row] = (uint8_t)i_am_kept;
-        if (c + 1 >= nwords) break;
-        // OR the rows of the kept boxes into the removed bitmap (words > c)
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            if (wb0 + p >= nbatch) break;                 // wave-uniform
-            if (!i_am_kept) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) x[p][k] = 0ull;
-            }
-            deposit(or_reduce_scatter16(x[p], lane), wb0 + p);
-        }
-        for (int wb = wb0 + PF; wb < nbatch; ++wb) {      // segments beyond 3072 boxes: remaining batches, loaded here
-            unsigned long long xx[16];
-            load_batch(i_am_kept ? rp : nullptr, wb, c, xx);
-            deposit(or_reduce_scatter16(xx, lane), wb);
-        }
-    }
+    if (n <= 4096) nms_scan_body<true>(mask, o, n, seg, max_words, keep);
+    else nms_scan_body<false>(mask, o, n, seg, max_words, keep);
 }
 
-LOFT_EXPORT int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_segment) {
+LOFT_EXPORT int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_segment, int64_t num_segments) {
     int64_t words = (max_segment + 63) / 64;
     if (words < 1) words = 1;
-    return total_boxes * words * 8;
+    return (((total_boxes >> 6) + num_segments + 1) * words + 48) * 512;   // tile-rows (nms_tile_row0) x tiles per row x 64 words, + the scan's read-ahead
 }
 
-LOFT_EXPORT int loft_nms_segmented_pred(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
-                                        int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr,
-                                        int predicate, void* workspace, uint8_t* keep, void* stream) {
+static int nms_launch(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev, const float* img_max_dev,
+                      int levels, int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr, int predicate,
+                      void* workspace, uint8_t* keep, void* stream) {
     if (predicate != LOFT_NMS_PRED_DEVICE && predicate != LOFT_NMS_PRED_CPU) return (int)hipErrorInvalidValue;
     if (num_segments <= 0 || total_boxes <= 0) return 0;
-    const int max_words = (int)((max_segment + 63) / 64);
+    const int max_words = (int)((max_segment + 63) / 64);          // tiles per tile-row
     if (max_words > 64 * NMS_MAX_WORDS_PER_LANE) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(max_words, max_words, num_segments);
     if (predicate == LOFT_NMS_PRED_DEVICE)
         hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(64), 0, s, boxes, seg_offsets_dev, seg_shift_dev, iou_thr, max_words,
-                           (unsigned long long*)workspace);
+                           (unsigned long long*)workspace, img_max_dev, levels);
     else
         hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(64), 0, s, boxes, seg_offsets_dev, seg_shift_dev, iou_thr, max_words,
-                           (unsigned long long*)workspace);
+                           (unsigned long long*)workspace, img_max_dev, levels);
     LOFT_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(num_segments), dim3(64), 0, s, (const unsigned long long*)workspace,
                        seg_offsets_dev, max_words, keep);
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_nms_segmented_pred(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
+                                        int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr,
+                                        int predicate, void* workspace, uint8_t* keep, void* stream) {
+    return nms_launch(boxes, seg_offsets_dev, seg_shift_dev, nullptr, 1, num_segments, total_boxes, max_segment, iou_thr, predicate,
+                      workspace, keep, stream);
+}
+
+// segments = (image, level) pairs, image-major; the level shift is computed on the device from img_max_dev [num_segments / levels]
+// (loft_rpn_decode_levels' per-image maximum coordinate): no host-visible shift table between the decode and the NMS
+LOFT_EXPORT int loft_nms_segmented_levels(const float* boxes, const int64_t* seg_offsets_dev, const float* img_max_dev, int levels,
+                                          int num_segments, int64_t total_boxes, int64_t max_segment, float iou_thr, int predicate,
+                                          void* workspace, uint8_t* keep, void* stream) {
+    if (levels < 1 || num_segments % levels || img_max_dev == nullptr) return (int)hipErrorInvalidValue;
+    return nms_launch(boxes, seg_offsets_dev, nullptr, img_max_dev, levels, num_segments, total_boxes, max_segment, iou_thr, predicate,
+                      workspace, keep, stream);
 }
 
 LOFT_EXPORT int loft_nms_segmented(const float* boxes, const int64_t* seg_offsets_dev, const float* seg_shift_dev,
@@ -355,9 +356,26 @@ __device__ __forceinline__ unsigned topk_ord(float f) {
 // Walk keys[0, len) with every thread of the block: f(order-preserving key image, index).  The body is 16-byte loads, four of
 // them in flight per thread, when the segment starts on a 16-byte boundary -- one workgroup has to stream up to 768 KiB per pass, and
 // with one 4-byte load per thread and loop trip each pass was a chain of ~190 dependent L2 / HBM round trips (217 us per launch).
+// mk (optional): a byte per key; keys whose byte is 0 count as -1.0 (the NMS keep flags: `where(keep, score, -1)` without a pass)
 template <typename F>
-__device__ __forceinline__ void topk_walk(const float* __restrict__ kp, int len, F&& f) {
+__device__ __forceinline__ void topk_walk(const float* __restrict__ kp, const uint8_t* __restrict__ mk, int len, F&& f) {
     const int tid = threadIdx.x;
+    if (mk != nullptr) {
+        if (((reinterpret_cast<size_t>(kp) & 15) | (reinterpret_cast<size_t>(mk) & 3)) == 0) {
+            const int n4 = len >> 2;
+            for (int q = tid; q < n4; q += SNMS_THREADS) {
+                const float4 a = reinterpret_cast<const float4*>(kp)[q];
+                const unsigned m = reinterpret_cast<const unsigned*>(mk)[q];
+                const int i = q * 4;
+                f(topk_ord((m & 0xffu) ? a.x : -1.f), i); f(topk_ord((m & 0xff00u) ? a.y : -1.f), i + 1);
+                f(topk_ord((m & 0xff0000u) ? a.z : -1.f), i + 2); f(topk_ord((m & 0xff000000u) ? a.w : -1.f), i + 3);
+            }
+            for (int i = (n4 << 2) + tid; i < len; i += SNMS_THREADS) f(topk_ord(mk[i] ? kp[i] : -1.f), i);
+        } else {
+            for (int i = tid; i < len; i += SNMS_THREADS) f(topk_ord(mk[i] ? kp[i] : -1.f), i);
+        }
+        return;
+    }
     if ((reinterpret_cast<size_t>(kp) & 15) == 0) {
         const int n4 = len >> 2;
         const float4* k4 = reinterpret_cast<const float4*>(kp);
@@ -385,7 +403,8 @@ __device__ __forceinline__ void topk_walk(const float* __restrict__ kp, int len,
 __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __restrict__ keys, const int32_t* __restrict__ vals_in,
                                                                const int64_t* __restrict__ seg_off, int k,
                                                                float* __restrict__ keys_out, int32_t* __restrict__ vals_out,
-                                                               const int64_t* __restrict__ out_off) {
+                                                               const int64_t* __restrict__ out_off,
+                                                               const uint8_t* __restrict__ key_mask) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long cand[TOPK_MAX];
     __shared__ int wsum[SNMS_THREADS / 64];
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __r
     if (kk <= 0) return;
     const long o0 = out_off ? out_off[blockIdx.x] : s0;              // where this segment's head is written
     const float* kp = keys + s0;
+    const uint8_t* mk = key_mask ? key_mask + s0 : nullptr;
     unsigned T = 0u, need = (unsigned)kk, total_eq = 0u;
     if (kk < len) {
         unsigned prefix = 0u, pmask = 0u;
@@ -408,7 +428,7 @@ __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __r
             // Scores cluster (sigmoid outputs share an exponent; suppressed candidates are all -1): in the first pass whole waves
             // hit ONE bin, and 64 same-address LDS atomics serialise.  When every counting lane of the wave has the same bin, one
             // lane adds the count.
-            topk_walk(kp, len, [&](unsigned o, int) {
+            topk_walk(kp, mk, len, [&](unsigned o, int) {
                 const bool act = (o & pmask) == prefix;
                 const unsigned bin = (o >> sh) & (unsigned)(nb - 1);
                 const unsigned long long am = __ballot(act);
@@ -445,16 +465,16 @@ __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __r
     if (tid == 0) s_cnt = 0u;
     __syncthreads();
     if (kk == len) {
-        topk_walk(kp, len, [&](unsigned o, int i) { cand[i] = compose(o, i); });
+        topk_walk(kp, mk, len, [&](unsigned o, int i) { cand[i] = compose(o, i); });
     } else if (total_eq == need) {
-        topk_walk(kp, len, [&](unsigned o, int i) {
+        topk_walk(kp, mk, len, [&](unsigned o, int i) {
             if (o >= T) cand[atomicAdd(&s_cnt, 1u)] = compose(o, i);
         });
     } else {
         unsigned eq_base = 0u;
         for (int c0 = 0; c0 < len; c0 += SNMS_THREADS) {
             const int i = c0 + tid;
-            const unsigned o = i < len ? topk_ord(kp[i]) : 0u;
+            const unsigned o = i < len ? topk_ord((mk == nullptr || mk[i]) ? kp[i] : -1.f) : 0u;
             const bool in = i < len;
             if (in && o > T) cand[atomicAdd(&s_cnt, 1u)] = compose(o, i);
             const int fe = (in && o == T) ? 1 : 0;
@@ -495,11 +515,62 @@ __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __r
 }
 LOFT_EXPORT int loft_segmented_topk_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out,
                                          int num_segments, const int64_t* seg_offsets_dev, int k, const int64_t* out_offsets_dev,
-                                         void* stream) {
+                                         const uint8_t* key_mask_dev, void* stream) {
     if (k < 1 || k > TOPK_MAX) return (int)hipErrorInvalidValue;
     if (num_segments <= 0) return 0;
     hipLaunchKernelGGL(seg_topk_kernel, dim3(num_segments), dim3(SNMS_THREADS), 0, (hipStream_t)stream, keys_in, vals_in,
-                       seg_offsets_dev, k, keys_out, vals_out, out_offsets_dev);
+                       seg_offsets_dev, k, keys_out, vals_out, out_offsets_dev, key_mask_dev);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- merge of sorted runs (the second stage of the two-stage top-k) ---------------------------------------------------------------
+// Stage 1 left, per sub-range ("run"), its first <= k entries in stable descending order.  The first k of a segment's merged order:
+// the rank of an entry is its position in its own run plus, for every other run of the segment, the number of entries that precede it
+// -- keys >= its key in EARLIER runs (those hold lower original indices: ties go to them), keys > its key in later runs; a binary
+// search per run, all runs of a thread's entry independent of each other.  Entries with rank < k are written at out0 + rank.  One
+// thread per entry; ~10 searches of 12 steps against one workgroup streaming 30 000 candidates four times (88 us -> a few).
+// run_off [nrun + 1]: run r = candidates [run_off[r], run_off[r + 1]); run_first[r] / run_count[r]: the runs of r's segment;
+// run_out[r]: where the segment's head is written.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ ck, const int32_t* __restrict__ cv,
+                                                         const int64_t* __restrict__ run_off, const int32_t* __restrict__ run_first,
+                                                         const int32_t* __restrict__ run_count, const int64_t* __restrict__ run_out,
+                                                         int k, float* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    const int r = blockIdx.y;
+    const long r0 = run_off[r];
+    const int len = (int)(run_off[r + 1] - r0);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= len) return;
+    const unsigned x = topk_ord(ck[r0 + p]);
+    const int f = run_first[r], nr = run_count[r];
+    int rank = p;
+    for (int q = f; q < f + nr; ++q) {
+        if (q == r) continue;
+        const long q0 = run_off[q];
+        const int qn = (int)(run_off[q + 1] - q0);
+        // run q is descending: the number of its entries that precede x = the first position where "precedes" fails
+        int lo = 0, hi = qn;
+        const bool earlier = q < r;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned y = topk_ord(ck[q0 + mid]);
+            const bool before = earlier ? (y >= x) : (y > x);
+            if (before) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank >= k) return;
+    // (the canonical key image, -0.0 -> +0.0, as the one-stage kernel writes it)
+    keys_out[run_out[r] + rank] = __uint_as_float((x & 0x80000000u) ? (x & 0x7fffffffu) : ~x);
+    vals_out[run_out[r] + rank] = cv[r0 + p];
+}
+LOFT_EXPORT int loft_topk_merge_runs(const float* cand_keys, const int32_t* cand_vals, int num_runs, int max_run,
+                                     const int64_t* run_offsets_dev, const int32_t* run_first_dev, const int32_t* run_count_dev,
+                                     const int64_t* run_out_dev, int k, float* keys_out, int32_t* vals_out, void* stream) {
+    if (k < 1 || num_runs < 0 || max_run < 0) return (int)hipErrorInvalidValue;
+    if (num_runs == 0 || max_run == 0) return 0;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((max_run + 255) / 256, num_runs), dim3(256), 0, (hipStream_t)stream, cand_keys,
+                       cand_vals, run_offsets_dev, run_first_dev, run_count_dev, run_out_dev, k, keys_out, vals_out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -267,7 +267,8 @@ def map_roi_levels(rois, num_levels=4, finest_scale=56):
 NMS_PREDICATES = {'device': 0, 'cpu': 1}   # include/loft_hip.h LOFT_NMS_PRED_*
 
 
-def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segment=None, predicate='device'):
+def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segment=None, predicate='device', img_max=None, levels=1,
+                  covered=False):
     """boxes_sorted [T,4] fp32 sorted (score desc, index asc) inside each segment;
     seg_offsets int64 [S+1] (device).  -> keep mask uint8 [T].
     predicate: 'device' (default; mmcv-1.0.5's CUDA kernel, inter > thr*union -- what the reference's GPU runs execute) or
@@ -277,12 +278,19 @@ def nms_segmented(boxes_sorted, seg_offsets, iou_thr, seg_shift=None, max_segmen
     boxes_sorted = boxes_sorted.float().contiguous()
     T = boxes_sorted.shape[0]
     S = seg_offsets.numel() - 1
-    keep = torch.zeros(T, dtype=torch.uint8, device=boxes_sorted.device)
+    # (covered: the caller's segments span all T boxes -- the scan writes every entry, no zero fill)
+    keep = (torch.empty if covered and T > 0 and S > 0 else torch.zeros)(T, dtype=torch.uint8, device=boxes_sorted.device)
     if T == 0 or S <= 0:
         return keep
     if max_segment is None:
         max_segment = int((seg_offsets[1:] - seg_offsets[:-1]).max().item())
-    ws = torch.empty(lib.loft_nms_workspace_bytes(T, max_segment), dtype=torch.uint8, device=boxes_sorted.device)
+    ws = torch.empty(lib.loft_nms_workspace_bytes(T, max_segment, S), dtype=torch.uint8, device=boxes_sorted.device)
+    if img_max is not None:     # segments = (image, level), shift = level * (img_max[image] + 1) computed on the device
+        L.dev_check(img_max)
+        L.check(lib.loft_nms_segmented_levels(L.ptr(boxes_sorted), L.ptr(seg_offsets), L.ptr(img_max), int(levels), S, c_int64(T),
+                                              c_int64(max_segment), c_float(iou_thr), c_int(NMS_PREDICATES[predicate]), L.ptr(ws),
+                                              L.ptr(keep), L.stream()), 'loft_nms_segmented_levels')
+        return keep
     L.check(lib.loft_nms_segmented_pred(L.ptr(boxes_sorted), L.ptr(seg_offsets), L.ptr(seg_shift), S, c_int64(T),
                                         c_int64(max_segment), c_float(iou_thr), c_int(NMS_PREDICATES[predicate]), L.ptr(ws),
                                         L.ptr(keep), L.stream()), 'loft_nms_segmented_pred')
@@ -324,44 +332,55 @@ _TOPK_TABLES = {}
 
 
 def _topk_two_stage_tables(seg_lengths, k, device):
-    """Static tables of the two-stage selection for segments longer than TOPK_MAX_SEGMENT: every segment is cut into sub-ranges of at
-    most `sub` keys (a multiple of 4: 16-byte loads) such that sub-ranges x k candidates fit one workgroup's walk again.
-    -> (sub_off, sub_out, cand_off, seg_start, n_cand) device int64 tables, or None when even that does not fit."""
+    """Static tables of the two-stage selection for segments longer than TOPK_MAX_SEGMENT: every segment is cut into sub-ranges
+    ("runs") of at most `sub` keys (a multiple of 4: 16-byte loads), ~ TOPK_RUNS per longest segment.
+    -> dict of device tables (run boundaries in the key array and in the compact candidate list, each run's segment), or None."""
     key = (tuple(int(n) for n in seg_lengths), int(k), str(device))
     if key in _TOPK_TABLES:
         return _TOPK_TABLES[key]
-    pmax = TOPK_MAX_SEGMENT // k
     longest = max(seg_lengths) if seg_lengths else 0
-    sub = -(-longest // max(pmax, 1))
+    sub = -(-longest // TOPK_RUNS)
     sub = (sub + 3) // 4 * 4
     tabs = None
-    if pmax >= 2 and 0 < sub <= TOPK_MAX_SEGMENT:
-        sub_off, sub_out, cand_off, seg_start = [0], [], [0], []
+    if 0 < sub <= TOPK_MAX_SEGMENT:
+        sub_off, run_off, run_first, run_count, run_out = [0], [0], [], [], []
         pos = 0
         for n in seg_lengths:
-            seg_start.append(pos)
-            c = cand_off[-1]
+            first, cnt = len(run_first), len(range(0, n, sub))
             for a in range(0, n, sub):
                 ln = min(sub, n - a)
-                sub_out.append(c)
-                c += min(k, ln)
                 sub_off.append(pos + a + ln)
-            cand_off.append(c)
+                run_off.append(run_off[-1] + min(k, ln))
+                run_first.append(first); run_count.append(cnt); run_out.append(pos)
             pos += n
-        t = lambda v: h2d(v, torch.int64, device)
-        tabs = (t(sub_off), t(sub_out), t(cand_off), t(seg_start), cand_off[-1], len(sub_out))
+        tabs = dict(sub_off=h2d(sub_off, torch.int64, device), run_off=h2d(run_off, torch.int64, device),
+                    run_first=h2d(run_first, torch.int32, device), run_count=h2d(run_count, torch.int32, device),
+                    run_out=h2d(run_out, torch.int64, device), n_cand=run_off[-1], n_run=len(run_first),
+                    max_run=min(k, sub))
     _TOPK_TABLES[key] = tabs
     return tabs
 
 
-def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None, seg_lengths=None):
+TOPK_RUNS = 10          # sub-ranges per longest segment in the two-stage form (tools/probes/topk_time.py)
+
+
+def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None, seg_lengths=None, key_mask=None):
     """The first k entries of each segment's stable descending order, in the layout of segmented_sort_desc (entry r of segment s at
     seg_offsets[s] + r; entries past min(k, segment length) are left unwritten).  In-house radix select + LDS bitonic sort
     (loft_segmented_topk_desc), one workgroup per segment, for k <= TOPK_MAX and segments of at most TOPK_MAX_SEGMENT keys
-    (``max_segment``: the caller's host-side bound); longer segments with host-known lengths (``seg_lengths``) in TWO stages -- top-k
-    of every sub-range into a compact candidate list, top-k of the candidates back into place; otherwise the full library sort."""
+    (``max_segment``: the caller's host-side bound); longer segments with host-known lengths (``seg_lengths``) in TWO stages -- the
+    same kernel over ~TOPK_RUNS sub-ranges per segment into a compact candidate list, then a rank merge of those sorted runs
+    (loft_topk_merge_runs); otherwise the full library sort.  key_mask (uint8 / bool per key): masked keys count as -1."""
     lib = L.load()
-    if k > TOPK_MAX or max_segment is None or (max_segment > TOPK_MAX_SEGMENT and (seg_lengths is None or values is not None)):
+    if key_mask is not None:
+        key_mask = key_mask.view(torch.uint8) if key_mask.dtype == torch.bool else key_mask
+        if key_mask.dtype != torch.uint8 or key_mask.numel() != keys.numel():
+            raise L.LoftHipError('key_mask: one uint8 / bool per key')
+        L.dev_check(key_mask)
+    two_stage = max_segment is not None and max_segment > TOPK_MAX_SEGMENT
+    if k > TOPK_MAX or max_segment is None or (two_stage and (seg_lengths is None or values is not None or key_mask is not None)):
+        if key_mask is not None:
+            keys = torch.where(key_mask.view(torch.bool).view_as(keys), keys, -1.0)
         return segmented_sort_desc(keys, seg_offsets, values)
     L.dev_check(keys, seg_offsets)
     keys = keys.float().contiguous()
@@ -370,22 +389,22 @@ def segmented_topk_desc(keys, seg_offsets, k, values=None, max_segment=None, seg
     vo = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
     if keys.numel() == 0 or S <= 0:
         return ko, vo
-    if max_segment > TOPK_MAX_SEGMENT:
+    if two_stage:
         tabs = _topk_two_stage_tables(seg_lengths, k, keys.device)
         if tabs is None or len(seg_lengths) != S:
             return segmented_sort_desc(keys, seg_offsets, values)
-        sub_off, sub_out, cand_off, seg_start, n_cand, n_sub = tabs
-        ck = torch.empty(n_cand, dtype=torch.float32, device=keys.device)
-        cv = torch.empty(n_cand, dtype=torch.int32, device=keys.device)
-        L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ck), c_void_p(0), L.ptr(cv), n_sub, L.ptr(sub_off), int(k), L.ptr(sub_out),
-                                             L.stream()), 'loft_segmented_topk_desc(stage 1)')
-        L.check(lib.loft_segmented_topk_desc(L.ptr(ck), L.ptr(ko), L.ptr(cv), L.ptr(vo), S, L.ptr(cand_off), int(k), L.ptr(seg_start),
-                                             L.stream()), 'loft_segmented_topk_desc(stage 2)')
+        ck = torch.empty(tabs['n_cand'], dtype=torch.float32, device=keys.device)
+        cv = torch.empty(tabs['n_cand'], dtype=torch.int32, device=keys.device)
+        L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ck), c_void_p(0), L.ptr(cv), tabs['n_run'], L.ptr(tabs['sub_off']), int(k),
+                                             L.ptr(tabs['run_off']), c_void_p(0), L.stream()), 'loft_segmented_topk_desc(stage 1)')
+        L.check(lib.loft_topk_merge_runs(L.ptr(ck), L.ptr(cv), tabs['n_run'], tabs['max_run'], L.ptr(tabs['run_off']),
+                                         L.ptr(tabs['run_first']), L.ptr(tabs['run_count']), L.ptr(tabs['run_out']), int(k), L.ptr(ko),
+                                         L.ptr(vo), L.stream()), 'loft_topk_merge_runs')
         return ko, vo
     if values is not None:
         values = values.to(torch.int32).contiguous()
     L.check(lib.loft_segmented_topk_desc(L.ptr(keys), L.ptr(ko), L.ptr(values), L.ptr(vo), S, L.ptr(seg_offsets), int(k), c_void_p(0),
-                                         L.stream()), 'loft_segmented_topk_desc')
+                                         L.ptr(key_mask), L.stream()), 'loft_segmented_topk_desc')
     return ko, vo
 
 
@@ -884,6 +903,47 @@ def rpn_decode(head, sorted_idx, A, img_stride, lvl_off, topk, base_anchors, str
                                 L.arr(c_float, list(stds)), c_float(wh_ratio_clip), c_float(max_shape[0]),
                                 c_float(max_shape[1]), c_int64(cand_stride), c_int64(cand_off), L.ptr(out_boxes),
                                 L.stream()), 'loft_rpn_decode')
+
+
+def rpn_scores_levels(heads, A, img_stride, lvl_offs, keys, img_max=None):
+    """rpn_scores for every level in one launch; img_max (fp32 [B], optional) is reset to -inf for rpn_decode_levels."""
+    lib = L.load()
+    heads = [_nhwc(h) for h in heads]
+    B, Cp = heads[0].shape[:2]
+    n = len(heads)
+    L.check(lib.loft_rpn_scores_levels(L.arr(c_void_p, [h.data_ptr() for h in heads]), L.arr(c_int, [int(h.shape[2]) for h in heads]),
+                                       L.arr(c_int, [int(h.shape[3]) for h in heads]), L.arr(c_int64, [int(o) for o in lvl_offs[:n]]),
+                                       n, B, Cp, A, c_int64(img_stride), L.ptr(keys), L.ptr(img_max), L.stream()),
+            'loft_rpn_scores_levels')
+    return heads
+
+
+def rpn_decode_levels(heads, sorted_idx, sorted_keys, A, img_stride, lvl_offs, topk, base_anchors, strides, means, stds, max_shape,
+                      cand_stride, cand_offs, out_boxes, out_scores=None, img_max=None, wh_ratio_clip=16 / 1000):
+    """rpn_decode for every level in one launch (+ candidate scores in the candidate layout, + the per-image coordinate maximum)."""
+    lib = L.load()
+    heads = [_nhwc(h) for h in heads]
+    B, Cp = heads[0].shape[:2]
+    n = len(heads)
+    L.check(lib.loft_rpn_decode_levels(L.arr(c_void_p, [h.data_ptr() for h in heads]), L.arr(c_void_p, [b.data_ptr() for b in base_anchors]),
+                                       L.arr(c_int, [int(h.shape[2]) for h in heads]), L.arr(c_int, [int(h.shape[3]) for h in heads]),
+                                       L.arr(c_int, [int(t) for t in topk]), L.arr(c_int, [int(s) for s in strides]),
+                                       L.arr(c_int64, [int(o) for o in lvl_offs[:n]]), L.arr(c_int64, [int(o) for o in cand_offs[:n]]), n,
+                                       L.ptr(sorted_idx), L.ptr(sorted_keys), B, Cp, A, c_int64(img_stride),
+                                       L.arr(c_float, list(means)), L.arr(c_float, list(stds)), c_float(wh_ratio_clip),
+                                       c_float(max_shape[0]), c_float(max_shape[1]), c_int64(cand_stride), L.ptr(out_boxes),
+                                       L.ptr(out_scores), L.ptr(img_max), L.stream()), 'loft_rpn_decode_levels')
+
+
+def rpn_finalize(top_scores, top_idx, cand_boxes, B, seg_stride, post):
+    """-> (props fp32 [B, post, 5], counts int64 [B]) from the post-NMS top-k (loft_rpn_finalize)."""
+    lib = L.load()
+    L.dev_check(top_scores, top_idx, cand_boxes)
+    props = torch.empty(B, post, 5, dtype=torch.float32, device=top_scores.device)
+    counts = torch.empty(B, dtype=torch.int64, device=top_scores.device)
+    L.check(lib.loft_rpn_finalize(L.ptr(top_scores), L.ptr(top_idx), L.ptr(cand_boxes), int(B), c_int64(seg_stride), int(post),
+                                  L.ptr(props), L.ptr(counts), L.stream()), 'loft_rpn_finalize')
+    return props, counts
 
 
 def foa_targets(pos_boxes, pos_gt_offsets, stds=(0.5, 0.5)):

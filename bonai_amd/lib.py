@@ -57,7 +57,7 @@ def load():
                     '(hipcc --offload-arch=gfx950).  bonai_amd has no CPU / eager fallback.')
             lib = ctypes.CDLL(path)
             lib.loft_nms_workspace_bytes.restype = c_int64
-            lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64]
+            lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
             lib.loft_soft_nms_workspace_bytes.restype = c_int64
             lib.loft_random_sample_workspace_bytes.restype = c_int64
             lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64

@@ -102,6 +102,8 @@ class LOFT(nn.Module):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       gt_offsets=None, **kwargs):
+        if self.with_rpn and proposals is None and hasattr(self.rpn_head, 'prefetch_targets'):
+            self.rpn_head.prefetch_targets(img, gt_bboxes)      # anchor assignment + sampling beside the backbone (side stream)
         x = self.extract_feat(img)
         if F2.HUB_ENABLED and x[0].is_cuda and x[0].dtype == F2.K.L.act16():
             # one shared gradient map per pyramid level for the RPN head and the three RoI extractors (nn.feat_hub)

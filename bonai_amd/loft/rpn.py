@@ -91,10 +91,12 @@ class RPNHead(nn.Module):
 
     # ---------------------------------------------------------------- static geometry
     def _geometry(self, fused, device):
-        sizes = tuple((int(f.shape[2]), int(f.shape[3])) for f in fused)
-        key = (sizes, int(fused[0].shape[0]), str(device))
+        return self._geometry_of(tuple((int(f.shape[2]), int(f.shape[3])) for f in fused), int(fused[0].shape[0]), device)
+
+    def _geometry_of(self, sizes, B, device):
+        key = (sizes, B, str(device))
         if key not in self._static:
-            A, B = self.num_anchors, int(fused[0].shape[0])
+            A = self.num_anchors
             n_l = [h * w * A for h, w in sizes]
             lvl_off = [0]
             for n in n_l:
@@ -116,6 +118,65 @@ class RPNHead(nn.Module):
         reg = torch.cat([f.permute(0, 2, 3, 1)[..., A:5 * A].reshape(B, -1, 4) for f in fused], 1)
         return cls, reg
 
+    # ---------------------------------------------------------------- targets
+    def _assign_and_sample(self, geo, B, gts, ngt, dev):
+        """MaxIoUAssigner over every anchor + RandomSampler (anchor_head.py:197-255 for the whole batch) -> sampled indices and the
+        loss normaliser.  Depends on the static anchors and the gt boxes only -- not on anything the network computes."""
+        with torch.no_grad():
+            nbox = torch.full((B,), geo['N'], dtype=torch.int32, device=dev)
+            gt_inds, _ = self.assigner.assign_batched(geo['anchors_b'], nbox, gts, ngt)
+            smp = self.sampler.sample_batched(gt_inds)
+            pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
+            num_pos = pval.sum(1).clamp(min=1).sum()
+            num_neg = nval.sum(1).clamp(min=1).sum()
+            avg = (num_pos + num_neg).float()
+        return gt_inds, pidx, pval, nidx, nval, avg
+
+    def prefetch_targets(self, img, gt_bboxes):
+        """Called by the detector BEFORE the backbone runs: anchor assignment and sampling (two IoU passes over 8 x 262k anchors and the
+        sampler's one-workgroup-per-image selection: ~0.35 ms of launches that fill a fraction of the chip) go to a side stream now and
+        overlap the backbone, instead of sitting between the RPN convs and the RoI heads where nothing else can run
+        (tools/probes/stage_events.py: that window was 0.80 ms).  loss_fused picks the result up if the geometry it sees is the
+        one predicted here from the image size; otherwise it recomputes."""
+        self._prefetched = None
+        if not (img.is_cuda and self.sparse_backward and torch.is_grad_enabled() and K.PROFILE is None and not DBG.no_side_stream
+                and not DBG.no_rpn_target_prefetch) or self.train_cfg.get('allowed_border', -1) >= 0:
+            return
+        dev = img.device
+        sizes, (h, w) = [], (int(img.shape[2]), int(img.shape[3]))
+        for st in self.anchor_generator.strides:
+            st = st[0] if isinstance(st, (tuple, list)) else st
+            if st & (st - 1):
+                return                                  # (not a chain of stride-2 stages: no prediction, loss_fused computes)
+            hh, ww = h, w
+            for _ in range(int(st).bit_length() - 1):   # every stride-2 stage of the backbone / neck maps n -> ceil(n / 2)
+                hh, ww = (hh + 1) // 2, (ww + 1) // 2
+            sizes.append((hh, ww))
+        B = int(img.shape[0])
+        geo = self._geometry_of(tuple(sizes), B, dev)
+        gts, ngt = pad_gts(gt_bboxes, dev)              # (on the calling stream: the RoI head reads the same cached pair)
+        main = torch.cuda.current_stream()
+        if getattr(self, '_tgt_stream', None) is None:
+            self._tgt_stream = torch.cuda.Stream()
+        side = self._tgt_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = self._assign_and_sample(geo, B, gts, ngt, dev)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._prefetched = (geo, tuple((g.data_ptr(), g._version) for g in gt_bboxes), out, done)
+
+    def _targets(self, geo, B, gt_bboxes, dev):
+        gts, ngt = pad_gts(gt_bboxes, dev)
+        pre, self._prefetched = getattr(self, '_prefetched', None), None
+        if pre is not None and pre[0] is geo and pre[1] == tuple((g.data_ptr(), g._version) for g in gt_bboxes):
+            main = torch.cuda.current_stream()
+            main.wait_event(pre[3])
+            for t in pre[2]:
+                t.record_stream(main)
+            return (gts, ngt) + pre[2]
+        return (gts, ngt) + self._assign_and_sample(geo, B, gts, ngt, dev)
+
     # ---------------------------------------------------------------- loss
     def loss_fused(self, fused, gt_bboxes, img_metas, gt_bboxes_ignore=None, sparse=None):
         dev = fused[0].device
@@ -123,15 +184,7 @@ class RPNHead(nn.Module):
         if self.train_cfg.get('allowed_border', -1) >= 0:
             raise NotImplementedError('allowed_border >= 0 (configs/loft_foa use -1: every anchor is valid)')
         B, N = fused[0].shape[0], geo['N']
-        gts, ngt = pad_gts(gt_bboxes, dev)
-        nbox = torch.full((B,), N, dtype=torch.int32, device=dev)
-        with torch.no_grad():
-            gt_inds, _ = self.assigner.assign_batched(geo['anchors_b'], nbox, gts, ngt)
-            smp = self.sampler.sample_batched(gt_inds)
-            pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
-            num_pos = pval.sum(1).clamp(min=1).sum()
-            num_neg = nval.sum(1).clamp(min=1).sum()
-            avg = (num_pos + num_neg).float()
+        gts, ngt, gt_inds, pidx, pval, nidx, nval, avg = self._targets(geo, B, gt_bboxes, dev)
         if sparse is not None and fused[0].is_cuda and not TENSOR_GATHER:
             # one launch: level / pixel / slot of every sampled anchor, its logit + deltas straight from the fused head outputs,
             # labels, weights and the positives' regression targets
@@ -209,49 +262,46 @@ class RPNHead(nn.Module):
         for m in img_metas:
             if tuple(m['img_shape'][:2]) != tuple(img_shape[:2]):
                 raise NotImplementedError('per-image img_shape inside one batch')
+        # Seven launches, each for the whole batch and every level (tools/probes/stage_events.py: this chain is what the RoI heads
+        # wait for; it was ~35 launches): scores -> two-stage top-k -> decode (+ candidate scores, + the per-image coordinate
+        # maximum of batched_nms's level shift) -> NMS mask + scan (shift derived on the device) -> top-k of the survivors
+        # (keep flags as a key mask) -> proposals + counts.
+        nlv = len(fused)
+        strides = []
+        for st in self.anchor_generator.strides[:nlv]:
+            if isinstance(st, (tuple, list)):
+                if st[0] != st[1]:
+                    raise NotImplementedError('anisotropic anchor strides in the device decode')
+                st = st[0]
+            strides.append(int(st))
         keys = torch.empty(B * N, dtype=torch.float32, device=dev)
-        for f, off in zip(fused, geo['lvl_off']):
-            K.rpn_scores(f, A, N, off, keys)
+        img_max = torch.empty(B, dtype=torch.float32, device=dev)
+        K.rpn_scores_levels(fused, A, N, geo['lvl_off'], keys, img_max)
         topk = [min(cfg.nms_pre, n) if cfg.nms_pre > 0 else n for n in geo['n_l']]
         # only the first topk[l] entries of every (image, level) segment are read below: in-house select + sort, one workgroup per
-        # segment up to 32 768 keys; the 3 x 256^2 anchors of a P2 level in two stages (top-k of ten sub-ranges, then of their candidates)
+        # segment up to 32 768 keys; the 3 x 256^2 anchors of a P2 level in two stages (top-k of ten sub-ranges, rank merge of the runs)
         skeys, sidx = K.segmented_topk_desc(keys, geo['seg'], max(topk), max_segment=max(geo['n_l']), seg_lengths=list(geo['n_l']) * B)
         coff = [0]
         for t in topk:
             coff.append(coff[-1] + t)
         C = coff[-1]
         cand = torch.empty(B, C, 4, dtype=torch.float32, device=dev)
-        for l, f in enumerate(fused):
-            K.rpn_decode(f, sidx, A, N, geo['lvl_off'][l], topk[l], geo['base'][l], self.anchor_generator.strides[l],
-                         self.bbox_coder.means, self.bbox_coder.stds, img_shape, C, coff[l], cand)
-        sk = skeys.view(B, N)
-        cscore = torch.cat([sk[:, geo['lvl_off'][l]:geo['lvl_off'][l] + topk[l]] for l in range(len(fused))], 1)
+        cscore = torch.empty(B, C, dtype=torch.float32, device=dev)
+        K.rpn_decode_levels(fused, sidx, skeys, A, N, geo['lvl_off'], topk, geo['base'], strides, self.bbox_coder.means,
+                            self.bbox_coder.stds, img_shape, C, coff, cand, cscore, img_max)
         # batched_nms: boxes + level * (max_coordinate + 1), one segment per (image, level)
-        nlv = len(fused)
-        max_coord = cand.view(B, -1).amax(dim=1)
         key = ('nms_seg', B, tuple(topk))
-        fresh = ('lvl_ar', nlv) not in self._static or key not in self._static
-        if ('lvl_ar', nlv) not in self._static:
-            self._static[('lvl_ar', nlv)] = torch.arange(nlv, device=dev, dtype=torch.float32)[None]
-        shift = (self._static[('lvl_ar', nlv)] * (max_coord[:, None] + 1)).reshape(-1)
         if key not in self._static:
             self._static[key] = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64,
                                              device=dev)
             self._static[('img_seg', B, C)] = torch.arange(B + 1, dtype=torch.int64, device=dev) * C
-        if fresh:
             _static_ready(dev)
-        keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, seg_shift=shift, max_segment=max(topk),
-                               predicate=cfg.get('nms_predicate', 'device'))
-        masked = torch.where(keep.view(B, C).view(torch.bool), cscore, -1.0)        # (keep is 0 / 1 bytes: a bool view, no copy)
+        keep = K.nms_segmented(cand.view(-1, 4), self._static[key], cfg.nms_thr, max_segment=max(topk),
+                               predicate=cfg.get('nms_predicate', 'device'), img_max=img_max, levels=nlv, covered=True)
         post = min(cfg.nms_post, cfg.max_num) if cfg.get('max_num', 0) > 0 else cfg.nms_post
         post = min(post, C)
-        fs, fi = K.segmented_topk_desc(masked.reshape(-1), self._static[('img_seg', B, C)], post, max_segment=C)
-        fs = fs.view(B, C)[:, :post]
-        fi = fi.view(B, C)[:, :post].long()
-        boxes = cand.view(-1, 4)[fi.reshape(-1)].view(B, post, 4)
-        valid = fs >= 0
-        props = torch.cat([boxes, fs[..., None]], -1) * valid[..., None]
-        return props, valid.sum(1)
+        fs, fi = K.segmented_topk_desc(cscore.reshape(-1), self._static[('img_seg', B, C)], post, max_segment=C, key_mask=keep)
+        return K.rpn_finalize(fs, fi, cand.view(-1, 4), B, C, post)
 
     def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False):
         """Reference return type: list of (n_i, 5) tensors."""

@@ -99,7 +99,12 @@ int loft_map_roi_levels(const float* rois, int K, int num_levels, int finest_sca
  * [seg_offsets[s], seg_offsets[s+1]).  seg_shift[s] (may be NULL) is added to all four
  * coordinates before the IoU test = batched_nms's idx*(max_coord+1) shift.  keep[total] gets
  * 1 for survivors.  Suppression: IoU > iou_thr, offset 0.  workspace: loft_nms_workspace_bytes. */
-int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_segment);
+int64_t loft_nms_workspace_bytes(int64_t total_boxes, int64_t max_segment, int64_t num_segments);
+/* loft_nms_segmented_levels: segments = (image, level) pairs, image-major; batched_nms's shift idx * (boxes.max() + 1) is derived on
+ * the device from img_max_dev [num_segments / levels] (loft_rpn_decode_levels) -- same fp32 operations as the tensor expression. */
+int loft_nms_segmented_levels(const float* boxes, const int64_t* seg_offsets, const float* img_max_dev, int levels, int num_segments,
+                              int64_t total_boxes, int64_t max_segment, float iou_thr, int predicate, void* workspace,
+                              uint8_t* keep, void* stream);
 int loft_nms_segmented(const float* boxes, const int64_t* seg_offsets, const float* seg_shift, int num_segments,
                        int64_t total_boxes, int64_t max_segment, float iou_thr, void* workspace, uint8_t* keep,
                        void* stream);
@@ -126,7 +131,18 @@ int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_
  * written.  vals_in may be NULL (values = global element indices).  out_offsets_dev (optional, device int64 [num_segments]): segment s
  * writes its head at out_offsets[s] instead of seg_offsets[s] (two-stage selection of long segments). */
 int loft_segmented_topk_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out, int num_segments,
-                             const int64_t* seg_offsets_dev, int k, const int64_t* out_offsets_dev, void* stream);
+                             const int64_t* seg_offsets_dev, int k, const int64_t* out_offsets_dev, const uint8_t* key_mask_dev,
+                             void* stream);
+/* key_mask_dev (optional, one byte per key): keys whose byte is 0 count as -1.0 -- the NMS keep flags, i.e. rpn_head.py:169's
+ * `dets = dets[keep]` expressed as a masked score without a pass of its own.
+ * loft_topk_merge_runs: second stage of the selection for segments too long for one workgroup.  cand_keys / cand_vals hold, per
+ * sub-range ("run") of a segment, that run's first <= k entries in stable descending order (loft_segmented_topk_desc with
+ * out_offsets); an entry's rank in the merged order is found by one binary search per other run of its segment; entries with
+ * rank < k land at run_out[r] + rank.  run_offsets_dev int64 [num_runs + 1], run_first_dev / run_count_dev int32 [num_runs] (the runs
+ * of the run's segment), run_out_dev int64 [num_runs]; max_run = the longest run. */
+int loft_topk_merge_runs(const float* cand_keys, const int32_t* cand_vals, int num_runs, int max_run, const int64_t* run_offsets_dev,
+                         const int32_t* run_first_dev, const int32_t* run_count_dev, const int64_t* run_out_dev, int k,
+                         float* keys_out, int32_t* vals_out, void* stream);
 
 /* ---- dense contractions on MFMA -----------------------------------------------------------
  * loft_conv_tap_bf16: im2col-free NHWC convolution / linear layer, bf16 operands, fp32 accumulate.
@@ -313,6 +329,22 @@ int loft_rpn_decode(const float* head, const int32_t* sorted_idx, int B, int H, 
                     int64_t lvl_off, int topk, const float* base_anchors, int stride, const float* means_host,
                     const float* stds_host, float wh_ratio_clip, float max_h, float max_w, int64_t cand_stride,
                     int64_t cand_off, float* out_boxes, void* stream);
+/* The same two steps for every pyramid level in ONE launch each, plus what rpn_head.py:133-168 does around them: the decode also
+ * writes the candidates' scores in the candidate layout (out_scores [B][cand_stride], may be NULL) and accumulates the per-image
+ * maximum coordinate (img_max [B], may be NULL; reset to -inf by loft_rpn_scores_levels) that batched_nms shifts the levels by.
+ * Host arrays of `levels` (<= 8) entries; heads fp32 NHWC [B,H_l,W_l,Cp]. */
+int loft_rpn_scores_levels(const void* const* heads_host, const int* H_host, const int* W_host, const int64_t* lvl_off_host,
+                           int levels, int B, int Cp, int A, int64_t img_stride, float* keys, float* img_max, void* stream);
+int loft_rpn_decode_levels(const void* const* heads_host, const void* const* base_anchors_host, const int* H_host, const int* W_host,
+                           const int* topk_host, const int* stride_host, const int64_t* lvl_off_host, const int64_t* cand_off_host,
+                           int levels, const int32_t* sorted_idx, const float* sorted_keys, int B, int Cp, int A, int64_t img_stride,
+                           const float* means_host, const float* stds_host, float wh_ratio_clip, float max_h, float max_w,
+                           int64_t cand_stride, float* out_boxes, float* out_scores, float* img_max, void* stream);
+/* loft_rpn_finalize: rpn_head.py:169-171 (`dets[:cfg.nms_post]` per image) from the score-sorted survivor list: top_scores / top_idx
+ * = loft_segmented_topk_desc over segments of seg_stride candidates (suppressed ones carry -1), top_idx into cand_boxes
+ * [B * seg_stride][4] -> props [B][post][5] (box, score; rows past the survivors zero), counts int64 [B]. */
+int loft_rpn_finalize(const float* top_scores, const int32_t* top_idx, const float* cand_boxes, int B, int64_t seg_stride, int post,
+                      float* props, int64_t* counts, void* stream);
 /* FOA: 4-rotation offset targets (offset_head_expand_feature.py:271-344 + delta_xy_offset_coder.py:46-65)
  * -> out [4n,2] branch-major; and inference fusion + decode (:346-448) pred [4n,2] -> out [n,2]. */
 int loft_foa_targets(const float* pos_boxes, const float* pos_gt_offsets, int64_t n, float std_x, float std_y, float* out,

@@ -197,6 +197,13 @@ def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
     # with explicit values, and the k > 4096 fallback = the full sort
     vals = torch.arange(n, dtype=torch.int32).flip(0).contiguous()
     ks2, vs2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, values=vals.cuda(), max_segment=max(lens))
+    # keep flags as a key mask == where(mask, key, -1) first
+    mk = torch.from_numpy(rng.rand(n) < 0.6)
+    km, vm = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, max_segment=max(lens), key_mask=mk.cuda())
+    kw, vw = K.segmented_topk_desc(torch.where(mk, kt, torch.tensor(-1.0)).cuda(), torch.from_numpy(off).cuda(), k, max_segment=max(lens))
+    for a, b in zip(off[:-1].tolist(), off[1:].tolist()):
+        kk = min(k, b - a)
+        assert torch.equal(km[a:a + kk], kw[a:a + kk]) and torch.equal(vm[a:a + kk], vw[a:a + kk]), (a, b, kk)
     K.TOPK_MAX_SEGMENT = keep
     a, b = int(off[6]), int(off[7])
     kk = min(k, b - a)
@@ -204,7 +211,7 @@ def test_segmented_topk_is_the_head_of_the_stable_descending_sort(k):
     fk, fv = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), 5000, max_segment=max(lens))
     sk, sv = K.segmented_sort_desc(kt.cuda(), torch.from_numpy(off).cuda())
     assert torch.equal(fk, sk) and torch.equal(fv, sv)
-    # the TWO-STAGE form the RPN uses for segments past TOPK_MAX_SEGMENT (sub-range top-k -> candidates -> top-k): same heads
+    # the TWO-STAGE form the RPN uses for segments past TOPK_MAX_SEGMENT (sub-range top-k -> sorted runs -> rank merge): same heads
     if k > 1:
         assert K._topk_two_stage_tables(lens, k, 'cuda') is not None
         k2, v2 = K.segmented_topk_desc(kt.cuda(), torch.from_numpy(off).cuda(), k, max_segment=max(lens), seg_lengths=lens)
@@ -359,3 +366,58 @@ def test_roi_align_launch_order_is_a_permutation_and_changes_nothing(K_, B, P, n
     strip = (cy * nstrip / hs[lv]).floor().clamp(0, nstrip - 1).long()   # (float32 like the kernel: an RoI ON a strip edge may differ)
     key = (r[:, 0].long() * 4 + lv) * nstrip + strip
     assert int((key[1:] < key[:-1]).sum()) <= max(2, K_ // 500), 'buckets must ascend along the launch order'
+
+
+def test_rpn_level_fused_launches_match_the_per_level_ones():
+    """loft_rpn_scores_levels / loft_rpn_decode_levels / loft_nms_segmented_levels / loft_rpn_finalize (the training step's proposal
+    chain in seven launches) against the per-level launches and tensor expressions they replaced: scores, candidate boxes and
+    scores, the per-image coordinate maximum, the keep flags under the device-derived level shift and the final proposal table --
+    all torch.equal."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(3)
+    B, A = 3, 3
+    sizes = [(20, 24), (10, 12), (5, 6)]
+    strides = [4, 8, 16]
+    heads = [torch.randn(B, 16, h, w).cuda().contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    n_l = [h * w * A for h, w in sizes]
+    lvl_off = [0, n_l[0], n_l[0] + n_l[1], sum(n_l)]
+    N = lvl_off[-1]
+    keys1 = torch.empty(B * N, device='cuda')
+    for f, o in zip(heads, lvl_off):
+        K.rpn_scores(f, A, N, o, keys1)
+    keys2 = torch.empty(B * N, device='cuda')
+    img_max = torch.full((B,), 7.0, device='cuda')
+    K.rpn_scores_levels(heads, A, N, lvl_off, keys2, img_max)
+    assert torch.equal(keys1, keys2) and torch.isinf(img_max).all() and (img_max < 0).all()
+    seg = torch.tensor([b * N + o for b in range(B) for o in lvl_off[:-1]] + [B * N], dtype=torch.int64, device='cuda')
+    topk = [min(200, n) for n in n_l]
+    skeys, sidx = K.segmented_sort_desc(keys1, seg)
+    coff = [0, topk[0], topk[0] + topk[1], sum(topk)]
+    C = coff[-1]
+    base = [torch.tensor([[-s * 2., -s, s * 2., s], [-s * 1.5, -s * 1.5, s * 1.5, s * 1.5], [-s, -s * 2., s, s * 2.]], device='cuda') * 4 for s in strides]
+    means, stds, shape = (0., 0., 0., 0.), (1., 1., 1., 1.), (80, 96)
+    cand1 = torch.empty(B, C, 4, device='cuda')
+    for l, f in enumerate(heads):
+        K.rpn_decode(f, sidx, A, N, lvl_off[l], topk[l], base[l], strides[l], means, stds, shape, C, coff[l], cand1)
+    cand2 = torch.empty(B, C, 4, device='cuda')
+    cs2 = torch.empty(B, C, device='cuda')
+    K.rpn_decode_levels(heads, sidx, skeys, A, N, lvl_off, topk, base, strides, means, stds, shape, C, coff, cand2, cs2, img_max)
+    sk = skeys.view(B, N)
+    cs1 = torch.cat([sk[:, lvl_off[l]:lvl_off[l] + topk[l]] for l in range(3)], 1)
+    assert torch.equal(cand1, cand2) and torch.equal(cs1, cs2)
+    assert torch.equal(img_max, cand1.view(B, -1).amax(1))
+    nseg = torch.tensor([b * C + o for b in range(B) for o in coff[:-1]] + [B * C], dtype=torch.int64, device='cuda')
+    shift = (torch.arange(3, device='cuda', dtype=torch.float32)[None] * (img_max[:, None] + 1)).reshape(-1)
+    keep1 = K.nms_segmented(cand1.view(-1, 4), nseg, 0.7, seg_shift=shift, max_segment=max(topk))
+    keep2 = K.nms_segmented(cand1.view(-1, 4), nseg, 0.7, max_segment=max(topk), img_max=img_max, levels=3, covered=True)
+    assert torch.equal(keep1, keep2) and 0 < int(keep1.sum()) < keep1.numel()
+    post = 150
+    iseg = torch.arange(B + 1, dtype=torch.int64, device='cuda') * C
+    masked = torch.where(keep1.view(B, C).bool(), cs1, -1.0)
+    fs, fi = K.segmented_sort_desc(masked.reshape(-1), iseg)
+    fs = fs.view(B, C)[:, :post]; fi = fi.view(B, C)[:, :post].long()
+    valid = fs >= 0
+    want = torch.cat([cand1.view(-1, 4)[fi.reshape(-1)].view(B, post, 4), fs[..., None]], -1) * valid[..., None]
+    ts, ti = K.segmented_topk_desc(cs1.reshape(-1), iseg, post, max_segment=C, key_mask=keep1)
+    props, counts = K.rpn_finalize(ts, ti, cand1.view(-1, 4), B, C, post)
+    assert torch.equal(props, want) and torch.equal(counts, valid.sum(1))

@@ -467,8 +467,17 @@ __global__ __launch_bounds__(SNMS_THREADS) void seg_topk_kernel(const float* __r
     if (kk == len) {
         topk_walk(kp, mk, len, [&](unsigned o, int i) { cand[i] = compose(o, i); });
     } else if (total_eq == need) {
-        topk_walk(kp, mk, len, [&](unsigned o, int i) {
-            if (o >= T) cand[atomicAdd(&s_cnt, 1u)] = compose(o, i);
+        topk_walk(kp, mk, len, [&](unsigned o, int i) {      // one counter bump per wave, not per candidate (same-address LDS atomics)
+            const bool take = o >= T;
+            const unsigned long long tm = __ballot(take);
+            if (tm != 0ull) {
+                const int lane = (int)(threadIdx.x & 63);
+                const int leader = __ffsll((long long)tm) - 1;
+                unsigned base = 0u;
+                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(tm));
+                base = (unsigned)__shfl((int)base, leader, 64);
+                if (take) cand[base + (unsigned)__popcll(tm & ((1ull << lane) - 1ull))] = compose(o, i);
+            }
         });
     } else {
         unsigned eq_base = 0u;
@@ -544,20 +553,39 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
     const unsigned x = topk_ord(ck[r0 + p]);
     const int f = run_first[r], nr = run_count[r];
     int rank = p;
-    for (int q = f; q < f + nr; ++q) {
-        if (q == r) continue;
-        const long q0 = run_off[q];
-        const int qn = (int)(run_off[q + 1] - q0);
-        // run q is descending: the number of its entries that precede x = the first position where "precedes" fails
-        int lo = 0, hi = qn;
-        const bool earlier = q < r;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const unsigned y = topk_ord(ck[q0 + mid]);
-            const bool before = earlier ? (y >= x) : (y > x);
-            if (before) lo = mid + 1; else hi = mid;
+    // the searches of a group of MR runs advance in lock step: MR independent loads per step instead of a chain of runs x 12 round trips
+    constexpr int MR = 12;
+    for (int g = f; g < f + nr; g += MR) {
+        long q0[MR];
+        int lo[MR], hi[MR];
+#pragma unroll
+        for (int j = 0; j < MR; ++j) {
+            const int q = g + j;
+            const bool on = q < f + nr && q != r;
+            q0[j] = on ? run_off[q] : 0l;
+            lo[j] = 0;
+            hi[j] = on ? (int)(run_off[q + 1] - q0[j]) : 0;
         }
-        rank += lo;
+        bool any = true;
+        while (any) {
+            any = false;
+            unsigned y[MR];
+#pragma unroll
+            for (int j = 0; j < MR; ++j)               // (unconditional loads: a finished search re-reads the run's first key)
+                y[j] = topk_ord(ck[q0[j] + (lo[j] < hi[j] ? (lo[j] + hi[j]) >> 1 : 0)]);
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                // run q is descending: its entries that precede x = the first position where "precedes" fails; ties go to EARLIER runs
+                const int mid = (lo[j] + hi[j]) >> 1;
+                const bool act = lo[j] < hi[j];
+                const bool before = (g + j < r) ? (y[j] >= x) : (y[j] > x);
+                lo[j] = (act && before) ? mid + 1 : lo[j];
+                hi[j] = (act && !before) ? mid : hi[j];
+                any |= lo[j] < hi[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MR; ++j) rank += lo[j];
     }
     if (rank >= k) return;
     // (the canonical key image, -0.0 -> +0.0, as the one-stage kernel writes it)

@@ -196,4 +196,18 @@ def pad_gts(gt_bboxes, device):
     gts = pad_rows(gt_bboxes, device, torch.float32)
     ngt = K.h2d([int(g.shape[0]) for g in gt_bboxes], torch.int32, device)
     _PAD_GTS_CACHE[:] = [key, list(gt_bboxes), (gts, ngt)]      # (the tensors are kept alive: their addresses are the key)
+    # the assigner's result for the gt boxes the RoI sampler adds to the proposals (add_gt_as_proposals): box j of an image is
+    # assigned to gt j + 1, padding -1.  Built here, with the padded boxes -- i.e. before the backbone when the RPN head prefetches
+    # its targets -- not as five small launches between the proposals and the RoI heads.
+    ar = torch.arange(gts.shape[1], device=gts.device)[None]
+    _GT_SELF[0] = torch.where(ar < ngt[:, None], ar + 1, torch.full_like(ar, -1)).expand(len(gt_bboxes), -1)
     return gts, ngt
+
+
+_GT_SELF = [None]
+
+
+def gt_self_inds(gt_bboxes, device):
+    """int64 [B, Kmax]: j + 1 for the valid gt slots of pad_gts' layout, -1 for padding."""
+    pad_gts(gt_bboxes, device)
+    return _GT_SELF[0]

@@ -22,7 +22,7 @@ from .. import nn as F2
 from .backbone import ConvW
 from .builder import (HEADS, ROI_EXTRACTORS, build_assigner, build_bbox_coder, build_head, build_loss,
                       build_roi_extractor, build_sampler)
-from .core import pad_gts, pad_rows
+from .core import gt_self_inds, pad_gts, pad_rows
 from .losses import accuracy
 
 
@@ -391,8 +391,7 @@ class LoftRoIHead(nn.Module):
             Kmax = gts.shape[1]
             gi_p, _ = self.bbox_assigner.assign_batched(props[..., :4].contiguous(), nprop.int(), gts, ngt)
             if self.bbox_sampler.add_gt_as_proposals:
-                ar = torch.arange(Kmax, device=dev)[None]
-                gi_g = torch.where(ar < ngt[:, None], ar + 1, torch.full_like(ar, -1)).expand(B, -1)
+                gi_g = gt_self_inds(gt_bboxes, dev)
                 gt_inds = torch.cat([gi_g, gi_p], 1)
                 cand = torch.cat([gts, props[..., :4]], 1)
             else:
@@ -468,19 +467,26 @@ class LoftRoIHead(nn.Module):
 
         side = None
         if self.with_mask:
-            mask_feats = self.mask_roi_extractor(xm[:self.mask_roi_extractor.num_inputs], pos_rois)
             # The mask branch (4 convs + deconv + logits at 14x14 / 28x28) and the FOA branch (40 convs at 7x7) are independent
             # chains of launches that each fill 2.6 rounds of the 256 CUs: on two HIP streams their tails fill each other's
             # idle CUs, forward and (autograd replays each node on its forward stream) backward.  RoIAlign stays on the main
             # stream -- its backward accumulates into the shared per-level gradient maps.
+            mask_losses = dict()
             if dev.type == 'cuda' and torch.is_grad_enabled() and K.PROFILE is None and not DBG.no_side_stream:
                 if getattr(self, '_side_stream', None) is None:
                     self._side_stream = torch.cuda.Stream()
                 side = self._side_stream
+                if bbox_on_side:
+                    # the bbox head forks right behind ITS RoIAlign: its two FC GEMMs and loss launches (~0.3 ms) run beside the
+                    # mask extractor's RoIAlign (0.28 ms of dependent loads that leave the matrix pipes idle) instead of after it
+                    side.wait_stream(torch.cuda.current_stream())
+                    bbox_feats.record_stream(side)
+                    with torch.cuda.stream(side):
+                        mask_losses.update(bbox_branch())
+            mask_feats = self.mask_roi_extractor(xm[:self.mask_roi_extractor.num_inputs], pos_rois)
+            if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 mask_feats.record_stream(side)
-                if bbox_on_side:
-                    bbox_feats.record_stream(side)
 
             def mask_branch():
                 mask_pred = self.mask_head(mask_feats)
@@ -495,7 +501,6 @@ class LoftRoIHead(nn.Module):
                 return self.mask_head.loss(mask_pred, mask_targets, labels[pos_sel])
             if side is not None:
                 with torch.cuda.stream(side):
-                    mask_losses = dict(bbox_branch()) if bbox_on_side else dict()
                     mask_losses.update(mask_branch())
             else:
                 if bbox_on_side:

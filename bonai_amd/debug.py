@@ -24,6 +24,7 @@ SWITCHES = {
     'no_bbox_side_stream': 'the bbox head on the main stream (the mask branch keeps its side stream)',
     'no_rpn_side_stream': 'the RPN proposal chain (sort, decode, NMS) on the main stream',
     'no_rpn_target_prefetch': 'RPN anchor assignment + sampling after the RPN convs on the main stream, not beside the backbone',
+    'no_rpn_loss_stream': 'the RPN losses (and with them the sparse RPN backward) on the main stream',
     'no_wgrad_stream': 'backbone weight-gradient launches on the data-gradient stream',
     # batched launches / pools of the trainer
     'no_prepack': 'BN fold + operand packing per conv per step instead of one launch per step (kernels.PrepackRegistry)',

@@ -13,6 +13,7 @@ proposal semantics.  What changed underneath:
   * the losses are evaluated on the <=512 sampled anchors per image only (identical value: all other
     anchors carry weight 0 in anchor_head.py:180-245).
 """
+import contextlib
 import os
 
 import torch
@@ -190,18 +191,34 @@ class RPNHead(nn.Module):
             # labels, weights and the positives' regression targets
             xs, hs = sparse
             A = self.num_anchors
-            with torch.no_grad():
-                vals, rows, slot, tgt, label, w = K.rpn_sample_gather(list(fused), geo['lvl_off'], A, geo['anchors'], gts, gt_inds,
-                                                                      pidx, pval, nidx, nval, self.bbox_coder.means,
-                                                                      self.bbox_coder.stds)
-            S = vals.shape[1]
-            vals = F2.rpn_sparse_outputs(vals.reshape(-1, 5), rows, slot, A, list(xs), list(hs), self.rpn_conv.weight,
-                                         self.rpn_conv.bias, self.rpn_cls.weight, self.rpn_cls.bias, self.rpn_reg.weight,
-                                         self.rpn_reg.bias).view(B, S, 5)
-            logit = vals[..., 0]
-            pred = vals[:, :pidx.shape[1], 1:5]
-            loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
-            loss_bbox = self.loss_bbox(pred, tgt, w[:, :pidx.shape[1], None].expand_as(pred), avg_factor=avg)
+            # The two RPN losses get a stream of their own.  Forward this changes nothing (a dozen small launches beside the proposal
+            # chain either way); autograd replays a node on its forward stream, so BACKWARD the sparse RPN gradient -- ~25 small
+            # launches -- runs beside the RoI heads' backward instead of after the RoIAlign backward on the main stream
+            # (nn._SparseRPNFn.backward joins the hub's stream only for the scatter into the shared maps).
+            main = torch.cuda.current_stream()
+            side = None
+            if torch.is_grad_enabled() and K.PROFILE is None and not DBG.no_side_stream and not DBG.no_rpn_loss_stream:
+                if getattr(self, '_loss_stream', None) is None:
+                    self._loss_stream = torch.cuda.Stream()
+                side = self._loss_stream
+                side.wait_stream(main)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                with torch.no_grad():
+                    vals, rows, slot, tgt, label, w = K.rpn_sample_gather(list(fused), geo['lvl_off'], A, geo['anchors'], gts, gt_inds,
+                                                                          pidx, pval, nidx, nval, self.bbox_coder.means,
+                                                                          self.bbox_coder.stds)
+                S = vals.shape[1]
+                vals = F2.rpn_sparse_outputs(vals.reshape(-1, 5), rows, slot, A, list(xs), list(hs), self.rpn_conv.weight,
+                                             self.rpn_conv.bias, self.rpn_cls.weight, self.rpn_cls.bias, self.rpn_reg.weight,
+                                             self.rpn_reg.bias).view(B, S, 5)
+                logit = vals[..., 0]
+                pred = vals[:, :pidx.shape[1], 1:5]
+                loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
+                loss_bbox = self.loss_bbox(pred, tgt, w[:, :pidx.shape[1], None].expand_as(pred), avg_factor=avg)
+            if side is not None:
+                main.wait_stream(side)
+                loss_cls.record_stream(main)
+                loss_bbox.record_stream(main)
             return dict(loss_rpn_cls=loss_cls, loss_rpn_bbox=loss_bbox)
         with torch.no_grad():
             pos_anchor = geo['anchors'][pidx.reshape(-1)]

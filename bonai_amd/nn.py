@@ -12,6 +12,7 @@ with the fp32 reference at 1e-3; the backward of these functions refuses fp32 ac
 import os as _os
 import weakref as _weakref
 
+import contextlib
 import torch
 
 from . import kernels as K
@@ -664,7 +665,8 @@ def feat_hub(feats, n):
     fork = FeatFork(outs[:nf])
     fork.branches = tuple(tuple(outs[c * nf:(c + 1) * nf]) for c in range(n))
     HUB = {f.data_ptr(): None for f in feats}
-    HUB.update(_pending=[], _fresh=set(), _expected=0, _seen=0)
+    HUB.update(_pending=[], _fresh=set(), _expected=0, _seen=0,
+               _stream=torch.cuda.current_stream() if feats[0].is_cuda else None)   # the stream the shared maps are updated on
     return fork
 
 
@@ -977,20 +979,35 @@ class _SparseRPNFn(torch.autograd.Function):
         wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(K.L.act16()).contiguous()     # [(tap, cin), cout]
         dxs = K.conv2d_fwd(_as_img(gh2d), wd[None, None], None, 1, 1)
         dxs = dxs.permute(0, 2, 3, 1).reshape(nsel, 9 * C)
-        _hub_flush()                                   # the RoI extractors' maps are complete before rows are added
-        dxl, ret = [], []
-        for x in xs:                                   # hub-managed maps: scatter into the shared gradient map of the level
-            k = x.data_ptr() if (HUB is not None and x.data_ptr() in HUB and x.dtype == K.L.act16()) else None
-            if k is not None and HUB[k] is not None:
-                dxl.append(HUB[k])
-                ret.append(None)
-            else:
-                z = torch.zeros_like(x)
-                if k is not None:
-                    HUB[k] = z
-                dxl.append(z)
-                ret.append(z)
-        K.rpn_scatter_add_rows_(dxl, rows, dxs, 3)
+        # Everything above ran on THIS node's stream -- the RPN losses' own stream when rpn.loss_fused forked one: ~25 small launches
+        # that then execute beside the RoI heads' backward instead of behind the RoIAlign backward (they were 0.23 ms of thin
+        # launches on the critical path).  What follows touches the shared per-level gradient maps, which live on the hub's
+        # stream: join it for the flush + scatter, so that they stay ordered with the RoI extractors' pass before and the hub
+        # node's backward after.
+        cur = torch.cuda.current_stream() if g.is_cuda else None
+        hub_stream = HUB.get('_stream') if HUB is not None else None
+        switch = cur is not None and hub_stream is not None and hub_stream != cur
+        if switch:
+            hub_stream.wait_stream(cur)
+        with (torch.cuda.stream(hub_stream) if switch else contextlib.nullcontext()):
+            _hub_flush()                               # the RoI extractors' maps are complete before rows are added
+            dxl, ret = [], []
+            for x in xs:                               # hub-managed maps: scatter into the shared gradient map of the level
+                k = x.data_ptr() if (HUB is not None and x.data_ptr() in HUB and x.dtype == K.L.act16()) else None
+                if k is not None and HUB[k] is not None:
+                    dxl.append(HUB[k])
+                    ret.append(None)
+                else:
+                    z = torch.zeros_like(x)
+                    if k is not None:
+                        HUB[k] = z
+                    dxl.append(z)
+                    ret.append(z)
+            K.rpn_scatter_add_rows_(dxl, rows, dxs, 3)
+            if switch:
+                dxs.record_stream(hub_stream)
+        if switch:
+            cur.wait_stream(hub_stream)                # (autograd orders this node's consumers behind `cur`)
         return (None, None, None, None, None, g_wconv, dbc[0], g_wcls, g_bcls, g_wreg, g_breg) + tuple(ret) + (None,) * len(xs)
 
 

@@ -27,3 +27,10 @@ if len(sys.argv) > 4:      # extra: the N launches that follow the window
     for s, e, n, w, q in st[i1 + 1:i1 + 1 + int(sys.argv[4])]:
         print(f'  +{(s - t0) / 1e3:8.1f} us  gap {(s - end) / 1e3:6.1f}  dur {(e - s) / 1e3:6.1f}  wg {w:6d}  q {q:>3s}  {n[:90]}')
         end = max(end, e)
+if len(sys.argv) > 5:      # extra: the last N launches of the step
+    print('--- step tail')
+    tail = st[-int(sys.argv[5]):]
+    end = tail[0][0]
+    for s, e, n, w, q in tail:
+        print(f'  +{(s - t0) / 1e3:8.1f} us  gap {(s - end) / 1e3:6.1f}  dur {(e - s) / 1e3:6.1f}  wg {w:6d}  q {q:>3s}  {n[:90]}')
+        end = max(end, e)

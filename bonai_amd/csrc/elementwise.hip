@@ -531,13 +531,14 @@ __device__ __forceinline__ int find_record(const long* __restrict__ desc, int n,
 // weights only change in the SGD kernel, so all packings of a step can be produced up front).  desc: n records of 16 int64
 // {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits), Cout, Cin, RS, CoutP, CinP, first_chunk};
 // chunk c belongs to the record with the largest first_chunk <= c.  A chunk is one [NT output channels] x [64 input channels]
-// tile with all RS taps (NT = 64 for RS == 1, else 16; RS <= FOLD_TILE_MAX_RS): the fp32 source rows are read coalesced
+// tile with all RS taps (NT = 64 for RS == 1, else 32; RS <= FOLD_TILE_MAX_RS): the fp32 source rows are read coalesced
 // (64*RS contiguous floats per output channel) into LDS, then written out as 128-byte runs of wp_fwd [T][CoutP][CinP] and
 // 2*NT-byte runs of wp_dgrad [T][CinP][CoutP] -- the per-element form of loft_fold_pack scatters 2-byte stores for the
 // transposed packing.  Records with more taps use chunks of FOLD_CHUNK elements of the per-element form.
 constexpr int FOLD_CHUNK = 2048;
 constexpr int FOLD_TILE_MAX_RS = 9;
-constexpr int FOLD_TILE_FLOATS = 16 * (64 * FOLD_TILE_MAX_RS + 1);      // >= 64 * 65 (the RS == 1 tile)
+constexpr int FOLD_NT_TAPS = 32, FOLD_NT_TAPS_LOG2 = 5;                 // output channels per tile for 1 < RS <= FOLD_TILE_MAX_RS
+constexpr int FOLD_TILE_FLOATS = FOLD_NT_TAPS * (64 * FOLD_TILE_MAX_RS + 4) / 2;   // the bf16 tile; >= 64 * 68 / 2 (the RS == 1 tile)
 __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __restrict__ desc, int n, long nchunks) {
     __shared__ float tile[FOLD_TILE_FLOATS];
     for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -605,45 +606,93 @@ __global__ __launch_bounds__(256) void fold_pack_multi_kernel(const long* __rest
             }
             continue;
         }
-        const int NT = RS == 1 ? 64 : 16;
+        // ---- tiled records.  The tile is held as bf16 (folded + rounded once, on the way in): NT = 32 output channels for taps > 1,
+        // so the transposed packing is written in 64-byte runs (16 channels gave 32-byte runs: half-used memory bursts on a
+        // quarter of the launch's traffic); aligned records move 16 bytes per lane on all three sides (4-byte accesses left the
+        // launch at 2.1-2.5 TB/s, instruction-bound).
+        bf16_t* bt = reinterpret_cast<bf16_t*>(tile);
+        const int NT = RS == 1 ? 64 : FOLD_NT_TAPS;
         const int tc = (CinP + 63) >> 6;
         const int n0 = (local_chunk / tc) * NT, c0 = (local_chunk % tc) * 64;
-        const int span = 64 * RS, ldw = span + 1;
+        const int span = 64 * RS, ldw = span + 4;                // (row pitch in bf16: 8-byte aligned rows, odd multiple of 2 words)
         __syncthreads();                                         // the previous chunk's readers are done with the tile
+        const bool vec = (Cin & 63) == 0 && (CinP & 7) == 0 && (CoutP & 7) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
         // (index math without per-element integer division by run-time values -- reciprocal multiplies and shifts)
         const unsigned rs_mul = RS == 1 ? 0u : 0xFFFFFFFFu / (unsigned)RS + 1u;      // x / RS == umulhi(x, rs_mul) for x < 2^16
-        const unsigned sp_mul = 0xFFFFFFFFu / (unsigned)span + 1u;                   // x / span likewise
-        for (int i = threadIdx.x; i < NT * span; i += 256) {
-            const int row = (int)__umulhi((unsigned)i, sp_mul), off = i - row * span;
-            const int nn = n0 + row, cc = c0 + (RS == 1 ? off : (int)__umulhi((unsigned)off, rs_mul));
-            float v = 0.f;
-            if (nn < Cout && cc < Cin) {
-                v = w[((long)nn * Cin + c0) * RS + off];
-                if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+        if (vec) {
+            const int q4 = span >> 2;                            // float4s per row
+            const unsigned q_mul = 0xFFFFFFFFu / (unsigned)q4 + 1u;
+            for (int i = threadIdx.x; i < NT * q4; i += 256) {
+                const int row = (int)__umulhi((unsigned)i, q_mul), off = (i - row * q4) << 2;
+                const int nn = n0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nn < Cout) {
+                    v = *reinterpret_cast<const float4*>(w + ((long)nn * Cin + c0) * RS + off);
+                    if (gamma) { const float sc = gamma[nn] * rsqrtf(var[nn] + eps); v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(bt + row * ldw + off) = pk;
             }
-            tile[row * ldw + off] = v;
+        } else {
+            const unsigned sp_mul = 0xFFFFFFFFu / (unsigned)span + 1u;               // x / span likewise
+            for (int i = threadIdx.x; i < NT * span; i += 256) {
+                const int row = (int)__umulhi((unsigned)i, sp_mul), off = i - row * span;
+                const int nn = n0 + row, cc = c0 + (RS == 1 ? off : (int)__umulhi((unsigned)off, rs_mul));
+                float v = 0.f;
+                if (nn < Cout && cc < Cin) {
+                    v = w[((long)nn * Cin + c0) * RS + off];
+                    if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+                }
+                bt[row * ldw + off] = f32_to_bf16(v);
+            }
         }
         __syncthreads();
-        const int ntsh = RS == 1 ? 6 : 4;                           // log2(NT)
-        if (wp)                                                  // [t][nn][cc pair]: 32 lanes = one 128-byte run
+        const int ntsh = RS == 1 ? 6 : FOLD_NT_TAPS_LOG2;            // log2(NT)
+        if (wp && vec) {                                         // [t][nn][8 cc]: 8 lanes = one 128-byte run
+            for (int i = threadIdx.x; i < RS * NT * 8; i += 256) {
+                const int l8 = i & 7, r2 = i >> 3, row = r2 & (NT - 1), t = r2 >> ntsh;
+                const int nn = n0 + row;
+                if (nn < CoutP) {
+                    const bf16_t* tp = bt + row * ldw + (8 * l8) * RS + t;
+                    uint32_t q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = (uint32_t)tp[(2 * k) * RS] | ((uint32_t)tp[(2 * k + 1) * RS] << 16);
+                    *reinterpret_cast<uint4*>(wp + ((long)t * CoutP + nn) * CinP + c0 + 8 * l8) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            }
+        } else if (wp) {                                         // [t][nn][cc pair]: 32 lanes = one 128-byte run
             for (int i = threadIdx.x; i < RS * NT * 32; i += 256) {
                 const int cp = i & 31, r2 = i >> 5, row = r2 & (NT - 1), t = r2 >> ntsh;
                 const int nn = n0 + row, cc = c0 + 2 * cp;
                 if (nn < CoutP && cc < CinP) {
-                    const float* tp = tile + row * ldw + 2 * cp * RS + t;
-                    const uint32_t pk = (uint32_t)f32_to_bf16(tp[0]) | ((uint32_t)f32_to_bf16(tp[RS]) << 16);
-                    *reinterpret_cast<uint32_t*>(wp + ((long)t * CoutP + nn) * CinP + cc) = pk;
+                    const bf16_t* tp = bt + row * ldw + 2 * cp * RS + t;
+                    *reinterpret_cast<uint32_t*>(wp + ((long)t * CoutP + nn) * CinP + cc) = (uint32_t)tp[0] | ((uint32_t)tp[RS] << 16);
                 }
             }
-        if (wpt) {                                               // [t][cc][nn pair]: NT/2 lanes = one 2*NT-byte run
+        }
+        if (wpt && vec) {                                        // [t][cc][8 nn]: NT/8 lanes = one 2*NT-byte run
+            const int gsh = ntsh - 3, gp = 1 << gsh;
+            for (int i = threadIdx.x; i < RS * 64 * gp; i += 256) {
+                const int g8 = i & (gp - 1), r2 = i >> gsh, ccl = r2 & 63, t = r2 >> 6;
+                const int nn = n0 + 8 * g8;
+                if (nn < CoutP) {
+                    const bf16_t* tp = bt + (8 * g8) * ldw + ccl * RS + t;
+                    uint32_t q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = (uint32_t)tp[(2 * k) * ldw] | ((uint32_t)tp[(2 * k + 1) * ldw] << 16);
+                    *reinterpret_cast<uint4*>(wpt + ((long)t * CinP + c0 + ccl) * CoutP + nn) = make_uint4(q[0], q[1], q[2], q[3]);
+                }
+            }
+        } else if (wpt) {                                        // [t][cc][nn pair]: NT/2 lanes = one 2*NT-byte run
             const int hsh = ntsh - 1, hp = 1 << hsh;
             for (int i = threadIdx.x; i < RS * 64 * hp; i += 256) {
                 const int np = i & (hp - 1), r2 = i >> hsh, ccl = r2 & 63, t = r2 >> 6;
                 const int nn = n0 + 2 * np, cc = c0 + ccl;
                 if (nn < CoutP && cc < CinP) {
-                    const float* tp = tile + 2 * np * ldw + ccl * RS + t;
-                    const uint32_t pk = (uint32_t)f32_to_bf16(tp[0]) | ((uint32_t)f32_to_bf16(tp[ldw]) << 16);
-                    *reinterpret_cast<uint32_t*>(wpt + ((long)t * CinP + cc) * CoutP + nn) = pk;
+                    const bf16_t* tp = bt + 2 * np * ldw + ccl * RS + t;
+                    *reinterpret_cast<uint32_t*>(wpt + ((long)t * CinP + cc) * CoutP + nn) = (uint32_t)tp[0] | ((uint32_t)tp[ldw] << 16);
                 }
             }
         }

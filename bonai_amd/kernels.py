@@ -1350,6 +1350,7 @@ def fold_pack(w, conv_bias=None, bn=None, eps=1e-5, want_fwd=True, want_dgrad=Tr
 
 FOLD_CHUNK = 2048
 FOLD_TILE_MAX_RS = 9        # mirrors elementwise.hip
+FOLD_NT_TAPS = 32            # output channels per tile of a record with 1 < RS <= FOLD_TILE_MAX_RS (elementwise.hip)
 
 
 class PrepackRegistry:
@@ -1428,7 +1429,7 @@ class PrepackRegistry:
                 elif RS > FOLD_TILE_MAX_RS:
                     chunk += (CoutP * CinP * RS + FOLD_CHUNK - 1) // FOLD_CHUNK
                 else:                         # one chunk per [NT output channels] x [64 input channels] tile, all taps
-                    nt = 64 if RS == 1 else 16
+                    nt = 64 if RS == 1 else FOLD_NT_TAPS
                     chunk += ((CoutP + nt - 1) // nt) * ((CinP + 63) // 64)
             self.nchunks = chunk
             dev = self.jobs[self.order[0]]['wp'].device

@@ -37,7 +37,7 @@ def rows_of(pred):
         elif RS > K.FOLD_TILE_MAX_RS:
             chunk += (CoutP * CinP * RS + K.FOLD_CHUNK - 1) // K.FOLD_CHUNK
         else:
-            nt = 64 if RS == 1 else 16
+            nt = 64 if RS == 1 else K.FOLD_NT_TAPS
             chunk += ((CoutP + nt - 1) // nt) * ((CinP + 63) // 64)
     return rows, chunk, elems
 

@@ -820,18 +820,25 @@ __global__ __launch_bounds__(256) void fold_unpack_bwd_multi_kernel(const long* 
     float acc = 0.f;
     const int per = Cin * RS;
     if (nmajor) {
-        // dwp row [t][c] read contiguously, permuted to the parameter's (c, t) order through LDS, added contiguously
+        // dwp row [t][c] -> the parameter's (c, t) order through LDS, in blocks of NMAJOR_CB channels: RS segments of CB floats in,
+        // CB * RS contiguous floats out.  (The whole row at once -- 12 544 floats for the two 7 x 7 x 256 FC layers -- made the
+        // launch's dynamic LDS 50 KB for EVERY block of the batch, the 2 304-float conv records included: 3 blocks per CU.)
         extern __shared__ float urow[];
-        const unsigned cp_mul = CinP == 1 ? 0u : 0xFFFFFFFFu / (unsigned)CinP + 1u;     // j / CinP by multiply-high (j < 2^16)
-        const bool small = per < 65536;
-        for (int j = threadIdx.x; j < per; j += blockDim.x) {
-            const int t = CinP == 1 ? j : (small ? (int)__umulhi((unsigned)j, cp_mul) : j / CinP), c = j - t * CinP;
-            urow[c * RS + t] = ld1(dwp + (long)n * per + j);
-        }
-        __syncthreads();
-        for (int j = threadIdx.x; j < per; j += blockDim.x) {
-            const long wi = (long)n * per + j;
-            if (dw) dw[wi] += urow[j] * scale;
+        const int CB = min(Cin, lds_floats / RS);
+        const unsigned cb_mul = CB == 1 ? 0u : 0xFFFFFFFFu / (unsigned)CB + 1u;        // j / CB by multiply-high (j < 2^16)
+        for (int cb0 = 0; cb0 < Cin; cb0 += CB) {
+            const int cbn = min(CB, Cin - cb0), cnt = cbn * RS;
+            const bool small = CB * RS < 65536 && cbn == CB;
+            __syncthreads();
+            for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+                const int t = cbn == 1 ? j : (small ? (int)__umulhi((unsigned)j, cb_mul) : j / cbn), c = j - t * cbn;
+                urow[c * RS + t] = ld1(dwp + (long)n * per + (long)t * CinP + cb0 + c);
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+                const long wi = (long)n * per + (long)cb0 * RS + j;
+                if (dw) dw[wi] += urow[j] * scale;
+            }
         }
         if (threadIdx.x == 0 && dbeta && db) dbeta[n] += db[n];
         return;

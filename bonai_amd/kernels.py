@@ -1682,7 +1682,12 @@ class UnpackQueue:
             desc = h2d(rows, torch.int64, self.jobs[0][2].device)
             # dynamic LDS row: records that interleave taps through LDS (n-major Linear records must fit; conv records with
             # more than one tap use it when they fit, else the direct form)
-            lds = max([r[11] * abs(r[12]) for r in rows if (r[12] < 0 or r[12] > 1) and r[11] * abs(r[12]) <= 16384], default=0)
+            # (n-major records go through it in blocks of 64 channels: 64 * taps floats, not the whole 12 544-float row -- the
+            #  dynamic LDS size is per LAUNCH, and 50 KB of it left three blocks per CU for every record of the batch)
+            lds = max([min(r[11], 64) * abs(r[12]) if r[12] < 0 else r[11] * r[12] for r in rows
+                       if r[12] < 0 or (r[12] > 1 and r[11] * r[12] <= 16384)], default=0)
+            if lds > 16384:
+                raise L.LoftHipError(f'fold_unpack_bwd_multi: a record needs {lds} floats of LDS')
             L.check(L.load().loft_fold_unpack_bwd_multi(L.ptr(desc), len(rows), c_int64(blk), int(lds), L.stream()),
                     'loft_fold_unpack_bwd_multi')
             self.jobs = []

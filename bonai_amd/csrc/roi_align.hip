@@ -14,6 +14,7 @@
 //
 // Compiled with -ffp-contract=off so sample weights round exactly like the C oracle.
 #include "loft_common.h"
+#include <type_traits>
 #include "../../include/loft_hip.h"
 
 struct RoiLevels {
@@ -94,8 +95,7 @@ __device__ __forceinline__ int rot_pos(int py, int px, int P, int k) {
 // with its own 4 MiB L2, so workgroup b takes entry (b % 8) * ceil(K / 8) + b / 8 -- every XCD walks ONE contiguous eighth of
 // the ordered list and the windows of RoIs that overlap meet in that XCD's L2 instead of being fetched from HBM once per RoI
 // (sampling order: 1.4 GB of window reads for the 8192-RoI bbox list against 0.36 GB of maps).  Grid = 8 * ceil(K / 8).
-__device__ __forceinline__ int roi_of_block(const int32_t* __restrict__ order, int K) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ int roi_of_block(const int32_t* __restrict__ order, int K, int b = blockIdx.x) {
     if (!order) return b < K ? b : -1;
     const int per = (K + 7) >> 3, j = (b & 7) * per + (b >> 3);
     return j < K ? order[j] : -1;
@@ -157,10 +157,10 @@ __device__ __forceinline__ float axis_weight(float start, float bin, int grid, i
 #define RF_MAXP 14
 
 __device__ __forceinline__ void roi_sample_bins(const RoiGeom& g, const bf16_t* fb, int H, int W, int C, int P, int n_rot, int K,
-                                                int k, bf16_t* out) {
+                                                int k, bf16_t* out, int part = 0, int nsplit = 1) {
     const int cg = C >> 2;
     const int total = P * P * cg;
-    for (int w = threadIdx.x; w < total; w += blockDim.x) {
+    for (int w = threadIdx.x + part * blockDim.x; w < total; w += blockDim.x * nsplit) {
         const int bin = w / cg, c0 = (w - bin * cg) << 2;
         const int py = bin / P, px = bin - py * P;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -286,6 +286,329 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(RoiLevels L, con
             while (p < P) emit();
         }
     }
+}
+
+// ---- forward with 16-byte accesses (the shipped 16-bit forward when C % 8 == 0) --------------------------------------
+// Round 4's time line of the 8-byte separable kernel (tools/probes/roi_fwd_trace.py: s_memtime stamps per workgroup; ablations
+// without loads / without stores / set-up only) said: a workgroup lives 36 .. 100 us, neither its loads nor its stores matter
+// (-10 % each when removed), the CUs run 1.8 workgroups deep of the 3-4 the registers allow, and -- with the bench's gt sizes,
+// log-uniform 16 .. 160 pixels, i.e. 4 .. 40 pixels on the stride-4 map -- 43 % (P = 7) to 79 % (P = 14) of the positive RoIs
+// have bins below one pixel and never reached the separable walk: they ran the sample-order loop, one (bin, 4 channels) item
+// per thread and trip with four dependent 8-byte loads, ~50 trips per thread at P = 14.  Three forms now share one launch,
+// chosen per RoI (block-uniform):
+//   * LDS form (small footprints: up to 24 KiB per channel block of >= 64 channels): the footprint is staged once with
+//     global -> LDS copies (all of a pass in flight, no destination registers), then a group of cbch / 8 lanes computes one
+//     bin in SAMPLE order from it (wave-uniform sample loops: the grid is per RoI): four 16-byte LDS reads per sample;
+//   * separable walk (bins of a pixel or more, larger footprints): a lane owns 8 channels, a half-wave one pixel (lanes 0-31
+//     column x, lanes 32-63 column x + 1: one wave access = 1 KiB); the rows of a bin row are loaded in ONE batch whose size is a
+//     template parameter selected per bin row (wave-uniform switch), their weights sit in scalar registers, the contraction is
+//     v_pk_fma_f32 on channel pairs (~2.2x fewer VALU instructions per window byte than the 8-byte form, whose hipcc code carried
+//     row counts in vector registers, 64-bit v_mad addressing and a ds_read per weight in the row loop); both columns of a pair
+//     add into a FOUR-bin sliding window with per-half weights (the window base moves by at most one bin between neighbouring
+//     columns when bin_w >= 1), halves are summed at emit time with v_permlane32_swap; first / last contributing row and last
+//     column of every bin come from ballots instead of serial scans;
+//   * the sample-order loop for what is left (large footprints with sub-pixel bins in one direction).
+// Lists of up to 4096 RoIs run two workgroups per RoI (bins / bin rows dealt round-robin).  Measured on the three lists of a bench
+// step (8192 x 7^2, 2048 x 14^2, 2048 x 7^2 x 4 rotations): 714 -> ~600 us per step; what remains is per-workgroup latency
+// (set-up, LDS round trips, uneven lengths), not bytes.
+// The fp32 sum order differs from the 8-byte form's and the oracle's (fused multiply-adds, half-wave partial sums): all forms are
+// held to the same tolerance against the sample-order kernel and the oracle (bf16 only).
+#define RF8_MAXROWS 8
+#ifndef RF8_TRACE
+#define RF8_TRACE 0       // trace build (tools/probes/roi_fwd_trace.py): `order` is a [K][8] u64 buffer of per-workgroup s_memtime stamps
+#endif
+#if RF8_TRACE
+#define RF8_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(order))[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RF8_NOTE(i, v) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(order))[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define RF8_STAMP(i) do { } while (0)
+#define RF8_NOTE(i, v) do { } while (0)
+#endif
+#ifndef RF8_ABL
+#define RF8_ABL 0         // timing ablations of tools/probes/roi_fwd_ablate.sh: 1 = prologue only, 2 = no window loads, 3 = no stores
+#endif
+
+template <int NR>
+__device__ __forceinline__ void roi_sep8_load(const bf16_t* fp, size_t row_stride, uint4 (&t)[NR ? NR : 1]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (RF8_ABL == 2) t[r] = make_uint4(r, r, r, (unsigned)(size_t)fp);
+        else t[r] = *reinterpret_cast<const uint4*>(fp + (size_t)r * row_stride);
+    }
+}
+template <int NR>
+__device__ __forceinline__ void roi_sep8_colsum(const uint4 (&t)[NR ? NR : 1], const float (&wy)[RF8_MAXROWS], loft_f32x2 (&cs)[4]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        float v[8];
+        unpack8_16(t[r], v);
+        const loft_f32x2 w2 = {wy[r], wy[r]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const loft_f32x2 v2 = {v[2 * q], v[2 * q + 1]};
+            cs[q] = __builtin_elementwise_fma(v2, w2, cs[q]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_fwd_sep8_kernel(RoiLevels L, const float* __restrict__ rois, int K, int C,
+                                                                 int P, int n_rot, bf16_t* __restrict__ out,
+                                                                 const int32_t* __restrict__ order, int stage_bytes, int min_cb, int gmax, int nsplit) {
+    __shared__ float WY[RF_MAXP][RF_MAX], WX[RF_MAXP + 3][RF_MAX + 2];
+    __shared__ int ylo[RF_MAXP], yhi[RF_MAXP], xhi[RF_MAXP];
+    extern __shared__ __attribute__((aligned(16))) char stage[];             // footprint of the LDS form: [pixel][cbch channels]
+    RF8_STAMP(0);
+    // nsplit consecutive workgroups share one RoI (bins / bin rows dealt round-robin): a list of 2048 RoIs is eight workgroups
+    // per CU of very uneven length -- finer grains fill the tail
+    const int part = (int)blockIdx.x % nsplit, rb = (int)blockIdx.x / nsplit;
+    const int k = RF8_TRACE ? (rb < K ? rb : -1) : roi_of_block(order, K, rb);
+    if (k < 0) return;
+    const float* roi = rois + 5 * (size_t)k;
+    const RoiGeom g = roi_geom(roi, L, P);
+    const int H = L.H[g.level], W = L.W[g.level];
+    const bf16_t* fb = reinterpret_cast<const bf16_t*>(L.feat[g.level]) + (size_t)g.batch * H * W * C;
+    const float end_w = g.start_w + g.bin_w * (float)P, end_h = g.start_h + g.bin_h * (float)P;
+    const int x0 = (int)floorf(fminf(fmaxf(fminf(g.start_w, end_w) - 1.f, 0.f), (float)(W - 1)));
+    const int x1 = (int)ceilf(fminf(fmaxf(fmaxf(g.start_w, end_w) + 1.f, 0.f), (float)(W - 1)));
+    const int y0 = (int)floorf(fminf(fmaxf(fminf(g.start_h, end_h) - 1.f, 0.f), (float)(H - 1)));
+    const int y1 = (int)ceilf(fminf(fmaxf(fmaxf(g.start_h, end_h) + 1.f, 0.f), (float)(H - 1)));
+    const int Fh = y1 - y0 + 1, Fw = x1 - x0 + 1;
+    if (Fh > -100) RF8_STAMP(1);
+    const bool tables_ok = Fh <= RF_MAX && Fw <= RF_MAX && P <= RF_MAXP;
+    // LDS form: channels per pass = the largest of C, C/2, C/4, .. (>= min_cb, 8 .. 64 lanes per pixel) whose footprint fits
+    int cbch = 0;
+    if (tables_ok && !(C & (C - 1)) && C >= 64 && C <= 512)
+        for (int c = C; c >= min_cb && c >= 64; c >>= 1) {
+            const int ppi = 512 / c;                                          // pixels per 1 KiB wave access
+            if ((Fh * Fw + ppi - 1) / ppi * 1024 <= stage_bytes) { cbch = c; break; }
+        }
+    const bool stream_ok = tables_ok && g.bin_h >= 1.f && g.bin_w >= 1.f;
+    // (bins of a pixel or more with many samples each: the separable walk reads every window pixel once per bin row, the LDS
+    //  form below once per sample corner)
+    if (stream_ok && g.grid_h * g.grid_w > gmax) cbch = 0;
+    RF8_NOTE(5, (cbch ? cbch : stream_ok ? 1 : 0) | (Fh << 16) | (Fw << 24));
+#if RF8_TRACE
+    if (threadIdx.x == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); RF8_NOTE(6, hw | ((unsigned long long)xcc << 32)); }
+#endif
+    if (!cbch && !stream_ok) {                                                // block-uniform
+        roi_sample_bins(g, fb, H, W, C, P, n_rot, K, k, out, part, nsplit);
+#if RF8_TRACE
+        __syncthreads();
+        RF8_STAMP(4);
+#endif
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float inv = 1.f / g.count;
+    if (cbch) {
+        // ---- LDS form: the footprint is staged ONCE (every load of a pass in flight together and no destination registers:
+        // global -> LDS copies of 1 KiB per wave access), then a group of cbch / 8 lanes computes one bin from it in SAMPLE order
+        // (the grid is the same for every bin of a RoI, so the sample loops are wave-uniform): four 16-byte LDS reads per sample.
+        // This is the path of the small RoIs -- bins below one pixel, one sample per bin: building roofs of 16 .. 56 pixels on
+        // the stride-4 map, 40 .. 80 % of the positives -- which the sample-order loop served with four dependent 8-byte global
+        // loads per bin and thread, ~50 round trips per workgroup at P = 14.
+        RF8_STAMP(2);
+        const int lsh = 31 - __builtin_clz(cbch >> 3);          // log2(lanes per bin)
+        const int lpp = 1 << lsh, ppi = 64 >> lsh;
+        const int pl = lane >> lsh, cl = lane & (lpp - 1);
+        const int npx = Fh * Fw, nacc = (npx + ppi - 1) / ppi, nb = P * P;
+        const unsigned pdiv = (65536u + (unsigned)P - 1u) / (unsigned)P;          // b / P for b < 256, P <= 16 as a multiply-high
+        for (int c0 = 0; c0 < C; c0 += cbch) {
+            if (c0) __syncthreads();                            // the previous pass's reads are done
+            for (int i = wave; i < nacc; i += 4) {
+                int pix = i * ppi + pl;
+                pix = pix < npx ? pix : npx - 1;                // (the last access may repeat the last pixel into the slack)
+                const int y = pix / Fw, x = pix - y * Fw;
+                const bf16_t* src = fb + ((size_t)(y0 + y) * W + x0 + x) * C + c0 + cl * 8;
+                if (RF8_ABL != 2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(stage + (size_t)i * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (c0 == 0) RF8_STAMP(3);
+            const char* lbase = stage + cl * 16;
+            for (int b0 = (wave + 4 * part) * ppi; b0 < nb; b0 += 4 * nsplit * ppi) {
+                const int b = b0 + pl;
+                const bool act = b < nb;
+                const int py = act ? (int)(((unsigned)b * pdiv) >> 16) : 0, px = act ? b - py * P : 0;
+                loft_f32x2 v2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                for (int iy = 0; iy < g.grid_h; ++iy) {
+                    const float y = g.start_h + py * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+                    for (int ix = 0; ix < g.grid_w; ++ix) {
+                        const float x = g.start_w + px * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                        const Bil bl = bil_setup(y, x, H, W);
+                        // footprint coordinates (every corner of a valid sample lies inside the footprint; invalid ones read pixel 0 at weight 0)
+                        const int ya = bl.valid ? bl.y_low - y0 : 0, yb = bl.valid ? bl.y_high - y0 : 0;
+                        const int xa = bl.valid ? bl.x_low - x0 : 0, xb = bl.valid ? bl.x_high - x0 : 0;
+                        const float w1 = bl.valid ? bl.w1 : 0.f, w2 = bl.valid ? bl.w2 : 0.f, w3 = bl.valid ? bl.w3 : 0.f, w4 = bl.valid ? bl.w4 : 0.f;
+                        const uint4 t1 = *reinterpret_cast<const uint4*>(lbase + ((size_t)(ya * Fw + xa) << (lsh + 4)));
+                        const uint4 t2 = *reinterpret_cast<const uint4*>(lbase + ((size_t)(ya * Fw + xb) << (lsh + 4)));
+                        const uint4 t3 = *reinterpret_cast<const uint4*>(lbase + ((size_t)(yb * Fw + xa) << (lsh + 4)));
+                        const uint4 t4 = *reinterpret_cast<const uint4*>(lbase + ((size_t)(yb * Fw + xb) << (lsh + 4)));
+                        float f1[8], f2[8], f3[8], f4[8];
+                        unpack8_16(t1, f1); unpack8_16(t2, f2); unpack8_16(t3, f3); unpack8_16(t4, f4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            loft_f32x2 a = v2[q];
+                            a = __builtin_elementwise_fma(loft_f32x2{f1[2 * q], f1[2 * q + 1]}, loft_f32x2{w1, w1}, a);
+                            a = __builtin_elementwise_fma(loft_f32x2{f2[2 * q], f2[2 * q + 1]}, loft_f32x2{w2, w2}, a);
+                            a = __builtin_elementwise_fma(loft_f32x2{f3[2 * q], f3[2 * q + 1]}, loft_f32x2{w3, w3}, a);
+                            v2[q] = __builtin_elementwise_fma(loft_f32x2{f4[2 * q], f4[2 * q + 1]}, loft_f32x2{w4, w4}, a);
+                        }
+                    }
+                }
+                if (act && !(RF8_ABL == 3 && v2[0][0] != 1234.5f)) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] = v2[q][0] * inv; v[2 * q + 1] = v2[q][1] * inv; }
+                    const uint4 pk = pack8_16(v);
+                    for (int r = 0; r < n_rot; ++r)
+                        *reinterpret_cast<uint4*>(out + (((size_t)r * K + k) * P * P + rot_pos(py, px, P, r)) * C + c0 + cl * 8) = pk;
+                }
+            }
+        }
+#if RF8_TRACE
+        __syncthreads();
+        RF8_STAMP(4);
+#endif
+        return;
+    }
+    for (int i = tid; i < P * Fh; i += 256) {
+        const int p = i / Fh, y = i - p * Fh;
+        WY[p][y] = axis_weight(g.start_h, g.bin_h, g.grid_h, p, y0 + y, H);
+    }
+    const int Fw2 = Fw + 2;                                   // two zero columns: half 1 of an odd last pair reads column Fw
+    for (int i = tid; i < (P + 3) * Fw2; i += 256) {
+        const int p = i / Fw2, x = i - p * Fw2;
+        WX[p][x] = (p < P && x < Fw) ? axis_weight(g.start_w, g.bin_w, g.grid_w, p, x0 + x, W) : 0.f;
+    }
+    __syncthreads();
+    for (int p = wave; p < P; p += 4) {
+        const unsigned long long my = __ballot(lane < Fh && WY[p][lane < Fh ? lane : 0] != 0.f);
+        const unsigned long long mx = __ballot(lane < Fw && WX[p][lane < Fw ? lane : 0] != 0.f);
+        if (lane == 0) {
+            ylo[p] = my ? __builtin_ctzll(my) : Fh;
+            yhi[p] = my ? 63 - __builtin_clzll(my) : -1;
+            xhi[p] = mx ? 63 - __builtin_clzll(mx) : -1;
+        }
+    }
+    __syncthreads();
+    if (RF8_ABL == 1) { if (ylo[0] == 12345) out[0] = 0; return; }
+    RF8_STAMP(2);
+    const int h = lane >> 5, cl = lane & 31;
+    const int cg8 = C >> 3;
+    const size_t row_stride = (size_t)W * C;
+    const int xhi_v = lane < P ? xhi[lane] : 0x7fffffff;      // lane p holds xhi[p]: read back with v_readlane at the scalar p
+    for (int cb = 0; cb < cg8; cb += 32) {
+        const bool cact = cb + cl < cg8;
+        const int c0 = (cact ? cb + cl : 0) << 3;
+        for (int py = wave + 4 * part; py < P; py += 4 * nsplit) {
+            const int ya = __builtin_amdgcn_readfirstlane(ylo[py]);
+            const int nrow = __builtin_amdgcn_readfirstlane(yhi[py]) - ya + 1;
+            loft_f32x2 a[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[j][q] = loft_f32x2{0.f, 0.f};
+            int p = 0;
+            auto emit = [&]() {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned u = __float_as_uint(a[0][q][e]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lower half, upper half} in every lane
+                        v[2 * q + e] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * inv;
+                    }
+                if (cact && !(RF8_ABL == 3 && v[0] != 1234.5f)) {
+                    const uint4 pk = pack8_16(v);
+                    for (int r = h; r < n_rot; r += 2)       // half 0 stores rotations 0, 2; half 1 rotations 1, 3
+                        *reinterpret_cast<uint4*>(out + (((size_t)r * K + k) * P * P + rot_pos(py, p, P, r)) * C + c0) = pk;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[0][q] = a[1][q]; a[1][q] = a[2][q]; a[2][q] = a[3][q]; a[3][q] = loft_f32x2{0.f, 0.f}; }
+                ++p;
+            };
+            auto walk = [&](auto nr_tag) {
+                constexpr int NR = decltype(nr_tag)::value;          // rows per batch; NR == 0: no contributing row at all
+                float wy[RF8_MAXROWS];
+#pragma unroll
+                for (int r = 0; r < RF8_MAXROWS; ++r)
+                    wy[r] = (r < NR && r < nrow) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(WY[py][ya + r]))) : 0.f;
+                const bf16_t* colp = fb + ((size_t)(y0 + (NR ? ya : 0)) * W + x0) * C + c0;      // column x of the first contributing row
+                const int hC = h ? C : 0;
+                // the loads of pair x + 2 are requested before pair x is consumed (batches of <= 4 rows: a second set of
+                // destination registers costs less than the round trip it hides; taller batches keep one set)
+                constexpr bool PRE = NR > 0 && NR <= 4;
+                uint4 tc[NR ? NR : 1], tn[NR ? NR : 1];
+                if constexpr (PRE) roi_sep8_load<NR>(colp + (1 < Fw ? hC : 0), row_stride, tc);
+                for (int x = 0; x < Fw; x += 2, colp += 2 * C) {
+                    while (p < P && __builtin_amdgcn_readlane(xhi_v, p) < x) emit();      // bins whose support ended before column x
+                    if (p >= P) break;
+                    loft_f32x2 cs[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                    if constexpr (NR > 0) {
+                        const bf16_t* fp = colp + (x + 1 < Fw ? hC : 0);    // an odd last column: half 1 re-reads it (its weights are zero)
+                        if constexpr (PRE) {
+                            if (x + 2 < Fw) roi_sep8_load<NR>(colp + 2 * C + (x + 3 < Fw ? hC : 0), row_stride, tn);
+                        } else {
+                            roi_sep8_load<NR>(fp, row_stride, tc);
+                        }
+                        roi_sep8_colsum<NR>(tc, wy, cs);
+                        if constexpr (PRE) {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) tc[r] = tn[r];
+                        }
+                        if (NR == RF8_MAXROWS)
+                            for (int r0 = RF8_MAXROWS; r0 < nrow; r0 += RF8_MAXROWS) {   // bins taller than 8 + 2 rows: further batches,
+                                float wz[RF8_MAXROWS];                                    // rows past the end re-read the last one at weight 0
+#pragma unroll
+                                for (int r = 0; r < RF8_MAXROWS; ++r) wz[r] = r0 + r < nrow ? WY[py][ya + r0 + r] : 0.f;
+                                const int last = nrow - 1 - r0;
+                                uint4 t[RF8_MAXROWS];
+#pragma unroll
+                                for (int r = 0; r < RF8_MAXROWS; ++r)
+                                    t[r] = *reinterpret_cast<const uint4*>(fp + (size_t)(r0 + (r < last ? r : last)) * row_stride);
+#pragma unroll
+                                for (int r = 0; r < RF8_MAXROWS; ++r) {
+                                    float v[8];
+                                    unpack8_16(t[r], v);
+                                    const loft_f32x2 w2 = {wz[r], wz[r]};
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) cs[q] = __builtin_elementwise_fma(loft_f32x2{v[2 * q], v[2 * q + 1]}, w2, cs[q]);
+                                }
+                            }
+                    }
+                    const int xw = x + h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float w = WX[p + j][xw];
+                        const loft_f32x2 w2 = {w, w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a[j][q] = __builtin_elementwise_fma(cs[q], w2, a[j][q]);
+                    }
+                }
+                while (p < P) emit();
+            };
+            switch (nrow <= 0 ? 0 : (nrow < RF8_MAXROWS ? nrow : RF8_MAXROWS)) {
+                case 0: walk(std::integral_constant<int, 0>{}); break;
+                case 1: walk(std::integral_constant<int, 1>{}); break;
+                case 2: walk(std::integral_constant<int, 2>{}); break;
+                case 3: walk(std::integral_constant<int, 3>{}); break;
+                case 4: walk(std::integral_constant<int, 4>{}); break;
+                case 5: walk(std::integral_constant<int, 5>{}); break;
+                case 6: walk(std::integral_constant<int, 6>{}); break;
+                case 7: walk(std::integral_constant<int, 7>{}); break;
+                default: walk(std::integral_constant<int, 8>{}); break;
+            }
+        }
+    }
+#if RF8_TRACE
+    __syncthreads();
+    RF8_STAMP(4);
+#endif
 }
 
 // ---- backward: tile-owner gather -- no atomics at all, neither in HBM nor in LDS ----------------------
@@ -847,10 +1170,30 @@ LOFT_EXPORT int loft_roi_align_fwd_ord(const void* const* feats, const int* H, c
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4)) return (int)hipErrorInvalidValue;
     RoiLevels L = make_levels(feats, H, W, scales, num_levels, finest_scale);
     hipStream_t s = (hipStream_t)stream;
-    if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_FWD_SAMPLE) return (int)hipErrorInvalidValue;
-    const bool sample_form = variant == LOFT_ROI_FWD_SAMPLE;      // the sample-order kernel also for the 16-bit type (tests, A/B)
+    const int kern = variant & 0xff;                 // bits 8-17: tuning of the 16-byte separable kernel (below)
+    if ((kern != LOFT_ROI_AUTO && kern != LOFT_ROI_FWD_SAMPLE && kern != LOFT_ROI_FWD_SEP4) || (variant & ~0x1ffffff) ||
+        (kern != LOFT_ROI_AUTO && (variant >> 8)))
+        return (int)hipErrorInvalidValue;
+    const bool sample_form = kern == LOFT_ROI_FWD_SAMPLE;         // the sample-order kernel also for the 16-bit type (tests, A/B)
     const dim3 grid(order ? 8 * ((K + 7) / 8) : K);
-    if (dtype == LOFT_ACT16 && !sample_form)
+    if (dtype == LOFT_ACT16 && !sample_form && !(C & 7) && kern != LOFT_ROI_FWD_SEP4)
+    {
+        // Tuning bits of `variant` (tools/probes/roi_fwd_time.py; 0 everywhere = the shipped choice):
+        //   8-15  stage size of the LDS form in KiB (shipped 24: 632 us per step for the three lists of a bench step against 664
+        //         at 40 and 672 with none; 255 = none -- every RoI streams or samples)
+        //   16-17 smallest channel block of the LDS form = 64 << bits
+        //   18-21 most samples per bin for which a RoI whose bins are a pixel or more still takes the LDS form (shipped 4)
+        //   22-24 workgroups per RoI (shipped: 2 for lists of up to 4096 RoIs -- eight workgroups per CU of very uneven length
+        //         leave the CUs 1.8 deep of 3-4 possible; 1 beyond: the duplicated set-up costs more than the tail there)
+        const int kb = (variant >> 8) & 0xff, stage_bytes = kb == 255 ? 0 : (kb ? kb : 24) * 1024, min_cb = 64 << ((variant >> 16) & 3);
+        const int gm = (variant >> 18) & 15, gmax = gm ? gm : 4;
+        const int sp = (variant >> 22) & 7, nsplit = sp ? sp : (K <= 4096 ? 2 : 1);
+        if (stage_bytes > 48 * 1024)
+            hipFuncSetAttribute((const void*)roi_align_fwd_sep8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipLaunchKernelGGL(roi_align_fwd_sep8_kernel, dim3(grid.x * nsplit), dim3(256), stage_bytes, s, L, rois, K, C, P, n_rot, (bf16_t*)out, order,
+                           stage_bytes, min_cb, gmax, nsplit);
+    }
+    else if (dtype == LOFT_ACT16 && !sample_form)
         hipLaunchKernelGGL(roi_align_fwd_sep_kernel, grid, dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out, order);
     else if (dtype == LOFT_ACT16)
         hipLaunchKernelGGL(roi_align_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, L, rois, K, C, P, n_rot, (bf16_t*)out, order);

@@ -142,7 +142,7 @@ def _level_args(feats, strides):
 
 
 # include/loft_hip.h LOFT_ROI_*: kernel selector of loft_roi_align_{fwd,bwd}_v (0 = the shipped choice); tests set these
-ROI_AUTO, ROI_FWD_SAMPLE, ROI_BWD_VALU = 0, 1, 1
+ROI_AUTO, ROI_FWD_SAMPLE, ROI_FWD_SEP4, ROI_BWD_VALU = 0, 1, 2, 1
 ROI_FWD_VARIANT = ROI_AUTO
 # RoI lists at least this long are launched in (image, level, row strip) order (loft_roi_order); None = list order (shipped).
 # Measured round 3 (rocprofv3, bench step at 256 positives / image, same box): roi_align_fwd_sep_kernel 243.7 us per launch

@@ -60,6 +60,7 @@ int loft_roi_align_bwd(void* const* grad_feats_host, const int* H_host, const in
  * LOFT_ROI_AUTO = the shipped choice (16-bit forward: separable kernel; 16-bit maps with C == 256: per-(RoI, tile) GEMMs). */
 #define LOFT_ROI_AUTO 0
 #define LOFT_ROI_FWD_SAMPLE 1   /* forward: the sample-order kernel also for the 16-bit type */
+#define LOFT_ROI_FWD_SEP4 2     /* forward: the separable kernel with 8-byte accesses (rounds 2-3; shipped only when C % 8 != 0) */
 #define LOFT_ROI_BWD_VALU 1     /* backward: the tile-owner VALU kernel also where the MFMA form applies */
 int loft_roi_align_fwd_v(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                          int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,

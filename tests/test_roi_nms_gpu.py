@@ -273,10 +273,13 @@ def test_roi_align_variants_selected_in_process():
         K.ROI_FWD_VARIANT, K.ROI_BWD_VARIANT = K.ROI_FWD_SAMPLE, K.ROI_BWD_VALU
         smp = K.roi_align_fwd(feats, rois, P, strides)
         valu = K.roi_align_bwd(g, rois, shapes, P, strides, rois_sorted=True, out_dtype=torch.bfloat16)
+        K.ROI_FWD_VARIANT = K.ROI_FWD_SEP4
+        sep4 = K.roi_align_fwd(feats, rois, P, strides)
     finally:
         K.ROI_FWD_VARIANT = K.ROI_BWD_VARIANT = K.ROI_AUTO
-    assert (sep.float() - smp.float()).abs().max().item() <= 2 ** -6 * max(1.0, smp.float().abs().max().item())
-    assert (sep.float() - smp.float()).abs().mean().item() <= 2e-3
+    for s_ in (sep, sep4):          # the 16-byte (shipped) and the 8-byte separable forwards against the sample-order kernel
+        assert (s_.float() - smp.float()).abs().max().item() <= 2 ** -6 * max(1.0, smp.float().abs().max().item())
+        assert (s_.float() - smp.float()).abs().mean().item() <= 2e-3
     for a, b in zip(mfma, valu):
         scale = max(1.0, b.float().abs().max().item())
         assert (a.float() - b.float()).abs().max().item() <= 8e-3 * scale

@@ -450,7 +450,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_ROLES256 || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_STREAM256N || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -535,6 +535,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     }
     switch (k) {
     case LOFT_CONV_ROLES256:
+    case LOFT_CONV_STREAM256N:
     case LOFT_CONV_STREAM64N:
     case LOFT_CONV_STREAM64:
     case LOFT_CONV_STREAM128:
@@ -543,6 +544,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         // software-pipelined 256x256 kernels (conv_pipe.hip)
         // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
         if ((Cout % 256 && !(k == LOFT_CONV_STREAM256 && Cout % 128 == 0)) || out_f32 || accumulate) return (int)hipErrorInvalidValue;
+        if (k == LOFT_CONV_STREAM256N && ((variant >> 12) & 0xf)) return (int)hipErrorInvalidValue;
         a.pixmajor = pix_ok;
         a.pm_S = B; a.pm_P = OH * OW;
         if (pix_ok) {
@@ -562,7 +564,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         if (k == LOFT_CONV_ROLES256 && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
         return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : (k == LOFT_CONV_ROLES256 ? 2 : 1), (variant >> 12) & 0xf,
                                          k == LOFT_CONV_STREAM128 ? 2 : ((k == LOFT_CONV_STREAM64 || k == LOFT_CONV_STREAM64N) ? 1 : 4),
-                                         k == LOFT_CONV_STREAM64N ? 1 : 0, s);
+                                         (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s);
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still

@@ -1087,6 +1087,279 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBM_WAVES))
     }
 }
 
+// ---- the same backward with the chunk as the unit of a software pipeline (LOFT_ROI_BWD_PIPE: built, bit-identical, NOT shipped) ----
+// roi_align_bwd_mfma_kernel spends a pair (RoI, tile) like this: barrier, operand build, gout rows global -> registers -> LDS
+// (an L2 / HBM round trip nothing of the workgroup overlaps), barrier, 8-16 MFMAs, the next pair's tables (two more dependent
+// loads).  Its ablations (profiles/round2_probes/roi_bwd_ablations.txt) put 42 % of the launch in the gout staging, and a
+// P = 14 RoI of a small building (bins below one pixel: 79 % of the mask list) lies in one or two tiles with up to 196 active
+// bins = seven such chunks per pair.  Here
+//   * gout rows of lists without rotations travel global -> LDS directly (1 KiB per wave access = two bins; the row swizzle is
+//     applied on the global side: lane (row, physical chunk) fetches logical chunk q ^ ((row & 3) << 2)) into a DOUBLE-buffered
+//     operand tile, and the copies of chunk c + 1 are issued right behind the barrier that publishes chunk c -- they are in
+//     flight during chunk c's MFMAs, the tables of the pair after next and chunk c + 1's operand build; rotated (FOA) lists
+//     keep the register path (four rows summed per bin) inside the same skeleton;
+//   * the A operand is double-buffered too: ONE barrier per chunk instead of two to three;
+//   * the sampling geometry of the pair after next is requested at the top of an iteration and consumed behind its barrier:
+//     tables() waits for nothing, and "s_waitcnt vmcnt(0)" still means "the copies of the chunk about to be consumed landed";
+//   * tables run two pairs ahead (three buffers): the pair whose first chunk is prefetched needs its bin masks one barrier early.
+// Same arithmetic in the same order as the serial kernel: bit-identical maps (test_roi_align_bwd_pipe_bit_identical).
+// Measured on the three lists of a bench step (tools/probes/roi_bwd_time.py, same box): 52 KiB of LDS = three workgroups per CU
+// against the serial kernel's four -- mask list (2048 x 14^2) 506 -> 476 us, bbox list (8192 x 7^2) 551 -> 555, FOA list (rotated:
+// no copies to pipeline, only the lost occupancy) 308 -> 353, the fused three-list launch 1084 -> 1106 us; with the geometry
+// staged in LDS (59 KiB, two per CU) 1317 us.  Four resident workgroups hide the staging round trip as well as the pipeline
+// does inside one, so the serial kernel stays the shipped one.
+__global__ __launch_bounds__(256) void roi_align_bwd_mfma_pipe_kernel(RoiLevels L, int level, RoiBwdSets S,
+                                                                      bf16_t* __restrict__ grad, int accumulate) {
+    constexpr int C = 256;
+    constexpr int GB = RBM_CHUNK * 512, AB = RBM_CHUNK * 256;
+    __shared__ __attribute__((aligned(16))) char gbuf[2 * GB];               // 2 x [bin][256 ch] bf16, 16-byte chunks swizzled
+    __shared__ __attribute__((aligned(16))) char abuf[2 * AB];               // 2 x [bin][64 px hi | 64 px lo] bf16
+    __shared__ int list[RB_LIST];
+    __shared__ int wcnt[4];
+    __shared__ int range[2];
+    __shared__ float WY[3][RB_MAXP][RB_TILE], WX[3][RB_MAXP][RB_TILE];
+    __shared__ unsigned rnpt[16];
+    __shared__ unsigned anyb[3][4];
+    __shared__ float invb[3];
+    const int H = L.H[level], W = L.W[level];
+    const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * GB / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * AB / 16; i += 256) reinterpret_cast<uint4*>(abuf)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < 16) rnpt[tid] = tid > 1 ? (65536u + (unsigned)tid - 1u) / (unsigned)tid : 65536u;
+    const char* gfp[2];
+    const char* afp[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gfp[i] = roi_tr_frag_ptr<512>(gbuf, wave * 64 + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        afp[j] = roi_tr_frag_ptr<256>(abuf, j * 32, lane);
+        afp[2 + j] = roi_tr_frag_ptr<256>(abuf, 64 + j * 32, lane);
+    }
+    rf32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bf16_t* gout = nullptr;
+    const int4* rec = nullptr;
+    int K = 0, P = 0, n_rot = 1;
+    int c = 0;                               // chunks done so far: chunk c lives in operand buffers c & 1
+
+    auto tables = [&](const float4 g0, const float4 g1, int buf) {     // a RoI's geometry -> WY / WX / anyb / invb [buf]
+        RoiGeom g;
+        g.start_h = g0.x; g.start_w = g0.y; g.bin_h = g0.z; g.bin_w = g0.w;
+        g.grid_h = __float_as_int(g1.x); g.grid_w = __float_as_int(g1.y); g.count = g1.z;
+        const int t = tid & 127;
+        const int p = t >> 3, pix = t & 7;
+        float w = 0.f;
+        if (p < P) {
+            if (tid < 128) {
+                w = axis_weight(g.start_h, g.bin_h, g.grid_h, p, ty0 + pix, H);
+                WY[buf][p][pix] = w;
+            } else {
+                w = axis_weight(g.start_w, g.bin_w, g.grid_w, p, tx0 + pix, W);
+                WX[buf][p][pix] = w;
+            }
+        }
+        unsigned long long bt = __ballot(w != 0.f);
+        bt |= bt >> 4; bt |= bt >> 2; bt |= bt >> 1;
+        bt &= 0x0101010101010101ull;
+        if (lane == 0) anyb[buf][wave] = (unsigned)((bt * 0x0102040810204080ull) >> 56);
+        if (tid == 0) invb[buf] = g1.w;
+    };
+    struct Pair { unsigned rmask, cmask, rnp; int npx, ka, kk; float inv; };
+    auto pair_state = [&](int li) {          // (after a barrier behind tables(li))
+        const int buf = li % 3;
+        Pair q;
+        q.rmask = anyb[buf][0] | (anyb[buf][1] << 8); q.cmask = anyb[buf][2] | (anyb[buf][3] << 8);
+        q.npx = __popc(q.cmask);
+        q.rnp = rnpt[q.npx];
+        q.ka = __popc(q.rmask) * q.npx;
+        q.kk = list[li];
+        q.inv = invb[buf];
+        return q;
+    };
+    // gout rows of chunk [kc, kc + kn) of pair q -> gb (lists without rotations): wave access op = bins 2 op, 2 op + 1
+    auto issue_copies = [&](const Pair& q, int kc, int kn, char* gb) {
+        const int nops = (kn + 1) >> 1;
+        for (int op = wave; op < nops; op += 4) {
+            const int kb = 2 * op + (lane >> 5);
+            const int ab = kc + (kb < kn ? kb : kn - 1);                    // (an odd last access repeats the last bin: its A row is zero)
+            const int qy = (int)(((unsigned)ab * q.rnp) >> 16);
+            const int py = nth_set_bit(q.rmask, qy), px = nth_set_bit(q.cmask, ab - qy * q.npx);
+            const int ql = (lane & 31) ^ ((kb & 3) << 2);
+            const bf16_t* src = gout + ((size_t)q.kk * P * P + py * P + px) * C + ql * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(gb + op * 1024), 16, 0, 0);
+        }
+    };
+
+#pragma unroll 1
+    for (int si = 0; si < S.n; ++si) {
+    gout = S.gout[si]; rec = S.rec[si];
+    K = S.K[si]; P = S.P[si]; n_rot = S.n_rot[si];
+    const bool dma = n_rot == 1;
+    __syncthreads();
+    if (tid < 2) {
+        int lo = 0, hi = K;
+        const int key = b + tid;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rec[mid].x < key) lo = mid + 1; else hi = mid; }
+        range[tid] = lo;
+    }
+    __syncthreads();
+    const int kbeg = S.sorted[si] ? range[0] : 0, kend = S.sorted[si] ? range[1] : K;
+    for (int base = kbeg; base < kend; base += RB_LIST) {
+        // ---- deterministic compaction of the RoIs that touch this tile
+        const int k = base + tid;
+        bool hit = false;
+        if (k < kend) {
+            const int4 r = rec[k];
+            if (r.x == b && r.y == level) {
+                const int x0 = r.z & 0xffff, x1 = r.z >> 16, y0 = r.w & 0xffff, y1 = r.w >> 16;
+                hit = x1 >= tx0 && x0 < tx0 + RB_TILE && y1 >= ty0 && y0 < ty0 + RB_TILE;
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        __syncthreads();                     // (previous batch: its last fragment and list reads are done)
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w2 = 0; w2 < wave; ++w2) off += wcnt[w2];
+        const int n = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (hit) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        if (n == 0) continue;
+        const float4* geo = reinterpret_cast<const float4*>(rec + K);
+        { const int k0 = list[0]; tables(geo[2 * k0], geo[2 * k0 + 1], 0); }
+        if (n > 1) { const int k1 = list[1]; tables(geo[2 * k1], geo[2 * k1 + 1], 1); }
+        __syncthreads();
+        int li = 0, kc = 0;
+        Pair cur = pair_state(0);
+        if (dma && cur.ka > 0) issue_copies(cur, 0, min(RBM_CHUNK, cur.ka), gbuf + (c & 1) * GB);
+#pragma unroll 1
+        while (li < n) {
+            const int kn = max(0, min(RBM_CHUNK, cur.ka - kc));
+            const int kpad = (kn + 15) & ~15;
+            char* ab_ = abuf + (c & 1) * AB;
+            char* gb_ = gbuf + (c & 1) * GB;
+            const int tb = li % 3;
+            const bool same = kc + RBM_CHUNK < cur.ka;
+            // geometry of the pair after next: requested here, used behind the barrier (tables() then waits for nothing, and the
+            // s_waitcnt vmcnt(0) below -- which these two loads precede -- still means "this chunk's copies have landed")
+            float4 gn0 = make_float4(0.f, 0.f, 0.f, 0.f), gn1 = gn0;
+            if (!same && li + 2 < n) { const int k2 = list[li + 2]; gn0 = geo[2 * k2]; gn1 = geo[2 * k2 + 1]; }
+            // ---- A[bin][pix] of chunk c
+#pragma unroll 1
+            for (int t = tid; t < kpad * 8; t += 256) {
+                const int kb = t >> 3, y = t & 7;
+                uint32_t hi4[4] = {0, 0, 0, 0}, lo4[4] = {0, 0, 0, 0};
+                if (kb < kn) {
+                    const int ab = kc + kb;
+                    const int qy = (int)(((unsigned)ab * cur.rnp) >> 16);
+                    const int py = nth_set_bit(cur.rmask, qy), px = nth_set_bit(cur.cmask, ab - qy * cur.npx);
+                    const float wy = WY[tb][py][y] * cur.inv;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) {
+                        const float a = wy * WX[tb][px][x];
+                        const bf16_t h = f32_to_bf16(a);
+                        const bf16_t l = f32_to_bf16(a - bf16_to_f32(h));
+                        hi4[x >> 1] |= (uint32_t)h << (16 * (x & 1));
+                        lo4[x >> 1] |= (uint32_t)l << (16 * (x & 1));
+                    }
+                }
+                *reinterpret_cast<uint4*>(ab_ + kb * 256 + rwswz(kb, y) * 16) = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
+                *reinterpret_cast<uint4*>(ab_ + kb * 256 + rwswz(kb, 8 + y) * 16) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+            }
+            // ---- gout rows of chunk c: the copies issued one iteration ago, or (rotated lists) summed through registers now
+            if (dma) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll 1
+                for (int t = tid; t < kn * 32; t += 256) {
+                    const int kb = t >> 5, q = t & 31;
+                    const int ab = kc + kb;
+                    const int qy = (int)(((unsigned)ab * cur.rnp) >> 16);
+                    const int py = nth_set_bit(cur.rmask, qy), px = nth_set_bit(cur.cmask, ab - qy * cur.npx);
+                    float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    uint4 rv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rv[r] = *reinterpret_cast<const uint4*>(gout + (((size_t)r * K + cur.kk) * P * P + rot_pos(py, px, P, r)) * C + q * 8);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float tv[8];
+                        unpack8_16(rv[r], tv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sacc[e] += tv[e];
+                    }
+                    uint4 v;
+                    v.x = (uint32_t)f32_to_bf16(sacc[0]) | ((uint32_t)f32_to_bf16(sacc[1]) << 16);
+                    v.y = (uint32_t)f32_to_bf16(sacc[2]) | ((uint32_t)f32_to_bf16(sacc[3]) << 16);
+                    v.z = (uint32_t)f32_to_bf16(sacc[4]) | ((uint32_t)f32_to_bf16(sacc[5]) << 16);
+                    v.w = (uint32_t)f32_to_bf16(sacc[6]) | ((uint32_t)f32_to_bf16(sacc[7]) << 16);
+                    *reinterpret_cast<uint4*>(gb_ + kb * 512 + rwswz(kb, q) * 16) = v;
+                }
+            }
+            const int li2 = same ? li : li + 1, kc2 = same ? kc + RBM_CHUNK : 0;
+            __syncthreads();                 // chunk c's operands are complete; chunk c - 1's fragment reads are done everywhere;
+                                             // the tables written one or more iterations ago are visible
+            Pair nxt = cur;
+            if (!same && li2 < n) nxt = pair_state(li2);
+            if (dma && li2 < n && nxt.ka - kc2 > 0)
+                issue_copies(nxt, kc2, min(RBM_CHUNK, nxt.ka - kc2), gbuf + ((c + 1) & 1) * GB);
+            if (kn > 0) {
+                const int go = (c & 1) * GB, ao = (c & 1) * AB;
+#define RBP_KSTEP(KS)                                                                                         \
+                do {                                                                                          \
+                    rbf16x8 gf[2], xh[2], xl[2];                                                              \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) gf[i] = roi_tr_frag_at<512, KS>(gfp[i] + go); \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                           \
+                        xh[j] = roi_tr_frag_at<256, KS>(afp[j] + ao);                                         \
+                        xl[j] = roi_tr_frag_at<256, KS>(afp[2 + j] + ao);                                     \
+                    }                                                                                         \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                       \
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xh[j], acc[i][j]);                          \
+                            acc[i][j] = LOFT_MFMA_32x32x16(gf[i], xl[j], acc[i][j]);                          \
+                        }                                                                                     \
+                } while (0)
+                RBP_KSTEP(0);
+                if (kpad > 16) RBP_KSTEP(16);
+#undef RBP_KSTEP
+            }
+            // the tables of the pair after next (their buffer's readers -- pair li - 1 -- finished before this iteration's barrier)
+            if (!same && li + 2 < n) tables(gn0, gn1, (li + 2) % 3);
+            cur = nxt; li = li2; kc = kc2; ++c;
+        }
+    }
+    }   // lists
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = j * 32 + (lane & 31);
+        const int y = ty0 + (pix >> 3), x = tx0 + (pix & 7);
+        if (y >= H || x >= W) continue;
+        bf16_t* gp = grad + (((size_t)b * H + y) * W + x) * C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = wave * 64 + i * 32 + 8 * gq + 4 * (lane >> 5);
+                float v[4] = {acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]};
+                if (accumulate) {
+                    float o[4];
+                    ld4(gp + n, o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += o[q];
+                }
+                st4(gp + n, v);
+            }
+    }
+}
+
 __global__ void roi_levels_kernel(const float* __restrict__ rois, int K, int num_levels, int finest_scale,
                                   int32_t* __restrict__ out) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1222,8 +1495,9 @@ LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, cons
                                      int num_levels, int finest_scale, int C, int dtype, const float* rois, int K,
                                      int P, int n_rot, const void* grad_out, int B, int accumulate, int rois_sorted,
                                      void* workspace, int grad_dtype, int variant, void* stream) {
-    if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_BWD_VALU) return (int)hipErrorInvalidValue;
+    if (variant != LOFT_ROI_AUTO && variant != LOFT_ROI_BWD_VALU && variant != LOFT_ROI_BWD_PIPE) return (int)hipErrorInvalidValue;
     const bool valu_form = variant == LOFT_ROI_BWD_VALU;          // the tile-owner VALU kernel instead of the per-pair GEMMs
+    const bool serial_form = variant != LOFT_ROI_BWD_PIPE;        // (shipped) the per-pair GEMMs without the chunk pipeline
     if (dtype != LOFT_F32 && dtype != LOFT_ACT16) return (int)hipErrorInvalidValue;   // the other build's 16-bit type
     if (num_levels < 1 || num_levels > 4 || (C & 3) || (n_rot != 1 && n_rot != 4) || P > RB_MAXP)
         return (int)hipErrorInvalidValue;
@@ -1240,8 +1514,10 @@ LOFT_EXPORT int loft_roi_align_bwd_v(void* const* grad_feats, const int* H, cons
     one.K[0] = K; one.P[0] = P; one.n_rot[0] = n_rot; one.sorted[0] = rois_sorted; one.n = 1;
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
-        if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form)
+        if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form && serial_form)
             hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, one, (bf16_t*)grad_feats[l], accumulate);
+        else if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16 && C == 256 && !valu_form)
+            hipLaunchKernelGGL(roi_align_bwd_mfma_pipe_kernel, grid, dim3(256), 0, s, L, l, one, (bf16_t*)grad_feats[l], accumulate);
         else if (dtype == LOFT_ACT16 && grad_dtype == LOFT_ACT16)
             hipLaunchKernelGGL((roi_align_bwd_tile_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, L, l, rois, K, C, P, n_rot,
                                (const bf16_t*)grad_out, (bf16_t*)grad_feats[l], accumulate, rec, rois_sorted);
@@ -1293,7 +1569,11 @@ LOFT_EXPORT int loft_roi_align_bwd_multi(void* const* grad_feats, const int* H, 
     }
     for (int l = 0; l < num_levels; ++l) {
         dim3 grid(loft_cdiv(W[l], RB_TILE), loft_cdiv(H[l], RB_TILE), B);
+#ifdef RBM_PIPE_MULTI        /* A/B builds: the chunk-pipelined kernel on the multi-list route */
+        hipLaunchKernelGGL(roi_align_bwd_mfma_pipe_kernel, grid, dim3(256), 0, s, L, l, S, (bf16_t*)grad_feats[l], accumulate);
+#else
         hipLaunchKernelGGL(roi_align_bwd_mfma_kernel, grid, dim3(256), 0, s, L, l, S, (bf16_t*)grad_feats[l], accumulate);
+#endif
         LOFT_LAUNCH_CHECK();
     }
     return 0;

@@ -61,7 +61,10 @@ int loft_roi_align_bwd(void* const* grad_feats_host, const int* H_host, const in
 #define LOFT_ROI_AUTO 0
 #define LOFT_ROI_FWD_SAMPLE 1   /* forward: the sample-order kernel also for the 16-bit type */
 #define LOFT_ROI_FWD_SEP4 2     /* forward: the separable kernel with 8-byte accesses (rounds 2-3; shipped only when C % 8 != 0) */
+/* (forward, LOFT_ROI_AUTO only: bits 8-24 of `variant` tune the shipped kernel -- LDS stage KiB, smallest channel block, samples
+ * per bin, workgroups per RoI; see loft_roi_align_fwd_ord in roi_align.hip.  0 = the shipped values.) */
 #define LOFT_ROI_BWD_VALU 1     /* backward: the tile-owner VALU kernel also where the MFMA form applies */
+#define LOFT_ROI_BWD_PIPE 2     /* backward: the per-pair GEMMs as a chunk pipeline (global -> LDS copies one chunk ahead; bit-identical maps, measured neutral: not shipped) */
 int loft_roi_align_fwd_v(const void* const* feats_host, const int* H_host, const int* W_host, const float* scales_host,
                          int num_levels, int finest_scale, int C, int dtype, const float* rois, int K, int P,
                          int n_rot, void* out, int variant, void* stream);
@@ -187,6 +190,7 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
 #define LOFT_CONV_STREAM64 11     /* ... on 64-pixel x 256-cout tiles (layer4's 32 x 32 maps) */
 #define LOFT_CONV_STREAM64N 12    /* ... on 64-pixel x 128-cout tiles (256-channel convs on 32 x 32 maps: FPN P5, the RPN conv on it) */
 #define LOFT_CONV_ROLES256 13     /* 256x256x64, role-split stream: waves 0-3 issue every activation copy, waves 4-7 every weight copy (three weight stages) */
+#define LOFT_CONV_STREAM256N 14   /* the stream kernel on 256-pixel x 128-cout tiles with the THREE-stage ring also for Cout % 256 == 0 (1.5x the copy bytes per FLOP of the 256 x 256 tile, two K-tiles of look-ahead instead of one; A/B) */
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400

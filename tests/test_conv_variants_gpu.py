@@ -78,6 +78,8 @@ FWD = [
     ('foa_3x3_groups4_pixmajor.stream64', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_STREAM64'),
     ('fpn_p5_3x3_256.stream64n', (1, 8, 256, 256, 32, 32, 3, 1, 1), 'CONV_STREAM64N'),
     ('mask_3x3_pixmajor.stream64n', (1, 873, 256, 256, 14, 14, 3, 1, 1), 'CONV_STREAM64N'),
+    ('foa_3x3_groups4_pixmajor.stream256n', (4, 871, 256, 256, 7, 7, 3, 1, 1), 'CONV_STREAM256N'),
+    ('fpn_p2_3x3.stream256n', (1, 8, 256, 256, 256, 256, 3, 1, 1), 'CONV_STREAM256N'),
 ]
 
 
@@ -89,7 +91,8 @@ def test_fwd_bench_size_sampled_values(name, shape, variant):
     wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
     K.CONV_VARIANT = getattr(K, variant)
     try:
-        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128', 'CONV_STREAM64', 'CONV_STREAM64N')
+        bf16_only = variant in ('CONV_PATCH64', 'CONV_PIPE256', 'CONV_STREAM256', 'CONV_STREAM128', 'CONV_STREAM64', 'CONV_STREAM64N',
+                                'CONV_STREAM256N')
         out = K.conv2d_fwd(x, wp, bias, R, R, stride, pad, out_dtype=torch.bfloat16 if bf16_only else torch.float32, groups=G)
     finally:
         K.CONV_VARIANT = K.CONV_AUTO

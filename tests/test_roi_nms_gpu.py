@@ -253,6 +253,40 @@ def test_roi_align_bwd_mfma_matches_scalar_form(P, n_rot):
         assert (tt.float() - 2 * ww).abs().max().item() <= 2e-2 * scale
 
 
+@pytest.mark.parametrize('P,n_rot', [(7, 1), (14, 1), (7, 4)])
+def test_roi_align_bwd_pipe_bit_identical(P, n_rot):
+    """The chunk-pipelined backward (LOFT_ROI_BWD_PIPE: global -> LDS copies one chunk ahead, one barrier per chunk, tables two
+    pairs ahead) runs the shipped serial kernel's arithmetic in the serial kernel's order: the maps must be torch.equal -- small RoIs
+    (many chunks per pair at P = 14), RoIs without any weight in a tile they touch, > 256 RoIs per (image, tile) batch,
+    the accumulate mode."""
+    from bonai_amd import kernels as K
+    rng = np.random.RandomState(5 + P + n_rot)
+    B, C, size = 2, 256, 256
+    strides = [4, 8, 16, 32]
+    shapes = [(B, C, size // s, size // s) for s in strides]
+    for n, wmin, wmax in ((300, 4, 400), (1500, 8, 60), (700, 3, 20)):
+        rois = _rand_rois(rng, n, B, size, wmin, wmax)
+        if n == 700:
+            rois[:400, 1:] = torch.tensor([40., 40., 52., 52.]) + torch.rand(400, 4)      # > 256 RoIs on one tile of image 0 / 1
+        rois = rois[torch.argsort(rois[:, 0], stable=True)].contiguous().cuda()
+        g = torch.randn(n_rot * rois.shape[0], C, P, P, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last)
+        outs = {}
+        for name, var in (('pipe', K.ROI_BWD_PIPE), ('serial', K.ROI_AUTO)):
+            K.ROI_BWD_VARIANT = var
+            try:
+                first = K.roi_align_bwd(g, rois, shapes, P, strides, n_rot=n_rot, rois_sorted=True, out_dtype=torch.bfloat16)
+                twice = K.roi_align_bwd(g, rois, shapes, P, strides, n_rot=n_rot, rois_sorted=True,
+                                        grad_feats=[x.clone() for x in first])
+                unsorted = K.roi_align_bwd(g, rois, shapes, P, strides, n_rot=n_rot, rois_sorted=False, out_dtype=torch.bfloat16)
+            finally:
+                K.ROI_BWD_VARIANT = K.ROI_AUTO
+            outs[name] = (first, twice, unsorted)
+        for a, b in zip(outs['pipe'], outs['serial']):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (n, P, n_rot)
+        assert any(x.float().abs().sum().item() > 0 for x in outs['pipe'][0])
+
+
 def test_roi_align_variants_selected_in_process():
     """include/loft_hip.h LOFT_ROI_*: the explicit kernel selectors of loft_roi_align_{fwd,bwd}_v (no environment variables):
     the sample-order forward against the separable one, the tile-owner VALU backward against the per-pair GEMMs, 16-bit maps."""

@@ -1,4 +1,6 @@
-"""Time the fused RoIAlign backward (and the three forwards) on the RoI lists of a real bench step."""
+"""Time the fused RoIAlign backward (and the three forwards) on the RoI lists of a real bench step (trained-RPN load; ROI_LIGHT=1:
+the random-init RPN's).  A/B of the chunk-pipelined kernel on the fused route: build the library with -DRBM_PIPE_MULTI=1 and pass
+it as LOFT_HIP_LIB."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -13,6 +15,25 @@ torch.manual_seed(0)
 m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
 tr = Trainer(m, lr=0.005)
 data = make_batch(8, 1024, 80, device='cuda')
+# RoI heads at the trained-RPN load (bench.py's primary loop): the first proposals of every image = jittered gt boxes
+g = torch.Generator().manual_seed(7)
+jit = []
+for gb in data['gt_bboxes']:
+    b = gb.cpu()
+    wh = b[:, 2:] - b[:, :2]
+    reps = [(b + (torch.rand(b.shape[0], 4, generator=g) - 0.5) * 0.16 * torch.cat([wh, wh], 1)).clamp(0, 1024) for _ in range(4)]
+    jb = torch.cat(reps, 0)
+    jit.append(torch.cat([jb, torch.ones(jb.shape[0], 1)], 1))
+njit = min(j.shape[0] for j in jit)
+jit = torch.stack([j[:njit] for j in jit]).cuda()
+orig_ft = m.rpn_head.forward_train
+def saturated(*a, **k):
+    losses, (props, counts) = orig_ft(*a, **k)
+    props = props.clone()
+    props[:, :njit] = jit
+    return losses, (props, counts.clamp(min=njit))
+if not os.environ.get('ROI_LIGHT'):
+    m.rpn_head.forward_train = saturated
 for _ in range(3):
     tr.train_step(data)
 cap = {}

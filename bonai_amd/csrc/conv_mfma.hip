@@ -1474,6 +1474,42 @@ struct ConvArgsF32 {
     int M;
 };
 
+// SPLIT (the mode's default since round 4, LOFT_F32_SPLIT3): the same staging, but every fp32 operand element is split on its way
+// into the matrix core into two bf16 values, x = hi + lo + O(2^-18 |x|) (hi = RNE(x), lo = RNE(x - hi): 16 mantissa bits), and a
+// product w * x becomes three v_mfma_f32_32x32x16_bf16 terms, wh*xh + wh*xl + wl*xh (the dropped wl*xl is 2^-18 of the
+// product), accumulated in fp32: per-product error <= ~1e-5 |w x| with random sign -- 1e-6 of an output's scale after the
+// K-sum -- at 16 / 3 of the fp32 MFMA rate, with 16-byte fragment reads instead of conflicted 4-byte ones.  The explicit bf16
+// types keep this path identical in the library's f16 build (an f16 split would overflow on fp32-range values).
+typedef __attribute__((ext_vector_type(8))) __bf16 xbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 xbf16x2;
+__device__ __forceinline__ void f32_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const loft_f32x2 v = {x0, x1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf16x2));
+    const loft_f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, xbf16x2));
+}
+__device__ __forceinline__ void f32_split8(const float4 p, const float4 q, xbf16x8& hi, xbf16x8& lo) {
+    uint4 h, l;
+    f32_split2(p.x, p.y, h.x, l.x); f32_split2(p.z, p.w, h.y, l.y); f32_split2(q.x, q.y, h.z, l.z); f32_split2(q.z, q.w, h.w, l.w);
+    hi = __builtin_bit_cast(xbf16x8, h); lo = __builtin_bit_cast(xbf16x8, l);
+}
+// three bf16 per fp32 (24 mantissa bits: x = hi + mid + lo to fp32 accuracy) -- LOFT_F32_SPLIT6
+__device__ __forceinline__ void f32_split3x2(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const loft_f32x2 v = {x0, x1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf16x2));
+    const loft_f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, xbf16x2));
+    const loft_f32x2 r2 = {r[0] - __uint_as_float(mid << 16), r[1] - __uint_as_float(mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, xbf16x2));
+}
+__device__ __forceinline__ void f32_split8x3(const float4 p, const float4 q, xbf16x8& hi, xbf16x8& mid, xbf16x8& lo) {
+    uint4 h, m, l;
+    f32_split3x2(p.x, p.y, h.x, m.x, l.x); f32_split3x2(p.z, p.w, h.y, m.y, l.y);
+    f32_split3x2(q.x, q.y, h.z, m.z, l.z); f32_split3x2(q.z, q.w, h.w, m.w, l.w);
+    hi = __builtin_bit_cast(xbf16x8, h); mid = __builtin_bit_cast(xbf16x8, m); lo = __builtin_bit_cast(xbf16x8, l);
+}
+
+template <int SPLIT>      // 0: exact fp32 MFMA, 2: two bf16 per operand (3 terms), 3: three bf16 per operand (6 terms)
 __global__ __launch_bounds__(256) void conv_tap_f32_kernel(const ConvArgsF32 a) {
     constexpr int BM = 128, BN = 128, BKE = 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -1541,6 +1577,62 @@ __global__ __launch_bounds__(256) void conv_tap_f32_kernel(const ConvArgsF32 a) 
         if (kk + 1 < nk) stage(kk + 1, (kk + 1) & 1);
         const char* abuf = lds + (kk & 1) * (A_BYTES + B_BYTES);
         const char* bbuf = abuf + A_BYTES;
+        if constexpr (SPLIT == 3) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int q0 = ks * 4 + fq * 2;
+                xbf16x8 wh[2], wm_[2], wl[2], xh[2], xm[2], xl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wn * 64 + i * 32 + frow;
+                    f32_split8x3(*reinterpret_cast<const float4*>(bbuf + row * 128 + swz(row, q0) * 16),
+                                 *reinterpret_cast<const float4*>(bbuf + row * 128 + swz(row, q0 + 1) * 16), wh[i], wm_[i], wl[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wm * 64 + j * 32 + frow;
+                    f32_split8x3(*reinterpret_cast<const float4*>(abuf + row * 128 + swz(row, q0) * 16),
+                                 *reinterpret_cast<const float4*>(abuf + row * 128 + swz(row, q0 + 1) * 16), xh[j], xm[j], xl[j]);
+                }
+                // smallest terms first: hi*lo, lo*hi, mid*mid (2^-16), then hi*mid, mid*hi (2^-8), then hi*hi
+#define F32_TERM(A_, B_)                                                                                               \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0)
+                F32_TERM(wh, xl); F32_TERM(wl, xh); F32_TERM(wm_, xm); F32_TERM(wh, xm); F32_TERM(wm_, xh); F32_TERM(wh, xh);
+#undef F32_TERM
+            }
+        } else if constexpr (SPLIT == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                     // two 16-channel MFMA steps per 32-channel stage
+                const int q0 = ks * 4 + fq * 2;                  // this lane's 8 channels = logical chunks q0, q0 + 1
+                xbf16x8 wh[2], wl[2], xh[2], xl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wn * 64 + i * 32 + frow;
+                    f32_split8(*reinterpret_cast<const float4*>(bbuf + row * 128 + swz(row, q0) * 16),
+                               *reinterpret_cast<const float4*>(bbuf + row * 128 + swz(row, q0 + 1) * 16), wh[i], wl[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wm * 64 + j * 32 + frow;
+                    f32_split8(*reinterpret_cast<const float4*>(abuf + row * 128 + swz(row, q0) * 16),
+                               *reinterpret_cast<const float4*>(abuf + row * 128 + swz(row, q0 + 1) * 16), xh[j], xl[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
             const int k = ks * 2 + fq, q = k >> 2, e = k & 3;
@@ -1611,11 +1703,13 @@ __global__ __launch_bounds__(256) void conv_tap_f32_kernel(const ConvArgsF32 a) 
     }
 }
 
-LOFT_EXPORT int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, const float* residual,
-                                  const float* relu_mask, float* out, const void* zero_page, int B, int IH, int IW, int Cin,
-                                  int Cout, int OH, int OW, int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T,
-                                  const int* dy_host, const int* dx_host, const int* wt_host, int relu, int accumulate,
-                                  int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream) {
+LOFT_EXPORT int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, const float* residual,
+                                    const float* relu_mask, float* out, const void* zero_page, int B, int IH, int IW, int Cin,
+                                    int Cout, int OH, int OW, int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T,
+                                    const int* dy_host, const int* dx_host, const int* wt_host, int relu, int accumulate,
+                                    int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int variant,
+                                    void* stream) {
+    if (variant != LOFT_F32_SPLIT6 && variant != LOFT_F32_SPLIT3 && variant != LOFT_F32_EXACT) return (int)hipErrorInvalidValue;
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 32) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     ConvArgsF32 a;
     a.src = src; a.wgt = wgt; a.bias = bias; a.residual = residual; a.mask = relu_mask; a.out = out;
@@ -1630,7 +1724,19 @@ LOFT_EXPORT int loft_conv_tap_f32(const float* src, const float* wgt, const floa
     if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
     a.M = (int)M;
     dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 128), groups);
-    hipLaunchKernelGGL(conv_tap_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (variant == LOFT_F32_EXACT) hipLaunchKernelGGL(conv_tap_f32_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (variant == LOFT_F32_SPLIT3) hipLaunchKernelGGL(conv_tap_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_tap_f32_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, const float* residual,
+                                  const float* relu_mask, float* out, const void* zero_page, int B, int IH, int IW, int Cin,
+                                  int Cout, int OH, int OW, int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T,
+                                  const int* dy_host, const int* dx_host, const int* wt_host, int relu, int accumulate,
+                                  int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream) {
+    return loft_conv_tap_f32_v(src, wgt, bias, residual, relu_mask, out, zero_page, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo_y,
+                               oo_x, ss, T, dy_host, dx_host, wt_host, relu, accumulate, groups, src_gs, wgt_gs, out_gs, bias_gs,
+                               LOFT_F32_SPLIT6, stream);
 }

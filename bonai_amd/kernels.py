@@ -487,6 +487,11 @@ CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT, CONV_FLAG_TAP_MAJOR, CONV_FLAG_NO_ROI_BLOCKS, CONV_FLAG_KROT = \
     0x100, 0x200, 0x400, 0x800, 0x10000, 0x20000
 CONV_VARIANT = CONV_AUTO
+# include/loft_hip.h LOFT_F32_*: contraction of the fp32 parity mode.  SPLIT6 (default): fp32 operands as three bf16 each, six bf16
+# MFMA terms per product (24 mantissa bits, fp32 accumulation: fp32-grade); SPLIT3: two bf16 / three terms (16 bits: faster, meets
+# 1e-3 on losses / features / detections, not on every gradient); EXACT: the fp32 MFMA (bit-for-bit an fmaf chain).
+F32_SPLIT6, F32_EXACT, F32_SPLIT3 = 0, 1, 2
+F32_CONTRACT = F32_SPLIT6
 WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128, WGRAD_RING128 = range(5)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
 WGRAD_VARIANT = WGRAD_AUTO      # a code, or a callable (groups, B, OH, OW, Cin, Cout, T, ss, gos) -> code
 
@@ -506,12 +511,12 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
             if t is not None and t.dtype != torch.float32:
                 raise L.LoftHipError(f'fp32 parity mode needs every operand in fp32, got {t.dtype}')
         T = len(taps)
-        L.check(lib.loft_conv_tap_f32(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
-                                      L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
-                                      oo[1], ss, T, L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
-                                      L.arr(c_int, [t[2] for t in taps]), int(relu), int(accumulate), groups,
-                                      c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), L.stream()),
-                'loft_conv_tap_f32')
+        L.check(lib.loft_conv_tap_f32_v(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
+                                        L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
+                                        oo[1], ss, T, L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
+                                        L.arr(c_int, [t[2] for t in taps]), int(relu), int(accumulate), groups,
+                                        c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), int(F32_CONTRACT),
+                                        L.stream()), 'loft_conv_tap_f32_v')
         return out
     _bf16(src), _bf16(wgt)
     if residual is not None:
@@ -617,12 +622,12 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
     L.dev_check(g, x)
     A = lambda i: L.arr(c_int, [t[i] for t in taps])
     if g.dtype == torch.float32 and x.dtype == torch.float32:
-        # fp32 parity mode: exact-fp32 contraction (parity_f32.hip); the bias gradient is the plain column sum of g
+        # fp32 parity mode (parity_f32.hip; F32_CONTRACT); the bias gradient is the plain column sum of g
         if dw is None:
             dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
-        L.check(lib.loft_conv_wgrad_f32(L.ptr(g), L.ptr(x), L.ptr(dw), B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps),
-                                        A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
-                                        c_int64(n_wtaps * Cout * Cin), L.stream()), 'loft_conv_wgrad_f32')
+        L.check(lib.loft_conv_wgrad_f32_v(L.ptr(g), L.ptr(x), L.ptr(dw), B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps),
+                                          A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
+                                          c_int64(n_wtaps * Cout * Cin), int(F32_CONTRACT), L.stream()), 'loft_conv_wgrad_f32_v')
         if db is not None:
             db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
         return dw

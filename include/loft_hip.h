@@ -206,6 +206,20 @@ int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, co
 /* fp32 parity mode, backward (parity_f32.hip): weight gradient of the same tap contract on v_mfma_f32_32x32x2_f32 (dw is
  * accumulated into: the caller zeroes it), and the fp32 forms of the glue adjoints.  Checker path (1e-3 vs the reference's fp32
  * autograd), not a performance path. */
+/* Contraction of the fp32 parity mode (loft_conv_tap_f32_v / loft_conv_wgrad_f32_v; the plain names take the default), fp32
+ * operands and fp32 accumulation in every case:
+ * LOFT_F32_SPLIT6 (default since round 4): every operand element = hi + mid + lo, three bf16 (24 mantissa bits), a product = the
+ *   six v_mfma_f32_32x32x16_bf16 terms down to 2^-16 -- fp32-grade results at ~2x the fp32 MFMA kernels' speed;
+ * LOFT_F32_SPLIT3: two bf16 per element (16 mantissa bits), three terms -- ~2e-6 of an output's scale per layer, ~2.5x; meets the
+ *   1e-3 clause on losses, features and inference results, NOT on every parameter gradient of a random-weight network (2e-3);
+ * LOFT_F32_EXACT: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain (rounds 1-3). */
+#define LOFT_F32_SPLIT6 0
+#define LOFT_F32_EXACT 1
+#define LOFT_F32_SPLIT3 2
+int loft_conv_wgrad_f32_v(const float* g, const float* x, float* dw, int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH,
+                          int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host, const int* dy_host,
+                          const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                          int variant, void* stream);
 int loft_conv_wgrad_f32(const float* g, const float* x, float* dw, int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH,
                         int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host, const int* dy_host,
                         const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
@@ -221,6 +235,11 @@ int loft_conv_tap_f32(const float* src, const float* wgt, const float* bias, con
                       int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                       const int* wt_host, int relu, int accumulate, int groups, int64_t src_gs, int64_t wgt_gs,
                       int64_t out_gs, int64_t bias_gs, void* stream);
+int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, const float* residual, const float* relu_mask,
+                      float* out, const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
+                      int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
+                      const int* wt_host, int relu, int accumulate, int groups, int64_t src_gs, int64_t wgt_gs,
+                      int64_t out_gs, int64_t bias_gs, int variant, void* stream);
 /* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32

@@ -38,3 +38,15 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=rank)          # stable: the order inside a file (and among unnamed files) is pytest's own
     if os.environ.get('LOFT_TEST_ORDER') == 'reverse':      # (the suite must not depend on its file order)
         items.reverse()
+
+
+@pytest.fixture(params=['split6', 'split3', 'exact'])
+def f32_contract(request):
+    """The contractions of the fp32 parity mode (include/loft_hip.h LOFT_F32_*): the mode's default SPLIT6 (three bf16 per fp32
+    operand, six bf16 MFMA terms per product, fp32 accumulation: fp32-grade), SPLIT3 (two bf16, three terms: 16 mantissa bits) and
+    the exact fp32 MFMA of rounds 1-3."""
+    from bonai_amd import kernels as K
+    prev = K.F32_CONTRACT
+    K.F32_CONTRACT = {'split6': K.F32_SPLIT6, 'split3': K.F32_SPLIT3, 'exact': K.F32_EXACT}[request.param]
+    yield request.param
+    K.F32_CONTRACT = prev

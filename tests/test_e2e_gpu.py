@@ -96,9 +96,12 @@ def test_e2e_vs_oracle_proposals_and_targets():
         assert (iou.max(dim=1)[0] > 0.85).float().mean().item() > 0.9
 
 
-def test_e2e_fp32_parity_mode_vs_reference_fixture():
-    """North-star tolerance (1e-3), forward AND backward: the same fixture as above with the fp32 parity mode (fp32 MFMA
-    contraction, fp32 activations) -- features, all seven losses and the gradient of every parameter at 1e-3."""
+def test_e2e_fp32_parity_mode_vs_reference_fixture(f32_contract):
+    """North-star tolerance (1e-3), forward AND backward: the same fixture as above with the fp32 parity mode (fp32 activations)
+    -- features, all seven losses and the gradient of every parameter at 1e-3, for the mode's default contraction (SPLIT6: three
+    bf16 per fp32 operand, six MFMA terms) and for the exact fp32 MFMA.  SPLIT3 (two bf16 per operand: 16 mantissa bits) meets
+    1e-3 on features and losses; on the gradients of this random-weight network its 2e-6 per layer grows to 2e-3 (median 3e-4:
+    tools/probes/f32_grad_errors.py), so its gradient norms are held to 3e-3 and single entries to 3e-2."""
     from bonai_amd.synth import make_batch
     gd = np.load(os.path.join(GOLD, 'e2e_256.npz'))
     size, batch, num_gt = [int(v) for v in gd['meta']]
@@ -138,10 +141,10 @@ def test_e2e_fp32_parity_mode_vs_reference_fixture():
         e1 = abs(gn - wn) / max(wn, 1e-12)
         e2 = float((gh - wh).abs().max()) / max(float(wh.abs().max()), rms, 1e-12)
         worst = max(worst, (e1, n), (e2, n))
-        assert e1 <= 1e-3, ('norm', n, gn, wn)
+        assert e1 <= (3e-3 if f32_contract == 'split3' else 1e-3), ('norm', n, gn, wn)
         # single entries: 1e-2 of max(largest listed entry, rms) -- the entries are sums of ~1e5 signed fp32 products whose order
         # differs from the reference's CPU kernels, on top of the few mask-target pixels that sit on the 0.5 edge
-        assert e2 <= 1e-2, ('head', n, gh, wh)
+        assert e2 <= (3e-2 if f32_contract == 'split3' else 1e-2), ('head', n, gh, wh)
     print('fp32 parity backward: worst relative error', worst)
 
 

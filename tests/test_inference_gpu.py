@@ -89,15 +89,19 @@ def test_simple_test_vs_reference_fixture():
     assert rel.median().item() < 0.1
 
 
-def test_simple_test_fp32_parity_mode_vs_reference_fixture():
-    """North-star tolerance on the inference 3-tuple: with the fp32 parity mode (fp32 MFMA contraction, forward only)
-    every one of the reference's 2000 soft-NMS detections has a twin of ours within 5e-3 px / 1e-4 score (1e-3 relative
-    on a 256 px tile is 0.256 px), offsets within 1e-2 px with a mean end-point error < 1e-3 px, mask areas within 4 px.
-    The comparison is order-insensitive: score near-ties (1e-5 apart) swap rows."""
+def test_simple_test_fp32_parity_mode_vs_reference_fixture(f32_contract):
+    """North-star tolerance on the inference 3-tuple in the fp32 parity mode (forward only), every contraction of it.
+    SPLIT6 (the mode's default: three bf16 per fp32 operand, six MFMA terms) and EXACT (fp32 MFMA): every one of the reference's
+    2000 soft-NMS detections has a twin of ours within 5e-3 px / 1e-4 score (1e-3 relative on a 256 px tile is 0.256 px), offsets
+    within 1e-2 px with a mean end-point error < 1e-3 px, mask areas within 4 px.  SPLIT3 (two bf16 per operand): the same
+    detections within the north-star's 1e-3 (0.256 px on this tile) -- scores 1e-3, boxes and offsets 0.05 px, mean offset error
+    2e-3 px -- on a network with random synthetic weights, which amplifies a contraction's 2e-6 to 2e-4 at the scores.  The
+    comparison is order-insensitive: score near-ties swap rows."""
     from bonai_amd.config import Config
     from bonai_amd.loft import build_detector
     from bonai_amd.synth import make_batch
     from oracle.synth_weights import synth_tensor
+    contract = f32_contract
     gd = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_test_256.npz'))
     size = int(gd['meta'][0])
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
@@ -109,19 +113,23 @@ def test_simple_test_fp32_parity_mode_vs_reference_fixture():
     with torch.no_grad():
         bbox_results, segm_results, offset_results = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False,
                                                        rescale=True)
+    tol_s, tol_b, tol_emax, tol_emean, tol_area = (1e-4, 5e-3, 1e-2, 1e-3, 4) if contract != 'split3' else (1e-3, 0.05, 0.05, 2e-3, 16)
     det, want = torch.from_numpy(bbox_results[0]), torch.from_numpy(gd['det'])
     assert det.shape == want.shape
-    assert (det[:, 4] - want[:, 4]).abs().max().item() < 1e-4            # sorted score lists agree row by row
+    ds = (det[:, 4] - want[:, 4]).abs().max().item()                     # sorted score lists agree row by row
     dbox = (want[:, None, :4] - det[None, :, :4]).abs().amax(-1)
-    dbox = torch.where((want[:, None, 4] - det[None, :, 4]).abs() < 1e-4, dbox, torch.full_like(dbox, 1e9))
+    dbox = torch.where((want[:, None, 4] - det[None, :, 4]).abs() < tol_s, dbox, torch.full_like(dbox, 1e9))
     best, arg = dbox.min(1)
-    assert best.max().item() < 5e-3, best.max().item()
     off, off_ref = torch.from_numpy(offset_results)[arg], torch.from_numpy(gd['offsets'])
     epe = (off - off_ref).norm(dim=1)
-    print('box max diff', best.max().item(), 'offset EPE mean', epe.mean().item(), 'max', epe.max().item())
-    assert epe.max().item() < 1e-2 and epe.mean().item() < 1e-3
     areas = torch.tensor([int(s.sum()) for s in segm_results[0]])[arg]
-    assert (areas - torch.from_numpy(gd['mask_area'])).abs().max().item() <= 4
+    da = (areas - torch.from_numpy(gd['mask_area'])).abs().max().item()
+    print(f'fp32 parity mode ({contract}): score max diff {ds:.2e}, box max diff {best.max().item():.2e} px, offset EPE mean '
+          f'{epe.mean().item():.2e} max {epe.max().item():.2e} px, mask area max diff {da} px')
+    assert ds < tol_s
+    assert best.max().item() < tol_b, best.max().item()
+    assert epe.max().item() < tol_emax and epe.mean().item() < tol_emean
+    assert da <= tol_area
 
 
 def test_simple_test_rle_masks_equal_bitmaps():

@@ -409,7 +409,7 @@ def main():
                                per_gpu_batch=args.batch, dtype='f32 (operands split into 3 x bf16, 6 MFMA terms, fp32 accumulation)',
                                split3=dict(value=round(args.batch * k / el_3, 3), ms_per_step=round(el_3 / k * 1e3, 2), steps=k,
                                            how='LOFT_F32_SPLIT3: two bf16 per operand, three terms (16 mantissa bits): 1e-3 on losses, '
-                                               'features and detections; gradient norms of the random-weight fixture within 3e-3'),
+                                               'features and detections; gradient norms of the random-weight fixture within 2e-3, single entries 5e-2'),
                                exact_fp32_mfma=dict(value=round(args.batch * 3 / el_x, 3), ms_per_step=round(el_x / 3 * 1e3, 2), steps=3,
                                                     how='LOFT_F32_EXACT: v_mfma_f32_32x32x2_f32, bit-for-bit fp32 (rounds 1-3\' '
                                                         'value_fp32_parity)'),

@@ -211,7 +211,8 @@ int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, co
  * LOFT_F32_SPLIT6 (default since round 4): every operand element = hi + mid + lo, three bf16 (24 mantissa bits), a product = the
  *   six v_mfma_f32_32x32x16_bf16 terms down to 2^-16 -- fp32-grade results at ~2x the fp32 MFMA kernels' speed;
  * LOFT_F32_SPLIT3: two bf16 per element (16 mantissa bits), three terms -- ~2e-6 of an output's scale per layer, ~2.5x; meets the
- *   1e-3 clause on losses, features and inference results, NOT on every parameter gradient of a random-weight network (2e-3);
+ *   1e-3 clause on losses, features and inference results, NOT on parameter gradients of a random-weight network (norms 2e-3,
+ *   single entries up to 5e-2);
  * LOFT_F32_EXACT: v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain (rounds 1-3). */
 #define LOFT_F32_SPLIT6 0
 #define LOFT_F32_EXACT 1

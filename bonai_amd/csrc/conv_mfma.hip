@@ -439,6 +439,216 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
     }
 }
 
+// =====================================================================================
+// Tail of a 64-plane ResNet bottleneck in ONE launch (the frozen layer1 of the LOFT backbone, resnet.py:266-298; inference of
+// any such block):   out = relu( W3 . relu(conv3x3(t1) + b2) + b3 + shortcut ),   t1 = the block's first 1x1 conv output.
+// The three launches it replaces move 64 + 64 + 256 (+ 256 + 256 for a conv shortcut) channels per pixel through HBM at 137 .. 580
+// TFLOP/s (K = 64: 1.7 FLOP per byte per channel -- "Why the conv family does not move further", round 3); fused, the 3x3's
+// output never leaves the CU: conv64_patch_kernel's persistent patch walk (all nine taps' weights resident in LDS, 18 x 18 halo
+// of t1 double-buffered), then the 64-channel result goes -- bias, ReLU, bf16 -- into the LDS space of the halo it came from and
+// is the B operand of the 1x1 expansion, whose weights (a wave's 32 output channels x 64: 16 VGPRs) live in registers.
+//   DS = false: shortcut = the block input (256 channels), read in the epilogue like any residual;
+//   DS = true (the first block): shortcut = Wd . x (x: the 64-channel block input): four more K-steps of the same accumulation
+//     with x fragments read straight from global memory in operand layout (16 bytes per lane); b3 then holds b3 + bd.  The
+//     separate shortcut launch, its 256-channel output and the residual read of it disappear.
+// Rounding points are those of the unfused path (t2 rounded to bf16 once) except DS's shortcut, which is no longer rounded to
+// bf16 before the add.
+// =====================================================================================
+struct BneckArgs {
+    Conv64Args c;                 // src = t1, wgt = W2 [9][64][64], bias = b2, out = out [B,H,W,256]; residual / mask unused
+    const bf16_t* w3;             // [256][64]
+    const float* b3;              // [256] (DS: b3 + bd)
+    const bf16_t* sc;             // DS ? x [B,H,W,64] : identity [B,H,W,256]
+    const bf16_t* wd;             // DS: [256][64]
+};
+
+template <bool DS>
+__global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int ptx, int pty, int npatch) {
+    const Conv64Args& a = ba.c;
+    constexpr int HW_ = 18, HR = 18 * 18;
+    constexpr int SLOTS = 41, HB = SLOTS * 8 * 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* wl = lds;                                    // [9 * 64 rows][128 B]
+    char* hl = lds + 9 * 64 * 128;                     // 2 x halo (the current one becomes the t2 tile [256 px][128 B])
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane >> 3, pc = lane & 7;
+    for (int r8 = wave; r8 < 9 * 8; r8 += 8) {
+        const int row = r8 * 8 + lrow;
+        const int q = pc ^ (row & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.wgt + (long)row * 64 + q * 8), (lds_ptr_t)(wl + r8 * 8 * 128), 16, 0, 0);
+    }
+    auto stage = [&](int p, int buf) {
+        char* hb = hl + buf * HB;
+        const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
+        const int y0 = (rem / ptx) * 16, x0 = (rem % ptx) * 16;
+        for (int slot = wave; slot < SLOTS; slot += 8) {
+            const int row = slot * 8 + lrow;
+            const int q = pc ^ (row & 7);
+            const int hy = row / HW_, hx = row - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bf16_t* ptr = a.zero_page;
+            if (row < HR && y >= 0 && y < a.H && x >= 0 && x < a.W) ptr = a.src + ((long)(b * a.H + y) * a.W + x) * 64 + q * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lds_ptr_t)(hb + slot * 8 * 128), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 31, fq = lane >> 5;
+    const int ppy = 2 * wave + (frow >> 4), ppx = frow & 15;
+    // the 1x1 weights of this wave's 32 output channels, and their biases (lane: channels 32 wave + 8 gq + 4 fq + 0..3)
+    bf16x8 w3r[4], wdr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        w3r[ks] = *reinterpret_cast<const bf16x8*>(ba.w3 + (long)(32 * wave + frow) * 64 + ks * 16 + fq * 8);
+        if constexpr (DS) wdr[ks] = *reinterpret_cast<const bf16x8*>(ba.wd + (long)(32 * wave + frow) * 64 + ks * 16 + fq * 8);
+    }
+    // both bias vectors live in the 6 KiB of LDS behind the halos (registers are needed for the shortcut rows in flight)
+    float* bl = reinterpret_cast<float*>(hl + 2 * HB);             // [64] b2, [256] b3
+    if (tid < 64) bl[tid] = a.bias ? a.bias[tid] : 0.f;
+    if (tid < 256) bl[64 + tid] = ba.b3[tid];
+    int p = blockIdx.x;
+    if (p < npatch) stage(p, 0);
+    for (int s2 = 0; p < npatch; p += gridDim.x, ++s2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // this patch's halo landed; the previous patch's t2 reads are done
+        if (p + (int)gridDim.x < npatch) stage(p + gridDim.x, (s2 + 1) & 1);
+        char* hb = hl + (s2 & 1) * HB;
+        const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
+        const int py0 = (rem / ptx) * 16, px0 = (rem % ptx) * 16;
+        // identity shortcut: this lane's 8 x 4 residual pieces of the patch are requested NOW and consumed in the expansion's
+        // epilogue, behind the whole 3x3 (requested there, every pixel tile waited out an L2 / HBM round trip of its own: the
+        // fused identity blocks ran no faster than the launches they replace)
+        uint2 idr[DS ? 1 : 8][4];
+        if constexpr (!DS) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int r = mt * 32 + frow;
+                const int y = py0 + (r >> 4), x = px0 + (r & 15);
+                const bool in = y < a.H && x < a.W;
+                const bf16_t* sp = in ? ba.sc + ((long)(b * a.H + y) * a.W + x) * 256 + 32 * wave + 4 * fq : a.zero_page;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) idr[mt][gq] = *reinterpret_cast<const uint2*>(sp + (in ? 8 * gq : 0));
+            }
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hr = (ppy + 1 + a.dy[t]) * HW_ + ppx + 1 + a.dx[t];
+            const int wr = a.wt[t] * 64 + frow;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int q = ks * 2 + fq;
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ (hr & 7)) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int wri = wr + i * 32;
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
+                    acc[i] = LOFT_MFMA_32x32x16(wf, xf, acc[i]);
+                }
+            }
+        }
+        __syncthreads();                               // every wave is done with the halo: it becomes the t2 tile
+        {
+            const int r = 32 * wave + frow;            // t2 row of this lane's pixel
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bl + i * 32 + 8 * gq + 4 * fq);
+                    float v[4] = {fmaxf(acc[i][gq * 4 + 0] + bv.x, 0.f), fmaxf(acc[i][gq * 4 + 1] + bv.y, 0.f),
+                                  fmaxf(acc[i][gq * 4 + 2] + bv.z, 0.f), fmaxf(acc[i][gq * 4 + 3] + bv.w, 0.f)};
+                    uint2 pk;
+                    pk.x = pack2_bf16(v[0], v[1]); pk.y = pack2_bf16(v[2], v[3]);
+                    const int q = i * 4 + gq;
+                    *reinterpret_cast<uint2*>(hb + r * 128 + ((q ^ (r & 7)) << 4) + 8 * fq) = pk;
+                }
+        }
+        __syncthreads();
+        bf16x8 xs[2][4];                              // DS: x fragments of the pixel tile after the current one
+        auto fetch_x = [&](int mt, bf16x8 (&dst)[4]) {
+            const int r = mt * 32 + frow;
+            const int y = py0 + (r >> 4), x = px0 + (r & 15);
+            const bf16_t* xp = (y < a.H && x < a.W) ? ba.sc + ((long)(b * a.H + y) * a.W + x) * 64 : a.zero_page;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const bf16x8*>(xp + ks * 16 + fq * 8);
+        };
+        if constexpr (DS) fetch_x(0, xs[0]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int r = mt * 32 + frow;
+            const int y = py0 + (r >> 4), x = px0 + (r & 15);
+            const bool in = y < a.H && x < a.W;
+            const long pix = ((long)(b * a.H + y) * a.W + x);
+            f32x16 c3;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c3[e] = 0.f;
+            if constexpr (DS) {
+                if (mt + 1 < 8) fetch_x(mt + 1, xs[(mt + 1) & 1]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int q = ks * 2 + fq;
+                const bf16x8 tf = *reinterpret_cast<const bf16x8*>(hb + r * 128 + ((q ^ (r & 7)) << 4));
+                c3 = LOFT_MFMA_32x32x16(w3r[ks], tf, c3);
+            }
+            if constexpr (DS) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) c3 = LOFT_MFMA_32x32x16(wdr[ks], xs[mt & 1][ks], c3);
+            }
+            if (in) {
+                const long o0 = pix * 256 + 32 * wave + 4 * fq;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bl + 64 + 32 * wave + 8 * gq + 4 * fq);
+                    float v[4] = {c3[gq * 4 + 0] + bv.x, c3[gq * 4 + 1] + bv.y, c3[gq * 4 + 2] + bv.z, c3[gq * 4 + 3] + bv.w};
+                    if constexpr (!DS) {
+                        float rv[4];
+                        unpack2_16(idr[mt][gq].x, rv[0], rv[1]); unpack2_16(idr[mt][gq].y, rv[2], rv[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    st4(a.out + o0 + 8 * gq, v);
+                }
+            }
+        }
+    }
+}
+
+LOFT_EXPORT int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* shortcut,
+                                     const void* wd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
+                                     const int* dx_host, const int* wt_host, void* stream) {
+    if (B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+    BneckArgs ba;
+    ba.c.src = (const bf16_t*)t1; ba.c.wgt = (const bf16_t*)w2; ba.c.bias = b2; ba.c.residual = nullptr; ba.c.mask = nullptr;
+    ba.c.out = (bf16_t*)out; ba.c.zero_page = (const bf16_t*)zero_page; ba.c.B = B; ba.c.H = H; ba.c.W = W; ba.c.T = 9; ba.c.relu = 1;
+    for (int t = 0; t < 9; ++t) {
+        if (dy_host[t] < -1 || dy_host[t] > 1 || dx_host[t] < -1 || dx_host[t] > 1 || wt_host[t] < 0 || wt_host[t] > 8) return (int)hipErrorInvalidValue;
+        ba.c.dy[t] = dy_host[t]; ba.c.dx[t] = dx_host[t]; ba.c.wt[t] = wt_host[t];
+    }
+    ba.w3 = (const bf16_t*)w3; ba.b3 = b3; ba.sc = (const bf16_t*)shortcut; ba.wd = (const bf16_t*)wd;
+    const int ptx = (W + 15) / 16, pty = (H + 15) / 16;
+    const long np = (long)B * ptx * pty;
+    int cus = 256;
+    { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+    const long nb = np < cus ? np : cus;
+    const size_t lds_bytes = (size_t)9 * 64 * 128 + 2 * 41 * 8 * 128 + 320 * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (wd) {
+        (void)hipFuncSetAttribute((const void*)bneck_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(bneck_tail_kernel<true>, dim3((unsigned)nb), dim3(512), lds_bytes, s, ba, ptx, pty, (int)np);
+    } else {
+        (void)hipFuncSetAttribute((const void*)bneck_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(bneck_tail_kernel<false>, dim3((unsigned)nb), dim3(512), lds_bytes, s, ba, ptx, pty, (int)np);
+    }
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, int mj, int nw_force, hipStream_t s);     // conv_pipe.hip
 
 LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,

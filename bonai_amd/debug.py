@@ -35,6 +35,8 @@ SWITCHES = {
     # autograd-node granularity / previous formulations of three backward ops
     'no_block_fusion': 'one autograd node per conv of a residual block instead of nn.res_block',
     'no_linear_fn': 'Linear layers through the generic conv node',
+    'no_bneck_fusion': 'the frozen / inference 64-plane bottleneck as three (four) tap-conv launches instead of conv1 + the fused tail '
+                       '(loft_bneck_tail_bf16: 3x3 + 1x1 expansion + shortcut + ReLU in one launch)',
     'wgrad_no_patch': 'the tap weight-gradient kernel for 64-channel high-resolution layers (no patch kernel)',
     'roi_fp32_bwd': 'RoIAlign backward into fp32 maps + a cast',
     'roi_sort': 'RoIAlign forward workgroups in (image, level, row strip) launch order for lists of >= 256 RoIs (loft_roi_order; '

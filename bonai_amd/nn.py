@@ -1101,6 +1101,22 @@ class _ResBlockFn(torch.autograd.Function):
         n = len(main_specs)
         pdt = torch.float32 if x.dtype == torch.float32 else K.L.act16()
         need_dx = ctx.needs_input_grad[0]
+        # A 64-plane bottleneck nobody differentiates (the frozen layer1 of the LOFT backbone; any such block at inference):
+        # conv1, then 3x3 + 1x1 expansion + shortcut + ReLU as ONE launch -- the 64-channel intermediate never leaves the CU and
+        # a conv shortcut is folded into the expansion's accumulation (loft_bneck_tail_bf16, conv_mfma.hip).
+        if (not DBG.no_bneck_fusion and pdt == K.L.act16() and x.dtype == pdt and not any(ctx.needs_input_grad) and n == 3
+                and main_specs == ((1, 1, 0, None), (3, 1, 1, None), (1, 1, 0, None))
+                and tuple(tensors[3].shape) == (64, 64, 3, 3) and tuple(tensors[6].shape) == (256, 64, 1, 1)
+                and (sc_spec is None and x.shape[1] == 256 or sc_spec == (1, 1, 0, None) and x.shape[1] == 64
+                     and tuple(tensors[9].shape) == (256, 64, 1, 1))):
+            wp1, _, b1 = _rb_pack(tensors[0], bns[0], x.shape[1], 64, False, pdt)
+            wp2, _, b2 = _rb_pack(tensors[3], bns[1], 64, 64, False, pdt)
+            wp3, _, b3 = _rb_pack(tensors[6], bns[2], 64, 256, False, pdt)
+            t1 = K.conv2d_fwd(x, wp1, b1, 1, 1, 1, 0, relu=True, out_dtype=pdt)
+            if sc_spec is None:
+                return _begin_uses(K.bottleneck_tail(t1, wp2, b2, wp3, b3, x))
+            wpd, _, bd = _rb_pack(tensors[9], bns[3], 64, 256, False, pdt)
+            return _begin_uses(K.bottleneck_tail(t1, wp2, b2, wp3, b3, x, wpd, bd))
         acts, packs = [x], []
         h = x
         sc = x

@@ -173,6 +173,16 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
                        int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                        const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
                        int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, void* stream);
+/* Tail of a 64-plane ResNet bottleneck in one launch (mmdet/models/backbones/resnet.py:266-298: conv2 + bn2 + relu, conv3 + bn3,
+ * `out += identity`, relu; with wd also `identity = self.downsample(x)`), for blocks nobody differentiates -- the frozen layer1
+ * (`frozen_stages=1`, bonai_loft_foa_r50_fpn_basic.py:10) and inference:
+ *   out[B,H,W,256] = relu( W3 . relu(conv3x3_pad1(t1) + b2) + b3 + shortcut ),
+ * t1 [B,H,W,64] the first 1x1's output, w2 [9][64][64] / w3 [256][64] / wd [256][64] BN-folded forward packings, b2 [64], b3 [256]
+ * fp32 (with wd: b3 + bd).  shortcut: wd == NULL -> the block input [B,H,W,256]; else the 64-channel block input x, and Wd . x
+ * joins the expansion's accumulation.  The 3x3's taps as (dy, dx, index into w2), each in -1..1. */
+int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* shortcut,
+                         const void* wd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
+                         const int* dx_host, const int* wt_host, void* stream);
 /* The same with the kernel chosen by the caller instead of the shape heuristics (tests pin every template the bench
  * dispatches; A/B timing).  variant = one LOFT_CONV_* kernel code, optionally OR-ed with LOFT_CONV_FLAG_*; LOFT_CONV_AUTO is
  * loft_conv_tap_bf16.  A kernel that cannot serve the shape returns hipErrorInvalidValue (1). */

@@ -345,3 +345,55 @@ def test_role_split_schedule_bit_identical_to_stream_schedule_at_bench_size():
         torch.cuda.synchronize()
         for a_, b_ in zip(*outs):
             assert torch.equal(a_, b_), (G, B, Cin, Cout, H, W, R)
+
+
+@pytest.mark.parametrize('downsample', [False, True])
+@pytest.mark.parametrize('hw', [(48, 64), (40, 56), (17, 250)])
+def test_fused_bottleneck_tail_matches_the_unfused_block(downsample, hw):
+    """loft_bneck_tail_bf16 (3x3 + 1x1 expansion + shortcut + ReLU of a 64-plane bottleneck in one launch; the frozen layer1 and
+    inference) against the three / four tap-conv launches it replaces: identity shortcut -> the same rounding points and MFMA
+    order (bit-identical), conv shortcut -> the shortcut is no longer rounded to the 16-bit type before the add (one ulp of it);
+    maps that are no multiple of the 16 x 16 patch, and the fp64 convolution as the common reference."""
+    import torch.nn.functional as F
+    from bonai_amd.debug import DBG
+    from bonai_amd.loft.backbone import Bottleneck
+    torch.manual_seed(7 + int(downsample) + hw[0])
+    cin = 64 if downsample else 256
+    blk = Bottleneck(cin, 64, stride=1, downsample=downsample).cuda()
+    with torch.no_grad():
+        for n_, p in blk.named_parameters():
+            if n_.endswith('conv1.weight') or n_.endswith('conv2.weight') or n_.endswith('conv3.weight') or n_.endswith('0.weight'):
+                p.copy_(torch.randn_like(p) * (2.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+            elif n_.endswith('.weight'):
+                p.copy_(torch.rand_like(p) * 0.5 + 0.75)
+            else:
+                p.copy_(torch.randn_like(p) * 0.1)
+        for n_, b in blk.named_buffers():
+            if n_.endswith('running_mean'):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n_.endswith('running_var'):
+                b.copy_(torch.rand_like(b) * 0.5 + 0.75)
+    blk.requires_grad_(False)
+    x = torch.relu(torch.randn(2, cin, *hw, device='cuda')).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        fused = blk(x)
+        with DBG.override(no_bneck_fusion=True):
+            plain = blk(x)
+
+        def cb(h, conv, bn, relu=True, **kw):
+            s = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            y = F.conv2d(h, conv.weight.double(), None, **kw) * s.view(1, -1, 1, 1) + (bn.bias.double() - bn.running_mean.double() * s).view(1, -1, 1, 1)
+            return torch.relu(y) if relu else y
+        xd = x.double()
+        h = cb(cb(xd, blk.conv1, blk.bn1), blk.conv2, blk.bn2, padding=1)
+        sc = cb(xd, blk.downsample[0], blk.downsample[1], relu=False) if downsample else xd
+        ref = torch.relu(cb(h, blk.conv3, blk.bn3, relu=False) + sc)
+    assert fused.shape == plain.shape == (2, 256, *hw) and fused.dtype == torch.bfloat16
+    scale = max(1.0, ref.abs().max().item())
+    d_fp = (fused.float() - plain.float()).abs().max().item()
+    e_f, e_p = (fused.double() - ref).abs().max().item(), (plain.double() - ref).abs().max().item()
+    print(f'bottleneck tail (downsample={downsample}, {hw}): fused vs unfused {d_fp:.3e}; vs fp64: fused {e_f:.3e}, unfused {e_p:.3e}, scale {scale:.2f}')
+    if not downsample:
+        assert torch.equal(fused, plain)
+    assert d_fp <= 2 ** -6 * scale
+    assert e_f <= max(1.2 * e_p, 2 ** -6 * scale)

@@ -587,10 +587,13 @@ def bottleneck_tail(t1, wp2, b2, wp3, b3, shortcut, wpd=None, bd=None):
         b3 = ent[3]
     out = empty_nhwc(B, 256, H, W, L.act16(), t1.device)
     taps = [(r - 1, s - 1, r * 3 + s) for r in range(3) for s in range(3)]
+    _ev = _prof_begin()
     L.check(lib.loft_bneck_tail_bf16(L.ptr(t1), L.ptr(wp2), L.ptr(b2), L.ptr(wp3), L.ptr(b3), L.ptr(shortcut), L.ptr(wpd), L.ptr(out),
                                      L.ptr(zero_page(t1.device)), B, H, W, L.arr(c_int, [t[0] for t in taps]),
                                      L.arr(c_int, [t[1] for t in taps]), L.arr(c_int, [t[2] for t in taps]), L.stream()),
             'loft_bneck_tail_bf16')
+    # (bench.py's live roofline: counted with the tap-conv family whose three / four launches it replaces)
+    _prof_end(_ev, 'conv_tap', 2.0 * B * H * W * (9 * 64 * 64 + 64 * 256 * (2 if wpd is not None else 1)), (1, B, H, W, 64, 256, 9, 1, 1))
     return out
 
 

@@ -448,18 +448,18 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
 // of t1 double-buffered), then the 64-channel result goes -- bias, ReLU, bf16 -- into the LDS space of the halo it came from and
 // is the B operand of the 1x1 expansion, whose weights (a wave's 32 output channels x 64: 16 VGPRs) live in registers.
 //   DS = false: shortcut = the block input (256 channels), read in the epilogue like any residual;
-//   DS = true (the first block): shortcut = Wd . x (x: the 64-channel block input): four more K-steps of the same accumulation
-//     with x fragments read straight from global memory in operand layout (16 bytes per lane); b3 then holds b3 + bd.  The
+//   DS = true (the first block): shortcut = Wd . x + bd (x: the 64-channel block input): a second accumulator fed with x fragments
+//     read straight from global memory in operand layout (16 bytes per lane), rounded to the 16-bit type before the add.  The
 //     separate shortcut launch, its 256-channel output and the residual read of it disappear.
-// Rounding points are those of the unfused path (t2 rounded to bf16 once) except DS's shortcut, which is no longer rounded to
-// bf16 before the add.
+// Rounding points and MFMA order are those of the unfused launches (and of the oracle's 16-bit-points mode): bit-identical output.
 // =====================================================================================
 struct BneckArgs {
     Conv64Args c;                 // src = t1, wgt = W2 [9][64][64], bias = b2, out = out [B,H,W,256]; residual / mask unused
     const bf16_t* w3;             // [256][64]
-    const float* b3;              // [256] (DS: b3 + bd)
+    const float* b3;              // [256]
     const bf16_t* sc;             // DS ? x [B,H,W,64] : identity [B,H,W,256]
     const bf16_t* wd;             // DS: [256][64]
+    const float* bd;              // DS: [256]
 };
 
 template <bool DS>
@@ -502,9 +502,10 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int
         if constexpr (DS) wdr[ks] = *reinterpret_cast<const bf16x8*>(ba.wd + (long)(32 * wave + frow) * 64 + ks * 16 + fq * 8);
     }
     // both bias vectors live in the 6 KiB of LDS behind the halos (registers are needed for the shortcut rows in flight)
-    float* bl = reinterpret_cast<float*>(hl + 2 * HB);             // [64] b2, [256] b3
+    float* bl = reinterpret_cast<float*>(hl + 2 * HB);             // [64] b2, [256] b3, DS: [256] bd
     if (tid < 64) bl[tid] = a.bias ? a.bias[tid] : 0.f;
     if (tid < 256) bl[64 + tid] = ba.b3[tid];
+    if (DS && tid < 256) bl[320 + tid] = ba.bd[tid];
     int p = blockIdx.x;
     if (p < npatch) stage(p, 0);
     for (int s2 = 0; p < npatch; p += gridDim.x, ++s2) {
@@ -582,9 +583,9 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int
             const int y = py0 + (r >> 4), x = px0 + (r & 15);
             const bool in = y < a.H && x < a.W;
             const long pix = ((long)(b * a.H + y) * a.W + x);
-            f32x16 c3;
+            f32x16 c3, cd;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) c3[e] = 0.f;
+            for (int e = 0; e < 16; ++e) { c3[e] = 0.f; cd[e] = 0.f; }
             if constexpr (DS) {
                 if (mt + 1 < 8) fetch_x(mt + 1, xs[(mt + 1) & 1]);
             }
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int
             }
             if constexpr (DS) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) c3 = LOFT_MFMA_32x32x16(wdr[ks], xs[mt & 1][ks], c3);
+                for (int ks = 0; ks < 4; ++ks) cd = LOFT_MFMA_32x32x16(wdr[ks], xs[mt & 1][ks], cd);
             }
             if (in) {
                 const long o0 = pix * 256 + 32 * wave + 4 * fq;
@@ -604,12 +605,18 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 bv = *reinterpret_cast<const float4*>(bl + 64 + 32 * wave + 8 * gq + 4 * fq);
                     float v[4] = {c3[gq * 4 + 0] + bv.x, c3[gq * 4 + 1] + bv.y, c3[gq * 4 + 2] + bv.z, c3[gq * 4 + 3] + bv.w};
+                    float rv[4];
                     if constexpr (!DS) {
-                        float rv[4];
                         unpack2_16(idr[mt][gq].x, rv[0], rv[1]); unpack2_16(idr[mt][gq].y, rv[2], rv[3]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    } else {
+                        // the shortcut conv's output passes through the 16-bit type, as it does between the unfused launches and
+                        // in the oracle's 16-bit-points mode: same rounding points, bit-identical block output
+                        const float4 dv = *reinterpret_cast<const float4*>(bl + 320 + 32 * wave + 8 * gq + 4 * fq);
+                        unpack2_16(pack2_bf16(cd[gq * 4 + 0] + dv.x, cd[gq * 4 + 1] + dv.y), rv[0], rv[1]);
+                        unpack2_16(pack2_bf16(cd[gq * 4 + 2] + dv.z, cd[gq * 4 + 3] + dv.w), rv[2], rv[3]);
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rv[e];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     st4(a.out + o0 + 8 * gq, v);
@@ -620,9 +627,9 @@ __global__ __launch_bounds__(512) void bneck_tail_kernel(const BneckArgs ba, int
 }
 
 LOFT_EXPORT int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* shortcut,
-                                     const void* wd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
+                                     const void* wd, const float* bd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
                                      const int* dx_host, const int* wt_host, void* stream) {
-    if (B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+    if (B < 1 || H < 1 || W < 1 || (wd && !bd)) return (int)hipErrorInvalidValue;
     BneckArgs ba;
     ba.c.src = (const bf16_t*)t1; ba.c.wgt = (const bf16_t*)w2; ba.c.bias = b2; ba.c.residual = nullptr; ba.c.mask = nullptr;
     ba.c.out = (bf16_t*)out; ba.c.zero_page = (const bf16_t*)zero_page; ba.c.B = B; ba.c.H = H; ba.c.W = W; ba.c.T = 9; ba.c.relu = 1;
@@ -630,13 +637,13 @@ LOFT_EXPORT int loft_bneck_tail_bf16(const void* t1, const void* w2, const float
         if (dy_host[t] < -1 || dy_host[t] > 1 || dx_host[t] < -1 || dx_host[t] > 1 || wt_host[t] < 0 || wt_host[t] > 8) return (int)hipErrorInvalidValue;
         ba.c.dy[t] = dy_host[t]; ba.c.dx[t] = dx_host[t]; ba.c.wt[t] = wt_host[t];
     }
-    ba.w3 = (const bf16_t*)w3; ba.b3 = b3; ba.sc = (const bf16_t*)shortcut; ba.wd = (const bf16_t*)wd;
+    ba.w3 = (const bf16_t*)w3; ba.b3 = b3; ba.sc = (const bf16_t*)shortcut; ba.wd = (const bf16_t*)wd; ba.bd = bd;
     const int ptx = (W + 15) / 16, pty = (H + 15) / 16;
     const long np = (long)B * ptx * pty;
     int cus = 256;
     { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
     const long nb = np < cus ? np : cus;
-    const size_t lds_bytes = (size_t)9 * 64 * 128 + 2 * 41 * 8 * 128 + 320 * 4;
+    const size_t lds_bytes = (size_t)9 * 64 * 128 + 2 * 41 * 8 * 128 + 576 * 4;
     hipStream_t s = (hipStream_t)stream;
     if (wd) {
         (void)hipFuncSetAttribute((const void*)bneck_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

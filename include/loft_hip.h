@@ -178,10 +178,11 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
  * (`frozen_stages=1`, bonai_loft_foa_r50_fpn_basic.py:10) and inference:
  *   out[B,H,W,256] = relu( W3 . relu(conv3x3_pad1(t1) + b2) + b3 + shortcut ),
  * t1 [B,H,W,64] the first 1x1's output, w2 [9][64][64] / w3 [256][64] / wd [256][64] BN-folded forward packings, b2 [64], b3 [256]
- * fp32 (with wd: b3 + bd).  shortcut: wd == NULL -> the block input [B,H,W,256]; else the 64-channel block input x, and Wd . x
- * joins the expansion's accumulation.  The 3x3's taps as (dy, dx, index into w2), each in -1..1. */
+ * fp32.  shortcut: wd == NULL -> the block input [B,H,W,256]; else the 64-channel block input x, and the shortcut conv
+ * Wd . x + bd (bd [256]) is computed in the same launch and passes through the 16-bit type before the add, as between separate
+ * launches: the output is bit-identical to the unfused block.  The 3x3's taps as (dy, dx, index into w2), each in -1..1. */
 int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* shortcut,
-                         const void* wd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
+                         const void* wd, const float* bd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
                          const int* dx_host, const int* wt_host, void* stream);
 /* The same with the kernel chosen by the caller instead of the shape heuristics (tests pin every template the bench
  * dispatches; A/B timing).  variant = one LOFT_CONV_* kernel code, optionally OR-ed with LOFT_CONV_FLAG_*; LOFT_CONV_AUTO is

@@ -240,11 +240,8 @@ def test_odd_map_sizes_16bit_backward_agrees_with_fp32_parity_backward(size, bat
     bad = []
     for n, g32 in gf.items():
         n32, n16 = float(g32.norm()), float(gb[n].norm())
-        # (a one-element gradient -- the mask logits' bias -- is a sum of ~1e5 signed terms that largely cancel: 14-24 % measured;
-        #  the others: 3-7 % typical, and a single small one -- neck.fpn_convs.2, a handful of positives on that level -- moved from
-        #  6 % to 15 % when layer1's fused tail brought every feature map CLOSER to the fp32 path, tools/probes/odd_size_dev.py:
-        #  at this size the norms of the small gradients are rounding-noise samples, so the bound is 0.18)
-        if abs(n16 - n32) > (0.3 if g32.numel() <= 8 else 0.18) * max(n32, 1e-2):
+        # (a one-element gradient -- the mask logits' bias -- is a sum of ~1e5 signed terms that largely cancel: 14 % measured)
+        if abs(n16 - n32) > (0.25 if g32.numel() <= 8 else 0.10) * max(n32, 1e-2):
             bad.append((n, n16, n32))
     assert not bad, bad[:8]
 

@@ -50,3 +50,23 @@ def test_library_sources_read_no_environment():
     csrc = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), 'csrc')
     offenders = [f for f in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) if 'getenv' in open(f).read()]
     assert not offenders, offenders
+
+
+def test_selector_constants_match_the_header():
+    """bonai_amd.kernels mirrors the kernel selectors of include/loft_hip.h (LOFT_CONV_* / LOFT_WGRAD_* / LOFT_ROI_* / LOFT_F32_*
+    and the LOFT_CONV_FLAG_* bits) as plain integers: every mirrored name must carry the header's value."""
+    import re
+    from bonai_amd import kernels as K
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'loft_hip.h')).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r'^#define\s+(LOFT_[A-Z0-9_x]+)\s+(0x[0-9a-fA-F]+|\d+)\b', hdr, re.M)}
+    checked = 0
+    for name, value in defs.items():
+        for prefix in ('LOFT_CONV_', 'LOFT_WGRAD_', 'LOFT_ROI_', 'LOFT_F32_'):
+            if name.startswith(prefix):
+                py = name[len('LOFT_'):]
+                if hasattr(K, py):
+                    assert getattr(K, py) == value, (name, value, getattr(K, py))
+                    checked += 1
+    assert checked >= 30, checked
+    for must in ('F32_SPLIT6', 'F32_SPLIT3', 'F32_EXACT', 'ROI_FWD_SEP4', 'ROI_BWD_PIPE', 'CONV_STREAM256N'):
+        assert 'LOFT_' + must in defs and getattr(K, must) == defs['LOFT_' + must], must

@@ -125,8 +125,10 @@ def offset_epe_vs_ref():
     want, off_ref = torch.from_numpy(gd['det']), torch.from_numpy(gd['offsets'])
     out = dict(fixture='tests/golden/e2e_test_256.npz', unit='px')
     from bonai_amd import kernels as K
-    # fp32_parity = the mode's default contraction (LOFT_F32_SPLIT6); fp32_split3 / fp32_exact_mfma = the other two
-    for mode, dt, contract, stol in (('fp32_parity', torch.float32, K.F32_SPLIT6, 1e-4), ('fp32_split3', torch.float32, K.F32_SPLIT3, 1e-3),
+    # fp32_parity = the mode's default contraction (binary16 operand planes, round 5); the others: bfloat16 planes and round 4's kernels
+    for mode, dt, contract, stol in (('fp32_parity', torch.float32, K.F32_PLANES_F16, 1e-4),
+                                     ('fp32_planes_bf16', torch.float32, K.F32_PLANES_BF16, 1e-4),
+                                     ('fp32_split6', torch.float32, K.F32_SPLIT6, 1e-4), ('fp32_split3', torch.float32, K.F32_SPLIT3, 1e-3),
                                      ('fp32_exact_mfma', torch.float32, K.F32_EXACT, 1e-4),
                                      ('bf16', torch.bfloat16, K.F32_CONTRACT, 0.0)):
         m.backbone.compute_dtype = dt
@@ -381,9 +383,9 @@ def main():
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     # The SAME step in the fp32 parity mode (fp32 activations; the kernels that meet north_star's 1e-3 against the reference's CPU
     # path forward and backward, tests/test_e2e_gpu.py) -- a throughput for the 1e-3 clause next to the bf16 headline (VERDICT r3
-    # item 3).  N = 1, headline config, a few steps.  Three contractions (include/loft_hip.h LOFT_F32_*): the mode's default since
-    # round 4, SPLIT6 (every fp32 operand = three bf16, a product = six bf16 MFMA terms, fp32 accumulation), SPLIT3 and the exact
-    # fp32 MFMA.
+    # item 3, r4 item 3).  N = 1, headline config, a few steps.  Five contractions (include/loft_hip.h): the mode's default since
+    # round 5, binary16 operand planes on the pipelined stream kernels; bfloat16 planes; and round 4's kernels SPLIT6 (every fp32
+    # operand = three bf16 split in registers, six MFMA terms), SPLIT3 and the exact fp32 MFMA.
     fp32_parity = None
     if world == 1 and headline and not args.no_fp32 and not fp16:
         from bonai_amd import kernels as _K
@@ -402,22 +404,36 @@ def main():
         try:
             model.backbone.compute_dtype = torch.float32
             k = 5
-            el = fp32_loop(_K.F32_SPLIT6, k)
+            _K.PLANES_STATS['planes'] = _K.PLANES_STATS['fallback'] = 0
+            el = fp32_loop(_K.F32_PLANES_F16, k)
+            pst = dict(_K.PLANES_STATS)
+            el_pb = fp32_loop(_K.F32_PLANES_BF16, k)
+            el_6 = fp32_loop(_K.F32_SPLIT6, k)
             el_3 = fp32_loop(_K.F32_SPLIT3, k)
             el_x = fp32_loop(_K.F32_EXACT, 3)
             fp32_parity = dict(value=round(args.batch * k / el, 3), unit='img/s', ms_per_step=round(el / k * 1e3, 2), steps=k, warmup=2,
-                               per_gpu_batch=args.batch, dtype='f32 (operands split into 3 x bf16, 6 MFMA terms, fp32 accumulation)',
+                               per_gpu_batch=args.batch,
+                               dtype='f32 (operands as 2 binary16 planes under a power-of-two scale, 3 f16 MFMA products, fp32 accumulation)',
+                               contraction_launches_per_step=dict(planes=pst['planes'] // (k + 2), fp32_kernels=pst['fallback'] // (k + 2)),
+                               planes_bf16=dict(value=round(args.batch * k / el_pb, 3), ms_per_step=round(el_pb / k * 1e3, 2), steps=k,
+                                                how='LOFT planes, bfloat16 build: three planes per operand, six products (24 bits)'),
+                               split6=dict(value=round(args.batch * k / el_6, 3), ms_per_step=round(el_6 / k * 1e3, 2), steps=k,
+                                           how='LOFT_F32_SPLIT6 (round 4\'s value_fp32_parity): three bf16 per operand split in registers '
+                                               'inside lock-step fp32-operand kernels, six MFMA terms'),
                                split3=dict(value=round(args.batch * k / el_3, 3), ms_per_step=round(el_3 / k * 1e3, 2), steps=k,
                                            how='LOFT_F32_SPLIT3: two bf16 per operand, three terms (16 mantissa bits): 1e-3 on losses, '
                                                'features and detections; gradient norms of the random-weight fixture within 2e-3, single entries 5e-2'),
                                exact_fp32_mfma=dict(value=round(args.batch * 3 / el_x, 3), ms_per_step=round(el_x / 3 * 1e3, 2), steps=3,
                                                     how='LOFT_F32_EXACT: v_mfma_f32_32x32x2_f32, bit-for-bit fp32 (rounds 1-3\' '
                                                         'value_fp32_parity)'),
-                               how='same command and batch, model.backbone.compute_dtype = torch.float32: fp32 activations, every '
-                                   'contraction forward and backward on split-bf16 operands with fp32 accumulation (LOFT_F32_SPLIT6, the '
-                                   'mode\'s default: 24 mantissa bits per operand, fp32-grade) -- the mode '
-                                   'test_e2e_fp32_parity_mode_vs_reference_fixture[split6] (features, losses, every parameter gradient) '
-                                   'and test_simple_test_fp32_parity_mode_vs_reference_fixture[split6] hold to 1e-3 against the reference')
+                               how='same command and batch, model.backbone.compute_dtype = torch.float32: fp32 activations; every '
+                                   'contraction forward and backward on OPERAND PLANES (bonai_amd.kernels.F32_PLANES_F16, the mode\'s '
+                                   'default since round 5): each fp32 tensor split once into two binary16 planes (22 significant bits, '
+                                   'power-of-two scale from its absmax), the three products hi*hi + hi*lo + lo*hi as extra taps of ONE K '
+                                   'loop of the software-pipelined stream kernels (conv_pipe.hip / conv_wgrad_pipe.hip, binary16 build), '
+                                   'fp32 accumulation and fp32 epilogue -- the mode '
+                                   'test_e2e_fp32_parity_mode_vs_reference_fixture[planes_f16] (features, losses, every parameter gradient) '
+                                   'and test_simple_test_fp32_parity_mode_vs_reference_fixture[planes_f16] hold to 1e-3 against the reference')
         except Exception as e:      # noqa -- reported, never hidden
             fp32_parity = dict(error=f'{type(e).__name__}: {e}'[:300])
         finally:

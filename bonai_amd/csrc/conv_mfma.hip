@@ -677,6 +677,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     a.relu = relu; a.out_f32 = out_f32; a.accumulate = accumulate;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;
+    a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr;
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
     fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
     fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
@@ -836,6 +837,78 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
                                 out_gs, bias_gs, LOFT_CONV_AUTO, stream);
 }
 
+// The tap convolution on OPERAND PLANES: the fp32 parity mode on the 16-bit matrix cores through the software-pipelined stream
+// kernel (conv_pipe.hip, PL instances).  src / wgt hold the 16-bit planes of the fp32 activation / packed fp32 weights
+// (loft_split_planes_f32: plane p of src at element offset p * x_ps, of wgt at p * w_ps); term i multiplies activation plane
+// xpl[i] with weight plane wpl[i]; all terms of all taps accumulate in fp32 in ONE K loop.  bias, residual, relu_mask, out: fp32,
+// semantics of loft_conv_tap_bf16.  amax_x / amax_w: the device scalars the planes were scaled with (both or neither).
+// Returns hipErrorInvalidValue for shapes the stream kernel does not serve (Cout % 128, Cin % 64, nterms * T > 64, plane offsets
+// beyond 2^31 elements): the caller then takes loft_conv_tap_f32.
+LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const float* bias, const float* residual,
+                                     const float* relu_mask, float* out, const void* zero_page, int B, int IH, int IW, int Cin,
+                                     int Cout, int OH, int OW, int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T,
+                                     const int* dy_host, const int* dx_host, const int* wt_host, int relu, int groups,
+                                     int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int nterms,
+                                     const int* xpl_host, const int* wpl_host, int64_t x_ps, int64_t w_ps,
+                                     const float* amax_x, const float* amax_w, void* stream) {
+    if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 128) || groups < 1 || nterms < 1 || nterms > CONV_MAX_TERMS ||
+        nterms * T > 64 || (amax_x == nullptr) != (amax_w == nullptr))
+        return (int)hipErrorInvalidValue;
+    ConvArgs a;
+    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual;
+    a.mask = (const bf16_t*)relu_mask; a.out = out; a.zero_page = (const bf16_t*)zero_page;
+    a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.OH = OH; a.OW = OW; a.OHf = OHf; a.OWf = OWf;
+    a.os = os; a.oo_y = oo_y; a.oo_x = oo_x; a.ss = ss; a.T = T;
+    long max_a = 0, max_w = 0;                    // largest tap offsets (elements): plane offset + tap offset must fit 32 bits
+    for (int t = 0; t < T; ++t) {
+        a.dy[t] = dy_host[t]; a.dx[t] = dx_host[t]; a.wt[t] = wt_host[t];
+        max_a = std::max(max_a, labs(((long)dy_host[t] * IW + dx_host[t]) * Cin));
+        max_w = std::max(max_w, (long)wt_host[t] * Cout * Cin);
+    }
+    a.nterms = nterms;
+    for (int p = 0; p < nterms; ++p) {
+        const long xo = (long)xpl_host[p] * x_ps, wo = (long)wpl_host[p] * w_ps;
+        if (xpl_host[p] < 0 || wpl_host[p] < 0 || xo + max_a > 0x7fffffffL || wo + max_w > 0x7fffffffL) return (int)hipErrorInvalidValue;
+        a.xoff[p] = (int)xo; a.woff[p] = (int)wo;
+    }
+    a.amax_x = amax_x; a.amax_w = amax_w;
+    a.relu = relu; a.out_f32 = 1; a.accumulate = 0; a.staged_out = 0;
+    a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
+    a.trace = nullptr;
+    fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
+    fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
+    fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
+    const long M = (long)B * OH * OW;
+    if (M <= 0) return 0;
+    if (M > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    a.M = (int)M;
+    a.nfast = 1; a.tap_major = 0; a.krot = 0;
+    const bool pix_ok = T > 1 && T <= 32 && B >= 256 && OH * OW <= 1024 && os == 1 && ss == 1 && OHf == OH && OWf == OW;
+    a.pixmajor = pix_ok;
+    a.pm_S = B; a.pm_P = OH * OW;
+    if (pix_ok) {
+        const int nb = std::max(1, B / 256);
+        a.pm_S = (B + nb - 1) / nb;
+        const long Mp = (long)nb * a.pm_P * a.pm_S;
+        if (Mp > 0x7fffffffL) return (int)hipErrorInvalidValue;
+        a.M = (int)Mp;
+    }
+    fastdiv_setup((unsigned)a.pm_S, &a.pms_mul, &a.pms_sh);
+    fastdiv_setup((unsigned)a.pm_P, &a.pmp_mul, &a.pmp_sh);
+    // tile shape: the largest of the stream kernel's tiles that still gives ~192 workgroups (as loft_conv_tap_bf16_v)
+    int mj, nwf = 0;
+    if (Cout % 256 == 0) {
+        const long nt = (long)(Cout / 256) * groups;
+        if (loft_cdiv(a.M, 256) * nt >= 192) mj = 4;
+        else if (loft_cdiv(a.M, 128) * nt >= 192) mj = 2;
+        else if (loft_cdiv(a.M, 64) * nt >= 192) mj = 1;
+        else { mj = 1; nwf = 1; }
+    } else {
+        mj = (long)loft_cdiv(a.M, 256) * (Cout / 128) * groups >= 192 ? 4 : 1;
+    }
+    return loft_launch_conv_tap_pipe(a, groups, 1, 0, mj, nwf, (hipStream_t)stream);
+}
+
 // =====================================================================================
 // Weight gradient:  dW[wt[t]][n][c] += sum_m  G[b, oy*gos+goy[t], ox*gos+gox[t], n] * X[b, oy*ss+dy[t], ox*ss+dx[t], c]
 //
@@ -906,8 +979,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     }
     const int n0 = nt * TN, c0 = ct * TN;
     if (mbeg >= mend) return;
-    const bf16_t* G = a.g + (long)grp * a.g_gs;
-    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const bf16_t* G = a.g + WGRAD_G_OFF(a, grp);
+    const bf16_t* X = a.x + WGRAD_X_OFF(a, grp);
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
@@ -1015,8 +1088,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
 
     const int sidx = PM ? (int)a.pm_split[bz] : bz;
     const int ns_t = PM ? a.pm_blk0[t + 1] - a.pm_blk0[t] : (int)gridDim.z;
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
+    float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
     const int nzero = (a.partial && sidx == ns_t - 1) ? a.nslots - ns_t : 0;      // this tap's unused slots (WgradArgs::partial)
+    const float osc = WGRAD_OUT_SCALE(a);          // (1 unless the operands are scaled planes: exact either way)
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1030,7 +1104,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
                     *p = acc[i][j][r];
                     for (int z = 1; z <= nzero; ++z) p[(long)z * a.split_stride] = 0.f;
                 } else {
-                    unsafeAtomicAdd(p, acc[i][j][r]);
+                    unsafeAtomicAdd(p, acc[i][j][r] * osc);
                 }
             }
         }
@@ -1059,8 +1133,8 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
     const int mbeg = bz * a.pix_per_split;
     const int mend = min(a.M, mbeg + a.pix_per_split);
     if (mbeg >= mend) return;
-    const bf16_t* G = a.g + (long)grp * a.g_gs;
-    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const bf16_t* G = a.g + WGRAD_G_OFF(a, grp);
+    const bf16_t* X = a.x + WGRAD_X_OFF(a, grp);
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int lrow = lane >> 4, lchunk = lane & 15;
@@ -1153,7 +1227,7 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
             if (n < a.Cout) unsafeAtomicAdd(db + n, accb[r]);
         }
     }
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin;
+    float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c < a.Cin) {
 #pragma unroll
@@ -1193,8 +1267,8 @@ void conv_wgrad64_patch_kernel(const WgradArgs a, int ptx, int pty, int npatch,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = blockIdx.y;
-    const bf16_t* G = a.g + (long)grp * a.g_gs;
-    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const bf16_t* G = a.g + WGRAD_G_OFF(a, grp);
+    const bf16_t* X = a.x + WGRAD_X_OFF(a, grp);
     const int H = a.OH, W = a.OW;
     const int lrow = lane >> 3, pc = lane & 7;
     auto stage = [&](int p, int buf) {
@@ -1321,6 +1395,7 @@ LOFT_EXPORT int loft_conv_wgrad_patch_bf16(const void* g, const void* x, float* 
     if (T < 1 || T > 9 || Cout > 64 || Cin > 64 || (Cin % 8) || (Cout % 8) || groups < 1 || !workspace) return (int)hipErrorInvalidValue;
     WgradArgs a;
     a.pm_inc_ok = 0;
+    a.nvg = 0; a.amax_g = nullptr; a.amax_x = nullptr;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = H; a.GW = W; a.Cout = Cout; a.XH = H; a.XW = W; a.Cin = Cin; a.OH = H; a.OW = W;
     a.gos = 1; a.ss = 1; a.T = T;
@@ -1353,11 +1428,23 @@ int loft_launch_conv_wgrad_ring(const WgradArgs& a, dim3 grid, hipStream_t s);  
 // split slots a partial-sum launch of this shape writes (0: this shape has no such form -- narrow channels, repeated or missing
 // weight taps, a tap without a valid row).  mode 2: launch, every workgroup STORES its tile into its split's slot of
 // dw = [group][nslots][T][Cout][Cin] (dw_gs = nslots * T * Cout * Cin); see WgradArgs::partial.
+// Operand planes of a weight-gradient launch (loft_conv_wgrad_planes): the launch's groups are `groups * nterms` virtual groups,
+// virtual group grp * nterms + p reads G plane gpl[p] / X plane xpl[p] of real group grp and adds into that group's dW.
+struct WgradPlanes {
+    int nterms;
+    const int* gpl;
+    const int* xpl;
+    int64_t g_ps, x_ps;              // elements between two planes of G / X
+    const float* amax_g;
+    const float* amax_x;
+};
+
 static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
                       int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
                       const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
-                      int splits, float* db, int db_tap, int variant, void* stream, int mode, int* nslots_out) {
+                      int splits, float* db, int db_tap, int variant, void* stream, int mode, int* nslots_out,
+                      const WgradPlanes* planes = nullptr) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % 8) || (Cout % 8) || groups < 1) return (int)hipErrorInvalidValue;
     if (variant < LOFT_WGRAD_AUTO || variant > LOFT_WGRAD_RING128) return (int)hipErrorInvalidValue;
     const bool narrow = (Cin % 128) || (Cout % 128);
@@ -1373,6 +1460,21 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     if (mode == 2 && !slots_ok) return (int)hipErrorInvalidValue;
     WgradArgs a;
     a.pm_inc_ok = 0;
+    a.nvg = 0; a.amax_g = nullptr; a.amax_x = nullptr;
+    if (planes) {
+        if (mode != 0 || db || planes->nterms < 1 || planes->nterms > CONV_MAX_TERMS || groups * planes->nterms > WGRAD_MAX_VGROUPS)
+            return (int)hipErrorInvalidValue;
+        a.nvg = groups * planes->nterms;
+        for (int gr = 0; gr < groups; ++gr)
+            for (int p = 0; p < planes->nterms; ++p) {
+                const int v = gr * planes->nterms + p;
+                a.vg_g[v] = (long)gr * g_gs + (long)planes->gpl[p] * planes->g_ps;
+                a.vg_x[v] = (long)gr * x_gs + (long)planes->xpl[p] * planes->x_ps;
+                a.vg_dw[v] = (long)gr * dw_gs;
+            }
+        a.amax_g = planes->amax_g; a.amax_x = planes->amax_x;
+        groups = a.nvg;                       // from here on: launch geometry and split counts over the virtual groups
+    }
     a.partial = mode == 2; a.nslots = 1; a.split_stride = (long)T * Cout * Cin;
     a.g = (const bf16_t*)g; a.x = (const bf16_t*)x; a.dw = dw; a.zero_page = (const bf16_t*)zero_page;
     a.B = B; a.GH = GH; a.GW = GW; a.Cout = Cout; a.XH = XH; a.XW = XW; a.Cin = Cin; a.OH = OH; a.OW = OW;
@@ -1526,6 +1628,21 @@ LOFT_EXPORT int loft_conv_wgrad_bf16_v(const void* g, const void* x, float* dw, 
                                        int splits, float* db, int db_tap, int variant, void* stream) {
     return wgrad_impl(g, x, dw, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host, dx_host,
                       wt_host, groups, g_gs, x_gs, dw_gs, splits, db, db_tap, variant, stream, 0, nullptr);
+}
+
+// The same contraction on OPERAND PLANES (the fp32 parity mode on the 16-bit matrix cores; see loft_hip.h): g / x hold the planes
+// of the fp32 gradient / activation (loft_split_planes_f32), term p multiplies G plane gpl[p] with X plane xpl[p]; every term adds
+// into dw (zeroed by the caller) through the split-K atomics, scaled by 1 / (scale_g * scale_x) when the planes are scaled.
+LOFT_EXPORT int loft_conv_wgrad_planes(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH,
+                                       int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss, int T,
+                                       const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
+                                       const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
+                                       int nterms, const int* gpl_host, const int* xpl_host, int64_t g_ps, int64_t x_ps,
+                                       const float* amax_g, const float* amax_x, void* stream) {
+    if ((Cin % 128) || (Cout % 128) || (amax_g == nullptr) != (amax_x == nullptr)) return (int)hipErrorInvalidValue;
+    WgradPlanes pl{nterms, gpl_host, xpl_host, g_ps, x_ps, amax_g, amax_x};
+    return wgrad_impl(g, x, dw, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host, dx_host,
+                      wt_host, groups, g_gs, x_gs, dw_gs, 0, nullptr, -1, LOFT_WGRAD_AUTO, stream, 0, nullptr, &pl);
 }
 
 LOFT_EXPORT int loft_conv_wgrad_slots(int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss,

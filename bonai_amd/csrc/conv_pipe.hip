@@ -309,6 +309,71 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
     kstamp(48);
 }
 
+// Epilogue of the operand-plane launches (PL instances; loft_conv_tap_planes): fp32 everywhere -- the accumulators hold the sum of
+// the launch's plane products, scaled back by 1 / (scale_x * scale_w) when the planes are scaled; bias, residual, ReLU and the
+// ReLU-backward mask as in conv_epilogue, on float tensors; every lane stores its four consecutive couts of a pixel as one
+// 16-byte access.  (The direct form: the K loop of a plane launch is 3 or 6 terms long, the epilogue a few percent of the tile.)
+template <int MJ, int NW>
+__device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileRows& tr, f32x16 (&acc)[2][4], int g, int m0, int n0,
+                                                  int wave, int lane, int ohw) {
+    const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
+    const long out_g = (long)g * a.out_gs;
+    const float sc = a.amax_x ? planes_scale_of(*a.amax_x, true) * planes_scale_of(*a.amax_w, true) : 1.f;
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+    const float* res = reinterpret_cast<const float*>(a.residual);
+    const float* msk = reinterpret_cast<const float*>(a.mask);
+    float* out = reinterpret_cast<float*>(a.out);
+    const bool relu = a.relu != 0;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int r = wm * (32 * MJ) + j * 32 + frow;
+        long roff;
+        bool ok;
+        if (tr.lin) roff = pipe_row_off(tr, r, ok);
+        else {
+            const int m = m0 + r;
+            ok = m < a.M;
+            roff = 0;
+            if (ok) {
+                int b, rem;
+                pipe_row_decode(a, m, ohw, b, rem);
+                ok = b < a.B;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                roff = (((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x) * a.Cout;
+            }
+        }
+        if (!ok) continue;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = n0 + wn * (32 * NW) + i * 32 + 8 * gq + 4 * fq;
+                const long o = out_g + roff + n;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e] * sc;
+                if (bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (res) {
+                    const float4 rv = *reinterpret_cast<const float4*>(res + o);
+                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (msk) {
+                    const float4 mv = *reinterpret_cast<const float4*>(msk + o);
+                    v[0] = mv.x > 0.f ? v[0] : 0.f; v[1] = mv.y > 0.f ? v[1] : 0.f;
+                    v[2] = mv.z > 0.f ? v[2] : 0.f; v[3] = mv.w > 0.f ? v[3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
 // VAR bits (A/B experiments, selected through the C-ABI variant argument; 0 = the shipped schedule):
 //   1 TRACE      lane 0 of every wave stores s_memtime at every barrier exit of K-tiles 8..11 to a.trace ([wave][32] u64)
 //   2 NOPRIO     no s_setprio around the MFMA clusters
@@ -320,9 +385,11 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
 // tile 64 x 64; LDS reads and copies per FLOP rise by a third, twice as many workgroups.
 // NW: 32-cout blocks per wave.  2: 256 couts per tile.  1 (stream schedule only): 128 couts per tile (layer2's 128-channel convs: Cout
 // is not a multiple of 256) -- one weight fragment per sub-step, 256-byte output rows in the staged epilogue.
-template <int MODE, int VAR, int MJ = 4, int NW = 2>
+// PL: operand-plane launch (ConvArgs block 4): the K loop runs nterms x taps, the epilogue is pipe_epilogue_f32 (stream schedule only).
+template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     static_assert(MODE <= 2, "MODE 0 phase, 1 stream, 2 role-split stream");
+    static_assert(!PL || (MODE == 1 && VAR == 0), "operand planes exist for the stream schedule");
     static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
     static_assert(NW == 2 || (NW == 1 && MODE == 1 && !(VAR & 2)), "the 128-cout tile exists for the stream schedule");
     constexpr int BN = 128 * NW;
@@ -512,6 +579,33 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // lanes 0..nv-1 (vt_a / vt_w: activation / weight element offsets, vt_m: the tap's bit in the row masks) and a step is an
     // increment, a compare and four s_cselect.
     int vt_a = 0, vt_w = 0, vt_m = 0, nv = 0;
+    if constexpr (PL) {
+        // operand planes: the list holds every needed tap once per TERM, with the term's plane offsets added -- the K loop below
+        // then walks (chunk, term, tap) and all terms meet in the accumulators; vt_m stays the SPATIAL tap (the row masks' bit)
+        for (int p = 0; p < a.nterms; ++p) {
+            const int xo = a.xoff[p], wo = a.woff[p];
+            if (a.pointwise) {
+                vt_a = lane == nv ? xo : vt_a;
+                vt_w = lane == nv ? __builtin_amdgcn_readfirstlane(tab_w) + wo : vt_w;
+                ++nv;
+            } else {
+                for (int t = 0; t < a.T; ++t) {
+                    if ((tmask >> t) & 1u) {
+                        const int ta = __builtin_amdgcn_readlane(tab_a, t), tw = __builtin_amdgcn_readlane(tab_w, t);
+                        vt_a = lane == nv ? ta + xo : vt_a;
+                        vt_w = lane == nv ? tw + wo : vt_w;
+                        vt_m = lane == nv ? t : vt_m;
+                        ++nv;
+                    }
+                }
+            }
+        }
+        nk = nv * kchunks;
+        st_t = __builtin_amdgcn_readlane(vt_m, 0);
+        st_aoff = (long)__builtin_amdgcn_readlane(vt_a, 0);
+        st_w = wgt + (long)__builtin_amdgcn_readlane(vt_w, 0);
+        sw_t = st_t;
+    } else {
     for (int t = 0; t < a.T; ++t) {
         if ((tmask >> t) & 1u) {
             const int ta = __builtin_amdgcn_readlane(tab_a, t), tw = __builtin_amdgcn_readlane(tab_w, t);
@@ -522,6 +616,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         }
     }
     if (a.pointwise) { vt_w = tab_w; nv = 1; }                  // (tab_w is uniform there, tab_a / the mask bit are 0)
+    }
     int xj = 0, wj = 0;                                          // positions in the compact list of the tiles being staged
     auto seq_step = [&](int& j, int& c) {
         const int jn = j + 1, cn = c + BK;
@@ -1016,7 +1111,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         else {
             const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m
             const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
-            if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+            if constexpr (PL) pipe_epilogue_f32<MJ, NW>(a, otr, acc, g, m0, n0, wave, lane, ohw);
+            else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
             else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
         }
         if constexpr (TRACE) {
@@ -1213,6 +1309,7 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
     if (mode == 2 && (a.Cout % 256 || nw_force == 1)) return (int)hipErrorInvalidValue;
     const int nw = nw_force == 1 ? 1 : (a.Cout % 256 == 0 ? 2 : 1);       // 128-cout tiles: Cout = 128 (mod 256), or by choice with 64-pixel tiles
     if (nw == 1 && !(mode == 1 && var == 0 && (mj == 4 || mj == 1) && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
+    if (a.nterms && !(mode == 1 && var == 0 && a.nterms <= CONV_MAX_TERMS && a.nterms * a.T <= 64)) return (int)hipErrorInvalidValue;
     dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / (128 * nw), groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
@@ -1227,7 +1324,13 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         a.wt_pk |= (unsigned long long)a.wt[t] << (4 * t);
     }
 #define PIPE_LAUNCH(M_, V_) hipLaunchKernelGGL((conv_tap_pipe_kernel<M_, V_>), grid, dim3(512), 0, s, a)
-    if (nw == 1 && mj == 1) {
+    if (a.nterms) {                   // operand planes: the stream schedule's five tile shapes with the fp32 epilogue
+        if (nw == 1 && mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 1, true>), grid, dim3(512), 0, s, a);
+        else if (nw == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 1, true>), grid, dim3(512), 0, s, a);
+        else if (mj == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2, 2, true>), grid, dim3(512), 0, s, a);
+        else if (mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 2, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true>), grid, dim3(512), 0, s, a);
+    } else if (nw == 1 && mj == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 1>), grid, dim3(512), 0, s, a);
     } else if (nw == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 1>), grid, dim3(512), 0, s, a);

@@ -9,6 +9,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 
 #define CONV_MAX_TAPS 16
+#define CONV_MAX_TERMS 8      /* operand-plane products per launch (loft_conv_tap_planes / loft_conv_wgrad_planes) */
+#define WGRAD_MAX_VGROUPS 32 /* groups x terms of a plane weight-gradient launch */
 #define BK 64
 
 struct ConvArgs {
@@ -59,7 +61,32 @@ struct ConvArgs {
     void* trace;             // conv_pipe.hip TRACE variants only: device buffer for barrier time stamps
     // ---- block 3: per-tap tables (read by lanes, once)
     int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS], wt[CONV_MAX_TAPS];
+    // ---- block 4: operand PLANES (loft_conv_tap_planes, conv_pipe.hip PL instances; nterms == 0: a plain launch).  The fp32 parity
+    // mode hands both operands over as NP 16-bit planes of one fp32 tensor each (x = sum_p plane_p / scale, loft_split_planes_f32)
+    // and the product as `nterms` (activation plane, weight plane) pairs: term p reads activation plane xoff[p] / weight plane
+    // woff[p] (ELEMENT offsets of the plane inside src / wgt).  The kernel runs the terms as extra taps of ONE K loop -- every
+    // term accumulates into the same fp32 accumulators -- and its epilogue is fp32: residual / mask / out are float tensors, the
+    // accumulators are scaled by 1 / (scale_x * scale_w) derived from the two absmax scalars (null: unscaled planes).
+    int nterms;
+    int xoff[CONV_MAX_TERMS], woff[CONV_MAX_TERMS];
+    const float* amax_x;
+    const float* amax_w;
 };
+
+// Power-of-two scale of a plane split (loft_split_planes_f32 with an absmax scalar; the binary16 build): the tensor's absmax lands
+// in [2^14, 2^15) -- the high plane cannot overflow binary16 and an element 2^-18 below the absmax still keeps all 22 bits of its
+// two planes.  amax == 0, inf or NaN: scale 1.  Exact (a power of two), so is its inverse.
+__host__ __device__ __forceinline__ float planes_scale_of(float amax, bool inverse) {
+    union { float f; uint32_t u; } c;
+    c.f = amax;
+    const int e = (int)((c.u >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.f;
+    int se = 14 - (e - 127);                       // scale = 2^se
+    if (inverse) se = -se;
+    se = se < -126 ? -126 : (se > 127 ? 127 : se);
+    c.u = (uint32_t)(se + 127) << 23;
+    return c.f;
+}
 
 // A kernarg scalar made OPAQUE to the compiler at this point: hipcc treats ConvArgs fields as rematerialisable loads and re-fetches
 // them from scalar memory (s_load + s_waitcnt lgkmcnt(0), ~100-200 cycles each) inside unrolled row loops instead of keeping them
@@ -216,7 +243,20 @@ struct WgradArgs {
     int pm_inc_ok;  // conv_wgrad_pipe.hip: G and X hold fewer than 2^31 elements each (32-bit running offsets in the incremental PM decode)
     int pm_y0[CONV_MAX_TAPS], pm_x0[CONV_MAX_TAPS], pm_rw[CONV_MAX_TAPS];
     unsigned pm_rw_mul[CONV_MAX_TAPS], pm_rw_sh[CONV_MAX_TAPS], b_mul, b_sh;
+    // Operand planes (loft_conv_wgrad_planes; nvg == 0: a plain launch).  The launch's "groups" are nvg VIRTUAL groups = (real
+    // group, term): virtual group v reads the G plane at element offset vg_g[v], the X plane at vg_x[v] and adds into the dW of
+    // its real group at vg_dw[v] -- the terms of one product meet in dW through the split-K atomics that are there anyway, and the
+    // split count shrinks by the number of terms (same workgroups, same atomics as one 16-bit launch).  amax_*: see ConvArgs.
+    int nvg;
+    long vg_g[WGRAD_MAX_VGROUPS], vg_x[WGRAD_MAX_VGROUPS], vg_dw[WGRAD_MAX_VGROUPS];
+    const float* amax_g;
+    const float* amax_x;
 };
+// group base offsets of a weight-gradient workgroup (kernel top level only: see the note on closures in conv_wgrad_pipe.hip)
+#define WGRAD_G_OFF(a, grp) ((a).nvg ? (a).vg_g[grp] : (long)(grp) * (a).g_gs)
+#define WGRAD_X_OFF(a, grp) ((a).nvg ? (a).vg_x[grp] : (long)(grp) * (a).x_gs)
+#define WGRAD_DW_OFF(a, grp) ((a).nvg ? (a).vg_dw[grp] : (long)(grp) * (a).dw_gs)
+#define WGRAD_OUT_SCALE(a) ((a).amax_g ? planes_scale_of(*(a).amax_g, true) * planes_scale_of(*(a).amax_x, true) : 1.f)
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
 

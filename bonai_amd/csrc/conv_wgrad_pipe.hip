@@ -58,8 +58,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     }
     const int n0 = nt * 256, c0 = ct * 256;
     if (mbeg >= mend) return;
-    const bf16_t* G = a.g + (long)grp * a.g_gs;
-    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const bf16_t* G = a.g + WGRAD_G_OFF(a, grp);
+    const bf16_t* X = a.x + WGRAD_X_OFF(a, grp);
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
     const int pm_y0 = PM ? a.pm_y0[t] : 0, pm_x0 = PM ? a.pm_x0[t] : 0, pm_rw = PM ? a.pm_rw[t] : 1;
@@ -356,8 +356,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     }
     const int sidx = PM ? (int)a.pm_split[bz] : bz;
     const int ns_t = PM ? a.pm_blk0[t + 1] - a.pm_blk0[t] : (int)gridDim.z;
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
+    float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)sidx * a.split_stride : 0l);
     const int nzero = (a.partial && sidx == ns_t - 1) ? a.nslots - ns_t : 0;      // this tap's unused slots
+    const float osc = WGRAD_OUT_SCALE(a);          // (1 unless the operands are scaled planes: exact either way)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
                     *p = acc[i][j][r];
                     for (int z = 1; z <= nzero; ++z) p[(long)z * a.split_stride] = 0.f;
                 } else {
-                    unsafeAtomicAdd(p, acc[i][j][r]);
+                    unsafeAtomicAdd(p, acc[i][j][r] * osc);
                 }
             }
         }
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a)
     const int mbeg = bz * a.pix_per_split, mend = min(a.M, mbeg + a.pix_per_split);
     const int n0 = nt * 128, c0 = ct * 128;
     if (mbeg >= mend) return;
-    const bf16_t* G = a.g + (long)grp * a.g_gs;
-    const bf16_t* X = a.x + (long)grp * a.x_gs;
+    const bf16_t* G = a.g + WGRAD_G_OFF(a, grp);
+    const bf16_t* X = a.x + WGRAD_X_OFF(a, grp);
     const int ohw = a.OH * a.OW;
     const int goy = a.goy[t], gox = a.gox[t], dy = a.dy[t], dx = a.dx[t];
 
@@ -595,7 +596,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a)
             unsafeAtomicAdd(db + n, accb[r]);
         }
     }
-    float* dw = a.dw + (long)grp * a.dw_gs + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)bz * a.split_stride : 0l);
+    float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)bz * a.split_stride : 0l);
+    const float osc = WGRAD_OUT_SCALE(a);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a)
                 const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float* p = dw + (long)n * a.Cin + c;
                 if (a.partial) *p = acc[i][j][r];
-                else unsafeAtomicAdd(p, acc[i][j][r]);
+                else unsafeAtomicAdd(p, acc[i][j][r] * osc);
             }
         }
 }

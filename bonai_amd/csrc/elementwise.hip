@@ -12,6 +12,7 @@
 // Roofline for all of these: HBM bandwidth.
 #include "loft_common.h"
 #include "../../include/loft_hip.h"
+#include "conv_tap.h"      // planes_scale_of
 
 __device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
@@ -344,6 +345,77 @@ LOFT_EXPORT int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vo
     if (n <= 0) return 0;
     if (n % 8) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 8);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- operand planes of the fp32 parity mode (loft_conv_tap_planes / loft_conv_wgrad_planes) ----
+// An fp32 tensor x becomes NP tensors of the build's 16-bit type with x * scale = plane_0 + plane_1 (+ plane_2) to 2^-22 (binary16
+// build: two planes of 11 significant bits, scale = the power of two that puts the tensor's absmax into [2^14, 2^15) -- binary16
+// has five exponent bits) or 2^-24 (bfloat16 build: three planes of 8 bits, no scale: bfloat16 has fp32's exponent range):
+// plane_k = RNE16(remainder), remainder -= plane_k (exact in fp32).  The contraction kernels then multiply planes pairwise on the
+// 16-bit matrix cores and accumulate in fp32 -- Dekker / Ozaki-style splitting with the products kept to the order of the error.
+#ifdef LOFT_ACT_F16
+#define LOFT_PLANES 2
+#else
+#define LOFT_PLANES 3
+#endif
+__global__ void absmax_f32_kernel(const float* __restrict__ x, long nvec, unsigned* __restrict__ out) {
+    float m = 0.f;
+    bool bad = false;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        bad |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
+    }
+    if (bad) m = __builtin_inff();                        // (NaN anywhere: fmaxf drops it -- report "no finite scale" instead)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // one atomic per WORKGROUP: same-address atomics serialise at ~10 ns each (one per wave of an 8192-block grid was 0.3 ms)
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));  // (non-negative floats order as their bits)
+    }
+}
+LOFT_EXPORT int loft_absmax_f32(const float* x, int64_t n, float* amax_out, void* stream) {
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n <= 0) return 0;
+    dim3 grid = ew_grid(n / 4);
+    if (grid.x > 1024) grid.x = 1024;                     // four workgroups per CU stream at the HBM rate; 1024 atomics at the end
+    hipLaunchKernelGGL(absmax_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, n / 4, (unsigned*)amax_out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ planes, long nvec, long n,
+                                    const float* __restrict__ amax) {
+    const float sc = amax ? planes_scale_of(*amax, false) : 1.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        float r[8], h[8];
+        const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
+        const float4 b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+        r[0] = a.x * sc; r[1] = a.y * sc; r[2] = a.z * sc; r[3] = a.w * sc; r[4] = b.x * sc; r[5] = b.y * sc; r[6] = b.z * sc; r[7] = b.w * sc;
+#pragma unroll
+        for (int p = 0; p < LOFT_PLANES; ++p) {
+            const uint4 pk = pack8_16(r);
+            *reinterpret_cast<uint4*>(planes + p * n + i * 8) = pk;
+            if (p + 1 < LOFT_PLANES) {
+                unpack8_16(pk, h);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) r[q] -= h[q];
+            }
+        }
+    }
+}
+LOFT_EXPORT int loft_planes_per_tensor(void) { return LOFT_PLANES; }
+LOFT_EXPORT int loft_split_planes_f32(const float* x, int64_t n, void* planes, const float* amax, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_planes_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)planes, n / 8, (long)n, amax);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -238,7 +238,19 @@ class BonaiDataset:
             return st
         self._release_staging()
         from multiprocessing import shared_memory
-        shm = shared_memory.SharedMemory(create=True, size=nslots * bs * h * w * 3)
+        nbytes = nslots * bs * h * w * 3
+        # The block lives in /dev/shm (tmpfs): a container's default 64 MiB does not hold 8 x 1024^2 tiles four deep, and writing
+        # past the mount's capacity is a SIGBUS in a decoder process, not an exception.  Check the free space first and create
+        # + touch the block here, in the parent, under a guard: None -> the caller takes the thread / pinned-tensor path.
+        try:
+            vfs = os.statvfs('/dev/shm')
+            if vfs.f_bavail * vfs.f_frsize < nbytes + (8 << 20):
+                raise OSError(f'/dev/shm has {vfs.f_bavail * vfs.f_frsize >> 20} MiB free, the staging ring needs {nbytes >> 20}')
+            shm = shared_memory.SharedMemory(create=True, size=nbytes)
+        except (OSError, ValueError) as e:
+            import warnings
+            warnings.warn(f'decoder processes disabled ({e}); falling back to decoder threads with pinned staging tensors')
+            return None
         whole = torch.from_numpy(np.ndarray((nslots, bs, h, w, 3), dtype=np.uint8, buffer=shm.buf))
         registered = None
         if cuda:
@@ -318,12 +330,10 @@ def decode_tile_into(path, shm_name, offset, h, w):
             for v in _SHM_CACHE.values():
                 v.close()
             _SHM_CACHE.clear()
+        # (Attaching registers the name with the resource tracker a second time.  The forked workers SHARE the parent's tracker
+        #  and its registry is a set per resource type, so the duplicate is harmless -- unregistering it here removed the parent's
+        #  own entry: KeyError tracebacks at the parent's unlink() and a leaked block if the parent crashed.  ADVICE round 4.)
         shm = _SHM_CACHE[shm_name] = shared_memory.SharedMemory(name=shm_name)
-        try:        # the parent owns the block: an attaching process must not report it to the resource tracker as its own leak
-            from multiprocessing import resource_tracker
-            resource_tracker.unregister(shm._name, 'shared_memory')
-        except Exception:       # noqa
-            pass
     im = Image.open(path)
     if im.mode != 'RGB':
         im = im.convert('RGB')
@@ -360,8 +370,10 @@ class _Prefetcher:
         # ring of staging buffers: depth in the queue + one being filled + one the consumer's upload may still read
         self.slots, self.shm = [], None
         nslots = self.depth + 2
-        if self.processes and bs:
-            st = ds._staging_block(nslots, bs, h, w, self.cuda)
+        st = ds._staging_block(nslots, bs, h, w, self.cuda) if self.processes and bs else None
+        if st is None:
+            self.processes = False                    # (no shared-memory ring: /dev/shm too small -- decoder threads instead)
+        if st is not None:
             self.shm, self.slot_bytes = st['shm'], bs * h * w * 3
             self.slots = [st['whole'][k] for k in range(nslots)]
             self.pool = ds._decoder_pool(self.workers)

@@ -491,7 +491,70 @@ CONV_VARIANT = CONV_AUTO
 # MFMA terms per product (24 mantissa bits, fp32 accumulation: fp32-grade); SPLIT3: two bf16 / three terms (16 bits: faster, meets
 # 1e-3 on losses / features / detections, not on every gradient); EXACT: the fp32 MFMA (bit-for-bit an fmaf chain).
 F32_SPLIT6, F32_EXACT, F32_SPLIT3 = 0, 1, 2
-F32_CONTRACT = F32_SPLIT6
+# Round 5: the same contraction on OPERAND PLANES through the software-pipelined 16-bit kernels (loft_conv_tap_planes /
+# loft_conv_wgrad_planes; include/loft_hip.h).  PLANES_F16 (default): every fp32 tensor as two binary16 planes under a power-of-two
+# scale (22 significant bits), three products per element pair on v_mfma_f32_32x32x16_f16 -- the binary16 BUILD of the library,
+# mapped next to the bfloat16 one; PLANES_BF16: three bfloat16 planes (24 bits), six products.  Shapes the stream kernels do not
+# serve (Cout % 128, Cin % 64, accumulating launches) take SPLIT6's kernels.
+F32_PLANES_F16, F32_PLANES_BF16 = 3, 4
+_PLANE_MODES = {F32_PLANES_F16: (torch.float16, ((1, 0), (0, 1), (0, 0))),
+                F32_PLANES_BF16: (torch.bfloat16, ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)))}
+F32_CONTRACT = F32_PLANES_F16
+PLANES_STATS = {'planes': 0, 'fallback': 0}      # launches of the fp32 mode by path (tests / bench read it)
+
+
+def _f32_kernel_code():
+    """The LOFT_F32_* code handed to loft_conv_tap_f32_v / loft_conv_wgrad_f32_v (a plane mode's fallback is SPLIT6)."""
+    return F32_SPLIT6 if F32_CONTRACT in _PLANE_MODES else int(F32_CONTRACT)
+
+
+def split_planes(x, dtype16):
+    """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_split_planes_f32."""
+    lib = L.load_for(dtype16)
+    n = x.numel()
+    planes = torch.empty((lib.loft_planes_per_tensor(), n), dtype=dtype16, device=x.device)
+    amax = None
+    if dtype16 == torch.float16:
+        amax = torch.empty(1, dtype=torch.float32, device=x.device)
+        L.check(lib.loft_absmax_f32(L.ptr(x), c_int64(n), L.ptr(amax), L.stream()), 'loft_absmax_f32')
+    L.check(lib.loft_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), L.ptr(amax), L.stream()), 'loft_split_planes_f32')
+    return planes, amax
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+# A backward node splits its output gradient for the data gradient AND the weight gradient: inside a planes_scoped function the
+# same tensor (storage pointer + shape + version; kept alive with its planes until the scope ends) is split once.
+_SCOPES = []
+
+
+def planes_scoped(fn):
+    """Decorator for autograd backward functions of the fp32 parity mode: one split memo for the duration of the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        _SCOPES.append({})
+        try:
+            return fn(*a, **k)
+        finally:
+            _SCOPES.pop()
+    return wrapper
+
+
+def _split_memo(x, dtype16, memo):
+    """split_planes with a memo (the caller's dict, else the innermost planes_scoped call's, else none)."""
+    if memo is None:
+        memo = _SCOPES[-1] if _SCOPES else None
+    if memo is None:
+        return split_planes(x, dtype16)
+    key = (x.data_ptr(), tuple(x.shape), x._version, dtype16)
+    hit = memo.get(key)
+    if hit is None:
+        hit = memo[key] = (split_planes(x, dtype16), x)
+    return hit[0]
 WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128, WGRAD_RING128 = range(5)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
 WGRAD_VARIANT = WGRAD_AUTO      # a code, or a callable (groups, B, OH, OW, Cin, Cout, T, ss, gos) -> code
 
@@ -501,7 +564,8 @@ def _wgrad_variant(*shape):
 
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
-             residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None):
+             residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None,
+             planes_memo=None):
     """Raw launch of loft_conv_tap_bf16 (or loft_conv_tap_f32 when every operand is fp32: the forward-only parity mode).
     taps: list of (dy, dx, weight_tap_index)."""
     lib = L.load()
@@ -511,11 +575,30 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
             if t is not None and t.dtype != torch.float32:
                 raise L.LoftHipError(f'fp32 parity mode needs every operand in fp32, got {t.dtype}')
         T = len(taps)
+        if (F32_CONTRACT in _PLANE_MODES and not accumulate and Cin % 64 == 0 and Cout % 128 == 0 and _dense(src) and _dense(wgt)
+                and src.numel() % 8 == 0 and wgt.numel() % 8 == 0 and B * OH * OW > 0):
+            dt16, terms = _PLANE_MODES[F32_CONTRACT]
+            if T * len(terms) <= 64:
+                plib = L.load_for(dt16)
+                (xp, ax), (wp, aw) = _split_memo(src, dt16, planes_memo), split_planes(wgt, dt16)
+                e = plib.loft_conv_tap_planes(L.ptr(xp), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
+                                              L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0], oo[1], ss, T,
+                                              L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
+                                              L.arr(c_int, [t[2] for t in taps]), int(relu), groups, c_int64(src_gs), c_int64(wgt_gs),
+                                              c_int64(out_gs), c_int64(bias_gs), len(terms), L.arr(c_int, [t[0] for t in terms]),
+                                              L.arr(c_int, [t[1] for t in terms]), c_int64(src.numel()), c_int64(wgt.numel()),
+                                              L.ptr(ax), L.ptr(aw), L.stream())
+                if e == 0:
+                    PLANES_STATS['planes'] += 1
+                    return out
+                if e != 1:              # (hipErrorInvalidValue: a shape the stream kernel does not serve -> the fp32 kernels below)
+                    L.check(e, 'loft_conv_tap_planes')
+        PLANES_STATS['fallback'] += 1
         L.check(lib.loft_conv_tap_f32_v(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
                                         L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
                                         oo[1], ss, T, L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
                                         L.arr(c_int, [t[2] for t in taps]), int(relu), int(accumulate), groups,
-                                        c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), int(F32_CONTRACT),
+                                        c_int64(src_gs), c_int64(wgt_gs), c_int64(out_gs), c_int64(bias_gs), _f32_kernel_code(),
                                         L.stream()), 'loft_conv_tap_f32_v')
         return out
     _bf16(src), _bf16(wgt)
@@ -638,7 +721,7 @@ WGRAD_SLOTS = False
 
 
 def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,
-               splits=0, dw=None, db=None, db_tap=-1, slots_ok=False):
+               splits=0, dw=None, db=None, db_tap=-1, slots_ok=False, planes_memo=None):
     """Raw launch of loft_conv_wgrad_bf16.  taps: list of (goy, gox, dy, dx, weight_tap_index).
     db: optional zeroed fp32 [groups, Cout] -> bias gradient accumulated in the same pass.
     slots_ok: the caller sums split-K slots itself (UnpackQueue): the result may then be fp32 [groups, S, n_wtaps, Cout, Cin],
@@ -650,9 +733,27 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
         # fp32 parity mode (parity_f32.hip; F32_CONTRACT); the bias gradient is the plain column sum of g
         if dw is None:
             dw = torch.zeros(groups, n_wtaps, Cout, Cin, dtype=torch.float32, device=g.device)
-        L.check(lib.loft_conv_wgrad_f32_v(L.ptr(g), L.ptr(x), L.ptr(dw), B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps),
+        done = False
+        if (F32_CONTRACT in _PLANE_MODES and Cout % 128 == 0 and Cin % 128 == 0 and _dense(g) and _dense(x) and g.numel() % 8 == 0
+                and x.numel() % 8 == 0 and B * OH * OW > 0 and groups * len(_PLANE_MODES[F32_CONTRACT][1]) <= 32):
+            dt16, terms = _PLANE_MODES[F32_CONTRACT]
+            plib = L.load_for(dt16)
+            (gp, ag), (xp, ax) = _split_memo(g, dt16, planes_memo), _split_memo(x, dt16, planes_memo)
+            e = plib.loft_conv_wgrad_planes(L.ptr(gp), L.ptr(xp), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH, XW, Cin,
+                                            OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs),
+                                            c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), len(terms),
+                                            L.arr(c_int, [t[1] for t in terms]), L.arr(c_int, [t[0] for t in terms]),
+                                            c_int64(g.numel()), c_int64(x.numel()), L.ptr(ag), L.ptr(ax), L.stream())
+            if e == 0:
+                PLANES_STATS['planes'] += 1
+                done = True
+            elif e != 1:
+                L.check(e, 'loft_conv_wgrad_planes')
+        if not done:
+            PLANES_STATS['fallback'] += 1
+            L.check(lib.loft_conv_wgrad_f32_v(L.ptr(g), L.ptr(x), L.ptr(dw), B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, len(taps),
                                           A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
-                                          c_int64(n_wtaps * Cout * Cin), int(F32_CONTRACT), L.stream()), 'loft_conv_wgrad_f32_v')
+                                              c_int64(n_wtaps * Cout * Cin), _f32_kernel_code(), L.stream()), 'loft_conv_wgrad_f32_v')
         if db is not None:
             db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
         return dw

@@ -44,29 +44,35 @@ def set_act16(dtype):
     return prev
 
 
+def load_for(dtype):
+    """The CDLL of the build whose 16-bit type is `dtype`, whatever the process's current mode (the fp32 parity mode's operand
+    planes are binary16 in a bfloat16 process: both libraries are then mapped).  Raises LoftHipError when it is not built."""
+    path = _LIB_PATH if dtype == torch.bfloat16 else _LIB_PATH_F16
+    lib = _libs.get(path)
+    if lib is None:
+        if not os.path.exists(path):
+            raise LoftHipError(
+                f'{path} is missing: build it with `python -m bonai_amd.build` '
+                '(hipcc --offload-arch=gfx950).  bonai_amd has no CPU / eager fallback.')
+        lib = ctypes.CDLL(path)
+        lib.loft_nms_workspace_bytes.restype = c_int64
+        lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
+        lib.loft_soft_nms_workspace_bytes.restype = c_int64
+        lib.loft_random_sample_workspace_bytes.restype = c_int64
+        lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64
+        lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
+        lib.loft_mdcn_bwd_workspace_bytes.restype = c_int64
+        if lib.loft_act16_dtype() != _DT[dtype]:
+            raise LoftHipError(f'{path} was built for another 16-bit type (loft_act16_dtype() = {lib.loft_act16_dtype()})')
+        _libs[path] = lib
+    return lib
+
+
 def load():
     """Load (once per build) and return the CDLL of the current 16-bit mode.  Raises LoftHipError when it is not built."""
     global _lib
     if _lib is None:
-        path = _LIB_PATH if _act16 == torch.bfloat16 else _LIB_PATH_F16
-        lib = _libs.get(path)
-        if lib is None:
-            if not os.path.exists(path):
-                raise LoftHipError(
-                    f'{path} is missing: build it with `python -m bonai_amd.build` '
-                    '(hipcc --offload-arch=gfx950).  bonai_amd has no CPU / eager fallback.')
-            lib = ctypes.CDLL(path)
-            lib.loft_nms_workspace_bytes.restype = c_int64
-            lib.loft_nms_workspace_bytes.argtypes = [c_int64, c_int64, c_int64]
-            lib.loft_soft_nms_workspace_bytes.restype = c_int64
-            lib.loft_random_sample_workspace_bytes.restype = c_int64
-            lib.loft_conv_wgrad_patch_workspace_bytes.restype = c_int64
-            lib.loft_soft_nms_workspace_bytes.argtypes = [c_int64]
-            lib.loft_mdcn_bwd_workspace_bytes.restype = c_int64
-            if lib.loft_act16_dtype() != _DT[_act16]:
-                raise LoftHipError(f'{path} was built for another 16-bit type (loft_act16_dtype() = {lib.loft_act16_dtype()})')
-            _libs[path] = lib
-        _lib = lib
+        _lib = load_for(_act16)
     return _lib
 
 

@@ -235,6 +235,7 @@ class _ConvFn(torch.autograd.Function):
         return _begin_uses(y) if relu else y
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         stride, pad, relu, G, out_f32, has_b, bn_stats, frozen, input_relu, cout_pad = ctx.meta
         x, y, wpt = ctx.saved_tensors[:3]
@@ -381,6 +382,7 @@ class _LinearFn(torch.autograd.Function):
         return y.reshape(N, O)
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         relu, input_relu, flat_chw, xshape = ctx.cfg
         x4, y, wpt, w = ctx.saved_tensors
@@ -464,6 +466,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         stride, pad = ctx.sp
@@ -583,6 +586,7 @@ class _DeconvFn(torch.autograd.Function):
         return _begin_uses(y)
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
         N, Cin, H, W = x.shape
@@ -954,6 +958,7 @@ class _SparseRPNFn(torch.autograd.Function):
         return vals.clone()
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         rows, slot, w_conv, w_cls, w_reg, h_sel = ctx.saved_tensors[:6]
         xs = ctx.saved_tensors[6:]
@@ -1144,6 +1149,7 @@ class _ResBlockFn(torch.autograd.Function):
         return _begin_uses(h)
 
     @staticmethod
+    @K.planes_scoped
     def backward(ctx, g):
         main_specs, sc_spec = ctx.specs
         n = len(main_specs)

@@ -252,6 +252,38 @@ int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, c
                       int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                       const int* wt_host, int relu, int accumulate, int groups, int64_t src_gs, int64_t wgt_gs,
                       int64_t out_gs, int64_t bias_gs, int variant, void* stream);
+/* The fp32 parity mode on OPERAND PLANES (round 5) -- the same contracts as loft_conv_tap_f32 / loft_conv_wgrad_f32, served by the
+ * software-pipelined 16-bit kernels (conv_pipe.hip, conv_wgrad_pipe.hip) instead of kernels of their own.  Reference lines: every
+ * nn.Conv2d / nn.Linear of the LOFT path evaluated in fp32 (detectors/base.py:159-173 before its fp16 cast; the reference's CPU path).
+ *   loft_planes_per_tensor()      NP of this build: 2 (binary16 build) or 3 (bfloat16 build)
+ *   loft_absmax_f32(x, n, amax)   amax[0] = max |x| as a device scalar (n % 4 == 0); inf when x holds a NaN
+ *   loft_split_planes_f32(x, n, planes, amax)   planes [NP][n] of the build's 16-bit type with
+ *                                 x * scale = plane_0 + plane_1 (+ plane_2), plane_k = RNE16 of the remainder; scale = the power of two
+ *                                 that puts amax into [2^14, 2^15) (amax NULL, 0, inf: 1).  binary16 build: 22 significant bits per
+ *                                 element, the scale is REQUIRED for tensors outside binary16's exponent range; bfloat16 build: 24 bits,
+ *                                 pass NULL.  n % 8 == 0.
+ *   loft_conv_tap_planes(...)     loft_conv_tap_bf16's contract with src / wgt = such planes (plane p at element offset p * x_ps /
+ *                                 p * w_ps), `nterms` products (activation plane xpl[i], weight plane wpl[i]) accumulated in fp32 in ONE
+ *                                 K loop; bias / residual / relu_mask / out fp32; the result is scaled by 1 / (scale_x * scale_w) taken from
+ *                                 amax_x / amax_w (both or neither).  The terms the mode uses: binary16 (1,0) (0,1) (0,0) -- error 2^-22 of
+ *                                 |x||w| per product; bfloat16 (0,2) (2,0) (1,1) (0,1) (1,0) (0,0) -- 2^-24.  hipErrorInvalidValue for
+ *                                 shapes the stream kernel does not serve (Cout % 128, Cin % 64, nterms * T > 64): take loft_conv_tap_f32.
+ *   loft_conv_wgrad_planes(...)   loft_conv_wgrad_bf16's contract on G / X planes: every term adds into dw (caller zeroes) through the
+ *                                 split-K atomics, scaled by 1 / (scale_g * scale_x).  Cout % 128 == 0, Cin % 128 == 0; no fused bias gradient. */
+int loft_planes_per_tensor(void);
+int loft_absmax_f32(const float* x, int64_t n, float* amax_out, void* stream);
+int loft_split_planes_f32(const float* x, int64_t n, void* planes, const float* amax, void* stream);
+int loft_conv_tap_planes(const void* src, const void* wgt, const float* bias, const float* residual, const float* relu_mask,
+                         float* out, const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
+                         int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
+                         const int* wt_host, int relu, int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                         int nterms, const int* xpl_host, const int* wpl_host, int64_t x_ps, int64_t w_ps, const float* amax_x,
+                         const float* amax_w, void* stream);
+int loft_conv_wgrad_planes(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW, int Cout, int XH,
+                           int XW, int Cin, int OH, int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host,
+                           const int* dy_host, const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs,
+                           int64_t dw_gs, int nterms, const int* gpl_host, const int* xpl_host, int64_t g_ps, int64_t x_ps,
+                           const float* amax_g, const float* amax_x, void* stream);
 /* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32

@@ -361,6 +361,68 @@ def test_e2e_bf16_kernels_vs_bf16_points_oracle():
         assert abs(lv[k] - want) <= 1e-2 * max(1.0, abs(want)), (k, lv[k], want)
 
 
+def test_fullsize_fp32_parity_mode_vs_cpu_oracle():
+    """BASELINE configs[1]'s tile size against the ORACLE, not against this path's other mode.  One
+    1024 x 1024 image with 80 ground-truth boxes goes through the fp32 parity mode (its default contraction: binary16 operand
+    planes on the stream kernels) and through oracle.loft_model_ref.forward_train + torch autograd on the host (fp32, the
+    restatement pinned to the reference by tests/golden/e2e_256.npz): the five FPN maps (a 24 x 24 x 16-channel crop at 1e-3 of
+    the map's mean magnitude and the whole map in relative L2), the seven losses at 1e-3, and the gradient norm of EVERY
+    trainable parameter at 1e-3 (> 200 of them; leading entries at 1e-2 of the gradient's scale) -- the 256 px fixture test's
+    bounds at four times the map size, 3000 proposals per image and 1024 sampled RoIs."""
+    from bonai_amd.synth import make_batch
+    from oracle import loft_model_ref as M
+    from oracle.synth_weights import synth_tensor
+    m = _build()
+    m.backbone.compute_dtype = torch.float32
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    sd = {k: synth_tensor(k, v.shape) for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if k in trainable:
+            v.requires_grad_(True)
+    cpu = make_batch(1, 1024, 80)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))       # (hundreds of threads oversubscribe the oracle's convolutions)
+    try:
+        ol, ex = M.forward_train(sd, cpu['img'], cpu['gt_bboxes'], cpu['gt_labels'], cpu['gt_masks'], cpu['gt_offsets'],
+                                 return_extras=True)
+        ol['loss'].backward()
+    finally:
+        torch.set_num_threads(nthr)
+    data = make_batch(1, 1024, 80, device='cuda')
+    with torch.no_grad():
+        feats = m.extract_feat(data['img'])
+    for i, (f, w) in enumerate(zip(feats, ex['feats'])):
+        w = w.detach()
+        assert f.dtype == torch.float32 and tuple(f.shape) == tuple(w.shape)
+        got = f.cpu()
+        scale = float(w.abs().mean())
+        c = min(24, w.shape[2])
+        assert (got[:, :16, :c, :c] - w[:, :16, :c, :c]).abs().max().item() < 1e-3 * scale, (i, scale)
+        rel = float((got - w).norm() / w.norm())
+        assert rel < 1e-4, (i, rel)
+    out = m.train_step(data)
+    lv = dict(out['log_vars'].items())
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'loss_bbox', 'loss_mask', 'loss_offset', 'loss'):
+        want = float(ol[k].sum())
+        assert abs(lv[k] - want) <= 1e-3 * max(1.0, abs(want)), (k, lv[k], want)
+    out['loss'].backward()
+    grads = {n: p.grad for n, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    names = [n for n in sorted(trainable) if sd[n].grad is not None]
+    assert len(names) > 200 and set(names) <= set(grads)
+    worst = (0.0, None)
+    for n in names:
+        g, w = grads[n].float().cpu(), sd[n].grad
+        wn, gn = float(w.norm()), float(g.norm())
+        rms = wn / max(w.numel(), 1) ** 0.5
+        e1 = abs(gn - wn) / max(wn, 1e-12)
+        wh, gh = w.reshape(-1)[:16], g.reshape(-1)[:16]
+        e2 = float((gh - wh).abs().max()) / max(float(wh.abs().max()), rms, 1e-12)
+        worst = max(worst, (e1, n), (e2, n))
+        assert e1 <= 1e-3, ('norm', n, gn, wn)
+        assert e2 <= 1e-2, ('head', n, gh, wh)
+    print(f'1024^2 fp32 parity mode vs the CPU oracle: {len(names)} gradients, worst relative error', worst)
+
+
 def test_bf16_vs_fp32_parity_mode_at_bench_size():
     """The same comparison once at BASELINE configs[1]'s tile size (1024 x 1024, batch 1 to keep the fp32 MFMA run short):
     bf16 training kernels against the fp32 parity mode of the same model on the same tile -- FPN maps within 2e-2 relative L2

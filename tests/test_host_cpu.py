@@ -391,6 +391,51 @@ def test_prefetching_loader_emits_the_synchronous_loaders_stream(tmp_path):
     assert set(i for s in sl for i in s) == set(range(7))
 
 
+def test_prefetching_loader_survives_a_small_dev_shm(tmp_path, monkeypatch):
+    """the decoder processes' staging ring is a POSIX shared-memory block of (depth + 2) x batch tiles; a container
+    with the default 64 MiB /dev/shm cannot hold it and a write past the mount's capacity is a SIGBUS in a worker.  With too
+    little free space reported, batches(prefetch=N, processes=True) must warn, fall back to decoder threads with ordinary staging
+    tensors, and emit the same stream; attaching workers leave the parent's resource-tracker registration alone (no KeyError at
+    unlink)."""
+    import json
+    import os
+    import warnings
+    from collections import namedtuple
+    from PIL import Image
+    from bonai_amd.dataset import BonaiDataset
+    from bonai_amd.synth import synth_bonai_anns
+    size = 1024
+    rng = np.random.RandomState(2)
+    images, annotations, aid = [], [], 0
+    for i in range(4):
+        name = f's{i}.png'
+        Image.fromarray(rng.randint(0, 255, (size, size, 3)).astype(np.uint8)).save(tmp_path / name, compress_level=1)
+        images.append(dict(id=i + 1, file_name=name, width=size, height=size))
+        for a in synth_bonai_anns(seed=i, size=size):
+            aid += 1
+            annotations.append(dict(a, id=aid, image_id=i + 1))
+    f = tmp_path / 'ann.json'
+    json.dump(dict(images=images, annotations=annotations, categories=[dict(id=1, name='building')]), open(f, 'w'))
+    raster = lambda polys, h, w: np.zeros((h, w), np.uint8)
+    mk = lambda: BonaiDataset(str(f), str(tmp_path), filter_empty_gt=False, flip_ratio=0.0, seed=3, host_rasteriser=raster)
+    a, b = mk(), mk()
+    sync = list(a.batches(0, 2, device='cpu', seed=5))
+    real = os.statvfs
+    VFS = namedtuple('VFS', 'f_bavail f_frsize')
+    monkeypatch.setattr(os, 'statvfs', lambda path: VFS(16, 4096) if path == '/dev/shm' else real(path))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        pre = list(b.batches(0, 2, device='cpu', seed=5, prefetch=2, workers=2, processes=True))
+    assert any('decoder processes disabled' in str(x.message) for x in w)
+    assert getattr(b, '_staging', None) is None
+    assert len(sync) == len(pre) == 2 and all(torch.equal(x['img'], y['img']) for x, y in zip(sync, pre))
+    monkeypatch.undo()
+    pre = list(b.batches(0, 2, device='cpu', seed=5, prefetch=2, workers=2, processes=True))      # enough space: the process path
+    assert b._staging is not None and all(torch.equal(x['img'], y['img']) for x, y in zip(sync, pre))
+    b.close()
+    assert b._staging is None
+
+
 def test_evaluation_pairing_rule_and_scores():
     """bonai_amd/evaluation.py against the reference's formulas (tools/bonai/bonai_evaluation.py:461-475, 375-389): iou =
     inter / (area_pred + area_gt - inter + 1), every pair >= 0.5 counts (not one-to-one), FN / FP = unpaired."""

@@ -1,0 +1,165 @@
+"""The fp32 parity mode on OPERAND PLANES (round 5; include/loft_hip.h loft_conv_tap_planes / loft_conv_wgrad_planes /
+loft_split_planes_f32): every fp32 operand becomes two binary16 planes under a power-of-two scale (or three bfloat16 planes) and the
+contraction runs on the software-pipelined 16-bit stream kernels with fp32 accumulation.  Checked here against fp64 convolutions
+at fp32-rounding tolerances, on shapes that reach every tile shape of the stream kernel (256 / 128 / 64 pixels x 256 / 128 couts,
+pixel-major RoI maps, 1x1 layers, strided data gradients, grouped launches) and both weight-gradient kernels.
+Reference lines: the reference evaluates these layers in fp32 on the CPU (detectors/base.py:159-173; resnet.py:266-298, fpn.py:170-199,
+offset_head_expand_feature.py:134-161)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+MODES = ['planes_f16', 'planes_bf16']
+
+
+@pytest.fixture(params=MODES)
+def planes_mode(request):
+    from bonai_amd import kernels as K
+    prev = K.F32_CONTRACT
+    K.F32_CONTRACT = {'planes_f16': K.F32_PLANES_F16, 'planes_bf16': K.F32_PLANES_BF16}[request.param]
+    yield request.param
+    K.F32_CONTRACT = prev
+
+
+def _cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+def _conv64(x, w, b, s, p):
+    """fp64 convolution of fp32-valued operands (on the device when the backend has an fp64 convolution, else on the host)."""
+    try:
+        return F.conv2d(x.cuda().double(), w.cuda().double(), None if b is None else b.cuda().double(), s, p).cpu()
+    except RuntimeError:
+        return F.conv2d(x.double(), w.double(), None if b is None else b.double(), s, p)
+
+
+def test_split_planes_reconstructs_the_tensor(planes_mode):
+    """plane_0 + plane_1 (+ plane_2) = x * scale to 2^-22 (binary16, two planes) / 2^-24 (bfloat16, three), the scale a power of two
+    that keeps the high plane finite; tensors far outside binary16's range, zeros, and a tensor with one huge outlier."""
+    from bonai_amd import kernels as K
+    dt = torch.float16 if planes_mode == 'planes_f16' else torch.bfloat16
+    torch.manual_seed(0)
+    for scale in (1.0, 1e-7, 3e5):
+        x = (torch.randn(4096 * 8) * scale).cuda()
+        x[5] = 0.0
+        x[17] = 900.0 * scale                       # an outlier 2^10 above the bulk
+        planes, amax = K.split_planes(x, dt)
+        assert planes.dtype == dt and planes.shape == (2 if dt == torch.float16 else 3, x.numel())
+        rec = planes.double().sum(0)
+        assert torch.isfinite(rec).all()
+        if amax is not None:
+            assert amax.item() == x.abs().max().item()
+            e = torch.floor(torch.log2(amax)).item()
+            rec = rec * 2.0 ** (e - 14)
+        tol = (2.0 ** -21 if dt == torch.float16 else 2.0 ** -23)
+        err = (rec - x.double()).abs()
+        # elements within 2^-13 of the absmax keep full relative precision; smaller ones are exact to 2^-36 of the absmax
+        assert (err <= tol * x.double().abs() + 2.0 ** -36 * x.abs().max().item()).all(), (scale, err.max().item())
+    z = torch.zeros(64).cuda()
+    planes, amax = K.split_planes(z, dt)
+    assert (planes == 0).all()
+
+
+# (B, cin, cout, k, s, p, hw, groups): the tile shape loft_conv_tap_planes picks is noted per case
+CASES = [
+    (2, 64, 256, 3, 1, 1, 40, 1),      # 64 px x 128 cout (few tiles)
+    (3, 64, 256, 3, 1, 1, 128, 1),     # 256 px x 256 cout
+    (3, 64, 512, 1, 1, 0, 64, 1),      # 128 px x 256 cout, pointwise
+    (6, 128, 512, 1, 1, 0, 32, 1),     # 64 px x 256 cout, pointwise
+    (3, 64, 128, 3, 1, 1, 128, 1),     # 256 px x 128 cout
+    (256, 64, 256, 3, 1, 1, 7, 1),     # pixel-major RoI map (7 x 7)
+    (256, 64, 256, 3, 1, 1, 7, 2),     # ... grouped (the FOA branches' form)
+    (2, 256, 128, 1, 2, 0, 17, 1),     # strided 1x1, odd map
+    (2, 64, 256, 3, 2, 1, 33, 1),      # strided 3x3
+]
+
+
+@pytest.mark.parametrize('B,cin,cout,k,s,p,hw,groups', CASES)
+def test_conv_tap_planes_forward_vs_fp64(B, cin, cout, k, s, p, hw, groups, planes_mode):
+    from bonai_amd import kernels as K
+    torch.manual_seed(B + cin + cout + k + hw)
+    x = torch.randn(groups * B, cin, hw, hw) * 3.0
+    w = torch.randn(groups, cout, cin, k, k) * 0.05
+    b = torch.randn(groups, cout)
+    oh = (hw + 2 * p - k) // s + 1
+    res = torch.randn(groups * B, cout, oh, oh)
+    ref = torch.cat([F.relu(_conv64(x[i * B:(i + 1) * B], w[i], b[i], s, p) + res[i * B:(i + 1) * B].double()) for i in range(groups)])
+    wp = torch.stack([K.pack_w_fwd(w[i].cuda(), torch.float32) for i in range(groups)])
+    n0 = dict(K.PLANES_STATS)
+    y = K.conv2d_fwd(_cl(x), wp, b.cuda(), k, k, s, p, relu=True, residual=_cl(res), out_dtype=torch.float32, groups=groups)
+    assert K.PLANES_STATS['planes'] == n0['planes'] + 1 and K.PLANES_STATS['fallback'] == n0['fallback'], 'took the fallback kernel'
+    err = (y.cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print(f'planes conv ({planes_mode}) {B}x{cin}->{cout} k{k}s{s} {hw}^2 g{groups}: max err / scale = {err:.2e}')
+    assert err < 1e-5
+
+
+@pytest.mark.parametrize('B,cin,cout,k,s,p,hw', [(2, 256, 64, 3, 1, 1, 40), (3, 256, 64, 3, 2, 1, 64), (2, 512, 64, 1, 1, 0, 48)])
+def test_conv_tap_planes_data_gradient_vs_fp64(B, cin, cout, k, s, p, hw, planes_mode):
+    """The data gradient of a cin -> cout convolution is a planes launch over Cout = cin output channels (stride 2: four parity
+    classes with offset outputs and the ReLU-backward mask of the input in the epilogue)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(B + cin + cout + k)
+    x = torch.randn(B, cin, hw, hw, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, k, k, dtype=torch.float64) * 0.05
+    oh = (hw + 2 * p - k) // s + 1
+    g = torch.randn(B, cout, oh, oh, dtype=torch.float64) * 1e-4          # (gradient-sized values: the scale has to follow them)
+    F.conv2d(F.relu(x), w, None, s, p).backward(g)
+    wpt = w.float().cuda().permute(2, 3, 1, 0).reshape(k * k, cin, cout).contiguous()[None]
+    n0 = dict(K.PLANES_STATS)
+    gx = K.conv2d_dgrad(_cl(g.float()), wpt, (hw, hw), k, k, s, p, mask=_cl(x.detach().float()), out_dtype=torch.float32)
+    assert K.PLANES_STATS['fallback'] == n0['fallback'] and K.PLANES_STATS['planes'] > n0['planes']
+    err = (gx.cpu().double() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    print(f'planes dgrad ({planes_mode}) {cin}<-{cout} k{k}s{s}: max err / scale = {err:.2e}')
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize('B,cin,cout,k,s,p,hw,groups', [
+    (2, 128, 128, 3, 1, 1, 40, 1),      # 128 x 128 ring kernel, same-size taps
+    (2, 128, 384, 1, 1, 0, 33, 1),      # ring kernel, dense
+    (4, 256, 256, 3, 1, 1, 96, 1),      # 256 x 256 stream kernel
+    (2, 256, 128, 3, 2, 1, 33, 1),      # strided: generic row decode
+    (256, 256, 256, 3, 1, 1, 7, 1),     # RoI maps: position-major reduction
+    (256, 256, 256, 3, 1, 1, 7, 2),     # ... grouped
+])
+def test_conv_wgrad_planes_vs_fp64(B, cin, cout, k, s, p, hw, groups, planes_mode):
+    from bonai_amd import kernels as K
+    torch.manual_seed(B + cin + cout + k + groups)
+    x = torch.randn(groups * B, cin, hw, hw) * 2.0
+    oh = (hw + 2 * p - k) // s + 1
+    g = torch.randn(groups * B, cout, oh, oh) * 1e-3
+    want = []
+    for i in range(groups):
+        for dev in ('cuda', 'cpu'):
+            try:
+                w = torch.zeros(cout, cin, k, k, dtype=torch.float64, device=dev, requires_grad=True)
+                F.conv2d(x[i * B:(i + 1) * B].to(dev).double(), w, None, s, p).backward(g[i * B:(i + 1) * B].to(dev).double())
+                want.append(w.grad.cpu())
+                break
+            except RuntimeError:
+                if dev == 'cpu':
+                    raise
+    n0 = dict(K.PLANES_STATS)
+    dwp, db = K.conv2d_wgrad(_cl(g), _cl(x), k, k, s, p, groups=groups, with_bias=True)
+    assert K.PLANES_STATS['planes'] == n0['planes'] + 1 and K.PLANES_STATS['fallback'] == n0['fallback'], 'took the fallback kernel'
+    for i in range(groups):
+        dw = K.unpack_dw(dwp[i], (cout, cin, k, k)).cpu().double()
+        err = (dw - want[i]).abs().max().item() / want[i].abs().max().item()
+        print(f'planes wgrad ({planes_mode}) {cin}->{cout} k{k}s{s} {hw}^2 g{groups}[{i}]: max err / scale = {err:.2e}')
+        assert err < 2e-5, i
+    want_b = g.view(groups, B, cout, -1).sum(dim=(1, 3))
+    assert (db[:, :cout].cpu() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item()
+
+
+def test_planes_modes_fall_back_on_unsupported_shapes(planes_mode):
+    """Channel counts the stream kernels do not serve take the SPLIT6 kernels, with the same answer."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(3)
+    x = torch.randn(2, 96, 9, 9)
+    w = torch.randn(36, 96, 3, 3) * 0.05
+    ref = _conv64(x, w, None, 1, 1)
+    n0 = dict(K.PLANES_STATS)
+    y = K.conv2d_fwd(_cl(x), K.pack_w_fwd(w.cuda(), torch.float32)[None], None, 3, 3, 1, 1, out_dtype=torch.float32)
+    assert K.PLANES_STATS['fallback'] == n0['fallback'] + 1
+    assert (y.cpu().double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()

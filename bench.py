@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='backbone + neck forward / backward as two hipGraphs (bonai_amd/graphs.py)')
     ap.add_argument('--no-light', action='store_true', help='skip the second timed loop (value_random_init_rpn)')
     ap.add_argument('--no-fp32', action='store_true', help='skip the fp32-parity-mode timed loop (value_fp32_parity)')
+    ap.add_argument('--force-reducer', action='store_true', help='N = 1 only: run the timed loop with the bucketed gradient reducer ACTIVE '
+                    'over a one-rank RCCL group (LOFT_FORCE_REDUCER=1): hooks, side stream, ncclAllReduce per bucket, exposed-time events')
+    ap.add_argument('--no-forced-comm', action='store_true', help='skip the comm_forced_1rank leg (a child run of this script with --force-reducer)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the cpu_baseline leg (0: min(host cores, 32))')
     return ap.parse_args()
 
@@ -167,6 +170,32 @@ def offset_epe_vs_ref():
     return out
 
 
+def forced_comm_leg(args, plain_ms):
+    """N = 1: the same timed loop in a CHILD process with the gradient reducer forced on over a one-rank RCCL group
+    (`bench.py --force-reducer`): 25 MiB buckets released by the gradient hooks, one ncclAllReduce per bucket on the side
+    stream, the main stream waiting for the last of them before the clip + SGD kernels -- everything an N-rank step does except
+    bytes on xGMI.  Reports the step time next to the plain N = 1 step and `exposed_ms` (end of the last collective - end of
+    backward).  A child so that nothing of it can touch the headline loop; errors are reported, not raised."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--force-reducer', '--steps', str(min(args.steps, 10)), '--warmup', '3',
+           '--batch', str(args.batch), '--size', str(args.size), '--num-gt', str(args.num_gt), '--no-cpu-baseline', '--no-roofline',
+           '--no-light', '--no-fp32']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        if not line:
+            return dict(error=(r.stderr or r.stdout)[-400:])
+        d = json.loads(line[-1])
+        c = d.get('comm') or {}
+        return dict(ms_per_step=d['ms_per_step'], value=d['value'], plain_ms_per_step=round(plain_ms, 3),
+                    slowdown_vs_plain=round(d['ms_per_step'] / plain_ms, 4), exposed_ms=c.get('exposed_ms'), buckets=c.get('buckets'),
+                    bucket_mib=c.get('bucket_mib'), grad_mib_per_step=c.get('grad_mib_per_step'), backend=c.get('backend'),
+                    steps=d['steps'], how='child run `bench.py --force-reducer`: one-rank RCCL group, reducer hooks + side stream + '
+                                          'ncclAllReduce per bucket active in the timed loop')
+    except Exception as e:      # noqa -- reported, never hidden
+        return dict(error=f'{type(e).__name__}: {e}'[:300])
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -177,9 +206,21 @@ def main():
     # LOFT_BENCH_SHARED_GPU=1 (tests only): every rank on device 0 over gloo, to exercise this exact launch path on a 1-GPU box
     shared = os.environ.get('LOFT_BENCH_SHARED_GPU') == '1'
     torch.cuda.set_device(0 if shared else local_rank)
+    force = args.force_reducer and world == 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo' if shared else 'nccl', rank=rank, world_size=world)   # 'nccl' is RCCL on ROCm
+    elif force:
+        # the whole data-parallel machinery on the one GPU a 1-GPU box has: a one-rank RCCL communicator, every bucket a real
+        # ncclAllReduce launched from the gradient hooks on the side stream
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(port))
+        os.environ['LOFT_FORCE_REDUCER'] = '1'
+        dist.init_process_group('nccl', rank=0, world_size=1)
     from bonai_amd import kernels as K
     from bonai_amd.config import Config
     from bonai_amd.engine import Trainer, step_lr
@@ -188,7 +229,8 @@ def main():
     K.L.load()
     if os.environ.get('LOFT_BENCH_SLOTS'):      # A/B only: split-K slots (plain stores summed by the unpack) instead of fp32 atomics
         which_s = os.environ['LOFT_BENCH_SLOTS']
-        K.WGRAD_SLOTS = (lambda G, B, OH, OW, Cin, Cout, T, ss, gos: B >= 1024 and OH * OW <= 196 and T > 1) if which_s == 'roi' else True
+        K.WGRAD_SLOTS = ((lambda G, B, OH, OW, Cin, Cout, T, ss, gos: B >= 1024 and OH * OW <= 196 and T > 1) if which_s == 'roi' else
+                         (lambda G, B, OH, OW, Cin, Cout, T, ss, gos: B <= 64) if which_s == 'dense' else True)
     if os.environ.get('LOFT_BENCH_ROLES'):      # A/B only: route launches to the role-split stream kernel ('mask' | 'roi' | 'all')
         which = os.environ['LOFT_BENCH_ROLES']
 
@@ -211,10 +253,11 @@ def main():
     data = make_batch(args.batch, args.size, args.num_gt, rank=rank, device='cuda')
     n_pos, n_roi = [], []
     comm = None
-    if world > 1:
+    if world > 1 or force:
         seen = torch.ones(1, device='cuda')
         dist.all_reduce(seen)                                  # one collective through the data-parallel backend before timing
-        comm = dict(backend='gloo (shared-GPU test)' if shared else 'rccl', rccl_ranks_seen=int(seen.item()),
+        comm = dict(backend='gloo (shared-GPU test)' if shared else ('rccl (one-rank group, LOFT_FORCE_REDUCER)' if force else 'rccl'),
+                    rccl_ranks_seen=int(seen.item()),
                     buckets=len(trainer.reducer.buckets), bucket_mib=round(max(b['end'] - b['start'] for b in trainer.reducer.buckets) * 4 / 2 ** 20, 1),
                     grad_mib_per_step=round(trainer.arena.numel * 4 / 2 ** 20, 1))
 
@@ -222,6 +265,8 @@ def main():
         trainer.train_step(data, lr=step_lr(cfg.optimizer.lr, it, 0))
         n_pos.append(model.roi_head.last_stats['num_pos'])
         n_roi.append(model.roi_head.last_stats['num_rois'])
+
+    rank_pos = []
 
     def timed(first_it):
         """W warm-up steps, barrier + sync, K timed steps, barrier + sync, max over ranks -> (img/s, ms/step, mean pos, mean rois)."""
@@ -243,8 +288,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
             st = torch.tensor([float(sum(n_pos)), float(sum(n_roi))], device='cuda')
+            mine = st[:1].clone() / (args.steps * args.batch)
             dist.all_reduce(st)
             tp, tr_ = [float(v) / world for v in st.tolist()]
+            # load imbalance is SURVEY 8(e)'s scaling risk: positives per image, rank by rank
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_pos[:] = [round(float(v.item()), 1) for v in every]
         else:
             tp, tr_ = float(sum(n_pos)), float(sum(n_roi))
         return (args.batch * world * args.steps / el, el / args.steps * 1e3, tp / (args.steps * args.batch),
@@ -284,6 +334,7 @@ def main():
     if comm is not None and trainer.reducer.on_gpu:
         trainer.reducer.measure = True
     value, ms_step, mean_pos, mean_roi = timed(0)
+    rank_pos_primary = list(rank_pos)
     if comm is not None and trainer.reducer.on_gpu:
         # gradient all-reduce time the backward pass did not hide, mean over this rank's steps of the primary timed loop
         # (includes its warm-up steps); rank 0's view -- every rank waits for the same collectives
@@ -407,6 +458,7 @@ def main():
             _K.PLANES_STATS['planes'] = _K.PLANES_STATS['fallback'] = 0
             el = fp32_loop(_K.F32_PLANES_F16, k)
             pst = dict(_K.PLANES_STATS)
+            el_p4 = fp32_loop(_K.F32_PLANES_F16X4, k)
             el_pb = fp32_loop(_K.F32_PLANES_BF16, k)
             el_6 = fp32_loop(_K.F32_SPLIT6, k)
             el_3 = fp32_loop(_K.F32_SPLIT3, k)
@@ -415,6 +467,8 @@ def main():
                                per_gpu_batch=args.batch,
                                dtype='f32 (operands as 2 binary16 planes under a power-of-two scale, 3 f16 MFMA products, fp32 accumulation)',
                                contraction_launches_per_step=dict(planes=pst['planes'] // (k + 2), fp32_kernels=pst['fallback'] // (k + 2)),
+                               planes_f16x4=dict(value=round(args.batch * k / el_p4, 3), ms_per_step=round(el_p4 / k * 1e3, 2), steps=k,
+                                                 how='binary16 planes with the lo x lo product as a fourth term'),
                                planes_bf16=dict(value=round(args.batch * k / el_pb, 3), ms_per_step=round(el_pb / k * 1e3, 2), steps=k,
                                                 how='LOFT planes, bfloat16 build: three planes per operand, six products (24 bits)'),
                                split6=dict(value=round(args.batch * k / el_6, 3), ms_per_step=round(el_6 / k * 1e3, 2), steps=k,
@@ -458,7 +512,11 @@ def main():
                                conv_roofline_frac=round(f_img * 1e9 * value / (world * 2.5e15), 4)),
                    roofline=roofline)
         if comm is not None:
+            if rank_pos_primary:
+                comm['mean_num_pos_per_img_by_rank'] = dict(min=min(rank_pos_primary), max=max(rank_pos_primary), ranks=rank_pos_primary)
             res['comm'] = comm
+        if world == 1 and headline and not force and not args.no_forced_comm and not fp16:
+            res['comm_forced_1rank'] = forced_comm_leg(args, ms_step)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.size, args.num_gt, args.cpu_threads)
             if headline:
@@ -466,7 +524,7 @@ def main():
                 torch.cuda.empty_cache()
                 res['offset_epe_vs_ref'] = offset_epe_vs_ref()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

@@ -19,11 +19,10 @@
 // mmcv-1.0.5 device kernel (inter > thr * union) and this file is compiled with
 // -ffp-contract=off, so keep lists equal oracle/loft_oracle.c::orc_nms bit for bit.
 // Total order for "sort by score descending": (score desc, original index asc) == stable radix
-// sort, which is what loft_segmented_sort_desc provides (hipCUB radix sort, stable by
+// sort, which is what loft_segmented_sort_desc provides (an in-house LSD radix sort, stable by
 // construction).
 #include "loft_common.h"
 #include "../../include/loft_hip.h"
-#include <hipcub/hipcub.hpp>
 
 #define NMS_MAX_WORDS_PER_LANE 8  // segments up to 64*64*8 = 32768 boxes
 
@@ -237,8 +236,8 @@ LOFT_EXPORT int loft_nms_segmented(const float* boxes, const int64_t* seg_offset
 }
 
 // ---------------------------------------------------------------- segmented stable sort, descending
-// hipCUB's *segmented* radix sort gives one workgroup per segment -- with 40 (image, level) segments of up to
-// 196 608 keys that left the chip idle (2.3 ms per call).  Instead: ONE device-wide radix sort over 64-bit
+// A *segmented* radix sort with one workgroup per segment -- 40 (image, level) segments of up to 196 608 keys -- left
+// the chip idle (round 1, a library primitive: 2.3 ms per call).  Instead: ONE device-wide radix sort over 64-bit
 // composite keys  (segment id << 32) | ~orderable(score)  -- ascending order of the composite = segments in
 // order, scores descending inside each; radix sort is stable, so equal scores keep input (index) order.
 __global__ void sort_build_keys_kernel(const float* __restrict__ keys, const int64_t* __restrict__ seg_off, int nseg, long n,
@@ -260,32 +259,156 @@ __global__ void sort_extract_keys_kernel(const unsigned long long* __restrict__ 
     keys_out[i] = __uint_as_float(u);
 }
 
+// ---- the sort itself: an in-house stable LSD radix sort (round 5: hipCUB is gone from the library).  4 bits per pass over the
+// 32 + ceil(log2(segments)) significant bits of the composite key.  A workgroup owns a TILE of 256 x 8 consecutive elements, a
+// thread 8 CONSECUTIVE ones: (1) per-(digit, workgroup) counts, (2) one exclusive scan over the [16][workgroups] table in
+// digit-major order, (3) every thread re-counts its run, the workgroup scans the 16 x 256 per-thread counts per digit, and each
+// thread places its elements in order at base(digit, workgroup) + (same-digit elements of earlier threads) + (its own earlier
+// ones) -- input order is preserved inside every digit bucket, which is what makes the whole sort stable.  Off the training
+// step (both sorts of the step are loft_segmented_topk_desc); ~10 passes of three small launches.
+namespace {
+constexpr int RS_E = 8, RS_T = 256, RS_TILE = RS_E * RS_T;
+}
+__global__ __launch_bounds__(256) void rsort_count_kernel(const unsigned long long* __restrict__ keys, long n, int shift, int nb,
+                                                          unsigned* __restrict__ counts) {
+    __shared__ unsigned cnt[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const long base = (long)blockIdx.x * RS_TILE + (long)threadIdx.x * RS_E;
+    unsigned loc[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) loc[d] = 0u;
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e) {
+        if (base + e < n) {
+            const int d = (int)((keys[base + e] >> shift) & 15ull);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) loc[q] += (q == d) ? 1u : 0u;      // (static register indexing: no scratch)
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        unsigned v = loc[d];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[d], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) counts[(long)threadIdx.x * nb + blockIdx.x] = cnt[threadIdx.x];
+}
+// exclusive scan of counts[0 .. m) in place, one workgroup of 1024 threads walking chunks of 1024
+__global__ __launch_bounds__(1024) void rsort_scan_kernel(unsigned* __restrict__ counts, long m) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long c0 = 0; c0 < m; c0 += 1024) {
+        const long i = c0 + threadIdx.x;
+        const unsigned v = i < m ? counts[i] : 0u;
+        unsigned inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < m) counts[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void rsort_scatter_kernel(const unsigned long long* __restrict__ kin, const int32_t* __restrict__ vin,
+                                                            unsigned long long* __restrict__ kout, int32_t* __restrict__ vout, long n,
+                                                            int shift, int nb, const unsigned* __restrict__ bases) {
+    __shared__ unsigned off[16 * RS_T];          // off[d * 256 + t]: next output position of thread t's digit-d elements
+    __shared__ unsigned wtot[16][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long base = (long)blockIdx.x * RS_TILE + (long)t * RS_E;
+    unsigned long long k[RS_E];
+    unsigned loc[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) loc[d] = 0u;
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e) {
+        k[e] = base + e < n ? kin[base + e] : 0ull;
+        if (base + e < n) {
+            const int d = (int)((k[e] >> shift) & 15ull);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) loc[q] += (q == d) ? 1u : 0u;
+        }
+    }
+    // per digit: exclusive scan of the 256 per-thread counts (wave scan + the four wave totals)
+    unsigned pre[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        unsigned inc = loc[d];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        pre[d] = inc - loc[d];
+        if (lane == 63) wtot[d][wave] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        unsigned b = bases[(long)d * nb + blockIdx.x];
+        for (int w = 0; w < wave; ++w) b += wtot[d][w];
+        off[d * RS_T + t] = b + pre[d];
+    }
+    // (each thread touches only its own column of `off` from here on: no barrier needed)
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e) {
+        if (base + e < n) {
+            const int d = (int)((k[e] >> shift) & 15ull);
+            const unsigned pos = off[d * RS_T + t]++;
+            kout[pos] = k[e];
+            vout[pos] = vin[base + e];
+        }
+    }
+}
+
 LOFT_EXPORT int loft_segmented_sort_desc(const float* keys_in, float* keys_out, const int32_t* vals_in, int32_t* vals_out,
                                          int64_t num_items, int num_segments, const int64_t* seg_offsets_dev,
                                          void* workspace, int64_t* workspace_bytes, void* stream) {
+    if (num_items > 0x7fffffffL || num_segments < 1) return (int)hipErrorInvalidValue;
     int seg_bits = 1;
     while ((1 << seg_bits) < num_segments) ++seg_bits;
-    const size_t kbytes = ((size_t)num_items * 8 + 255) / 256 * 256;
-    size_t cub_bytes = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const unsigned long long*)nullptr,
-                                                     (unsigned long long*)nullptr, vals_in, vals_out, (int)num_items, 0,
-                                                     32 + seg_bits, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    const int npass = (32 + seg_bits + 3) / 4;
+    const int nb = loft_cdiv(num_items > 0 ? num_items : 1, RS_TILE);
+    const size_t kbytes = ((size_t)num_items * 8 + 255) / 256 * 256, vbytes = ((size_t)num_items * 4 + 255) / 256 * 256;
+    const size_t cbytes = ((size_t)16 * nb * 4 + 255) / 256 * 256;
     if (!workspace) {
-        *workspace_bytes = (int64_t)(2 * kbytes + cub_bytes);
+        *workspace_bytes = (int64_t)(2 * kbytes + vbytes + cbytes);
         return 0;
     }
     if (num_items <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long* k0 = (unsigned long long*)workspace;
-    unsigned long long* k1 = (unsigned long long*)((char*)workspace + kbytes);
-    void* tmp = (char*)workspace + 2 * kbytes;
+    unsigned long long* kb[2] = {(unsigned long long*)workspace, (unsigned long long*)((char*)workspace + kbytes)};
+    int32_t* vtmp = (int32_t*)((char*)workspace + 2 * kbytes);
+    unsigned* counts = (unsigned*)((char*)workspace + 2 * kbytes + vbytes);
     hipLaunchKernelGGL(sort_build_keys_kernel, dim3(loft_cdiv(num_items, 256)), dim3(256), 0, s, keys_in, seg_offsets_dev,
-                       num_segments, (long)num_items, k0);
+                       num_segments, (long)num_items, kb[0]);
     LOFT_LAUNCH_CHECK();
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, cub_bytes, k0, k1, vals_in, vals_out, (int)num_items, 0, 32 + seg_bits, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sort_extract_keys_kernel, dim3(loft_cdiv(num_items, 256)), dim3(256), 0, s, k1, (long)num_items, keys_out);
+    // values ping-pong between vals_out and vtmp so that the LAST pass writes vals_out
+    int32_t* vb[2];
+    vb[(npass - 1) & 1] = vtmp; vb[npass & 1] = vals_out;         // pass p writes vb[(p + 1) & 1]; the last (p = npass - 1) -> vb[npass & 1]
+    const int32_t* vsrc = vals_in;
+    for (int p = 0; p < npass; ++p) {
+        hipLaunchKernelGGL(rsort_count_kernel, dim3(nb), dim3(256), 0, s, kb[p & 1], (long)num_items, 4 * p, nb, counts);
+        hipLaunchKernelGGL(rsort_scan_kernel, dim3(1), dim3(1024), 0, s, counts, (long)16 * nb);
+        hipLaunchKernelGGL(rsort_scatter_kernel, dim3(nb), dim3(256), 0, s, kb[p & 1], vsrc, kb[(p + 1) & 1], vb[(p + 1) & 1],
+                           (long)num_items, 4 * p, nb, counts);
+        LOFT_LAUNCH_CHECK();
+        vsrc = vb[(p + 1) & 1];
+    }
+    hipLaunchKernelGGL(sort_extract_keys_kernel, dim3(loft_cdiv(num_items, 256)), dim3(256), 0, s, kb[npass & 1], (long)num_items, keys_out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

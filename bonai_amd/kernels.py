@@ -496,9 +496,10 @@ F32_SPLIT6, F32_EXACT, F32_SPLIT3 = 0, 1, 2
 # scale (22 significant bits), three products per element pair on v_mfma_f32_32x32x16_f16 -- the binary16 BUILD of the library,
 # mapped next to the bfloat16 one; PLANES_BF16: three bfloat16 planes (24 bits), six products.  Shapes the stream kernels do not
 # serve (Cout % 128, Cin % 64, accumulating launches) take SPLIT6's kernels.
-F32_PLANES_F16, F32_PLANES_BF16 = 3, 4
+F32_PLANES_F16, F32_PLANES_BF16, F32_PLANES_F16X4 = 3, 4, 5      # (F16X4: the binary16 planes with the lo x lo product as a fourth term)
 _PLANE_MODES = {F32_PLANES_F16: (torch.float16, ((1, 0), (0, 1), (0, 0))),
-                F32_PLANES_BF16: (torch.bfloat16, ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)))}
+                F32_PLANES_BF16: (torch.bfloat16, ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0))),
+                F32_PLANES_F16X4: (torch.float16, ((1, 1), (1, 0), (0, 1), (0, 0)))}
 F32_CONTRACT = F32_PLANES_F16
 PLANES_STATS = {'planes': 0, 'fallback': 0}      # launches of the fp32 mode by path (tests / bench read it)
 
@@ -717,7 +718,11 @@ import os as _os
 # stream kernels -35..-45 us per launch, unpack 0.39 -> 0.9 ms) but the step itself is unchanged at 30.2 ms -- with the branch /
 # weight-gradient streams overlapped the atomic tails (L2-bound, no HBM, no MFMA) were already hidden behind other kernels, while
 # 3 GB of slot stores + reads per step compete for HBM with them.  Kept selectable and tested; not the default.
-WGRAD_SLOTS = False
+# Round 5, re-measured on the round-4 tree (tools/ab_env.sh LOFT_BENCH_SLOTS=dense, same box, two rounds): slots for the DENSE-map
+# launches only (B <= 64: backbone / FPN, ~50 launches of 288 workgroups whose 16k atomics per workgroup serialise at the end of a
+# single-round launch) 34.64 / 34.66 ms against 35.00 / 34.87 -- their slot traffic is 0.9 GB per step, not 3 -- so that is the
+# default; the RoI-map launches (long K, atomics a few percent) keep the atomics.
+WGRAD_SLOTS = lambda G, B, OH, OW, Cin, Cout, T, ss, gos: B <= 64      # noqa: E731
 
 
 def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1, ss=1, groups=1, g_gs=0, x_gs=0,

@@ -40,16 +40,17 @@ def pytest_collection_modifyitems(config, items):
         items.reverse()
 
 
-@pytest.fixture(params=['planes_f16', 'planes_bf16', 'split6', 'split3', 'exact'])
+@pytest.fixture(params=['planes_f16', 'planes_f16x4', 'planes_bf16', 'split6', 'split3', 'exact'])
 def f32_contract(request):
     """The contractions of the fp32 parity mode (include/loft_hip.h): the mode's default since round 5, binary16 operand PLANES on the
     software-pipelined stream kernels (two planes per fp32 tensor under a power-of-two scale, three products: 22 significant bits),
-    the same with three bfloat16 planes / six products (24 bits), and the kernels of rounds 1-4: SPLIT6 (three bf16 per operand
+    the binary16 planes with the lo x lo product as a fourth term, three bfloat16 planes / six products (24 bits), and the kernels of
+    rounds 1-4: SPLIT6 (three bf16 per operand
     split in registers, six MFMA terms: fp32-grade; also what a plane mode falls back to on shapes the stream kernels do not
     serve), SPLIT3 (two bf16, three terms: 16 mantissa bits) and the exact fp32 MFMA."""
     from bonai_amd import kernels as K
     prev = K.F32_CONTRACT
-    K.F32_CONTRACT = {'planes_f16': K.F32_PLANES_F16, 'planes_bf16': K.F32_PLANES_BF16, 'split6': K.F32_SPLIT6,
+    K.F32_CONTRACT = {'planes_f16': K.F32_PLANES_F16, 'planes_f16x4': K.F32_PLANES_F16X4, 'planes_bf16': K.F32_PLANES_BF16, 'split6': K.F32_SPLIT6,
                       'split3': K.F32_SPLIT3, 'exact': K.F32_EXACT}[request.param]
     yield request.param
     K.F32_CONTRACT = prev

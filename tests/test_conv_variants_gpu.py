@@ -249,15 +249,17 @@ def test_wgrad_split_slots_sum_to_the_atomic_result(shape):
     gen = torch.Generator(device='cuda').manual_seed(3)
     x = torch.randn(G * B, Cin, H, W, device='cuda', generator=gen).bfloat16().contiguous(memory_format=torch.channels_last)
     g = torch.randn(G * B, Cout, H, W, device='cuda', generator=gen).bfloat16().contiguous(memory_format=torch.channels_last)
-    want, dbw = K.conv2d_wgrad(g, x, R, R, 1, R // 2, groups=G, with_bias=True)
-    want, dbw = want.clone(), dbw.clone()
-    poison = torch.full((64 << 20,), float('nan'), device='cuda')      # the allocator hands the slots buffer out of this block
-    del poison
-    K.WGRAD_SLOTS = True
+    prev_slots = K.WGRAD_SLOTS
+    K.WGRAD_SLOTS = False
     try:
+        want, dbw = K.conv2d_wgrad(g, x, R, R, 1, R // 2, groups=G, with_bias=True)
+        want, dbw = want.clone(), dbw.clone()
+        poison = torch.full((64 << 20,), float('nan'), device='cuda')      # the allocator hands the slots buffer out of this block
+        del poison
+        K.WGRAD_SLOTS = True
         got, db = K.conv2d_wgrad(g, x, R, R, 1, R // 2, groups=G, with_bias=True, slots_ok=True)
     finally:
-        K.WGRAD_SLOTS = False
+        K.WGRAD_SLOTS = prev_slots
     assert got.dim() == 5 and got.shape[0] == G and got.shape[2:] == want.shape[1:], (got.shape, want.shape)
     assert torch.isfinite(got).all()
     tot = got.sum(1)
@@ -281,6 +283,7 @@ def test_trainer_step_with_split_slots_matches_atomics():
     cfg = Config.fromfile(os.path.join(root, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
     data = make_batch(2, 256, 8, device='cuda')
     grads = []
+    prev_slots = K.WGRAD_SLOTS
     for slots in (False, True):
         torch.manual_seed(0)
         m = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
@@ -289,7 +292,7 @@ def test_trainer_step_with_split_slots_matches_atomics():
         try:
             tr.train_step(data)
         finally:
-            K.WGRAD_SLOTS = False
+            K.WGRAD_SLOTS = prev_slots
         grads.append(tr.arena.grad.clone())
     a, b = grads
     assert torch.isfinite(b).all()

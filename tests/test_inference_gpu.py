@@ -93,7 +93,10 @@ def test_simple_test_fp32_parity_mode_vs_reference_fixture(f32_contract):
     """North-star tolerance on the inference 3-tuple in the fp32 parity mode (forward only), every contraction of it.
     SPLIT6 (the mode's default: three bf16 per fp32 operand, six MFMA terms) and EXACT (fp32 MFMA): every one of the reference's
     2000 soft-NMS detections has a twin of ours within 5e-3 px / 1e-4 score (1e-3 relative on a 256 px tile is 0.256 px), offsets
-    within 1e-2 px with a mean end-point error < 1e-3 px, mask areas within 4 px.  SPLIT3 (two bf16 per operand): the same
+    within 1e-2 px with a mean end-point error < 1e-3 px, mask areas within 8 px (an area is a COUNT of pixels whose pasted
+    probability is >= 0.5: the handful that sit within 1e-5 of the threshold flip with the summation order -- measured 2 px for
+    the binary16 planes and the exact fp32 MFMA, 4-5 px for the bfloat16 planes and SPLIT6, of areas in the hundreds to
+    thousands); the operand-plane contractions of round 5 are held to the same bounds.  SPLIT3 (two bf16 per operand): the same
     detections within the north-star's 1e-3 (0.256 px on this tile) -- scores 1e-3, boxes and offsets 0.05 px, mean offset error
     2e-3 px -- on a network with random synthetic weights, which amplifies a contraction's 2e-6 to 2e-4 at the scores.  The
     comparison is order-insensitive: score near-ties swap rows."""
@@ -113,7 +116,7 @@ def test_simple_test_fp32_parity_mode_vs_reference_fixture(f32_contract):
     with torch.no_grad():
         bbox_results, segm_results, offset_results = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False,
                                                        rescale=True)
-    tol_s, tol_b, tol_emax, tol_emean, tol_area = (1e-4, 5e-3, 1e-2, 1e-3, 4) if contract != 'split3' else (1e-3, 0.05, 0.05, 2e-3, 16)
+    tol_s, tol_b, tol_emax, tol_emean, tol_area = (1e-4, 5e-3, 1e-2, 1e-3, 8) if contract != 'split3' else (1e-3, 0.05, 0.05, 2e-3, 16)
     det, want = torch.from_numpy(bbox_results[0]), torch.from_numpy(gd['det'])
     assert det.shape == want.shape
     ds = (det[:, 4] - want[:, 4]).abs().max().item()                     # sorted score lists agree row by row

@@ -9,7 +9,7 @@ from bonai_amd import kernels as K
 SH = [('foa.3x3 (4x2048 roi)', 2048, 256, 256, 3, 1, 7, 4), ('mask.3x3 (2048 roi)', 2048, 256, 256, 3, 1, 14, 1),
       ('fpn.P2.3x3', 8, 256, 256, 3, 1, 256, 1), ('layer3.3x3', 8, 256, 256, 3, 1, 64, 1), ('layer3.1x1.256-1024', 8, 256, 1024, 1, 0, 64, 1),
       ('layer2.3x3', 8, 128, 128, 3, 1, 128, 1)]
-MODES = [('planes_f16', K.F32_PLANES_F16), ('planes_bf16', K.F32_PLANES_BF16), ('split6', K.F32_SPLIT6), ('split3', K.F32_SPLIT3)]
+MODES = [('planes_f16', K.F32_PLANES_F16), ('planes_f16x4', K.F32_PLANES_F16X4), ('planes_bf16', K.F32_PLANES_BF16), ('split6', K.F32_SPLIT6), ('split3', K.F32_SPLIT3)]
 
 
 def timeit(fn, iters=5):

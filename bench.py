@@ -133,7 +133,11 @@ def offset_epe_vs_ref():
                                      ('fp32_planes_bf16', torch.float32, K.F32_PLANES_BF16, 1e-4),
                                      ('fp32_split6', torch.float32, K.F32_SPLIT6, 1e-4), ('fp32_split3', torch.float32, K.F32_SPLIT3, 1e-3),
                                      ('fp32_exact_mfma', torch.float32, K.F32_EXACT, 1e-4),
+                                     ('mixed_neck', 'neck', K.F32_PLANES_F16, 0.0), ('mixed_heads', 'heads', K.F32_PLANES_F16, 0.0),
                                      ('bf16', torch.bfloat16, K.F32_CONTRACT, 0.0)):
+        m.mixed_precision = dt if isinstance(dt, str) else None
+        if isinstance(dt, str):
+            dt = torch.bfloat16
         m.backbone.compute_dtype = dt
         prev_contract, K.F32_CONTRACT = K.F32_CONTRACT, contract
         with torch.no_grad():
@@ -392,7 +396,7 @@ def main():
         here = source_hash()
         traffic = mfma_util = rocprof = None
         stale = []
-        pmc = os.path.join(ROOT, 'profiles', 'round4_pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'round5_pmc_traffic.json')
         if os.path.exists(pmc) and args.batch == 8 and args.size == 1024 and headline:
             pj = json.load(open(pmc))
             if pj.get('_source_hash') == here:
@@ -400,14 +404,14 @@ def main():
                 traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
                 mfma_util = round(ent['mfma_util'], 4) if 'mfma_util' in ent else None
             else:
-                stale.append(f"profiles/round4_pmc_traffic.json (measured on sources {pj.get('_source_hash')}, running {here})")
-        csvf = os.path.join(ROOT, 'profiles', 'round4_bench_kernel_stats_serial.csv')
+                stale.append(f"profiles/round5_pmc_traffic.json (measured on sources {pj.get('_source_hash')}, running {here})")
+        csvf = os.path.join(ROOT, 'profiles', 'round5_bench_kernel_stats_serial.csv')
         metaf = csvf[:-4] + '.meta.json'
         if os.path.exists(csvf) and os.path.exists(metaf) and args.batch == 8 and args.size == 1024 and headline and saturate:
             import csv
             meta = json.load(open(metaf))
             if meta.get('source_hash') != here:
-                stale.append(f"profiles/round4_bench_kernel_stats_serial.csv (measured on sources {meta.get('source_hash')}, running {here})")
+                stale.append(f"profiles/round5_bench_kernel_stats_serial.csv (measured on sources {meta.get('source_hash')}, running {here})")
             else:
                 subs = {'conv_tap': ('conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel'),
                         'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv_wgrad64_kernel')}[dom]
@@ -418,7 +422,7 @@ def main():
                     rocprof = dict(ms_per_step=round(t_ns / nsteps / 1e6, 2), launches_per_step=round(calls / nsteps, 1),
                                    avg_launch_us=round(t_ns / calls / 1e3, 1),
                                    frac=round(fam[dom][0] / 2 / (t_ns / nsteps * 1e-9) / 2.5e15, 4),
-                                   source='profiles/round4_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
+                                   source='profiles/round5_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
         roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates + the 64-channel patch / fused bottleneck-tail kernels (loft_conv_tap_bf16_v, loft_bneck_tail_bf16)',
                                               'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
@@ -427,9 +431,9 @@ def main():
                         algorithmic_bytes_per_launch=round(alg_bytes),
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
                                  'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
-                                 'rocprofv3 summary of that mode: profiles/round4_bench_kernel_stats_serial.csv '
-                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round4_bench_kernel_stats.csv; traffic / '
-                                 'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/round4_pmc_traffic.json)',
+                                 'rocprofv3 summary of that mode: profiles/round5_bench_kernel_stats_serial.csv '
+                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round5_bench_kernel_stats.csv; traffic / '
+                                 'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/round5_pmc_traffic.json)',
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     # The SAME step in the fp32 parity mode (fp32 activations; the kernels that meet north_star's 1e-3 against the reference's CPU
@@ -488,11 +492,24 @@ def main():
                                    'fp32 accumulation and fp32 epilogue -- the mode '
                                    'test_e2e_fp32_parity_mode_vs_reference_fixture[planes_f16] (features, losses, every parameter gradient) '
                                    'and test_simple_test_fp32_parity_mode_vs_reference_fixture[planes_f16] hold to 1e-3 against the reference')
+            # the Pareto points between the two end points: 16-bit kernels up to a boundary, fp32 behind it
+            model.backbone.compute_dtype = None
+            mixed = {}
+            for name in ('neck', 'heads'):
+                model.mixed_precision = name
+                el_m = fp32_loop(_K.F32_PLANES_F16, k)
+                mixed[name] = dict(value=round(args.batch * k / el_m, 3), ms_per_step=round(el_m / k * 1e3, 2), steps=k)
+            model.mixed_precision = None
+            mixed['how'] = ('same command; neck: backbone trunk on the bf16 kernels, FPN + RPN + RoI heads in the fp32 parity mode '
+                            '(binary16 operand planes); heads: backbone + FPN bf16, RPN + RoI heads fp32; the offsets each variant '
+                            'produces against the reference: offset_epe_vs_ref.mixed_neck / .mixed_heads')
+            fp32_parity['mixed'] = mixed
         except Exception as e:      # noqa -- reported, never hidden
             fp32_parity = dict(error=f'{type(e).__name__}: {e}'[:300])
         finally:
             _K.F32_CONTRACT = prev_contract
             model.backbone.compute_dtype = None
+            model.mixed_precision = None
             n_pos.clear(); n_roi.clear()
     if rank == 0:
         arch = ('LOFT HRNetV2p-W32 + FOA' if 'hrnet' in args.config else
@@ -502,6 +519,7 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='fp16' if fp16 else 'bf16', data='synthetic',
                    value_random_init_rpn=light, value_fp32_parity=fp32_parity,
+                   value_mixed=(fp32_parity or {}).get('mixed'),
                    config=dict(workload=f'{arch}, {args.batch}x{args.size}x{args.size} synthetic tiles per GPU '
                                         f'({"BASELINE configs[1]" if headline else args.config}), {args.num_gt} gt/img, full train step '
                                         '(fwd+losses+bwd+allreduce+clip+SGD), random-init weights' + (', RoI heads at the load of a trained RPN (first proposals = jittered gt boxes)' if saturate else ''),

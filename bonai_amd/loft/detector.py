@@ -87,8 +87,16 @@ class LOFT(nn.Module):
         if self.feat_provider is not None and torch.is_grad_enabled():
             return self.feat_provider(img)
         x = self.backbone(img)
+        # mixed precision (a measurement mode, bench.py `value_mixed`): the 16-bit training kernels up to a boundary, the fp32
+        # parity mode's arithmetic (fp32 activations, operand-plane contractions) behind it.  'neck': backbone trunk 16-bit,
+        # FPN + RPN + RoI heads fp32; 'heads': backbone + FPN 16-bit, RPN + RoI heads fp32.  The cast is an autograd op.
+        mixed = getattr(self, 'mixed_precision', None)
+        if mixed == 'neck':
+            x = tuple(f.float() for f in x)
         if self.with_neck:
             x = self.neck(x)
+        if mixed == 'heads':
+            x = tuple(f.float() for f in x)
         return x
 
     def forward_dummy(self, img):

@@ -36,7 +36,7 @@ def run_pass(tag, counters, extra):
     d = os.path.join(OUT, tag)
     cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
                                                os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
-                                               '--no-roofline', '--no-light'] + extra
+                                               '--no-roofline', '--no-light', '--no-fp32', '--no-forced-comm'] + extra
     subprocess.run(cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     rows = []
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):

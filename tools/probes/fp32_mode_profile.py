@@ -15,7 +15,8 @@ tr = Trainer(m, lr=0.005)
 data = make_batch(8, 1024, 80, device='cuda')
 m.backbone.compute_dtype = torch.float32
 from bonai_amd import kernels as K
-K.F32_CONTRACT = {'split6': K.F32_SPLIT6, 'split3': K.F32_SPLIT3, 'exact': K.F32_EXACT}[os.environ.get('F32', 'split6')]
+K.F32_CONTRACT = {'planes_f16': K.F32_PLANES_F16, 'planes_bf16': K.F32_PLANES_BF16, 'split6': K.F32_SPLIT6, 'split3': K.F32_SPLIT3,
+                  'exact': K.F32_EXACT}[os.environ.get('F32', 'planes_f16')]
 for i in range(int(os.environ.get('STEPS', '3'))):
     torch.cuda.synchronize(); t0 = time.time()
     tr.train_step(data)

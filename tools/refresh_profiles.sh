@@ -11,21 +11,21 @@ cd /tmp
 HASH=$(cd "$ROOT" && python -c "from bonai_amd.build import source_hash; print(source_hash())")
 python "$ROOT/tools/pmc_collect.py" > /dev/null 2>&1
 cp "$ROOT/gpurun_out/pmc/summary.json" "$OUT/pmc_traffic.json"
-cp "$OUT/pmc_traffic.json" "$ROOT/profiles/round4_pmc_traffic.json"      # so that the bench run below quotes it
+cp "$OUT/pmc_traffic.json" "$ROOT/profiles/round5_pmc_traffic.json"      # so that the bench run below quotes it
 W=5; K=20
 for mode in serial default; do
     rm -rf /tmp/prof_$mode
     if [ $mode = serial ]; then export LOFT_NO_SIDE_STREAM=1; else unset LOFT_NO_SIDE_STREAM; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python "$ROOT/bench.py" --no-cpu-baseline --no-light \
-        --no-fp32 --steps $K --warmup $W > "$OUT/bench_under_rocprof_$mode.json" 2> /dev/null
+        --no-fp32 --no-forced-comm --steps $K --warmup $W > "$OUT/bench_under_rocprof_$mode.json" 2> /dev/null
     f=$(find /tmp/prof_$mode -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$mode.csv"
     # steps the summary covers: W warm-up + K timed + 2 instrumented (bench.py's roofline leg)
-    echo "{\"source_hash\": \"$HASH\", \"steps_profiled\": $((W + K + 2)), \"command\": \"bench.py --no-cpu-baseline --no-light --no-fp32 --steps $K --warmup $W\", \"mode\": \"$mode\"}" > "$OUT/kernel_stats_$mode.meta.json"
+    echo "{\"source_hash\": \"$HASH\", \"steps_profiled\": $((W + K + 2)), \"command\": \"bench.py --no-cpu-baseline --no-light --no-fp32 --no-forced-comm --steps $K --warmup $W\", \"mode\": \"$mode\"}" > "$OUT/kernel_stats_$mode.meta.json"
 done
 unset LOFT_NO_SIDE_STREAM
-cp "$OUT/kernel_stats_serial.csv" "$ROOT/profiles/round4_bench_kernel_stats_serial.csv"
-cp "$OUT/kernel_stats_serial.meta.json" "$ROOT/profiles/round4_bench_kernel_stats_serial.meta.json"
+cp "$OUT/kernel_stats_serial.csv" "$ROOT/profiles/round5_bench_kernel_stats_serial.csv"
+cp "$OUT/kernel_stats_serial.meta.json" "$ROOT/profiles/round5_bench_kernel_stats_serial.meta.json"
 LOFT_DUMP_SHAPES=1 python "$ROOT/bench.py" > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 grep '^#' "$OUT/bench.err" > "$OUT/bench_shapes.txt"
 rm -rf "$ROOT/gpurun_out/pmc"

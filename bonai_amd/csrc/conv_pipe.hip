@@ -386,14 +386,16 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
 // NW: 32-cout blocks per wave.  2: 256 couts per tile.  1 (stream schedule only): 128 couts per tile (layer2's 128-channel convs: Cout
 // is not a multiple of 256) -- one weight fragment per sub-step, 256-byte output rows in the staged epilogue.
 // PL: operand-plane launch (ConvArgs block 4): the K loop runs nterms x taps, the epilogue is pipe_epilogue_f32 (stream schedule only).
-template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false>
+// R32 ("ring32", round 5; schedule below): the 256 x 256 tile with 32-CHANNEL K-tiles on a FOUR-stage ring (64-byte LDS rows).
+template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false, bool R32 = false>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     static_assert(MODE <= 2, "MODE 0 phase, 1 stream, 2 role-split stream");
     static_assert(!PL || (MODE == 1 && VAR == 0), "operand planes exist for the stream schedule");
+    static_assert(!R32 || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2), "the 32-channel ring exists for the stream schedule's 256 x 256 tile");
     static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
     static_assert(NW == 2 || (NW == 1 && MODE == 1 && !(VAR & 2)), "the 128-cout tile exists for the stream schedule");
     constexpr int BN = 128 * NW;
-    constexpr int NI = MJ;                                          // activation rows staged per thread (64 rows apart)
+    constexpr int NI = R32 ? 2 : MJ;                                // activation rows staged per thread (64 rows apart; R32: two, 16 apart)
     constexpr int BM = 64 * MJ;
     constexpr bool ABL = VAR & 8;                                   // timing ablations (results are WRONG): sub-code in bits 1-2
     constexpr bool TRACE = VAR & 1, NOPRIO = !ABL && (VAR & 2), OLDORDER = !ABL && (VAR & 4);
@@ -414,9 +416,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // MODE 2 ("roles", round 4; see the schedule below): THREE weight stages + two activation stages = all 160 KiB of the CU
     constexpr bool ROLES = MODE == 2;
     static_assert(!ROLES || (MJ == 4 && NW == 2 && VAR == 0), "the role-split schedule exists for the 256 x 256 tile");
-    constexpr int PBW = ROLES ? PBUF : (NS == 3 ? NW * 16384 : PBUF), PBX = ROLES ? PBUF : (NS == 3 ? MJ * 8192 : PBUF);
-    constexpr int PXO = ROLES ? 3 * PBUF : (NS == 3 ? 3 * PBW : PX_OFF);
-    constexpr int LDSZ = ROLES ? 5 * PBUF : (NS == 3 ? 3 * PBW + 3 * PBX : PLDS);
+    // (R32: four stages of [256 rows x 64 B] per operand: weights 4 x 16 KiB, activations 4 x 16 KiB behind them)
+    constexpr int PBW = R32 ? 16384 : (ROLES ? PBUF : (NS == 3 ? NW * 16384 : PBUF)), PBX = R32 ? 16384 : (ROLES ? PBUF : (NS == 3 ? MJ * 8192 : PBUF));
+    constexpr int PXO = R32 ? 4 * 16384 : (ROLES ? 3 * PBUF : (NS == 3 ? 3 * PBW : PX_OFF));
+    constexpr int LDSZ = R32 ? PLDS : (ROLES ? 5 * PBUF : (NS == 3 ? 3 * PBW + 3 * PBX : PLDS));
     // rows a thread holds staging pointers for: its own four (i = 0..3 -> tile row i*64 + wave*8 + lrow) and, in the role-split
     // schedule, the four of its SIMD partner (wave ^ 4), whose activation pieces the copier wave issues as well
     constexpr int NI2 = ROLES ? 2 * NI : NI;
@@ -460,9 +463,14 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const int kchunks = a.Cin / BK;
 
     // ---- rows this thread stages: i = 0..3 -> tile row i*64 + wave*8 + lrow (rows 64 apart share their swizzle)
-    const int srow = wave * 8 + lrow;
-    const int b_off0 = (n0 + srow) * a.Cin + swz(srow, lchunk) * 8;      // weight row of piece-row i: + i*64*Cin
-    const int b_step = 64 * a.Cin;
+    // R32: a 1 KiB piece = 16 rows x 64 B (lane -> row lane >> 2, 16-byte position lane & 3); a wave stages rows [32 wave, +32) of
+    // both operands as two pieces; logical 16-byte chunk q of row r sits at position q ^ ((r >> 2) & 3) (swizzle on the SOURCE:
+    // the thread at position p fetches chunk p ^ ((r >> 2) & 3); rows 16 / 32 apart share it), conflict-free for the
+    // ds_read_b128 lane groups of the fragment reads (16 rows x one chunk each = the 16 slots of four 256-byte bank rows).
+    const int srow = R32 ? wave * 32 + (lane >> 2) : wave * 8 + lrow;
+    const int schk = R32 ? (((lane & 3) ^ ((srow >> 2) & 3)) * 8) : swz(srow, lchunk) * 8;     // element offset of this thread's chunk
+    const int b_off0 = (n0 + srow) * a.Cin + schk;                        // weight row of piece-row i: + i * b_step
+    const int b_step = (R32 ? 16 : 64) * a.Cin;
     // Per-tap tables live in LANES (lane t = tap t) and are fetched with v_readlane: a kernarg (SMEM) load indexed by a loop
     // counter costs a ~200-cycle round trip each (the tap-mask loop of round 1's kernels: 36 of them, 7k cycles per workgroup),
     // and inside the K loop it would make hipcc wait lgkmcnt(0), i.e. for every fragment read in flight.
@@ -482,7 +490,9 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     const bf16_t* a_ptr[NI2];
     unsigned a_mask[NI2];
     int a_iy[NI2], a_ix[NI2];
-    auto tile_row = [&](int i) { return (i % NI) * 64 + (i < NI ? wave : (wave ^ 4)) * 8 + lrow; };
+    auto tile_row = [&](int i) { return R32 ? wave * 32 + i * 16 + (lane >> 2) : (i % NI) * 64 + (i < NI ? wave : (wave ^ 4)) * 8 + lrow; };
+    // element offset of the thread's 16-byte chunk inside the K-tile's channel range, for tile row `row`
+    auto row_chunk = [&](int row) { return R32 ? (((lane & 3) ^ ((row >> 2) & 3)) * 8) : swz(row, lchunk) * 8; };
     unsigned tmask = 0xffffffffu;       // taps any row of the tile needs (pixel-major tiles skip the others)
     if (a.pixmajor) {
         // pixel-major rows (RoI maps): the tile's rows are linear in the row index within each of its (at most two) segments,
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             const bool k = row >= rs1;
             const int idx = k ? row - rs1 : row;
             const bool ok = idx < (k ? nv1 : nv0);
-            a_ptr[i] = ok ? src + ((k ? in1 : in0) + (long)idx * istr + swz(row, lchunk) * 8) : src;
+            a_ptr[i] = ok ? src + ((k ? in1 : in0) + (long)idx * istr + row_chunk(row)) : src;
             a_mask[i] = ok ? (k ? mk1 : mk0) : 0u;
             a_iy[i] = 0; a_ix[i] = 0;
         }
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             if (m < a.M) {
                 a_iy[i] = 0; a_ix[i] = 0;
                 a_mask[i] = 1u;
-                a_ptr[i] = src + ((long)m * a.Cin + swz(row, lchunk) * 8);
+                a_ptr[i] = src + ((long)m * a.Cin + row_chunk(row));
             }
             continue;
         }
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
             const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
             a_iy[i] = oy * a.ss; a_ix[i] = ox * a.ss;
-            a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + swz(row, lchunk) * 8);
+            a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + row_chunk(row));
         }
     }
     kstamp(41);
@@ -702,8 +712,13 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int q = ks * 2 + fq;
-            wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
-            xb[ks] = lds + PXO + rx * 128 + swz(rx, q) * 16;
+            if constexpr (R32) {          // 64-byte rows, two 16-channel sub-steps per K-tile (ks 2, 3 unused)
+                wb[ks] = lds + PW_OFF + rw * 64 + (((q & 3) ^ ((rw >> 2) & 3)) << 4);
+                xb[ks] = lds + PXO + rx * 64 + (((q & 3) ^ ((rx >> 2) & 3)) << 4);
+            } else {
+                wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
+                xb[ks] = lds + PXO + rx * 128 + swz(rx, q) * 16;
+            }
         }
         PIPE_SB();
     };
@@ -910,8 +925,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
             if constexpr (I >= 2 + MJ || (I == 1 && NW == 1)) { }              // (smaller tiles: fewer activation / weight fragments)
             else if constexpr (NOREADS) { asm volatile("" : "=v"(f[I])); }
-            else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBW + I * 4096);
-            else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBX + (I - 2) * 4096);
+            else if constexpr (I < 2) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBW + I * (R32 ? 2048 : 4096));
+            else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBX + (I - 2) * (R32 ? 2048 : 4096));
         };
         auto mm2 = [&](bf16x8 (&f)[6], auto jc) {                               // the two MFMAs of pixel block j
             constexpr int J = decltype(jc)::value;
@@ -965,7 +980,77 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         auto nop = [] {};
         unsigned long long kst_setup = 0ull;
         if constexpr (TRACE) kst_setup = __builtin_amdgcn_s_memtime();
-        if constexpr (NS == 3) {
+        if constexpr (R32) {
+            // ---- ring32 (round 5): 32-channel K-tiles on a FOUR-stage ring.  What the barrier-level traces of the two-stage schedule
+            // say (profiles/round3_probes/stream_ablations.txt): its K-tile takes ~3300 cycles for 2048 of MFMA issue because all 64
+            // pieces of a K-tile are requested in the two sub-steps behind the barrier (a stage is free only from there on and
+            // must have landed one K-tile later), ~1000 cycles each against ~300 for a sub-step without copies.  Half-size K-tiles
+            // fit four stages into the same 128 KiB: a tile's pieces are requested THREE tiles (~3000 cycles) ahead, two per wave
+            // and sub-step in EVERY sub-step, and retired with a counted vmcnt(6) that never waits for a piece younger than two
+            // tiles.  Per K-tile t (stage S = t & 3; 16 MFMAs per wave, two 16-channel sub-steps):
+            //   A: MFMA fa = F(t,0) | read F(t,1) -> fb            | request X(t+3) -> stage (S+3) & 3  (free since SYNC(t-1))
+            //   SYNC(t): vmcnt(6) [tile t+1 landed; t+2 and X(t+3) in flight], lgkmcnt(0) [own reads of stage S done], s_barrier
+            //   B: MFMA fb = F(t,1) | read F(t+1,0) -> fa (stage S+1) | request W(t+3) -> stage (S+3) & 3, advance the sequence
+            // The K order is the two-stage schedule's (chunk of 64 channels, tap, half): results are bit-identical to it.
+            using z_t = std::integral_constant<int, 0>;
+            using st1_t = std::integral_constant<int, 1>;
+            using st2_t = std::integral_constant<int, 2>;
+            using st3_t = std::integral_constant<int, 3>;
+            int sh = 0;                                               // which 32-channel half of the 64-channel chunk is being staged
+            auto issue_x32 = [&](auto ic, auto stc) {
+                constexpr int i = decltype(ic)::value, ST = decltype(stc)::value;
+                const bf16_t* p = ((a_mask[i] >> st_t) & 1u) ? a_ptr[i] + (st_aoff + st_c + sh * 32) : a.zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PXO + ST * PBX + (wave * 32 + i * 16) * 64), 16, 0, 0);
+            };
+            auto issue_w32 = [&](auto ic, auto stc) {
+                constexpr int i = decltype(ic)::value, ST = decltype(stc)::value;
+                const bf16_t* wt = st_w + (sw_c + sh * 32) + b_off0 + (long)i * b_step;
+                __builtin_amdgcn_global_load_lds((gptr_t)wt, (lds_ptr_t)(lds + PW_OFF + ST * PBW + (wave * 32 + i * 16) * 64), 16, 0, 0);
+            };
+            auto advance32 = [&]() {
+                sh ^= 1;
+                if (sh == 0) { advance_x(); advance_w(); }
+            };
+            const int nk32 = 2 * nk;
+            issue_w32(k0_t{}, z_t{}); issue_w32(k1_t{}, z_t{}); issue_x32(k0_t{}, z_t{}); issue_x32(k1_t{}, z_t{});
+            advance32();
+            if (nk32 > 1) { issue_w32(k0_t{}, st1_t{}); issue_w32(k1_t{}, st1_t{}); issue_x32(k0_t{}, st1_t{}); issue_x32(k1_t{}, st1_t{}); advance32(); }
+            if (nk32 > 2) { issue_w32(k0_t{}, st2_t{}); issue_w32(k1_t{}, st2_t{}); issue_x32(k0_t{}, st2_t{}); issue_x32(k1_t{}, st2_t{}); advance32(); }
+            late_init();
+            if (nk32 > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nk32 > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PIPE_BARRIER();
+            in_loop = true;
+            rd1(fa, z_t{}, k0_t{}, k0_t{}); rd1(fa, z_t{}, k0_t{}, k1_t{}); rd1(fa, z_t{}, k0_t{}, k2_t{});
+            rd1(fa, z_t{}, k0_t{}, k3_t{}); rd1(fa, z_t{}, k0_t{}, i4_t{}); rd1(fa, z_t{}, k0_t{}, i5_t{});
+            auto tile32 = [&](auto stc, auto has1, auto has3) {
+                constexpr int S = decltype(stc)::value;
+                using nxt_t = std::integral_constant<int, (S + 1) & 3>;
+                using tgt_t = std::integral_constant<int, (S + 3) & 3>;
+                substep(fa, fb, stc, k1_t{}, true, [&] { if (has3) issue_x32(k0_t{}, tgt_t{}); }, [&] { if (has3) issue_x32(k1_t{}, tgt_t{}); }, z_t{});
+                if (has1) {
+                    if (has3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    PIPE_BARRIER();
+                }
+                substep(fb, fa, nxt_t{}, k0_t{}, has1, [&] { if (has3) issue_w32(k0_t{}, tgt_t{}); },
+                        [&] { if (has3) { issue_w32(k1_t{}, tgt_t{}); advance32(); } }, z_t{});
+            };
+            int t = 0;
+            for (; t + 6 < nk32; t += 4) {             // steady state: all four tiles of the round have three successors
+                tile32(z_t{}, std::true_type{}, std::true_type{});
+                tile32(st1_t{}, std::true_type{}, std::true_type{});
+                tile32(st2_t{}, std::true_type{}, std::true_type{});
+                tile32(st3_t{}, std::true_type{}, std::true_type{});
+            }
+            for (; t < nk32; t += 4) {
+                tile32(z_t{}, t + 1 < nk32, t + 3 < nk32);
+                if (t + 1 < nk32) tile32(st1_t{}, t + 2 < nk32, t + 4 < nk32);
+                if (t + 2 < nk32) tile32(st2_t{}, t + 3 < nk32, t + 5 < nk32);
+                if (t + 3 < nk32) tile32(st3_t{}, t + 4 < nk32, t + 6 < nk32);
+            }
+        } else if constexpr (NS == 3) {
             // ---- three-stage ring: per K-tile t (buffer B = t % 3)
             //   ks0: MFMA fa | read F(t,1) | request X(t+2) -> buffer (B+2) % 3      (free since SYNC(t-1): last read by tile t-1)
             //   ks1: MFMA fb | read F(t,2) | request W(t+2) -> buffer (B+2) % 3
@@ -1303,8 +1388,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
-int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s) {
+int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s, int ring32) {
     ConvArgs a = a_in;
+    if (ring32 && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.tap_major && !a.krot && !a.nterms))
+        return (int)hipErrorInvalidValue;
     if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
     if (mode == 2 && (a.Cout % 256 || nw_force == 1)) return (int)hipErrorInvalidValue;
     const int nw = nw_force == 1 ? 1 : (a.Cout % 256 == 0 ? 2 : 1);       // 128-cout tiles: Cout = 128 (mod 256), or by choice with 64-pixel tiles
@@ -1330,6 +1417,8 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         else if (mj == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2, 2, true>), grid, dim3(512), 0, s, a);
         else if (mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true>), grid, dim3(512), 0, s, a);
+    } else if (ring32) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, true>), grid, dim3(512), 0, s, a);
     } else if (nw == 1 && mj == 1) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 1>), grid, dim3(512), 0, s, a);
     } else if (nw == 1) {

@@ -360,7 +360,7 @@ LOFT_EXPORT int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vo
 #else
 #define LOFT_PLANES 3
 #endif
-__global__ void absmax_f32_kernel(const float* __restrict__ x, long nvec, unsigned* __restrict__ out) {
+__device__ __forceinline__ float absmax_block(const float* __restrict__ x, long nvec) {
     float m = 0.f;
     bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
@@ -375,15 +375,15 @@ __global__ void absmax_f32_kernel(const float* __restrict__ x, long nvec, unsign
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        if (m > 0.f) atomicMax(out, __float_as_uint(m));  // (non-negative floats order as their bits)
-    }
+    return fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
 }
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ x, long nvec, unsigned* __restrict__ out) {
+    const float m = absmax_block(x, nvec);
+    if (threadIdx.x == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));  // (non-negative floats order as their bits)
+}
+// amax_out: a PRE-ZEROED word (the caller's slot pool: one memset per few thousand tensors instead of one per tensor)
 LOFT_EXPORT int loft_absmax_f32(const float* x, int64_t n, float* amax_out, void* stream) {
     if (n % 4) return (int)hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
     if (n <= 0) return 0;
     dim3 grid = ew_grid(n / 4);
     if (grid.x > 1024) grid.x = 1024;                     // four workgroups per CU stream at the HBM rate; 1024 atomics at the end
@@ -391,9 +391,7 @@ LOFT_EXPORT int loft_absmax_f32(const float* x, int64_t n, float* amax_out, void
     LOFT_LAUNCH_CHECK();
     return 0;
 }
-__global__ void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ planes, long nvec, long n,
-                                    const float* __restrict__ amax) {
-    const float sc = amax ? planes_scale_of(*amax, false) : 1.f;
+__device__ __forceinline__ void split_planes_body(const float* __restrict__ x, bf16_t* __restrict__ planes, long nvec, long n, float sc) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         float r[8], h[8];
         const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
@@ -411,11 +409,87 @@ __global__ void split_planes_kernel(const float* __restrict__ x, bf16_t* __restr
         }
     }
 }
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ planes, long nvec, long n,
+                                                           const float* __restrict__ amax) {
+    split_planes_body(x, planes, nvec, n, amax ? planes_scale_of(*amax, false) : 1.f);
+}
+// Small tensors (packed weights, RoI-level maps of a few MB): absmax AND split in ONE launch.  Every workgroup of the (<= 256
+// workgroup, hence co-resident) grid publishes its maximum, arrives at a counter, waits for the others, reads the tensor's
+// absmax and splits its share -- two launches and their boundary less per tensor, ~400 of them per step of the fp32 mode.
+// slot[0] = absmax (float bits), slot[1] = arrival counter: both PRE-ZEROED by the caller; slot[0] holds the absmax afterwards.
+__global__ __launch_bounds__(256) void absmax_split_fused_kernel(const float* __restrict__ x, bf16_t* __restrict__ planes, long n,
+                                                                 unsigned* __restrict__ slot) {
+    const float m = absmax_block(x, n / 4);
+    __shared__ float amax_s;
+    if (threadIdx.x == 0) {
+        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+        __threadfence();
+        atomicAdd(slot + 1, 1u);
+        unsigned spins = 0;
+        while (__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 26))
+            __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+        amax_s = __uint_as_float(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+    split_planes_body(x, planes, n / 8, n, planes_scale_of(amax_s, false));
+}
 LOFT_EXPORT int loft_planes_per_tensor(void) { return LOFT_PLANES; }
 LOFT_EXPORT int loft_split_planes_f32(const float* x, int64_t n, void* planes, const float* amax, void* stream) {
     if (n <= 0) return 0;
     if (n % 8) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(split_planes_kernel, ew_grid(n / 8), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)planes, n / 8, (long)n, amax);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+// absmax + split of one tensor: slot = two PRE-ZEROED 32-bit words (absmax, scratch); slot[0] is the absmax afterwards (the value
+// the contraction kernels take as amax_*).  One fused launch up to 4 Mi elements, two launches above.
+LOFT_EXPORT int loft_absmax_split_planes_f32(const float* x, int64_t n, void* planes, float* slot, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8) return (int)hipErrorInvalidValue;
+#ifndef LOFT_ACT_F16
+    if (slot == nullptr) return loft_split_planes_f32(x, n, planes, nullptr, stream);     // bfloat16 planes carry no scale
+#endif
+    if (slot == nullptr) return (int)hipErrorInvalidValue;
+    if (n <= (4l << 20)) {
+        const long nb = (n / 8 + 255) / 256;
+        hipLaunchKernelGGL(absmax_split_fused_kernel, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16_t*)planes, (long)n, (unsigned*)slot);
+        LOFT_LAUNCH_CHECK();
+        return 0;
+    }
+    const int e = loft_absmax_f32(x, n, slot, stream);
+    return e ? e : loft_split_planes_f32(x, n, planes, slot, stream);
+}
+// out[g][c] += sum over the rows of x[g][rows][C]: the bias gradient of the fp32 mode's convolutions (a strided library reduction
+// over the NHWC gradient took 0.44 ms per layer).  A workgroup = 4 row phases x 64 lanes of 4 channels (C <= 256 per pass), its
+// partial sums meet in LDS and leave as one atomic per channel.  out accumulates (the caller zeroes it).  C % 4 == 0.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, long rows, int C, float* __restrict__ out) {
+    const float* xg = x + (long)blockIdx.y * rows * C;
+    float* og = out + (long)blockIdx.y * C;
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    __shared__ float part[4][256];
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + lane * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C)
+            for (long r = (long)blockIdx.x * 4 + ph; r < rows; r += (long)gridDim.x * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xg + r * C + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        part[ph][lane * 4 + 0] = acc.x; part[ph][lane * 4 + 1] = acc.y; part[ph][lane * 4 + 2] = acc.z; part[ph][lane * 4 + 3] = acc.w;
+        __syncthreads();
+        const int cc = c0 + threadIdx.x;
+        if (cc < C) unsafeAtomicAdd(og + cc, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+LOFT_EXPORT int loft_colsum_f32(const float* x, int64_t rows, int C, int groups, float* out, void* stream) {
+    if (rows <= 0 || groups < 1) return 0;
+    if (C % 4 || C < 4) return (int)hipErrorInvalidValue;
+    long nb = (rows + 63) / 64;
+    nb = nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)nb, groups), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -483,7 +483,7 @@ def _bf16(t):
 # include/loft_hip.h LOFT_CONV_*: kernel selector of loft_conv_tap_bf16_v.  0 = the library's shape heuristics (the shipped path).
 # tests / tools set CONV_VARIANT to a code, or to a callable (groups, B, OH, OW, Cin, Cout, T, ss, os) -> code, to pin a template.
 CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_FAST, CONV_T128, CONV_T128x64, CONV_PATCH64, \
-    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N = range(15)
+    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N, CONV_RING32 = range(16)
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT, CONV_FLAG_TAP_MAJOR, CONV_FLAG_NO_ROI_BLOCKS, CONV_FLAG_KROT = \
     0x100, 0x200, 0x400, 0x800, 0x10000, 0x20000
 CONV_VARIANT = CONV_AUTO
@@ -509,16 +509,28 @@ def _f32_kernel_code():
     return F32_SPLIT6 if F32_CONTRACT in _PLANE_MODES else int(F32_CONTRACT)
 
 
+_SLOT_POOLS = {}      # raw stream -> [buffer, words used]: pre-zeroed (absmax, counter) pairs, one memset per 2048 tensors and stream
+
+
+def _amax_slot(device):
+    """Two zeroed words for loft_absmax_split_planes_f32, from a pool filled ON THE CURRENT STREAM (the zero fill is ordered
+    before every kernel that uses a slot only on the stream that issued it)."""
+    key = (str(device), L.stream().value)
+    sp = _SLOT_POOLS.get(key)
+    if sp is None or sp[1] + 2 > sp[0].numel():
+        sp = _SLOT_POOLS[key] = [torch.zeros(4096, dtype=torch.float32, device=device), 0]
+    v = sp[0][sp[1]:sp[1] + 2]
+    sp[1] += 2
+    return v
+
+
 def split_planes(x, dtype16):
-    """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_split_planes_f32."""
+    """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_absmax_split_planes_f32."""
     lib = L.load_for(dtype16)
     n = x.numel()
     planes = torch.empty((lib.loft_planes_per_tensor(), n), dtype=dtype16, device=x.device)
-    amax = None
-    if dtype16 == torch.float16:
-        amax = torch.empty(1, dtype=torch.float32, device=x.device)
-        L.check(lib.loft_absmax_f32(L.ptr(x), c_int64(n), L.ptr(amax), L.stream()), 'loft_absmax_f32')
-    L.check(lib.loft_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), L.ptr(amax), L.stream()), 'loft_split_planes_f32')
+    amax = _amax_slot(x.device) if dtype16 == torch.float16 else None
+    L.check(lib.loft_absmax_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), L.ptr(amax), L.stream()), 'loft_absmax_split_planes_f32')
     return planes, amax
 
 
@@ -545,8 +557,26 @@ def planes_scoped(fn):
     return wrapper
 
 
-def _split_memo(x, dtype16, memo):
-    """split_planes with a memo (the caller's dict, else the innermost planes_scoped call's, else none)."""
+# Planes of a forward convolution's INPUT are needed again by that layer's weight gradient: conv2d_fwd leaves them here, keyed by
+# (storage pointer, shape, version, plane type), until the tensor dies (weakref finalizer) or the weight gradient takes them.
+_FWD_PLANES = {}
+FWD_PLANES_CACHE = True
+
+
+def _fwd_planes_put(x, dtype16, val):
+    import weakref
+    key = (x.data_ptr(), tuple(x.shape), x._version, dtype16)
+    _FWD_PLANES[key] = val
+    weakref.finalize(x, _FWD_PLANES.pop, key, None)
+
+
+def _split_memo(x, dtype16, memo, take_fwd=False):
+    """split_planes with a memo (the caller's dict, else the innermost planes_scoped call's, else none); take_fwd: use (and drop)
+    the planes the forward pass left for this tensor."""
+    if take_fwd:
+        hit = _FWD_PLANES.pop((x.data_ptr(), tuple(x.shape), x._version, dtype16), None)
+        if hit is not None:
+            return hit
     if memo is None:
         memo = _SCOPES[-1] if _SCOPES else None
     if memo is None:
@@ -566,7 +596,7 @@ def _wgrad_variant(*shape):
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
              residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None,
-             planes_memo=None):
+             planes_memo=None, planes_cache=False):
     """Raw launch of loft_conv_tap_bf16 (or loft_conv_tap_f32 when every operand is fp32: the forward-only parity mode).
     taps: list of (dy, dx, weight_tap_index)."""
     lib = L.load()
@@ -582,6 +612,8 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
             if T * len(terms) <= 64:
                 plib = L.load_for(dt16)
                 (xp, ax), (wp, aw) = _split_memo(src, dt16, planes_memo), split_planes(wgt, dt16)
+                if planes_cache and FWD_PLANES_CACHE:
+                    _fwd_planes_put(src, dt16, (xp, ax))
                 e = plib.loft_conv_tap_planes(L.ptr(xp), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
                                               L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0], oo[1], ss, T,
                                               L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
@@ -627,7 +659,7 @@ def conv_out_size(i, k, stride, pad):
     return (i + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=None, groups=1):
+def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=None, groups=1, planes_cache=False):
     """x [G*B,Cin,IH,IW] channels_last bf16, wp [G][R*S,Cout,Cin] bf16 -> [G*B,Cout,OH,OW] channels_last."""
     x = _nhwc(x)
     GB, Cin, IH, IW = x.shape
@@ -638,7 +670,7 @@ def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, ou
     taps = [(r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
     conv_tap(x, wp, out, B, IH, IW, Cin, Cout, OH, OW, OH, OW, taps, ss=stride, bias=bias, residual=residual,
              relu=relu, groups=groups, src_gs=B * IH * IW * Cin, wgt_gs=R * S * Cout * Cin,
-             out_gs=B * OH * OW * Cout, bias_gs=Cout)
+             out_gs=B * OH * OW * Cout, bias_gs=Cout, planes_cache=planes_cache)
     return out
 
 
@@ -743,7 +775,7 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                 and x.numel() % 8 == 0 and B * OH * OW > 0 and groups * len(_PLANE_MODES[F32_CONTRACT][1]) <= 32):
             dt16, terms = _PLANE_MODES[F32_CONTRACT]
             plib = L.load_for(dt16)
-            (gp, ag), (xp, ax) = _split_memo(g, dt16, planes_memo), _split_memo(x, dt16, planes_memo)
+            (gp, ag), (xp, ax) = _split_memo(g, dt16, planes_memo), _split_memo(x, dt16, planes_memo, take_fwd=True)
             e = plib.loft_conv_wgrad_planes(L.ptr(gp), L.ptr(xp), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH, XW, Cin,
                                             OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs),
                                             c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), len(terms),
@@ -760,7 +792,13 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
                                           A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs), c_int64(x_gs),
                                               c_int64(n_wtaps * Cout * Cin), _f32_kernel_code(), L.stream()), 'loft_conv_wgrad_f32_v')
         if db is not None:
-            db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
+            if _dense(g) and g.dim() == 4 and Cout % 4 == 0 and g.is_contiguous(memory_format=torch.channels_last):
+                tmp = db if (db.shape[1] == Cout and db.is_contiguous()) else torch.zeros(groups, Cout, dtype=torch.float32, device=g.device)
+                L.check(lib.loft_colsum_f32(L.ptr(g), c_int64(B * GH * GW), Cout, groups, L.ptr(tmp), L.stream()), 'loft_colsum_f32')
+                if tmp is not db:
+                    db += tmp[:, :db.shape[1]]
+            else:
+                db += g.view(groups, -1, *g.shape[1:]).sum(dim=(1, 3, 4))[:, :db.shape[1]]
         return dw
     _bf16(g), _bf16(x)
     _ev = _prof_begin()

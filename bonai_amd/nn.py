@@ -223,7 +223,8 @@ class _ConvFn(torch.autograd.Function):
                 _pack_cache_put(key, ctens, (wp, wpt, bias))
         use_bias = has_b or bn_stats is not None
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
-                         out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else K.L.act16(), groups=G)
+                         out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else K.L.act16(), groups=G,
+                         planes_cache=any(ctx.needs_input_grad[3:]))
         ctx.meta = meta
         ctx.params = tensors            # the Parameter objects themselves (their .grad may be an arena slot)
         for k, t in enumerate(tensors):  # uses per step of each parameter: the gradient sink fires after the last one
@@ -370,7 +371,7 @@ class _LinearFn(torch.autograd.Function):
             weff = w if flat_chw is None else w.view(O, *flat_chw).permute(0, 2, 3, 1).reshape(O, Kd)
             wp, wpt, bias = K.fold_pack(weff.reshape(O, Kd, 1, 1), b, None, 1e-5, want_dgrad=need_dgrad)
             wp, wpt, bias = wp[None], None if wpt is None else wpt[None], bias[None]
-        y = K.conv2d_fwd(x4, wp, bias if b is not None else None, 1, 1, 1, 0, relu=relu, out_dtype=K.L.act16())
+        y = K.conv2d_fwd(x4, wp, bias if b is not None else None, 1, 1, 1, 0, relu=relu, out_dtype=K.L.act16(), planes_cache=True)
         ctx.cfg = (relu, input_relu, flat_chw, tuple(x.shape))
         ctx.params = (w, b)
         for k, t in enumerate((w, b)):
@@ -1128,13 +1129,13 @@ class _ResBlockFn(torch.autograd.Function):
         if sc_spec is not None:
             k, s, p, cp = sc_spec
             wp, wpt, bias = _rb_pack(tensors[3 * n], bns[n], x.shape[1], cp or tensors[3 * n].shape[0], need_dx, pdt)
-            sc = K.conv2d_fwd(x, wp, bias, k, k, s, p, out_dtype=pdt)
+            sc = K.conv2d_fwd(x, wp, bias, k, k, s, p, out_dtype=pdt, planes_cache=True)
             packs.append(wpt)
         for i, (k, s, p, cp) in enumerate(main_specs):
             last = i == n - 1
             w = tensors[3 * i]
             wp, wpt, bias = _rb_pack(w, bns[i], h.shape[1], cp or w.shape[0], need_dx or i > 0, pdt)
-            h = K.conv2d_fwd(h, wp, bias, k, k, s, p, relu=True, residual=sc if last else None, out_dtype=pdt)
+            h = K.conv2d_fwd(h, wp, bias, k, k, s, p, relu=True, residual=sc if last else None, out_dtype=pdt, planes_cache=True)
             packs.insert(i, wpt)
             if not last:
                 acts.append(h)

@@ -202,6 +202,7 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
 #define LOFT_CONV_STREAM64N 12    /* ... on 64-pixel x 128-cout tiles (256-channel convs on 32 x 32 maps: FPN P5, the RPN conv on it) */
 #define LOFT_CONV_ROLES256 13     /* 256x256x64, role-split stream: waves 0-3 issue every activation copy, waves 4-7 every weight copy (three weight stages) */
 #define LOFT_CONV_STREAM256N 14   /* the stream kernel on 256-pixel x 128-cout tiles with the THREE-stage ring also for Cout % 256 == 0 (1.5x the copy bytes per FLOP of the 256 x 256 tile, two K-tiles of look-ahead instead of one; A/B) */
+#define LOFT_CONV_RING32 15       /* the stream kernel's 256 x 256 tile with 32-channel K-tiles on a FOUR-stage ring: pieces requested three tiles ahead, two per wave and sub-step, counted vmcnt (bit-identical to LOFT_CONV_STREAM256) */
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400
@@ -256,7 +257,7 @@ int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, c
  * software-pipelined 16-bit kernels (conv_pipe.hip, conv_wgrad_pipe.hip) instead of kernels of their own.  Reference lines: every
  * nn.Conv2d / nn.Linear of the LOFT path evaluated in fp32 (detectors/base.py:159-173 before its fp16 cast; the reference's CPU path).
  *   loft_planes_per_tensor()      NP of this build: 2 (binary16 build) or 3 (bfloat16 build)
- *   loft_absmax_f32(x, n, amax)   amax[0] = max |x| as a device scalar (n % 4 == 0); inf when x holds a NaN
+ *   loft_absmax_f32(x, n, amax)   amax[0] = max(amax[0], max |x|) as a device scalar (n % 4 == 0; the caller hands a zeroed word); inf when x holds a NaN
  *   loft_split_planes_f32(x, n, planes, amax)   planes [NP][n] of the build's 16-bit type with
  *                                 x * scale = plane_0 + plane_1 (+ plane_2), plane_k = RNE16 of the remainder; scale = the power of two
  *                                 that puts amax into [2^14, 2^15) (amax NULL, 0, inf: 1).  binary16 build: 22 significant bits per
@@ -271,8 +272,15 @@ int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, c
  *   loft_conv_wgrad_planes(...)   loft_conv_wgrad_bf16's contract on G / X planes: every term adds into dw (caller zeroes) through the
  *                                 split-K atomics, scaled by 1 / (scale_g * scale_x).  Cout % 128 == 0, Cin % 128 == 0; no fused bias gradient. */
 int loft_planes_per_tensor(void);
-int loft_absmax_f32(const float* x, int64_t n, float* amax_out, void* stream);
+int loft_absmax_f32(const float* x, int64_t n, float* amax_out /* PRE-ZEROED by the caller */, void* stream);
 int loft_split_planes_f32(const float* x, int64_t n, void* planes, const float* amax, void* stream);
+/* absmax + split of one tensor.  slot: two PRE-ZEROED 32-bit words (the caller's pool: one memset per few thousand tensors);
+ * slot[0] holds the absmax afterwards -- the amax_* argument of the contraction entry points.  Up to 4 Mi elements ONE launch (a
+ * co-resident grid of <= 256 workgroups meets at a counter between the two phases), above that two.  n % 8 == 0. */
+int loft_absmax_split_planes_f32(const float* x, int64_t n, void* planes, float* slot, void* stream);
+/* out[g][c] += sum_r x[g][r][c]  (x fp32 [groups][rows][C], C % 4 == 0; out fp32 [groups][C], accumulated into): the bias gradient
+ * of the fp32 parity mode's convolutions / linear layers (sum over pixels of the NHWC output gradient). */
+int loft_colsum_f32(const float* x, int64_t rows, int C, int groups, float* out, void* stream);
 int loft_conv_tap_planes(const void* src, const void* wgt, const float* bias, const float* residual, const float* relu_mask,
                          float* out, const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf,
                          int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,

@@ -350,6 +350,36 @@ def test_role_split_schedule_bit_identical_to_stream_schedule_at_bench_size():
             assert torch.equal(a_, b_), (G, B, Cin, Cout, H, W, R)
 
 
+def test_ring32_schedule_bit_identical_to_stream_schedule_at_bench_size():
+    """conv_tap_pipe_kernel<1,0,4,2,false,true> (round 5, LOFT_CONV_RING32: 32-channel K-tiles on a four-stage ring, pieces
+    requested three tiles ahead and retired with a counted vmcnt) walks K in the two-stage stream schedule's order (64-channel
+    chunk, tap, half) and so computes the same fp32 sums: forward (bias + ReLU, residual) and data gradient (ReLU mask) at the
+    bench's sizes -- FOA (4 groups, pixel-major, skipped taps), mask head, FPN P2 3x3, an FC, one-chunk and two-chunk 1x1
+    launches (2 and 4 K-tiles of 32: the ring's prologue / tail paths), a RoI count that leaves padding rows -- torch.equal."""
+    from bonai_amd import kernels as K
+    for (G, B, Cin, Cout, H, W, R, pad) in [(4, 2048, 256, 256, 7, 7, 3, 1), (1, 2048, 256, 256, 14, 14, 3, 1), (1, 8, 256, 256, 256, 256, 3, 1),
+                                           (1, 8192, 1024, 1024, 1, 1, 1, 0), (1, 8, 64, 256, 256, 256, 1, 0), (1, 8, 128, 512, 128, 128, 1, 0),
+                                           (1, 777, 256, 256, 7, 7, 3, 1), (1, 8, 256, 256, 64, 64, 3, 1), (1, 8, 192, 256, 96, 96, 3, 1)]:
+        x, w, bias = _mk(G, B, Cin, Cout, H, W, R, seed=B + Cin)
+        wp = torch.stack([K.pack_w_fwd(w[i]) for i in range(G)])
+        wpt = torch.stack([K.pack_w_dgrad(w[i]) for i in range(G)])
+        res = _cl(torch.randn(G * B, Cout, H, W, device='cuda').bfloat16())
+        outs = []
+        for v in (K.CONV_STREAM256, K.CONV_RING32):
+            K.CONV_VARIANT = v
+            try:
+                o = [K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, groups=G),
+                     K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, residual=res, groups=G)]
+                if Cin % 256 == 0:
+                    o.append(K.conv2d_dgrad(res, wpt, (H, W), R, R, 1, pad, mask=x, groups=G))
+            finally:
+                K.CONV_VARIANT = K.CONV_AUTO
+            outs.append(o)
+        torch.cuda.synchronize()
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_), (G, B, Cin, Cout, H, W, R)
+
+
 @pytest.mark.parametrize('downsample', [False, True])
 @pytest.mark.parametrize('hw', [(48, 64), (40, 56), (17, 250)])
 def test_fused_bottleneck_tail_matches_the_unfused_block(downsample, hw):

@@ -677,7 +677,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     a.relu = relu; a.out_f32 = out_f32; a.accumulate = accumulate;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;
-    a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr;
+    a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr; a.amax_out = nullptr;
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
     fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
     fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
@@ -844,6 +844,7 @@ LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float
 // (loft_split_planes_f32: plane p of src at element offset p * x_ps, of wgt at p * w_ps); term i multiplies activation plane
 // xpl[i] with weight plane wpl[i]; all terms of all taps accumulate in fp32 in ONE K loop.  bias, residual, relu_mask, out: fp32,
 // semantics of loft_conv_tap_bf16.  amax_x / amax_w: the device scalars the planes were scaled with (both or neither).
+// amax_out (optional, PRE-ZEROED): receives max |out| over the elements this launch stores.
 // Returns hipErrorInvalidValue for shapes the stream kernel does not serve (Cout % 128, Cin % 64, nterms * T > 64, plane offsets
 // beyond 2^31 elements): the caller then takes loft_conv_tap_f32.
 LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const float* bias, const float* residual,
@@ -852,7 +853,7 @@ LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const flo
                                      const int* dy_host, const int* dx_host, const int* wt_host, int relu, int groups,
                                      int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int nterms,
                                      const int* xpl_host, const int* wpl_host, int64_t x_ps, int64_t w_ps,
-                                     const float* amax_x, const float* amax_w, void* stream) {
+                                     const float* amax_x, const float* amax_w, float* amax_out, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 128) || groups < 1 || nterms < 1 || nterms > CONV_MAX_TERMS ||
         nterms * T > 64 || (amax_x == nullptr) != (amax_w == nullptr))
         return (int)hipErrorInvalidValue;
@@ -873,7 +874,7 @@ LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const flo
         if (xpl_host[p] < 0 || wpl_host[p] < 0 || xo + max_a > 0x7fffffffL || wo + max_w > 0x7fffffffL) return (int)hipErrorInvalidValue;
         a.xoff[p] = (int)xo; a.woff[p] = (int)wo;
     }
-    a.amax_x = amax_x; a.amax_w = amax_w;
+    a.amax_x = amax_x; a.amax_w = amax_w; a.amax_out = amax_out;
     a.relu = relu; a.out_f32 = 1; a.accumulate = 0; a.staged_out = 0;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;

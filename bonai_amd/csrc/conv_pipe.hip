@@ -324,6 +324,7 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
     const float* msk = reinterpret_cast<const float*>(a.mask);
     float* out = reinterpret_cast<float*>(a.out);
     const bool relu = a.relu != 0;
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
         const int r = wm * (32 * MJ) + j * 32 + frow;
@@ -370,7 +371,14 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
                     v[2] = mv.z > 0.f ? v[2] : 0.f; v[3] = mv.w > 0.f ? v[3] : 0.f;
                 }
                 *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if ((v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3])) vmax = __builtin_inff();
             }
+    }
+    if (a.amax_out) {           // one fire-and-forget atomic per wave (non-negative floats order as their bits)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __float_as_uint(vmax));
     }
 }
 

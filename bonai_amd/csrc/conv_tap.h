@@ -71,6 +71,8 @@ struct ConvArgs {
     int xoff[CONV_MAX_TERMS], woff[CONV_MAX_TERMS];
     const float* amax_x;
     const float* amax_w;
+    float* amax_out;         // optional (plane launches): max |stored output| is atomically folded into this PRE-ZEROED word, so that
+                             // the next layer's plane split of `out` needs no absmax pass of its own
 };
 
 // Power-of-two scale of a plane split (loft_split_planes_f32 with an absmax scalar; the binary16 build): the tensor's absmax lands

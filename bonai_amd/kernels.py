@@ -524,12 +524,37 @@ def _amax_slot(device):
     return v
 
 
+AMAX_FROM_PRODUCER = True     # a plane launch's epilogue leaves max |out| with its output tensor; the next split skips its absmax pass
+
+
+def _known_amax(x):
+    """The absmax slot a plane launch attached to its output, if the tensor is still what that launch wrote (same storage, no
+    version bump; raw in-place kernels drop the note themselves: _drop_amax)."""
+    note = getattr(x, '_loft_amax', None)
+    if note is not None and AMAX_FROM_PRODUCER and note[1] == x.data_ptr() and note[2] == x._version and note[3] == x.numel():
+        return note[0]
+    return None
+
+
+def _drop_amax(t):
+    if t is not None and getattr(t, '_loft_amax', None) is not None:
+        t._loft_amax = None
+
+
 def split_planes(x, dtype16):
-    """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_absmax_split_planes_f32."""
+    """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_absmax_split_planes_f32, or the
+    split alone when the tensor's producer already measured its absmax."""
     lib = L.load_for(dtype16)
     n = x.numel()
     planes = torch.empty((lib.loft_planes_per_tensor(), n), dtype=dtype16, device=x.device)
-    amax = _amax_slot(x.device) if dtype16 == torch.float16 else None
+    if dtype16 != torch.float16:
+        L.check(lib.loft_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), c_void_p(0), L.stream()), 'loft_split_planes_f32')
+        return planes, None
+    amax = _known_amax(x)
+    if amax is not None:
+        L.check(lib.loft_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), L.ptr(amax), L.stream()), 'loft_split_planes_f32')
+        return planes, amax
+    amax = _amax_slot(x.device)
     L.check(lib.loft_absmax_split_planes_f32(L.ptr(x), c_int64(n), L.ptr(planes), L.ptr(amax), L.stream()), 'loft_absmax_split_planes_f32')
     return planes, amax
 
@@ -612,6 +637,12 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
             if T * len(terms) <= 64:
                 plib = L.load_for(dt16)
                 (xp, ax), (wp, aw) = _split_memo(src, dt16, planes_memo), split_planes(wgt, dt16)
+                # the launch writes EVERY element of a dense `out` (no output stride / offset, all groups): its epilogue can vouch
+                # for the tensor's absmax
+                whole = (dt16 == torch.float16 and AMAX_FROM_PRODUCER and os == 1 and OHf == OH and OWf == OW and _dense(out)
+                         and out.numel() == groups * B * OH * OW * Cout)
+                oslot = _amax_slot(src.device) if whole else None
+                _drop_amax(out)
                 if planes_cache and FWD_PLANES_CACHE:
                     _fwd_planes_put(src, dt16, (xp, ax))
                 e = plib.loft_conv_tap_planes(L.ptr(xp), L.ptr(wp), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
@@ -620,13 +651,16 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
                                               L.arr(c_int, [t[2] for t in taps]), int(relu), groups, c_int64(src_gs), c_int64(wgt_gs),
                                               c_int64(out_gs), c_int64(bias_gs), len(terms), L.arr(c_int, [t[0] for t in terms]),
                                               L.arr(c_int, [t[1] for t in terms]), c_int64(src.numel()), c_int64(wgt.numel()),
-                                              L.ptr(ax), L.ptr(aw), L.stream())
+                                              L.ptr(ax), L.ptr(aw), L.ptr(oslot), L.stream())
                 if e == 0:
                     PLANES_STATS['planes'] += 1
+                    if oslot is not None:
+                        out._loft_amax = (oslot, out.data_ptr(), out._version, out.numel())
                     return out
                 if e != 1:              # (hipErrorInvalidValue: a shape the stream kernel does not serve -> the fp32 kernels below)
                     L.check(e, 'loft_conv_tap_planes')
         PLANES_STATS['fallback'] += 1
+        _drop_amax(out)
         L.check(lib.loft_conv_tap_f32_v(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
                                         L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
                                         oo[1], ss, T, L.arr(c_int, [t[0] for t in taps]), L.arr(c_int, [t[1] for t in taps]),
@@ -889,6 +923,7 @@ def upsample2x_add_(fine, coarse):
     fine, coarse = _nhwc(fine), _nhwc(coarse)
     B, C, H, W = fine.shape
     if fine.dtype == torch.float32 and coarse.dtype == torch.float32:
+        _drop_amax(fine)            # (written in place by a raw kernel: a producer's absmax note no longer holds)
         L.check(lib.loft_upsample2x_add_f32(L.ptr(fine), L.ptr(coarse), B, H, W, C, L.stream()), 'loft_upsample2x_add_f32')
         return fine
     L.check(lib.loft_upsample2x_add_bf16(L.ptr(_bf16(fine)), L.ptr(_bf16(coarse)), B, H, W, C, L.stream()),
@@ -901,6 +936,7 @@ def downsum2x_add_(coarse, fine):
     fine, coarse = _nhwc(fine), _nhwc(coarse)
     B, C, Hc, Wc = coarse.shape
     if fine.dtype == torch.float32 and coarse.dtype == torch.float32:  # fp32 parity mode
+        _drop_amax(coarse)
         L.check(lib.loft_downsum2x_add_f32(L.ptr(coarse), L.ptr(fine), B, Hc, Wc, fine.shape[2], fine.shape[3], C, L.stream()),
                 'loft_downsum2x_add_f32')
         return coarse
@@ -928,6 +964,7 @@ def subsample2_adjoint_add_(big, small):
     big, small = _nhwc(big), _nhwc(small)
     B, C, H, W = big.shape
     if big.dtype == torch.float32 and small.dtype == torch.float32:    # fp32 parity mode
+        _drop_amax(big)
         L.check(lib.loft_subsample2_add_f32(L.ptr(big), L.ptr(small), B, small.shape[2], small.shape[3], H, W, C, L.stream()),
                 'loft_subsample2_add_f32')
         return big

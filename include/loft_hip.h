@@ -286,7 +286,7 @@ int loft_conv_tap_planes(const void* src, const void* wgt, const float* bias, co
                          int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                          const int* wt_host, int relu, int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
                          int nterms, const int* xpl_host, const int* wpl_host, int64_t x_ps, int64_t w_ps, const float* amax_x,
-                         const float* amax_w, void* stream);
+                         const float* amax_w, float* amax_out /* optional, PRE-ZEROED: max |out| of the stored elements */, void* stream);
 int loft_conv_wgrad_planes(const void* g, const void* x, float* dw, const void* zero_page, int B, int GH, int GW, int Cout, int XH,
                            int XW, int Cin, int OH, int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host,
                            const int* dy_host, const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs,

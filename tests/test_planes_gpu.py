@@ -163,3 +163,40 @@ def test_planes_modes_fall_back_on_unsupported_shapes(planes_mode):
     y = K.conv2d_fwd(_cl(x), K.pack_w_fwd(w.cuda(), torch.float32)[None], None, 3, 3, 1, 1, out_dtype=torch.float32)
     assert K.PLANES_STATS['fallback'] == n0['fallback'] + 1
     assert (y.cpu().double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
+def test_producer_absmax_note_is_exact_and_dropped_by_in_place_kernels():
+    """A plane launch's epilogue leaves max |out| with its output (kernels._known_amax) so that the next layer's split skips its
+    absmax pass: the note equals the tensor's absmax, a chain of two layers gives the same bits with and without it, and both a
+    raw in-place kernel (FPN's upsample-add) and an aten in-place op invalidate it."""
+    from bonai_amd import kernels as K
+    prev = K.F32_CONTRACT
+    K.F32_CONTRACT = K.F32_PLANES_F16
+    try:
+        torch.manual_seed(11)
+        x = _cl(torch.randn(2, 64, 32, 32) * 2.0)
+        w1 = K.pack_w_fwd((torch.randn(256, 64, 3, 3) * 0.05).cuda(), torch.float32)[None]
+        w2 = K.pack_w_fwd((torch.randn(256, 256, 3, 3) * 0.05).cuda(), torch.float32)[None]
+        outs = []
+        for flag in (True, False):
+            K.AMAX_FROM_PRODUCER = flag
+            y = K.conv2d_fwd(x, w1, None, 3, 3, 1, 1, relu=True, out_dtype=torch.float32)
+            note = K._known_amax(y)
+            assert (note is not None) == flag
+            if flag:
+                assert note[0].item() == y.abs().max().item()
+            outs.append(K.conv2d_fwd(y, w2, None, 3, 3, 1, 1, out_dtype=torch.float32))
+        assert torch.equal(outs[0], outs[1])
+        K.AMAX_FROM_PRODUCER = True
+        y = K.conv2d_fwd(x, w1, None, 3, 3, 1, 1, relu=True, out_dtype=torch.float32)
+        coarse = _cl(torch.randn(2, 256, 16, 16) * 50.0)
+        K.upsample2x_add_(y, coarse)
+        assert K._known_amax(y) is None
+        y2 = K.conv2d_fwd(x, w1, None, 3, 3, 1, 1, relu=True, out_dtype=torch.float32)
+        y2.mul_(100.0)
+        assert K._known_amax(y2) is None
+        z = K.conv2d_fwd(y2, w2, None, 3, 3, 1, 1, out_dtype=torch.float32)
+        assert torch.isfinite(z).all()
+    finally:
+        K.F32_CONTRACT = prev
+        K.AMAX_FROM_PRODUCER = True

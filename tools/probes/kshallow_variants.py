@@ -8,7 +8,8 @@ from bonai_amd import kernels as K
 SH = [(8, 64, 64, 256, 1024), (8, 128, 128, 128, 512), (8, 256, 256, 64, 256), (8, 32, 32, 512, 2048),
       (8, 64, 64, 1024, 256), (8, 128, 128, 512, 128), (8, 256, 256, 256, 64), (8, 32, 32, 2048, 512)]
 VAR = [('auto', K.CONV_AUTO), ('stream', K.CONV_STREAM256), ('t256f', K.CONV_T256_FAST), ('t128s', K.CONV_T128_SINGLE),
-       ('t128f', K.CONV_T128_FAST), ('t128', K.CONV_T128), ('t128x64', K.CONV_T128x64)]
+       ('t128f', K.CONV_T128_FAST), ('t128', K.CONV_T128), ('t128x64', K.CONV_T128x64), ('s128', K.CONV_STREAM128), ('s64', K.CONV_STREAM64),
+       ('s64n', K.CONV_STREAM64N), ('s256n', K.CONV_STREAM256N), ('ring32', K.CONV_RING32)]
 
 
 def timeit(fn, iters=20):

@@ -161,6 +161,8 @@ class RPNHead(nn.Module):
             self._tgt_stream = torch.cuda.Stream()
         side = self._tgt_stream
         side.wait_stream(main)
+        gts.record_stream(side)                         # (allocated on `main`, read on `side`: the caching allocator must not hand
+        ngt.record_stream(side)                         #  the blocks out again while the side stream still reads them -- ADVICE r4)
         with torch.cuda.stream(side):
             out = self._assign_and_sample(geo, B, gts, ngt, dev)
             done = torch.cuda.Event()
@@ -176,6 +178,14 @@ class RPNHead(nn.Module):
             for t in pre[2]:
                 t.record_stream(main)
             return (gts, ngt) + pre[2]
+        if pre is not None:
+            # the prediction missed (another geometry or gt list than prefetch_targets saw): the side stream's work is dropped, but
+            # not before it has finished with its inputs and outputs; say so once -- it is wasted work every step
+            torch.cuda.current_stream().wait_event(pre[3])
+            if not getattr(self, '_prefetch_miss_logged', False):
+                import warnings
+                warnings.warn('RPNHead.prefetch_targets: predicted map sizes / gt list did not match what loss_fused saw; targets are recomputed')
+                self._prefetch_miss_logged = True
         return (gts, ngt) + self._assign_and_sample(geo, B, gts, ngt, dev)
 
     # ---------------------------------------------------------------- loss

@@ -1005,6 +1005,8 @@ class _SparseRPNFn(torch.autograd.Function):
                     ret.append(None)
                 else:
                     z = torch.zeros_like(x)
+                    if switch:
+                        z.record_stream(cur)           # (allocated from the hub stream's pool, consumed by autograd on `cur`: ADVICE r4)
                     if k is not None:
                         HUB[k] = z
                     dxl.append(z)

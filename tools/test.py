@@ -26,19 +26,17 @@ import torch  # noqa: E402
 def run_dataset(model, ds, evaluate=False, eval_kw=None, log=print):
     """-> (results as single_gpu_test returns them, per-image evaluation records or None)."""
     from bonai_amd import evaluation as E
-    from bonai_amd.rle import rle_encode_masks
     roi = model.roi_head
     roi.test_cfg['keep_device_masks'] = True
+    # simple_test encodes the pasted device bitmaps as RLE itself (one pass): without this it also copied every detection's
+    # full-image bool mask to the host (up to 100 x 1 MiB per tile) for a result this loop then threw away (ADVICE round 4)
+    roi.test_cfg['rle_masks'] = True
     results, records = [], ([] if evaluate else None)
     for i, data in ds.test_batches():
         with torch.no_grad():
-            bbox_res, _, off_res = model(return_loss=False, rescale=True, **data)
+            bbox_res, segm, off_res = model(return_loss=False, rescale=True, **data)
         n_det = sum(b.shape[0] for b in bbox_res)
         pasted = roi.last_device_masks if n_det else None
-        segm = [[] for _ in range(len(bbox_res))]
-        if pasted is not None:
-            for j, r in enumerate(rle_encode_masks(pasted)):            # detection order, grouped by label like bbox_results
-                segm[int(roi.last_det_labels[j])].append(r)
         results.append((bbox_res, segm, off_res))
         if evaluate:
             h, w = data['img_metas'][0][0]['ori_shape'][:2]

@@ -18,6 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 
+# Tolerances of the bf16 end-to-end comparison against the reference-made fixture (tests/golden/e2e_256.npz): 1.5 x what the shipped
+# kernels measure (the measured values are printed by the test and recorded in
+# profiles/round5_probes/bf16_e2e_measured.txt), so that a regression cannot hide inside a generous bound.
+# Measured (three runs, identical to the digit): features 0.0467 of the map's mean magnitude; losses rpn_cls 5.3e-4, rpn_bbox 1e-4,
+# cls 3.7e-3, bbox 1.3e-3, mask 6.2e-3, offset 1.7e-3, total 2.3e-3; gradient norms 5.5e-3; leading entries inside the 0.5 rms floor.
+# (Rounds 1-4 allowed 12 % / 2-5 % / 8 % / 12 %.)
+TOL_BF16 = dict(feat=0.07, loss=dict(loss_rpn_cls=2e-3, loss_rpn_bbox=2e-3, loss_cls=6e-3, loss_bbox=3e-3, loss_mask=1e-2, loss_offset=3e-3,
+                                     loss=4e-3), gradnorm=9e-3, gradhead=0.03)
+
+
 def _build(sample_first=True):
     from bonai_amd.config import Config
     from bonai_amd.loft import build_detector
@@ -37,18 +47,19 @@ def test_e2e_losses_features_grads_vs_reference_fixture():
     m = _build()
     data = make_batch(batch, size, num_gt, device='cuda')
     feats = m.extract_feat(data['img'])
+    meas = dict(feat=0.0, loss={}, gradnorm=0.0, gradhead=0.0)
     for i, f in enumerate(feats):
         want = torch.from_numpy(gd[f'feat_{i}_crop'])
         got = f[:, :8, :6, :6].float().cpu()
         scale = float(gd[f'feat_{i}_absmean'])
-        # bf16 operands through up to 53 convs: 3% of the map's mean magnitude
-        assert (got - want).abs().max().item() < 0.03 * scale * 4, (i, (got - want).abs().max().item(), scale)
+        meas['feat'] = max(meas['feat'], (got - want).abs().max().item() / scale)
+        # bf16 operands through up to 53 convs, worst entry of a 6 x 6 x 8 crop relative to the map's mean magnitude: TOL_FEAT
+        assert (got - want).abs().max().item() < TOL_BF16['feat'] * scale, (i, (got - want).abs().max().item(), scale)
     out = m.train_step(data)
     lv = dict(out['log_vars'].items())
-    tol = dict(loss_rpn_cls=0.02, loss_rpn_bbox=0.05, loss_cls=0.03, loss_bbox=0.05, loss_mask=0.03, loss_offset=0.05,
-               loss=0.05)
-    for k, t in tol.items():
+    for k, t in TOL_BF16['loss'].items():
         want = float(gd['log_' + k])
+        meas['loss'][k] = abs(lv[k] - want) / max(1.0, abs(want))
         assert abs(lv[k] - want) <= t * max(1.0, abs(want)), (k, lv[k], want)
     assert abs(lv['acc'] - float(gd['log_acc'])) <= 3.0
     out['loss'].backward()
@@ -58,14 +69,18 @@ def test_e2e_losses_features_grads_vs_reference_fixture():
             n = k[len('gradnorm_'):]
             want = float(gd[k])
             got = float(grads[n].norm()) if n in grads else 0.0
-            assert abs(got - want) <= 0.08 * max(1e-2, want), (n, got, want)
+            meas['gradnorm'] = max(meas['gradnorm'], abs(got - want) / max(1e-2, want))
+            assert abs(got - want) <= TOL_BF16['gradnorm'] * max(1e-2, want), (n, got, want)
             # element level (first 16 gradient entries of the reference run): a sign / permutation error inside a composite
-            # autograd node cannot hide behind a matching norm.  bf16 chain: 12 % of the head's own norm + a floor of the
+            # autograd node cannot hide behind a matching norm.  bf16 chain: a fraction of the head's own norm + a floor of the
             # tensor's RMS entry.
             wh = torch.from_numpy(gd['gradhead_' + n])
             gh = grads[n].float().reshape(-1)[:16].cpu()
             rms = want / grads[n].numel() ** 0.5
-            assert (gh - wh).norm().item() <= 0.12 * wh.norm().item() + 0.5 * rms, (n, gh, wh)
+            meas['gradhead'] = max(meas['gradhead'], max(0.0, (gh - wh).norm().item() - 0.5 * rms) / max(wh.norm().item(), 1e-12))
+            assert (gh - wh).norm().item() <= TOL_BF16['gradhead'] * wh.norm().item() + 0.5 * rms, (n, gh, wh)
+    print('bf16 e2e vs the reference fixture, measured / allowed:', {k: (round(v, 5) if not isinstance(v, dict) else {a: round(b, 5) for a, b in v.items()})
+                                                                   for k, v in meas.items()}, TOL_BF16)
 
 
 def test_e2e_vs_oracle_proposals_and_targets():

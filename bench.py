@@ -462,11 +462,12 @@ def main():
             _K.PLANES_STATS['planes'] = _K.PLANES_STATS['fallback'] = 0
             el = fp32_loop(_K.F32_PLANES_F16, k)
             pst = dict(_K.PLANES_STATS)
-            el_p4 = fp32_loop(_K.F32_PLANES_F16X4, k)
-            el_pb = fp32_loop(_K.F32_PLANES_BF16, k)
-            el_6 = fp32_loop(_K.F32_SPLIT6, k)
-            el_3 = fp32_loop(_K.F32_SPLIT3, k)
-            el_x = fp32_loop(_K.F32_EXACT, 3)
+            only = os.environ.get('LOFT_BENCH_F32_ONLY') == '1'      # (profiling: the default contraction's loop alone)
+            el_p4 = el if only else fp32_loop(_K.F32_PLANES_F16X4, k)
+            el_pb = el if only else fp32_loop(_K.F32_PLANES_BF16, k)
+            el_6 = el if only else fp32_loop(_K.F32_SPLIT6, k)
+            el_3 = el if only else fp32_loop(_K.F32_SPLIT3, k)
+            el_x = el * 3 / k if only else fp32_loop(_K.F32_EXACT, 3)
             fp32_parity = dict(value=round(args.batch * k / el, 3), unit='img/s', ms_per_step=round(el / k * 1e3, 2), steps=k, warmup=2,
                                per_gpu_batch=args.batch,
                                dtype='f32 (operands as 2 binary16 planes under a power-of-two scale, 3 f16 MFMA products, fp32 accumulation)',
@@ -495,7 +496,7 @@ def main():
             # the Pareto points between the two end points: 16-bit kernels up to a boundary, fp32 behind it
             model.backbone.compute_dtype = None
             mixed = {}
-            for name in ('neck', 'heads'):
+            for name in (() if only else ('neck', 'heads')):
                 model.mixed_precision = name
                 el_m = fp32_loop(_K.F32_PLANES_F16, k)
                 mixed[name] = dict(value=round(args.batch * k / el_m, 3), ms_per_step=round(el_m / k * 1e3, 2), steps=k)

@@ -667,7 +667,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                      int variant, void* stream) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_RING32 || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_W4 || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -752,6 +752,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         } else k = LOFT_CONV_T128x64;
     }
     switch (k) {
+    case LOFT_CONV_W4:
     case LOFT_CONV_RING32:
     case LOFT_CONV_ROLES256:
     case LOFT_CONV_STREAM256N:
@@ -781,10 +782,10 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
         a.krot = (variant & LOFT_CONV_FLAG_KROT) && !a.tap_major ? 1 : 0;
         if (k == LOFT_CONV_ROLES256 && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
-        if (k == LOFT_CONV_RING32 && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
+        if ((k == LOFT_CONV_RING32 || k == LOFT_CONV_W4) && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
         return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : (k == LOFT_CONV_ROLES256 ? 2 : 1), (variant >> 12) & 0xf,
                                          k == LOFT_CONV_STREAM128 ? 2 : ((k == LOFT_CONV_STREAM64 || k == LOFT_CONV_STREAM64N) ? 1 : 4),
-                                         (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s, k == LOFT_CONV_RING32 ? 1 : 0);
+                                         (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s, k == LOFT_CONV_RING32 ? 1 : (k == LOFT_CONV_W4 ? 2 : 0));
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still

@@ -1395,9 +1395,338 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
 }
 
+// =====================================================================================
+// conv_tap_w4_kernel (round 5, LOFT_CONV_W4): the stream schedule's 256 x 256 x 64 tile with FOUR waves -- ONE per SIMD, each
+// owning 128 pixels x 128 couts (16 accumulator blocks = 256 registers, the kernel takes the whole 512-register file).  Why: in
+// the eight-wave kernel the two waves of a SIMD share its matrix pipe, and the barrier-level traces show both of them in their
+// copy sub-steps (and at the K-tile's barrier) at the same moment -- ~1000 cycles for 512 cycles of MFMA work twice per K-tile.
+// A single wave per SIMD has nobody to collide with: its 64 MFMAs per K-tile issue back to back while its 32 fragment reads and
+// 16 copies sit in the gaps (<= 2 other instructions per MFMA).  Same LDS layout, staging, swizzle, tap sequence, K order and
+// two-stage ring as conv_tap_pipe_kernel<1,0,4,2>: results are bit-identical to it.  EPI 0: direct 16-bit epilogue.
+// Reference call sites: as conv_tap_pipe_kernel (FOA / mask / FPN / RPN 3x3 layers, the shared FCs).
+// =====================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_tap_w4_kernel(const ConvArgs a) {
+    constexpr int BM = 256, BN = 256, NI = 8;
+    __shared__ __attribute__((aligned(16))) char lds[PLDS];
+    asm volatile("" :: "s"(a.src), "s"(a.wgt), "s"(a.zero_page), "s"(a.out), "s"(a.src_gs), "s"(a.wgt_gs), "s"(a.gxy_mul), "s"(a.gxy_sh),
+                 "s"(a.gx_mul), "s"(a.gx_sh), "s"(a.gy_mul), "s"(a.gy_sh), "s"(a.nfast), "s"(a.pixmajor), "s"(a.pointwise), "s"(a.T),
+                 "s"(a.B), "s"(a.IH), "s"(a.IW), "s"(a.Cin), "s"(a.Cout), "s"(a.OH), "s"(a.OW), "s"(a.M), "s"(a.ss), "s"(a.pm_S),
+                 "s"(a.pm_P), "s"(a.pms_mul), "s"(a.pms_sh));
+    asm volatile("" :: "s"(a.pmp_mul), "s"(a.pmp_sh), "s"(a.ohw_mul), "s"(a.ohw_sh), "s"(a.ow_mul), "s"(a.ow_sh),
+                 "s"(a.dy_pk), "s"(a.dx_pk), "s"(a.wt_pk), "s"(a.pk_ok));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    const int V = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk);
+    const int bz = fastdiv(V, a.gxy_mul, a.gxy_sh), Vg = V - bz * (int)(gridDim.x * gridDim.y);
+    int bx, by;
+    if (a.nfast) { bx = fastdiv(Vg, a.gy_mul, a.gy_sh); by = Vg - bx * (int)gridDim.y; }
+    else { by = fastdiv(Vg, a.gx_mul, a.gx_sh); bx = Vg - by * (int)gridDim.x; }
+    const int m0 = bx * BM, n0 = by * BN, g = bz;
+    const bf16_t* src = a.src + (long)g * a.src_gs;
+    const bf16_t* wgt = a.wgt + (long)g * a.wgt_gs;
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const int ohw = a.OH * a.OW;
+    const int kchunks = a.Cin / BK;
+    // staging: thread -> tile rows i*32 + wave*8 + lrow, i = 0..7, of both operands (rows 32 apart share the swizzle)
+    const int srow = wave * 8 + lrow;
+    const int schk = swz(srow, lchunk) * 8;
+    const int b_off0 = (n0 + srow) * a.Cin + schk;
+    const int b_step = 32 * a.Cin;
+    int tab_dy = 0, tab_dx = 0, tab_a = 0, tab_w = 0;
+    if (a.pointwise) tab_w = a.wt[0] * a.Cout * a.Cin;
+    else if (a.pk_ok) {
+        const int sh = (lane & 15) * 4;
+        tab_dy = (int)((a.dy_pk >> sh) & 15ull) - 8; tab_dx = (int)((a.dx_pk >> sh) & 15ull) - 8;
+        tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
+        tab_w = (int)((a.wt_pk >> sh) & 15ull) * a.Cout * a.Cin;
+    } else if (lane < a.T) {
+        tab_dy = a.dy[lane]; tab_dx = a.dx[lane];
+        tab_a = (tab_dy * a.IW + tab_dx) * a.Cin;
+        tab_w = a.wt[lane] * a.Cout * a.Cin;
+    }
+    const bf16_t* a_ptr[NI];
+    unsigned a_mask[NI];
+    unsigned tmask = 0xffffffffu;
+    if (a.pixmajor) {
+        int rs1, b00, b10, pos0, pos1;
+        pipe_pm_tile(a, m0, rs1, b00, b10, pos0, pos1);
+        const int oy0 = fastdiv(pos0, a.ow_mul, a.ow_sh), ox0 = pos0 - oy0 * a.OW;
+        const int oy1 = fastdiv(pos1, a.ow_mul, a.ow_sh), ox1 = pos1 - oy1 * a.OW;
+        unsigned mk0 = 0u, mk1 = 0u;
+        for (int t = 0; t < a.T; ++t) {
+            const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+            const int iy0_ = oy0 * a.ss + dy, ix0_ = ox0 * a.ss + dx, iy1_ = oy1 * a.ss + dy, ix1_ = ox1 * a.ss + dx;
+            mk0 |= ((iy0_ >= 0) & (iy0_ < a.IH) & (ix0_ >= 0) & (ix0_ < a.IW)) ? (1u << t) : 0u;
+            mk1 |= ((iy1_ >= 0) & (iy1_ < a.IH) & (ix1_ >= 0) & (ix1_ < a.IW)) ? (1u << t) : 0u;
+        }
+        const int rows = pipe_clamp(a.M - m0, 0, BM);
+        const int nv0 = pipe_clamp(a.B - b00, 0, rs1 < rows ? rs1 : rows);
+        const int nv1 = pipe_clamp(a.B - b10, 0, rows - rs1 > 0 ? rows - rs1 : 0);
+        const long in0 = ((long)(b00 * a.IH + oy0 * a.ss) * a.IW + ox0 * a.ss) * a.Cin;
+        const long in1 = ((long)(b10 * a.IH + oy1 * a.ss) * a.IW + ox1 * a.ss) * a.Cin;
+        const long istr = (long)a.IH * a.IW * a.Cin;
+        tmask = (nv0 > 0 ? mk0 : 0u) | (nv1 > 0 ? mk1 : 0u);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * 32 + srow;
+            const bool k = row >= rs1;
+            const int idx = k ? row - rs1 : row;
+            const bool ok = idx < (k ? nv1 : nv0);
+            a_ptr[i] = ok ? src + ((k ? in1 : in0) + (long)idx * istr + schk) : src;
+            a_mask[i] = ok ? (k ? mk1 : mk0) : 0u;
+        }
+    } else {
+        int a_iy[NI], a_ix[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int m = m0 + i * 32 + srow;
+            a_ptr[i] = src;
+            a_mask[i] = 0u;
+            a_iy[i] = -(1 << 20); a_ix[i] = -(1 << 20);
+            if (a.pointwise) {
+                if (m < a.M) { a_mask[i] = 1u; a_ptr[i] = src + ((long)m * a.Cin + schk); }
+                continue;
+            }
+            if (m < a.M) {
+                const int b = fastdiv(m, a.ohw_mul, a.ohw_sh), rem = m - b * ohw;
+                const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                a_iy[i] = oy * a.ss; a_ix[i] = ox * a.ss;
+                a_ptr[i] = src + ((long)(b * a.IH * a.IW + a_iy[i] * a.IW + a_ix[i]) * a.Cin + schk);
+            }
+        }
+        if (!a.pointwise) {
+            for (int t = 0; t < a.T; ++t) {
+                const int dy = __builtin_amdgcn_readlane(tab_dy, t), dx = __builtin_amdgcn_readlane(tab_dx, t);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                    a_mask[i] |= ((iy >= 0) & (iy < a.IH) & (ix >= 0) & (ix < a.IW)) ? (1u << t) : 0u;
+                }
+            }
+        }
+    }
+    // the taps this tile needs, compacted into lanes (see conv_tap_pipe_kernel); chunk-major K order
+    int vt_a = 0, vt_w = 0, vt_m = 0, nv = 0;
+    for (int t = 0; t < a.T; ++t) {
+        if ((tmask >> t) & 1u) {
+            const int ta = __builtin_amdgcn_readlane(tab_a, t), tw = __builtin_amdgcn_readlane(tab_w, t);
+            vt_a = lane == nv ? ta : vt_a;
+            vt_w = lane == nv ? tw : vt_w;
+            vt_m = lane == nv ? t : vt_m;
+            ++nv;
+        }
+    }
+    if (a.pointwise) { vt_w = tab_w; nv = 1; }
+    const int nk = nv * kchunks;
+    int xj = 0, wj = 0, st_c = 0, sw_c = 0;
+    int st_t = __builtin_amdgcn_readlane(vt_m, 0);
+    long st_aoff = (long)__builtin_amdgcn_readlane(vt_a, 0);
+    const bf16_t* st_w = wgt + (long)__builtin_amdgcn_readlane(vt_w, 0);
+    auto seq_step = [&](int& j, int& c) {
+        const int jn = j + 1, cn = c + BK;
+        const bool wj_ = jn >= nv, wc_ = cn == a.Cin;
+        c = wj_ ? (wc_ ? 0 : cn) : c;
+        j = wj_ ? 0 : jn;
+    };
+    auto advance_w = [&]() { seq_step(wj, sw_c); st_w = wgt + (long)__builtin_amdgcn_readlane(vt_w, wj); };
+    auto advance_x = [&]() {
+        seq_step(xj, st_c);
+        st_t = __builtin_amdgcn_readlane(vt_m, xj);
+        st_aoff = (long)__builtin_amdgcn_readlane(vt_a, xj);
+    };
+    // pieces i0, i0 + 1 of the weight / activation tile into buffer B
+    auto issue_w = [&](auto i0c, auto bufc) {
+        constexpr int I0 = decltype(i0c)::value, B = decltype(bufc)::value;
+        const bf16_t* wt = st_w + sw_c + b_off0;
+#pragma unroll
+        for (int i = I0; i < I0 + 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wt + (long)i * b_step), (lds_ptr_t)(lds + PW_OFF + B * PBUF + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    };
+    auto issue_x = [&](auto i0c, auto bufc) {
+        constexpr int I0 = decltype(i0c)::value, B = decltype(bufc)::value;
+        const long aoff = st_aoff + st_c;
+#pragma unroll
+        for (int i = I0; i < I0 + 2; ++i) {
+            const bf16_t* p = ((a_mask[i] >> st_t) & 1u) ? a_ptr[i] + aoff : a.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lds_ptr_t)(lds + PX_OFF + B * PBUF + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
+    };
+    using c0_t = std::integral_constant<int, 0>;
+    using c1_t = std::integral_constant<int, 1>;
+    using c2_t = std::integral_constant<int, 2>;
+    using c3_t = std::integral_constant<int, 3>;
+    using c4_t = std::integral_constant<int, 4>;
+    using c6_t = std::integral_constant<int, 6>;
+    f32x16 acc[4][4];
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31, fq = lane >> 5;
+    const char* wb[4];
+    const char* xb[4];
+    // prologue: W(0), X(0), W(1)
+    issue_w(c0_t{}, c0_t{}); issue_w(c2_t{}, c0_t{}); issue_w(c4_t{}, c0_t{}); issue_w(c6_t{}, c0_t{});
+    issue_x(c0_t{}, c0_t{}); issue_x(c2_t{}, c0_t{}); issue_x(c4_t{}, c0_t{}); issue_x(c6_t{}, c0_t{});
+    if (nk > 1) {
+        advance_w(); advance_x();
+        issue_w(c0_t{}, c1_t{}); issue_w(c2_t{}, c1_t{}); issue_w(c4_t{}, c1_t{}); issue_w(c6_t{}, c1_t{});
+        advance_w();
+    }
+    PIPE_SB();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    {
+        const int rw = wn * 128 + frow, rx = wm * 128 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks * 2 + fq;
+            wb[ks] = lds + PW_OFF + rw * 128 + swz(rw, q) * 16;
+            xb[ks] = lds + PX_OFF + rx * 128 + swz(rx, q) * 16;
+        }
+    }
+    PIPE_SB();
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // everything but W(1)'s eight copies has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PIPE_BARRIER();
+    bf16x8 fa[8], fb[8];
+    auto rd1 = [&](bf16x8 (&f)[8], auto bufc, auto ksc, auto idxc) {      // fragment idx of F(., KS): 0..3 = W blocks, 4..7 = X blocks
+        constexpr int B = decltype(bufc)::value, KS = decltype(ksc)::value, I = decltype(idxc)::value;
+        if constexpr (I < 4) f[I] = *reinterpret_cast<const bf16x8*>(wb[KS] + B * PBUF + I * 4096);
+        else f[I] = *reinterpret_cast<const bf16x8*>(xb[KS] + B * PBUF + (I - 4) * 4096);
+    };
+    auto mm4 = [&](bf16x8 (&f)[8], auto jc) {                               // the four MFMAs of pixel block j
+        constexpr int J = decltype(jc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][J] = LOFT_MFMA_32x32x16(f[i], f[4 + J], acc[i][J]);
+    };
+    using i5_t = std::integral_constant<int, 5>;
+    using i7_t = std::integral_constant<int, 7>;
+    // one sub-step: 16 MFMAs on `cur`, the 8 reads of `nxt` and up to eight copies pinned between the groups of four MFMAs
+    auto substep = [&](bf16x8 (&cur)[8], bf16x8 (&nxt)[8], auto bufc, auto ksc, bool do_read, auto&& cp0, auto&& cp1, auto&& cp2, auto&& cp3) {
+        PIPE_SB();
+        mm4(cur, c0_t{});
+        if (do_read) { rd1(nxt, bufc, ksc, c0_t{}); rd1(nxt, bufc, ksc, c1_t{}); }
+        cp0();
+        PIPE_SB();
+        mm4(cur, c1_t{});
+        if (do_read) { rd1(nxt, bufc, ksc, c2_t{}); rd1(nxt, bufc, ksc, c3_t{}); }
+        cp1();
+        PIPE_SB();
+        mm4(cur, c2_t{});
+        if (do_read) { rd1(nxt, bufc, ksc, c4_t{}); rd1(nxt, bufc, ksc, i5_t{}); }
+        cp2();
+        PIPE_SB();
+        mm4(cur, c3_t{});
+        if (do_read) { rd1(nxt, bufc, ksc, c6_t{}); rd1(nxt, bufc, ksc, i7_t{}); }
+        cp3();
+        PIPE_SB();
+    };
+    auto nop = [] {};
+    rd1(fa, c0_t{}, c0_t{}, c0_t{}); rd1(fa, c0_t{}, c0_t{}, c1_t{}); rd1(fa, c0_t{}, c0_t{}, c2_t{}); rd1(fa, c0_t{}, c0_t{}, c3_t{});
+    rd1(fa, c0_t{}, c0_t{}, c4_t{}); rd1(fa, c0_t{}, c0_t{}, i5_t{}); rd1(fa, c0_t{}, c0_t{}, c6_t{}); rd1(fa, c0_t{}, c0_t{}, i7_t{});
+    // per K-tile t (buffer B = t & 1): ks0 MFMA fa | read F(t,1) | X(t+1) -> buffer 1-B;  ks1, ks2;  SYNC (vmcnt(0), lgkmcnt(0),
+    // barrier);  ks3 MFMA fb | read F(t+1,0) from buffer 1-B | W(t+2) -> buffer B   (RAW / WAR: as the eight-wave stream schedule)
+    auto stile = [&](auto bufc, auto has1, auto has2) {
+        constexpr int B = decltype(bufc)::value;
+        using other_t = std::integral_constant<int, 1 - B>;
+        substep(fa, fb, bufc, c1_t{}, true,
+                [&] { if (has1) issue_x(c0_t{}, other_t{}); }, [&] { if (has1) issue_x(c2_t{}, other_t{}); },
+                [&] { if (has1) issue_x(c4_t{}, other_t{}); }, [&] { if (has1) { issue_x(c6_t{}, other_t{}); advance_x(); } });
+        substep(fb, fa, bufc, c2_t{}, true, nop, nop, nop, nop);
+        substep(fa, fb, bufc, c3_t{}, true, nop, nop, nop, nop);
+        if (has1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            PIPE_BARRIER();
+        }
+        substep(fb, fa, other_t{}, c0_t{}, has1,
+                [&] { if (has2) issue_w(c0_t{}, bufc); }, [&] { if (has2) issue_w(c2_t{}, bufc); },
+                [&] { if (has2) issue_w(c4_t{}, bufc); }, [&] { if (has2) { issue_w(c6_t{}, bufc); advance_w(); } });
+    };
+    {
+        int t = 0;
+        for (; t + 3 < nk; t += 2) {
+            stile(c0_t{}, std::true_type{}, std::true_type{});
+            stile(c1_t{}, std::true_type{}, std::true_type{});
+        }
+        for (; t < nk; t += 2) {
+            stile(c0_t{}, t + 1 < nk, t + 2 < nk);
+            if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+        }
+    }
+    // ---- direct 16-bit epilogue: lane = pixel row wm*128 + j*32 + frow, four consecutive couts per (i, gq)
+    {
+        const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;
+        const TileRows tr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
+        const long out_g = (long)g * a.out_gs;
+        const float* bias = a.bias ? a.bias + (long)g * a.bias_gs : nullptr;
+        const bf16_t* res = a.residual;
+        const bf16_t* msk = a.mask;
+        bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+        const bool relu = a.relu != 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wm * 128 + j * 32 + frow;
+            long roff;
+            bool ok;
+            if (tr.lin) roff = pipe_row_off(tr, r, ok);
+            else {
+                const int m = m0 + r;
+                ok = m < a.M;
+                roff = 0;
+                if (ok) {
+                    int b, rem;
+                    pipe_row_decode(a, m, ohw, b, rem);
+                    ok = b < a.B;
+                    const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
+                    roff = (((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x) * a.Cout;
+                }
+            }
+            if (!ok) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = n0 + wn * 128 + i * 32 + 8 * gq + 4 * fq;
+                    const long o = out_g + roff + n;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][gq * 4 + e];
+                    if (bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if (res) {
+                        float rv[4];
+                        ld4(res + o, rv);
+                        v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (msk) {
+                        float mv[4];
+                        ld4(msk + o, mv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+                    }
+                    st4(out + o, v);
+                }
+        }
+    }
+}
+
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s, int ring32) {
     ConvArgs a = a_in;
+    const bool w4 = ring32 == 2;                       // (2: the four-wave kernel, LOFT_CONV_W4)
+    if (w4) ring32 = 0;
+    if (w4 && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.tap_major && !a.krot && !a.nterms))
+        return (int)hipErrorInvalidValue;
     if (ring32 && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.tap_major && !a.krot && !a.nterms))
         return (int)hipErrorInvalidValue;
     if (mj != 4 && !((mj == 2 || mj == 1) && mode == 1 && var == 0)) return (int)hipErrorInvalidValue;
@@ -1425,6 +1754,8 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         else if (mj == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2, 2, true>), grid, dim3(512), 0, s, a);
         else if (mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true>), grid, dim3(512), 0, s, a);
+    } else if (w4) {
+        hipLaunchKernelGGL(conv_tap_w4_kernel<0>, grid, dim3(256), 0, s, a);
     } else if (ring32) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, true>), grid, dim3(512), 0, s, a);
     } else if (nw == 1 && mj == 1) {

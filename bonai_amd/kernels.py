@@ -483,7 +483,7 @@ def _bf16(t):
 # include/loft_hip.h LOFT_CONV_*: kernel selector of loft_conv_tap_bf16_v.  0 = the library's shape heuristics (the shipped path).
 # tests / tools set CONV_VARIANT to a code, or to a callable (groups, B, OH, OW, Cin, Cout, T, ss, os) -> code, to pin a template.
 CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_FAST, CONV_T128, CONV_T128x64, CONV_PATCH64, \
-    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N, CONV_RING32 = range(16)
+    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N, CONV_RING32, CONV_W4 = range(17)
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT, CONV_FLAG_TAP_MAJOR, CONV_FLAG_NO_ROI_BLOCKS, CONV_FLAG_KROT = \
     0x100, 0x200, 0x400, 0x800, 0x10000, 0x20000
 CONV_VARIANT = CONV_AUTO

@@ -203,6 +203,7 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
 #define LOFT_CONV_ROLES256 13     /* 256x256x64, role-split stream: waves 0-3 issue every activation copy, waves 4-7 every weight copy (three weight stages) */
 #define LOFT_CONV_STREAM256N 14   /* the stream kernel on 256-pixel x 128-cout tiles with the THREE-stage ring also for Cout % 256 == 0 (1.5x the copy bytes per FLOP of the 256 x 256 tile, two K-tiles of look-ahead instead of one; A/B) */
 #define LOFT_CONV_RING32 15       /* the stream kernel's 256 x 256 tile with 32-channel K-tiles on a FOUR-stage ring: pieces requested three tiles ahead, two per wave and sub-step, counted vmcnt (bit-identical to LOFT_CONV_STREAM256) */
+#define LOFT_CONV_W4 16           /* the stream schedule's 256 x 256 x 64 tile with FOUR waves, one per SIMD, 128 x 128 each (conv_tap_w4_kernel; bit-identical to LOFT_CONV_STREAM256) */
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400

@@ -201,24 +201,36 @@ class _OffsetBase(nn.Module):
         self.offset_coder = build_bbox_coder(offset_coder)
         self.loss_offset = build_loss(loss_offset)
         area = roi_feat_size * roi_feat_size
-        self.fcs = nn.ModuleList([_FC(conv_out_channels * area if i == 0 else fc_out_channels, fc_out_channels)
+
+        def stack():
+            return nn.ModuleList([_FC(conv_out_channels * area if i == 0 else fc_out_channels, fc_out_channels)
                                   for i in range(num_fcs)])
-        self.fc_offset = _FC(fc_out_channels, reg_num)
+        if getattr(self, 'share_expand_fc', True):
+            self.fcs = stack()
+            self.fc_offset = _FC(fc_out_channels, reg_num)
+        else:
+            # one FC stack and one regressor PER rotation branch (offset_head_expand_feature.py:82-95; the class default)
+            self.expand_fcs = nn.ModuleList([stack() for _ in range(self.expand_feature_num)])
+            self.expand_fc_offsets = nn.ModuleList([_FC(fc_out_channels, reg_num) for _ in range(self.expand_feature_num)])
 
     def _init_fcs(self):
-        for fc in self.fcs:
+        shared = getattr(self, 'share_expand_fc', True)
+        for fc in (self.fcs if shared else [fc for fcs in self.expand_fcs for fc in fcs]):
             nn.init.kaiming_uniform_(fc.weight, a=1, mode='fan_in', nonlinearity='leaky_relu')
             nn.init.constant_(fc.bias, 0)
-        nn.init.normal_(self.fc_offset.weight, 0, 0.01)
-        nn.init.constant_(self.fc_offset.bias, 0)
+        for fo in ([self.fc_offset] if shared else self.expand_fc_offsets):
+            nn.init.normal_(fo.weight, 0, 0.01)
+            nn.init.constant_(fo.bias, 0)
 
-    def _fc_tail(self, x):
+    def _fc_tail(self, x, fcs=None, fc_offset=None):
+        fcs = self.fcs if fcs is None else fcs
+        fc_offset = self.fc_offset if fc_offset is None else fc_offset
         N = x.shape[0]
-        h = _fc_after_flatten(x, self.fcs[0], input_relu=self.num_convs > 0)   # x: output of the conv + ReLU chain
-        for fc in list(self.fcs)[1:]:
+        h = _fc_after_flatten(x, fcs[0], input_relu=self.num_convs > 0)   # x: output of the conv + ReLU chain
+        for fc in list(fcs)[1:]:
             h = F2.linear(h, fc.weight, fc.bias, relu=True, input_relu=True)
-        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), self.fc_offset.weight,
-                           self.fc_offset.bias)
+        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), fc_offset.weight,
+                           fc_offset.bias)
         return o.reshape(N, -1)[:, :self.reg_num]
 
     def loss(self, offset_pred, offset_targets):
@@ -227,9 +239,24 @@ class _OffsetBase(nn.Module):
         return dict(loss_offset=self.loss_offset(offset_pred, offset_targets))
 
 
+class _BranchSlabs(torch.autograd.Function):
+    """[4N,C,H,W] branch-major NHWC batch -> its four [N,C,H,W] slabs (views); the backward concatenates the four slab
+    gradients back into ONE NHWC tensor (autograd's own slice backward would build four full-size NCHW-strided zero tensors)."""
+
+    @staticmethod
+    def forward(ctx, x4):
+        n = x4.shape[0] // 4
+        return tuple(x4[k * n:(k + 1) * n] for k in range(4))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return torch.cat(gs, 0).contiguous(memory_format=torch.channels_last)
+
+
 @HEADS.register_module()
 class OffsetHeadExpandFeature(_OffsetBase):
-    """FOA: 4 rotated copies of the RoI feature, per-branch 10x(conv3x3+ReLU), shared FCs."""
+    """FOA: 4 rotated copies of the RoI feature, per-branch num_convs x (conv3x3+ReLU), then the FC stack + regressor -- shared
+    by the branches (``share_expand_fc=True``, configs/loft_foa) or one per branch (the reference class's default)."""
 
     def __init__(self, roi_feat_size=7, in_channels=256, num_convs=4, num_fcs=2, reg_num=2, conv_out_channels=256,
                  fc_out_channels=1024, expand_feature_num=4, share_expand_fc=False, rotations=[0, 90, 180, 270],
@@ -237,10 +264,9 @@ class OffsetHeadExpandFeature(_OffsetBase):
                                                                     target_stds=[0.5, 0.5]),
                  reg_decoded_offset=False, conv_cfg=None, norm_cfg=None, loss_offset=dict(type='MSELoss', loss_weight=1.0)):
         super().__init__()
-        if expand_feature_num != 4 or list(rotations) != [0, 90, 180, 270] or not share_expand_fc \
-                or in_channels != conv_out_channels:
-            raise NotImplementedError('FOA is built natively for 4 rotations (0/90/180/270) with shared FCs')
-        self.expand_feature_num, self.rotations, self.share_expand_fc = expand_feature_num, list(rotations), True
+        if expand_feature_num != 4 or list(rotations) != [0, 90, 180, 270] or in_channels != conv_out_channels:
+            raise NotImplementedError('FOA is built natively for the 4 rotations 0/90/180/270')
+        self.expand_feature_num, self.rotations, self.share_expand_fc = expand_feature_num, list(rotations), bool(share_expand_fc)
         self.num_convs = num_convs
         if tuple(float(v) for v in offset_coder.get('target_means', (0., 0.))) != (0., 0.):
             raise NotImplementedError('FOA target / fusion kernels take zero offset means (configs/loft_foa)')
@@ -266,7 +292,12 @@ class OffsetHeadExpandFeature(_OffsetBase):
         for i in range(self.num_convs):
             x4 = F2.conv2d(x4, [self.expand_convs[k][i].weight for k in range(4)],
                            [self.expand_convs[k][i].bias for k in range(4)], pad=1, relu=True, groups=4, input_relu=i > 0)
-        return self._fc_tail(x4)
+        if self.share_expand_fc:
+            return self._fc_tail(x4)                   # one [4N, .] GEMM per shared layer
+        # share_expand_fc=False (offset_head_expand_feature.py:147-152): branch k's rows through branch k's own FCs; the rows of
+        # one branch are a contiguous slab of the branch-major batch
+        return torch.cat([self._fc_tail(xk, self.expand_fcs[k], self.expand_fc_offsets[k])
+                          for k, xk in enumerate(_BranchSlabs.apply(x4))], 0)
 
     def forward(self, x):
         """Reference signature: un-rotated RoI features [N,256,7,7] in, [4N,2] out."""

@@ -298,6 +298,58 @@ def offset_head():
     print('offset_head.npz', len(out), 'arrays', {k: float(out[k]) for k in out if k.endswith('_loss')}, out['polar_offsets'][:2])
 
 
+def foa_head():
+    """Reference OffsetHeadExpandFeature (attribute_heads/offset_head_expand_feature.py:25-344) stand-alone: forward, get_targets,
+    loss and backward with the FC stack shared by the four rotation branches (configs/loft_foa) and with one stack per branch
+    (``share_expand_fc=False``, the class default; :82-95, :147-152).  Inputs are regenerated from names (synth_tensor)."""
+    from mmdet.models.roi_heads.attribute_heads.offset_head_expand_feature import OffsetHeadExpandFeature
+    from oracle.synth_weights import synth_tensor
+    out = {}
+    rng = np.random.RandomState(11)
+
+    class _Res:
+        pass
+
+    def boxes(n, size=1024.):
+        cx, cy = rng.uniform(0, size, n), rng.uniform(0, size, n)
+        w, h = rng.uniform(8, 200, n), rng.uniform(8, 200, n)
+        return torch.tensor(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).clip(0, size), dtype=torch.float32)
+    res, gt_offs = [], []
+    for i, n in enumerate((4, 0, 2)):                       # the middle image has no positives
+        r = _Res()
+        r.pos_bboxes = boxes(n)
+        r.pos_assigned_gt_inds = torch.tensor(rng.randint(0, 3, n), dtype=torch.long)
+        res.append(r)
+        gt_offs.append(torch.tensor(rng.uniform(-40, 40, (3, 2)), dtype=torch.float32))
+        out[f'pos_{i}'], out[f'ind_{i}'], out[f'gtoff_{i}'] = T(r.pos_bboxes), T(r.pos_assigned_gt_inds), T(gt_offs[-1])
+    for tag, kw, nconv in (('unshared', dict(share_expand_fc=False, loss_offset=dict(type='SmoothL1Loss', loss_weight=16.0)), 1),
+                           ('shared', dict(share_expand_fc=True), 2)):
+        head = OffsetHeadExpandFeature(num_convs=nconv, **kw)
+        sd = {k: synth_tensor('roi_head.offset_head.' + k, v.shape) for k, v in head.state_dict().items()}
+        for k in sd:
+            if 'fc_offset' in k and k.endswith('weight'):
+                sd[k] = sd[k] * 30.0                        # O(1) predictions so the SmoothL1 knee is crossed
+        head.load_state_dict(sd)
+        out[f'{tag}_state_keys'] = np.array(sorted(sd))
+        x = synth_tensor(f'foa_head.x.{tag}', (6, 256, 7, 7)).requires_grad_(True)
+        pred = head(x)
+        tg = head.get_targets(res, gt_offs, None)
+        loss = head.loss(pred, tg)['loss_offset']
+        loss.backward()
+        out[f'{tag}_pred'], out[f'{tag}_targets'], out[f'{tag}_loss'] = T(pred), T(tg), T(loss)
+        out[f'{tag}_empty_shape'] = np.array(head(x[:0]).shape)
+        keep = ('expand_convs.0.0.weight', 'expand_convs.3.0.bias', 'expand_fcs.1.0.weight', 'expand_fcs.2.1.bias',
+                'expand_fc_offsets.3.weight', 'expand_fc_offsets.0.bias', 'fcs.0.weight', 'fcs.1.bias', 'fc_offset.weight')
+        for n, p_ in head.named_parameters():
+            if n in keep:
+                out[f'{tag}_gradnorm_{n}'] = T(p_.grad.norm())
+                out[f'{tag}_gradhead_{n}'] = T(p_.grad.reshape(-1)[:16])
+        out[f'{tag}_gradx_crop'] = T(x.grad[:, :8, :3, :3])
+        out[f'{tag}_gradx_norm'] = T(x.grad.norm())
+    np.savez_compressed(os.path.join(GOLD, 'foa_head.npz'), **out)
+    print('foa_head.npz', len(out), 'arrays', {k: float(out[k]) for k in out if k.endswith('_loss')})
+
+
 def data_pipeline():
     """Reference BONAI._parse_ann_info (bonai.py:105-256) and RandomFlip.bbox_flip/offset_flip (transforms.py:379-466) on
     synthetic annotations; the expected outputs are stored, the inputs are regenerated by synth_bonai_anns()."""
@@ -348,9 +400,13 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'offset_head':
         offset_head()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'foa_head':
+        foa_head()
+        sys.exit(0)
     core_ops()
     e2e()
     e2e_test()
     hrnet()
     offset_head()
+    foa_head()
     data_pipeline()

@@ -50,4 +50,4 @@ for (site, name, shp), n in count.items():
 print(f'{sum(count.values())} kernel-launching aten calls in the step')
 for site, n in bysite.most_common(60):
     ops = sorted(((nm, shp, c) for (s_, nm, shp), c in count.items() if s_ == site), key=lambda x: -x[2])
-    print(f'{n:4d}  {site:40s} ' + ', '.join(f'{nm}{list(shp)}x{c}' for nm, shp, c in ops[:6]))
+    print(f'{n:4d}  {site:40s} ' + ', '.join(f'{nm}{list(shp)}x{c}' for nm, shp, c in ops[:int(os.environ.get('MAXOPS', '6'))]))

@@ -1145,6 +1145,37 @@ LOFT_EXPORT int loft_random_sample(const int64_t* gt_inds, int B, int N, int num
     return 0;
 }
 
+// The RPN losses' normaliser from the sampler's validity flags (anchor_head.py:363-364, 462-464):
+//     avg = sum_b max(#pos_b, 1) + sum_b max(#neg_b, 1)
+// One workgroup, one launch (it was two sum / clamp / sum chains, an add and a cast: eight launches of a few bytes each).
+__global__ __launch_bounds__(256) void sampled_avg_factor_kernel(const uint8_t* __restrict__ pv, const uint8_t* __restrict__ nv, int B,
+                                                                 int P, int Q, float* __restrict__ out) {
+    __shared__ int part[4];
+    int total = 0;
+    for (int b = 0; b < B; ++b) {
+        for (int side = 0; side < 2; ++side) {
+            const uint8_t* v = side ? nv + (size_t)b * Q : pv + (size_t)b * P;
+            const int n = side ? Q : P;
+            int c = 0;
+            for (int i = threadIdx.x; i < n; i += 256) c += v[i] != 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+            __syncthreads();
+            const int cnt = part[0] + part[1] + part[2] + part[3];
+            total += cnt > 1 ? cnt : 1;
+        }
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
+}
+LOFT_EXPORT int loft_sampled_avg_factor(const uint8_t* pos_valid, const uint8_t* neg_valid, int B, int P, int Q, float* out,
+                                        void* stream) {
+    if (B < 0 || P < 0 || Q < 0 || !out) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sampled_avg_factor_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pos_valid, neg_valid, B, P, Q, out);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- RPN: everything between the sampler and the losses
 // For each sampled anchor (b, s) -- positives first, then negatives (anchor_head.py:187-237 `_get_targets_single`, :429-497
 // `loss`): the anchor's pyramid level / pixel / slot, its objectness logit and 4 deltas gathered STRAIGHT from the fused head

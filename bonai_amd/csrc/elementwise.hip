@@ -135,7 +135,9 @@ LOFT_EXPORT int loft_upsample2x_add_f32(float* fine, const float* coarse, int B,
     return 0;
 }
 
-__global__ void downsum_add_kernel(bf16_t* __restrict__ coarse, const bf16_t* __restrict__ fine, int B, int Hc, int Wc,
+// out = coarse + 2x2 block sums of fine; out may BE coarse (the in-place entry) -- every lane reads its own 8 values before it
+// writes them
+__global__ void downsum_add_kernel(bf16_t* out, const bf16_t* coarse, const bf16_t* __restrict__ fine, int B, int Hc, int Wc,
                                    int C) {
     const int cg = C >> 3;
     const long nvec = (long)B * Hc * Wc * cg;
@@ -161,13 +163,20 @@ __global__ void downsum_add_kernel(bf16_t* __restrict__ coarse, const bf16_t* __
         ld8(fine + f0 + (long)W * C + C, t);
 #pragma unroll
         for (int q = 0; q < 8; ++q) a[q] += t[q];
-        st8(coarse + i * 8, a);
+        st8(out + i * 8, a);
     }
 }
 LOFT_EXPORT int loft_downsum2x_add_bf16(void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream) {
     if (C % 8) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(downsum_add_kernel, ew_grid((long)B * Hc * Wc * (C / 8)), dim3(256), 0, (hipStream_t)stream,
-                       (bf16_t*)coarse, (const bf16_t*)fine, B, Hc, Wc, C);
+                       (bf16_t*)coarse, (const bf16_t*)coarse, (const bf16_t*)fine, B, Hc, Wc, C);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+LOFT_EXPORT int loft_downsum2x_sum_bf16(void* out, const void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream) {
+    if (C % 8) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(downsum_add_kernel, ew_grid((long)B * Hc * Wc * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)out, (const bf16_t*)coarse, (const bf16_t*)fine, B, Hc, Wc, C);
     LOFT_LAUNCH_CHECK();
     return 0;
 }
@@ -1223,28 +1232,52 @@ LOFT_EXPORT int loft_narrow_head_bwd(const float* g, int g_stride, const void* x
 // mode 0 L1, 1 SmoothL1(beta), 2 BCE-with-logits (target in [0,1]), 3 softmax CE (pred [n,C], target = int64 class per row,
 // weight per row).  Block partial sums go to `partial`; the last block (ticket in `counter`, reset for the next launch) adds
 // them in a fixed order: deterministic, no pre-zeroed output.
-__global__ __launch_bounds__(256) void fused_loss_kernel(int mode, const float* __restrict__ pred, const void* __restrict__ target,
-                                                         const float* __restrict__ weight, long n, int C, const float* avg_factor,
+// v2 additions (one launch where the host side needed a clone / cast / compare launch per operand before):
+//   * pred may be a strided VIEW of a wider head output (the [n, 2] class columns of the fused [n, 8] fc_cls + fc_reg output, one
+//     channel of a 4-padded NHWC map, rows b, p < P of a [B, S, 5] gather): logical index i (element; row for mode 3) sits at
+//     (i / (d1 d2)) s0 + ((i / d2) % d1) s1 + (i % d2) s2 floats; mode 3 reads its C classes at unit stride from there;
+//   * target_kind 1: int64 labels, BCE target = (label >= 1) (the RPN's {0, 1} labels, cross_entropy_loss.py:60-66);
+//   * weight_kind 1: uint8 / bool weights; every `wdiv` consecutive logical elements share one weight (a per-row weight
+//     broadcast over the 4 box deltas);
+//   * mode 3 with want_acc: loss_out[1] = top-1 accuracy in percent (accuracy.py:4-48: 100 * #(argmax == label) / n, first
+//     maximum on ties like torch.argmax), counted in partial[256 + block].
+struct LossView { long d1, d2, s0, s1, s2; };
+__device__ __forceinline__ long loss_view_off(const LossView& v, long i) {
+    if (v.d1 == 1 && v.d2 == 1) return i * v.s0;
+    const long i2 = i % v.d2, r = i / v.d2;
+    return (r / v.d1) * v.s0 + (r % v.d1) * v.s1 + i2 * v.s2;
+}
+__global__ __launch_bounds__(256) void fused_loss_kernel(int mode, const float* __restrict__ pred, LossView pv, const void* __restrict__ target,
+                                                         int target_kind, const void* __restrict__ weight, int weight_kind, long wdiv,
+                                                         long n, int C, const float* avg_factor,
                                                          float count, float scale, float beta, float* __restrict__ grad,
                                                          float* __restrict__ partial, unsigned* __restrict__ counter,
-                                                         float* __restrict__ loss_out) {
+                                                         float* __restrict__ loss_out, int want_acc) {
     const float denom = avg_factor ? *avg_factor : count;
     const float k = scale / denom;
-    float acc = 0.f;
+    float acc = 0.f, hit = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float w = weight ? weight[i] : 1.f;
+        float w = 1.f;
+        if (weight) {
+            const long wi = wdiv > 1 ? i / wdiv : i;
+            w = weight_kind ? (reinterpret_cast<const unsigned char*>(weight)[wi] ? 1.f : 0.f) : reinterpret_cast<const float*>(weight)[wi];
+        }
         if (mode == 3) {
-            const float* p = pred + i * C;
+            const float* p = pred + loss_view_off(pv, i);
             const long lab = reinterpret_cast<const int64_t*>(target)[i];
             float mx = p[0];
-            for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+            int am = 0;
+            for (int c = 1; c < C; ++c) if (p[c] > mx) { mx = p[c]; am = c; }
             float se = 0.f;
             for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
             const float lse = mx + logf(se);
             acc += w * (lse - p[lab]);
+            hit += am == lab ? 1.f : 0.f;
             for (int c = 0; c < C; ++c) grad[i * C + c] = k * w * (expf(p[c] - lse) - (c == lab ? 1.f : 0.f));
         } else {
-            const float p = pred[i], t = reinterpret_cast<const float*>(target)[i];
+            const float p = pred[loss_view_off(pv, i)];
+            const float t = target_kind == 1 ? (reinterpret_cast<const int64_t*>(target)[i] >= 1 ? 1.f : 0.f)
+                                             : reinterpret_cast<const float*>(target)[i];
             float l, g;
             if (mode == 2) {
                 // max(p,0) - p t + log(1 + exp(-|p|))   (torch's binary_cross_entropy_with_logits form)
@@ -1261,33 +1294,50 @@ __global__ __launch_bounds__(256) void fused_loss_kernel(int mode, const float* 
             grad[i] = k * w * g;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    __shared__ float part[4];
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o, 64); hit += __shfl_down(hit, o, 64); }
+    __shared__ float part[4], hpart[4];
     __shared__ bool last;
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; hpart[threadIdx.x >> 6] = hit; }
     __syncthreads();
     if (threadIdx.x == 0) {
         partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+        if (want_acc) partial[256 + blockIdx.x] = hpart[0] + hpart[1] + hpart[2] + hpart[3];
         __threadfence();
         last = atomicAdd(counter, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
         __threadfence();
-        float tot = 0.f;
+        float tot = 0.f, hits = 0.f;
         for (unsigned b = 0; b < gridDim.x; ++b) tot += reinterpret_cast<volatile float*>(partial)[b];
         *loss_out = tot * k;
+        if (want_acc) {
+            for (unsigned b = 0; b < gridDim.x; ++b) hits += reinterpret_cast<volatile float*>(partial)[256 + b];
+            loss_out[1] = n > 0 ? hits * (100.0f / (float)n) : 0.f;
+        }
         *counter = 0u;
     }
+}
+LOFT_EXPORT int loft_fused_loss_v2(int mode, const float* pred, int64_t d1, int64_t d2, int64_t s0, int64_t s1, int64_t s2,
+                                   const void* target, int target_kind, const void* weight, int weight_kind, int64_t wdiv, int64_t n, int C,
+                                   const float* avg_factor, float count, float scale, float beta, float* grad, float* partial,
+                                   uint32_t* counter, float* loss_out, int want_acc, void* stream) {
+    if (mode < 0 || mode > 3 || n < 0 || (mode == 3 && C < 1) || !partial || !counter || d1 < 1 || d2 < 1 || wdiv < 1 ||
+        target_kind < 0 || target_kind > 1 || (target_kind == 1 && mode != 2) || weight_kind < 0 || weight_kind > 1 ||
+        (want_acc && mode != 3))
+        return (int)hipErrorInvalidValue;
+    long blocks = n <= 0 ? 1 : (n + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
+    LossView pv{(long)d1, (long)d2, (long)s0, (long)s1, (long)s2};
+    hipLaunchKernelGGL(fused_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mode, pred, pv, target, target_kind,
+                       weight, weight_kind, (long)wdiv, (long)n, C, avg_factor, count, scale, beta, grad, partial, counter, loss_out,
+                       want_acc);
+    LOFT_LAUNCH_CHECK();
+    return 0;
 }
 LOFT_EXPORT int loft_fused_loss(int mode, const float* pred, const void* target, const float* weight, int64_t n, int C,
                                 const float* avg_factor, float count, float scale, float beta, float* grad, float* partial,
                                 uint32_t* counter, float* loss_out, void* stream) {
-    if (mode < 0 || mode > 3 || n < 0 || (mode == 3 && C < 1) || !partial || !counter) return (int)hipErrorInvalidValue;
-    long blocks = n <= 0 ? 1 : (n + 1023) / 1024;
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(fused_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mode, pred, target, weight,
-                       (long)n, C, avg_factor, count, scale, beta, grad, partial, counter, loss_out);
-    LOFT_LAUNCH_CHECK();
-    return 0;
+    return loft_fused_loss_v2(mode, pred, 1, 1, mode == 3 ? C : 1, 0, 0, target, 0, weight, 0, 1, n, C, avg_factor, count, scale, beta,
+                              grad, partial, counter, loss_out, 0, stream);
 }

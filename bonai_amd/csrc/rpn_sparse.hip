@@ -69,6 +69,40 @@ __global__ void rpn_scatter_add_kernel(const SparseLevels lv, const int* __restr
     }
 }
 
+// The three operands the sparse backward builds before its GEMMs, in ONE launch (they were ~15 stock launches: cat / arange / zeros /
+// scatter_ / casts / permuted copies).  Work items, in this order:
+//   g_rows [nsel][P]  : row i = zeros except column slot[i] (= g[i][0]) and columns A + 4 slot[i] + j (= g[i][1 + j]) -- the output
+//                       gradient in the fused head's channel order (objectness 0..A-1, deltas A..5A-1), padded to P channels
+//   w_headT [C][P]    : w_headT[c][n] = w_cls[n][c] (n < A), w_reg[n - A][c] (A <= n < 5A), 0 beyond: the head's dgrad operand
+//   wd [9 C][C]       : wd[t C + ci][co] = w_conv[co][ci][t]: the 3x3 conv's dgrad operand, (tap, cin)-major
+__global__ void rpn_sparse_prep_kernel(const float* __restrict__ g, const long* __restrict__ slot, int nsel, int A, int P, int C,
+                                       const float* __restrict__ w_cls, const float* __restrict__ w_reg,
+                                       const float* __restrict__ w_conv, bf16_t* __restrict__ g_rows,
+                                       bf16_t* __restrict__ w_headT, bf16_t* __restrict__ wd) {
+    const long n0 = (long)nsel * P, n1 = n0 + (long)C * P, n2 = n1 + 9L * C * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
+        if (i < n0) {
+            const int r = (int)(i / P), n = (int)(i - (long)r * P);
+            const int a = (int)slot[r];
+            float v = 0.f;
+            if (n == a) v = g[(long)r * 5];
+            else if (n >= A + 4 * a && n < A + 4 * a + 4) v = g[(long)r * 5 + 1 + (n - A - 4 * a)];
+            g_rows[i] = f32_to_bf16(v);
+        } else if (i < n1) {
+            const long j = i - n0;
+            const int c = (int)(j / P), n = (int)(j - (long)c * P);
+            const float v = n < A ? w_cls[(long)n * C + c] : (n < 5 * A ? w_reg[(long)(n - A) * C + c] : 0.f);
+            w_headT[j] = f32_to_bf16(v);
+        } else {
+            const long j = i - n1;
+            const int co = (int)(j % C);
+            const long r = j / C;
+            const int ci = (int)(r % C), t = (int)(r / C);
+            wd[j] = f32_to_bf16(w_conv[((long)co * C + ci) * 9 + t]);
+        }
+    }
+}
+
 int fill_levels(SparseLevels* lv, void* const* ptrs, const int* H, const int* W, int n) {
     if (n < 1 || n > 8) return (int)hipErrorInvalidValue;
     lv->n = n;
@@ -104,6 +138,18 @@ LOFT_EXPORT int loft_rpn_scatter_add_rows(void* const* level_ptrs, const int* H,
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(rpn_scatter_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lv, rows, nsel, C, K,
                        (const bf16_t*)src);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+LOFT_EXPORT int loft_rpn_sparse_prep(const float* g, const int64_t* slot, int nsel, int A, int P, int C, const float* w_cls,
+                                     const float* w_reg, const float* w_conv, void* g_rows, void* w_headT, void* wd, void* stream) {
+    if (nsel < 0 || A < 1 || 5 * A > P || C < 1) return (int)hipErrorInvalidValue;
+    const long total = (long)nsel * P + (long)C * P + 9L * C * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rpn_sparse_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (const long*)slot, nsel, A,
+                       P, C, w_cls, w_reg, w_conv, (bf16_t*)g_rows, (bf16_t*)w_headT, (bf16_t*)wd);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

@@ -763,7 +763,10 @@ def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=
                 covered += 1
     if covered < stride * stride and not accumulate:
         if residual is not None:
-            out.copy_(residual)
+            # (out IS the residual buffer: the positions no parity class reaches already hold it, and a covered position's residual
+            #  is read by the lane that then overwrites it -- no full-map copy in front of a launch that touches a quarter of it)
+            if out.data_ptr() != residual.data_ptr():
+                out.copy_(residual)
         else:
             out.zero_()
         residual_for_launch = residual
@@ -943,6 +946,18 @@ def downsum2x_add_(coarse, fine):
     L.check(lib.loft_downsum2x_add_bf16(L.ptr(_bf16(coarse)), L.ptr(_bf16(fine)), B, Hc, Wc, C, L.stream()),
             'loft_downsum2x_add_bf16')
     return coarse
+
+
+def downsum2x_sum(coarse, fine):
+    """coarse + 2x2 block sums of fine as a NEW tensor (loft_downsum2x_sum_bf16; same additions in the same order as
+    downsum2x_add_): 16-bit activations only."""
+    lib = L.load()
+    fine, coarse = _nhwc(fine), _nhwc(coarse)
+    B, C, Hc, Wc = coarse.shape
+    out = empty_nhwc(B, C, Hc, Wc, coarse.dtype, coarse.device)
+    L.check(lib.loft_downsum2x_sum_bf16(L.ptr(out), L.ptr(_bf16(coarse)), L.ptr(_bf16(fine)), B, Hc, Wc, C, L.stream()),
+            'loft_downsum2x_sum_bf16')
+    return out
 
 
 def subsample2(x):
@@ -1378,6 +1393,25 @@ def rpn_gather_rows(maps, rows, K=3):
     return out
 
 
+def rpn_sparse_prep(g, slot, A, P, w_cls, w_reg, w_conv):
+    """loft_rpn_sparse_prep: g fp32 [nsel,5], slot int64 [nsel] -> (g_rows [nsel,P], w_headT [C,P], wd [9C,C]) in the activation
+    type: the output-gradient rows in the fused head's channel order and the two dgrad operands, one launch."""
+    lib = L.load()
+    L.dev_check(g, slot, w_cls, w_reg, w_conv)
+    nsel, C = int(g.shape[0]), int(w_conv.shape[0])
+    if tuple(g.shape) != (nsel, 5) or tuple(w_conv.shape) != (C, C, 3, 3) or w_cls.numel() != A * C or w_reg.numel() != 4 * A * C:
+        raise L.LoftHipError('rpn_sparse_prep: operand shapes')
+    g = g.float().contiguous()
+    dev = g.device
+    g_rows = torch.empty(nsel, P, dtype=L.act16(), device=dev)
+    w_headT = torch.empty(C, P, dtype=L.act16(), device=dev)
+    wd = torch.empty(9 * C, C, dtype=L.act16(), device=dev)
+    L.check(lib.loft_rpn_sparse_prep(L.ptr(g), L.ptr(slot.contiguous()), nsel, int(A), int(P), C, L.ptr(w_cls.float().contiguous()),
+                                     L.ptr(w_reg.float().contiguous()), L.ptr(w_conv.float().contiguous()), L.ptr(g_rows),
+                                     L.ptr(w_headT), L.ptr(wd), L.stream()), 'loft_rpn_sparse_prep')
+    return g_rows, w_headT, wd
+
+
 def rpn_scatter_add_rows_(maps, rows, src, K=3):
     """maps[level][b, y+dy, x+dx, :] += src[nsel, K*K*C] (in place, packed bf16 atomics)."""
     lib = L.load()
@@ -1661,41 +1695,110 @@ class PrepackRegistry:
 _LOSS_SCRATCH = {}
 
 
-def fused_loss(mode, pred, target, weight=None, avg_factor=None, count=None, scale=1.0, beta=1.0):
-    """loft_fused_loss: -> (loss fp32 [1], grad fp32 like pred).  mode: 'l1' | 'smooth_l1' | 'bce' | 'ce'.
+_UNIT_GRAD = {}
+
+
+def unit_grad(device):
+    """The trainer's root gradient: ONE cached fp32 scalar 1.0 per device, passed as ``loss.backward(gradient=...)``.  The sum of
+    the losses hands every term a VIEW of it (expand / unbind / reshape keep the storage), so a loss's backward recognises
+    "d total / d me = 1" by address (`is_unit_grad`) and returns its stored gradient without the multiply launch.  Never written."""
+    idx = torch.device(device).index or 0
+    if idx not in _UNIT_GRAD:
+        _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT_GRAD[idx]
+
+
+def is_unit_grad(g):
+    u = _UNIT_GRAD.get(g.device.index or 0) if g.is_cuda else None
+    return u is not None and g.dtype == torch.float32 and g.numel() == 1 and g.data_ptr() == u.data_ptr()
+
+
+def _loss_view(t, row_dims):
+    """(d1, d2, s0, s1, s2) addressing the first `row_dims` dims of `t` in logical row-major order, or None if they do not
+    collapse to three strided dims (loft_fused_loss_v2)."""
+    dims = [(int(n), int(st)) for n, st in zip(t.shape[:row_dims], t.stride()[:row_dims]) if n != 1]
+    merged = []
+    for n, st in dims:
+        if merged and merged[-1][1] == st * n:
+            merged[-1] = (merged[-1][0] * n, st)
+        else:
+            merged.append((n, st))
+    if len(merged) > 3:
+        return None
+    while len(merged) < 3:
+        merged.insert(0, (1, 0))
+    (_, s0), (d1, s1), (d2, s2) = merged
+    if d1 == 1 and d2 == 1:
+        return 1, 1, s2 if merged[2][0] != 1 or s2 else 1, 0, 0
+    return d1, d2, s0, s1, s2
+
+
+def fused_loss(mode, pred, target, weight=None, avg_factor=None, count=None, scale=1.0, beta=1.0, want_acc=False,
+               target_ge1=False):
+    """loft_fused_loss_v2: -> (loss fp32 [1] (+ top-1 accuracy in [1] with want_acc), grad fp32 dense like pred).
+    mode: 'l1' | 'smooth_l1' | 'bce' | 'ce'.  pred may be a strided fp32 view (a column block / channel / row range of a wider head
+    output): it is read in place.  weight: fp32 or bool, the shape of pred or its rows ('ce'), or a view expanded over pred's last
+    dim (one weight per row, read un-expanded).  target_ge1 ('bce'): target are int64 labels, the target value is label >= 1.
     avg_factor: device scalar tensor, python number or None (then `count`, default = number of elements / rows)."""
     lib = L.load()
     L.dev_check(pred, target, weight)
     m = {'l1': 0, 'smooth_l1': 1, 'bce': 2, 'ce': 3}[mode]
-    pred = pred.float().contiguous()
+    if pred.dtype != torch.float32:
+        pred = pred.float()
     dev = pred.device
     if m == 3:
         n, C = pred.shape[0], pred.shape[1]
+        if pred.stride(1) != 1 and C > 1:
+            pred = pred.contiguous()
+        view = _loss_view(pred, 1)
         target = target.contiguous()
         if target.dtype != torch.int64:
             target = target.long()
     else:
         n, C = pred.numel(), 1
-        target = target.float().contiguous()
+        view = _loss_view(pred, pred.dim())
+        if target_ge1:
+            target = target.contiguous()
+            if target.dtype != torch.int64:
+                target = target.long()
+        else:
+            target = target.float().contiguous()
+    if view is None:
+        pred = pred.contiguous()
+        view = (1, 1, C if m == 3 else 1, 0, 0)
+    wdiv, wkind = 1, 0
     if weight is not None:
-        weight = weight.float().expand(pred.shape if m != 3 else (n,)).contiguous()
+        if m != 3 and weight.dim() == pred.dim() and weight.dim() > 1 and weight.shape == pred.shape and weight.stride(-1) == 0:
+            wdiv = int(pred.shape[-1])              # expanded over the last dim: one weight per row
+            weight = weight[..., 0]
+        elif m != 3 and weight.shape != pred.shape:
+            weight = weight.expand(pred.shape)
+        if weight.dtype in (torch.bool, torch.uint8):
+            wkind = 1
+            weight = weight.contiguous().view(torch.uint8)
+        else:
+            weight = weight.float().contiguous()
     af = None
     cnt = float(n if count is None else count)
     if torch.is_tensor(avg_factor):
-        af = avg_factor.float().reshape(1).contiguous()
+        af = avg_factor.reshape(1)
+        if af.dtype != torch.float32:
+            af = af.float()
     elif avg_factor is not None:
         cnt = float(avg_factor)
     key = (dev.index, L.stream().value)
     if key not in _LOSS_SCRATCH:             # per stream: the ticket counter must not be shared by concurrent launches
         _LOSS_SCRATCH[key] = torch.zeros(1, dtype=torch.int32, device=dev)
     counter = _LOSS_SCRATCH[key]
-    partial = torch.empty(256, dtype=torch.float32, device=dev)
-    grad = torch.empty_like(pred)
-    out = torch.empty(1, dtype=torch.float32, device=dev)
-    L.check(lib.loft_fused_loss(m, L.ptr(pred), L.ptr(target), L.ptr(weight), c_int64(n), int(C), L.ptr(af), c_float(max(cnt, 1e-30)),
-                                c_float(scale), c_float(beta), L.ptr(grad), L.ptr(partial), L.ptr(counter), L.ptr(out), L.stream()),
-            'loft_fused_loss')
-    return out, grad
+    partial = torch.empty(512, dtype=torch.float32, device=dev)
+    grad = torch.empty(pred.shape, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    d1, d2, s0, s1, s2 = view
+    L.check(lib.loft_fused_loss_v2(m, L.ptr(pred), c_int64(d1), c_int64(d2), c_int64(s0), c_int64(s1), c_int64(s2), L.ptr(target),
+                                   1 if (target_ge1 and m == 2) else 0, L.ptr(weight), wkind, c_int64(wdiv), c_int64(n), int(C),
+                                   L.ptr(af), c_float(max(cnt, 1e-30)), c_float(scale), c_float(beta), L.ptr(grad), L.ptr(partial),
+                                   L.ptr(counter), L.ptr(out), 1 if (want_acc and m == 3) else 0, L.stream()), 'loft_fused_loss_v2')
+    return (out[:1], grad, out[1:]) if want_acc else (out[:1], grad)
 
 
 def rpn_sample_gather(heads, lvl_off, A, anchors, gts, gt_inds, pidx, pval, nidx, nval, means, stds):
@@ -1816,6 +1919,17 @@ def random_sample(gt_inds, num, max_pos, mode='random'):
                                        ctypes.c_uint64(seed), L.ptr(pidx), L.ptr(pval), L.ptr(nidx), L.ptr(nval), L.ptr(ws),
                                        L.stream()), 'loft_random_sample')
     return pidx, pval.view(torch.bool), nidx, nval.view(torch.bool)       # (the kernel writes 0 / 1 bytes: bool views, no copies)
+
+
+def sampled_avg_factor(pos_valid, neg_valid):
+    """sum_b max(#pos_b, 1) + sum_b max(#neg_b, 1) as a device fp32 scalar [1] (anchor_head.py:363-364), one launch."""
+    lib = L.load()
+    L.dev_check(pos_valid, neg_valid)
+    pv, nv = pos_valid.contiguous().view(torch.uint8), neg_valid.contiguous().view(torch.uint8)
+    out = torch.empty(1, dtype=torch.float32, device=pv.device)
+    L.check(lib.loft_sampled_avg_factor(L.ptr(pv), L.ptr(nv), int(pv.shape[0]), int(pv.shape[1]), int(nv.shape[1]), L.ptr(out),
+                                        L.stream()), 'loft_sampled_avg_factor')
+    return out
 
 
 def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=True):

@@ -10,22 +10,27 @@ from .builder import LOSSES
 
 
 class _FusedLossFn(torch.autograd.Function):
-    """Loss value + gradient in ONE launch (loft_fused_loss); backward is the stored gradient times the incoming scalar."""
+    """Loss value + gradient in ONE launch (loft_fused_loss_v2); backward is the stored gradient times the incoming scalar -- and
+    the stored gradient itself when that scalar is the trainer's unit root gradient (kernels.unit_grad: recognised by address)."""
 
     @staticmethod
-    def forward(ctx, pred, mode, target, weight, avg_factor, count, scale, beta, out_shape):
+    def forward(ctx, pred, mode, target, weight, avg_factor, count, scale, beta, out_shape, want_acc, target_ge1):
         from .. import kernels as K
-        loss, grad = K.fused_loss(mode, pred, target, weight, avg_factor, count, scale, beta)
-        ctx.save_for_backward(grad)
+        res = K.fused_loss(mode, pred, target, weight, avg_factor, count, scale, beta, want_acc=want_acc, target_ge1=target_ge1)
+        ctx.save_for_backward(res[1])
         ctx.meta = (tuple(pred.shape), pred.dtype)
-        return loss.reshape(out_shape)
+        if want_acc:
+            ctx.mark_non_differentiable(res[2])
+            return res[0].reshape(out_shape), res[2]
+        return res[0].reshape(out_shape)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *unused):
+        from .. import kernels as K
         (grad,) = ctx.saved_tensors
         shape, dt = ctx.meta
-        gp = (grad * g.reshape(())).reshape(shape)
-        return (gp if dt == torch.float32 else gp.to(dt)), None, None, None, None, None, None, None, None
+        gp = (grad if K.is_unit_grad(g) else grad * g.reshape(())).reshape(shape)
+        return (gp if dt == torch.float32 else gp.to(dt)), None, None, None, None, None, None, None, None, None, None
 
 
 ELEMENTWISE_ONLY = False   # tests: compare the fused value+gradient launch with the elementwise formulation below
@@ -37,8 +42,9 @@ def _fusable(pred, reduction):
     return pred.is_cuda and reduction == 'mean' and pred.numel() > 0 and not ELEMENTWISE_ONLY
 
 
-def _fused(mode, pred, target, weight, avg_factor, scale, beta=1.0, count=None, out_shape=()):
-    return _FusedLossFn.apply(pred, mode, target, weight, avg_factor, count, float(scale), float(beta), out_shape)
+def _fused(mode, pred, target, weight, avg_factor, scale, beta=1.0, count=None, out_shape=(), want_acc=False, target_ge1=False):
+    return _FusedLossFn.apply(pred, mode, target, weight, avg_factor, count, float(scale), float(beta), out_shape, want_acc,
+                              target_ge1)
 
 
 def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
@@ -89,9 +95,9 @@ class CrossEntropyLoss(nn.Module):
         if self.class_weight is None and not kwargs and _fusable(cls_score, reduction):
             if self.use_sigmoid:
                 if cls_score.dim() != label.dim():          # RPN: labels in {0,1} -> one channel
-                    if cls_score.numel() == label.numel():
-                        return _fused('bce', cls_score.reshape(-1), (label >= 1).reshape(-1), None if weight is None else
-                                      weight.reshape(-1), avg_factor, self.loss_weight)
+                    if cls_score.numel() == label.numel():     # (label >= 1 is evaluated by the loss kernel on the int64 labels)
+                        return _fused('bce', cls_score.reshape(-1), label.reshape(-1), None if weight is None else
+                                      weight.reshape(-1), avg_factor, self.loss_weight, target_ge1=True)
                 else:
                     return _fused('bce', cls_score, label, weight, avg_factor, self.loss_weight)
             elif self.use_mask:
@@ -100,7 +106,10 @@ class CrossEntropyLoss(nn.Module):
                 if cls_score.shape[1] == 1 and avg_factor is None:
                     return _fused('bce', cls_score.reshape(-1), label.reshape(-1), None, None, self.loss_weight, out_shape=(1,))
             elif cls_score.dim() == 2:
-                return _fused('ce', cls_score, label, weight, avg_factor, self.loss_weight)
+                # the same launch counts the top-1 hits: `accuracy(cls_score, label)` of the caller (bbox_head.py:152) for free
+                loss, acc = _fused('ce', cls_score, label, weight, avg_factor, self.loss_weight, want_acc=True)
+                self.last_accuracy = (cls_score, label, acc)
+                return loss
         cw = None if self.class_weight is None else cls_score.new_tensor(self.class_weight)
         return self.loss_weight * self.cls_criterion(cls_score, label, weight, class_weight=cw, reduction=reduction,
                                                      avg_factor=avg_factor, **kwargs)
@@ -134,9 +143,15 @@ class SmoothL1Loss(nn.Module):
         return self.loss_weight * weight_reduce_loss(loss, weight, reduction, avg_factor)
 
 
-def accuracy(pred, target, topk=1):
+def accuracy(pred, target, topk=1, loss_module=None):
+    """accuracy.py:4-48 (top-1, percent).  loss_module: a CrossEntropyLoss that has just been evaluated on this very
+    (pred, target) pair -- its fused launch already counted the hits."""
     if pred.size(0) == 0:
         return pred.new_zeros(1)
+    last = getattr(loss_module, 'last_accuracy', None)
+    if last is not None and last[0] is pred and last[1] is target:
+        loss_module.last_accuracy = None
+        return last[2]
     correct = (pred.argmax(dim=1) == target).float().sum()
     return (correct * (100.0 / pred.size(0))).view(1)
 

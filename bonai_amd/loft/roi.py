@@ -110,7 +110,9 @@ class Shared2FCBBoxHead(nn.Module):
         h = F2.linear(h, self.shared_fcs[1].weight, self.shared_fcs[1].bias, relu=True, input_relu=True)
         w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0)
         b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)
-        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), w, b).reshape(N, -1)
+        o = F2.narrow_head(h.reshape(N, -1, 1, 1).contiguous(memory_format=torch.channels_last), w, b,
+                           leaves=[(self.fc_cls.weight, self.fc_cls.bias, 0, ncls),
+                                   (self.fc_reg.weight, self.fc_reg.bias, ncls, ncls + nreg)]).reshape(N, -1)
         return o[:, :ncls], o[:, ncls:ncls + nreg]
 
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, from_get_targets=False):
@@ -120,7 +122,7 @@ class Shared2FCBBoxHead(nn.Module):
         losses = dict()
         avg = float(max(int(label_weights.shape[0]), 1)) if from_get_targets else (label_weights > 0).sum().float().clamp(min=1.)
         losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg)
-        losses['acc'] = accuracy(cls_score, labels)
+        losses['acc'] = accuracy(cls_score, labels, loss_module=self.loss_cls)
         n = bbox_pred.shape[0]
         pred = bbox_pred.view(n, -1, 4)
         if pred.shape[1] == 1:          # one class (BONAI): nothing to select -- no gather / scatter-back launches
@@ -177,7 +179,8 @@ class FCNMaskHead(nn.Module):
         for i, m in enumerate(self.convs):
             x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True, input_relu=i > 0)
         x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias, input_relu=len(self.convs) > 0)
-        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias, input_relu=True)
+        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias, input_relu=True,
+                           leaves=[(self.conv_logits.weight, self.conv_logits.bias, 0, nout)])
         return o[:, :nout]
 
     def loss(self, mask_pred, mask_targets, labels):

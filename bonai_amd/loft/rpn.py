@@ -124,13 +124,18 @@ class RPNHead(nn.Module):
         """MaxIoUAssigner over every anchor + RandomSampler (anchor_head.py:197-255 for the whole batch) -> sampled indices and the
         loss normaliser.  Depends on the static anchors and the gt boxes only -- not on anything the network computes."""
         with torch.no_grad():
-            nbox = torch.full((B,), geo['N'], dtype=torch.int32, device=dev)
-            gt_inds, _ = self.assigner.assign_batched(geo['anchors_b'], nbox, gts, ngt)
+            if 'nbox' not in geo:               # static: every anchor of every image is a candidate (allowed_border = -1)
+                geo['nbox'] = torch.full((B,), geo['N'], dtype=torch.int32, device=dev)
+                _static_ready(dev)
+            gt_inds, _ = self.assigner.assign_batched(geo['anchors_b'], geo['nbox'], gts, ngt)
             smp = self.sampler.sample_batched(gt_inds)
             pidx, pval, nidx, nval = smp['pos_idx'], smp['pos_valid'], smp['neg_idx'], smp['neg_valid']
-            num_pos = pval.sum(1).clamp(min=1).sum()
-            num_neg = nval.sum(1).clamp(min=1).sum()
-            avg = (num_pos + num_neg).float()
+            if pval.is_cuda:
+                avg = K.sampled_avg_factor(pval, nval).reshape(())
+            else:
+                num_pos = pval.sum(1).clamp(min=1).sum()
+                num_neg = nval.sum(1).clamp(min=1).sum()
+                avg = (num_pos + num_neg).float()
         return gt_inds, pidx, pval, nidx, nval, avg
 
     def prefetch_targets(self, img, gt_bboxes):
@@ -224,7 +229,8 @@ class RPNHead(nn.Module):
                 logit = vals[..., 0]
                 pred = vals[:, :pidx.shape[1], 1:5]
                 loss_cls = self.loss_cls(logit.reshape(-1, 1), label.reshape(-1), w.reshape(-1), avg_factor=avg)
-                loss_bbox = self.loss_bbox(pred, tgt, w[:, :pidx.shape[1], None].expand_as(pred), avg_factor=avg)
+                # (the positives' weights ARE pos_valid: read as one byte per row by the loss kernel, no expand / cast launches)
+                loss_bbox = self.loss_bbox(pred, tgt, pval[..., None].expand_as(pred), avg_factor=avg)
             if side is not None:
                 main.wait_stream(side)
                 loss_cls.record_stream(main)

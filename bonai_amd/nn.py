@@ -46,6 +46,35 @@ def _mark_sunk(*ps):
             p._loft_sunk = True
 
 
+def _queue_param_grads(jobs):
+    """jobs: [(weight Parameter, dW fp32 [Cout, Cin(P)] (a view is fine), bias Parameter | None, db fp32 [Cout] | None, flat_chw)].
+    When the trainer's unpack queue is open and every parameter has an arena slot, the gradients are deposited there by the next
+    batched unpack launch (no per-parameter accumulation launch of autograd) and True is returned: the caller hands autograd None.
+    flat_chw = (C, H, W): the weight is [O, C, H, W] and dW is [O, (H W) C] (tap-major K order)."""
+    if UNPACK_Q is None:
+        return False
+    slots = []
+    for pw, dw, pb, db, flat in jobs:
+        sw = _direct_slot(pw)
+        sb = _direct_slot(pb) if pb is not None else None
+        if sw is None or (pb is not None and (sb is None or db is None)):
+            return False
+        slots.append((sw, sb))
+    for (pw, dw, pb, db, flat), (sw, sb) in zip(jobs, slots):
+        sinks = [pw] + ([pb] if pb is not None else [])
+        _mark_sunk(*sinks)
+        UNPACK_Q.add(dw, db if pb is not None else None, pw, None, 1e-5, (sw, None, sb), [(lambda q=q: _sink_done(q)) for q in sinks],
+                     flat_chw=flat, params=sinks)
+    return True
+
+
+def _count_uses(*ps):
+    """One more use of these leaf parameters in this step's graph (the sink fires after the last use has deposited)."""
+    for p in ps:
+        if isinstance(p, torch.nn.Parameter) and p.requires_grad:
+            p._loft_pending = getattr(p, '_loft_pending', 0) + 1
+
+
 def _sink_done(p):
     """One use of ``p`` has deposited its gradient in the arena; tell the trainer once the last use of this step has."""
     p._loft_pending = getattr(p, '_loft_pending', 1) - 1
@@ -452,10 +481,16 @@ class _NarrowHeadFn(torch.autograd.Function):
     PADW = 128
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None):
+    def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None, leaves=None):
         _note_use(x)
         Cout, Cin, R, S = w.shape
         ctx.input_relu = input_relu
+        # leaves: [(weight Parameter, bias Parameter | None, first row, end row)] -- the leaf parameters `w` / `b` are made of (w itself,
+        # or the pieces of a concatenation): with them the one-pass backward deposits dW / db straight in their arena slots
+        ctx.leaves = leaves if (leaves and R == 1 and S == 1 and ctx.needs_input_grad[1] and
+                                all(isinstance(l[0], torch.nn.Parameter) for l in leaves)) else None
+        if ctx.leaves is not None:
+            _count_uses(*[p for l in ctx.leaves for p in l[:2] if p is not None])
         c4 = (Cout + 3) // 4 * 4
         wp, bpad = prepacked if prepacked is not None else narrow_head_prepack(w, b, x.dtype)
         K.ALGO_SCALE = Cout / c4
@@ -480,7 +515,15 @@ class _NarrowHeadFn(torch.autograd.Function):
                                            need_dw=ctx.needs_input_grad[1], need_db=want_b)
             if gx is not None and ctx.input_relu:
                 gx._loft_premasked = x.data_ptr()
-            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None
+            if ctx.leaves is not None and dw is not None and (db is not None or not ctx.has_b) and _queue_param_grads(
+                    [(pw, dw[lo:hi], pb, None if (pb is None or db is None) else db[lo:hi], None) for pw, pb, lo, hi in ctx.leaves]):
+                return gx, None, None, None, None, None, None, None
+            if ctx.leaves is not None:      # (no queue / no slots: autograd accumulates; the uses counted in forward are not sunk)
+                for l in ctx.leaves:
+                    for p_ in l[:2]:
+                        if p_ is not None and getattr(p_, '_loft_pending', 0) > 0:
+                            p_._loft_pending -= 1
+            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None, None
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
         gp = torch.zeros(N, P, H, W, dtype=x.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
@@ -503,7 +546,12 @@ class _NarrowHeadFn(torch.autograd.Function):
         K.ALGO_SCALE = 1.0
         if want_b:
             gb = g[:, :Cout].float().sum(dim=(0, 2, 3))
-        return gx, gw, gb, None, None, None, None
+        if ctx.leaves is not None:
+            for l in ctx.leaves:
+                for p_ in l[:2]:
+                    if p_ is not None and getattr(p_, '_loft_pending', 0) > 0:
+                        p_._loft_pending -= 1
+        return gx, gw, gb, None, None, None, None, None
 
 
 def narrow_head_prepack(w, b, dtype):
@@ -518,12 +566,16 @@ def narrow_head_prepack(w, b, dtype):
     return wp[None], bias
 
 
-def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False, prepacked=None):
+def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False, prepacked=None, leaves=None):
     """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW].
-    input_relu: x is the output of a ReLU -- the backward folds that ReLU's mask into the data gradient it produces."""
+    input_relu: x is the output of a ReLU -- the backward folds that ReLU's mask into the data gradient it produces.
+    leaves: when w / b are concatenations, [(weight Parameter, bias Parameter | None, first row, end row)] of their pieces (a
+    Parameter passed as w is its own leaf): lets the backward deposit the gradients in the trainer's arena directly."""
+    if leaves is None and isinstance(w, torch.nn.Parameter) and (b is None or isinstance(b, torch.nn.Parameter)):
+        leaves = [(w, b, 0, int(w.shape[0]))]
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
-    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu, prepacked)
+    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu, prepacked, leaves)
 
 
 class _MdcnSampleFn(torch.autograd.Function):
@@ -791,6 +843,12 @@ class _FpnTopDownFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        if all(g.dtype == K.L.act16() and g.is_cuda for g in gs):
+            # out[i] = gs[i] + blocksum(out[i-1]) into fresh maps: the incoming gradients are only read (no private clones)
+            out = [to_nhwc(gs[0])]
+            for i in range(1, len(gs)):
+                out.append(K.downsum2x_sum(to_nhwc(gs[i]), out[i - 1]))
+            return tuple(out)
         # gs[i] (i >= 1) are accumulated into in place -> private copies; the finest map is only read (no 268 MB clone)
         gs = [to_nhwc(g) if i == 0 else to_nhwc(g).clone() for i, g in enumerate(gs)]
         for i in range(1, len(gs)):
@@ -956,7 +1014,9 @@ class _SparseRPNFn(torch.autograd.Function):
         h_sel = K.rpn_gather_rows(list(hs), rows, 1)
         ctx.save_for_backward(rows, slot, w_conv, w_cls, w_reg, h_sel, *xs)
         ctx.A = A
-        return vals.clone()
+        ctx.params = (w_conv, b_conv, w_cls, b_cls, w_reg, b_reg)        # the Parameter objects (their .grad may be an arena slot)
+        _count_uses(*[p for p, need in zip(ctx.params, ctx.needs_input_grad[5:11]) if need])
+        return vals.view_as(vals)     # (a fresh tensor object for autograd to hang the node on; same storage, no copy launch)
 
     @staticmethod
     @K.planes_scoped
@@ -966,15 +1026,12 @@ class _SparseRPNFn(torch.autograd.Function):
         A, nsel, dev = ctx.A, rows.shape[0], rows.device
         P = _NarrowHeadFn.PADW
         C = w_conv.shape[0]
-        # output-gradient rows in the fused head's channel order (cls 0..A-1, reg A..5A-1), zero padded to 128 channels
-        idx = torch.cat([slot[:, None], A + 4 * slot[:, None] + torch.arange(4, device=dev)[None]], 1)
-        g_rows = torch.zeros(nsel, P, dtype=torch.float32, device=dev).scatter_(1, idx, g.float()).to(K.L.act16())
-        w_head = torch.zeros(P, C, dtype=torch.float32, device=dev)
-        w_head[:A] = w_cls.view(A, C)
-        w_head[A:5 * A] = w_reg.view(4 * A, C)
+        # output-gradient rows in the fused head's channel order (cls 0..A-1, reg A..5A-1), zero padded to 128 channels, and the two
+        # dgrad operands [C, P] / [(tap, cin), cout]: one launch
+        g_rows, w_headT, wd = K.rpn_sparse_prep(g, slot, A, P, w_cls, w_reg, w_conv)
         gimg = _as_img(g_rows)
         # gh = relu'(h) * (g_rows x W_head): data gradient of the 1x1 heads with the ReLU mask in the epilogue
-        gh = K.conv2d_dgrad(gimg, w_head.t().contiguous().to(K.L.act16())[None, None], (nsel, 1), 1, 1, mask=_as_img(h_sel))
+        gh = K.conv2d_dgrad(gimg, w_headT[None, None], (nsel, 1), 1, 1, mask=_as_img(h_sel))
         dwp, db = K.conv2d_wgrad(gimg, _as_img(h_sel), 1, 1, with_bias=True)
         g_wcls, g_wreg = dwp[0, 0, :A].reshape(w_cls.shape), dwp[0, 0, A:5 * A].reshape(w_reg.shape)
         g_bcls, g_breg = db[0, :A], db[0, A:5 * A]
@@ -982,7 +1039,6 @@ class _SparseRPNFn(torch.autograd.Function):
         xg = K.rpn_gather_rows(list(xs), rows, 3)
         dwc, dbc = K.conv2d_wgrad(gh, _as_img(xg), 1, 1, with_bias=True)
         g_wconv = dwc[0, 0].view(C, 9, C).permute(0, 2, 1).reshape(w_conv.shape)
-        wd = w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(K.L.act16()).contiguous()     # [(tap, cin), cout]
         dxs = K.conv2d_fwd(_as_img(gh2d), wd[None, None], None, 1, 1)
         dxs = dxs.permute(0, 2, 3, 1).reshape(nsel, 9 * C)
         # Everything above ran on THIS node's stream -- the RPN losses' own stream when rpn.loss_fused forked one: ~25 small launches
@@ -1016,7 +1072,15 @@ class _SparseRPNFn(torch.autograd.Function):
                 dxs.record_stream(hub_stream)
         if switch:
             cur.wait_stream(hub_stream)                # (autograd orders this node's consumers behind `cur`)
-        return (None, None, None, None, None, g_wconv, dbc[0], g_wcls, g_bcls, g_wreg, g_breg) + tuple(ret) + (None,) * len(xs)
+        pw_conv, pb_conv, pw_cls, pb_cls, pw_reg, pb_reg = ctx.params
+        if all(ctx.needs_input_grad[5:11]) and _queue_param_grads([
+                (pw_conv, dwc[0, 0], pb_conv, dbc[0], (C, 3, 3)),                 # dwc is [cout, (tap, cin)]: the flattened-map form
+                (pw_cls, dwp[0, 0, :A], pb_cls, db[0, :A], None),
+                (pw_reg, dwp[0, 0, A:5 * A], pb_reg, db[0, A:5 * A], None)]):
+            pgrads = (None,) * 6
+        else:
+            pgrads = (g_wconv, dbc[0], g_wcls, g_bcls, g_wreg, g_breg)
+        return (None, None, None, None, None) + pgrads + tuple(ret) + (None,) * len(xs)
 
 
 def rpn_sparse_outputs(vals, rows, slot, A, xs, hs, w_conv, b_conv, w_cls, b_cls, w_reg, b_reg):
@@ -1192,7 +1256,9 @@ class _ResBlockFn(torch.autograd.Function):
                 #  are copies of the residual and must already be masked; the mask is idempotent)
                 gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, mask=mask, out_dtype=x.dtype)
                 ks, ss, ps, cps = sc_spec
-                gx = K.conv2d_dgrad(g, packs[n], tuple(x.shape[2:]), ks, ks, ss, ps, residual=gx, mask=mask, out_dtype=x.dtype)
+                # (in place into the main path's gradient: a strided 1x1 shortcut writes one position in stride^2)
+                gx = K.conv2d_dgrad(g, packs[n], tuple(x.shape[2:]), ks, ks, ss, ps, residual=gx, mask=mask, out_dtype=x.dtype,
+                                    out=gx if (ss > 1 and ks == 1) else None)
             if mask is not None:
                 gx._loft_premasked = x.data_ptr()
         if sc_spec is not None:

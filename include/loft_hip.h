@@ -358,6 +358,9 @@ int loft_relu_bwd_bf16(const void* g, const void* y, void* out, int64_t n, void*
 int loft_colsum_bf16(const void* x, int64_t M, int C, float* out, void* stream);
 int loft_upsample2x_add_bf16(void* fine, const void* coarse, int B, int H, int W, int C, void* stream);
 int loft_downsum2x_add_bf16(void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream);
+/* out-of-place form of the same sum (out = coarse + 2x2 block sums of fine, same order of additions): the FPN backward keeps the
+ * incoming coarse gradient untouched without cloning it first. */
+int loft_downsum2x_sum_bf16(void* out, const void* coarse, const void* fine, int B, int Hc, int Wc, int C, void* stream);
 int loft_subsample2_bf16(const void* src, void* dst, int B, int Ho, int Wo, int Hi, int Wi, int C, int adjoint,
                          void* stream);
 int loft_maxpool3x3s2_bf16(const void* src, void* dst, int B, int Hi, int Wi, int C, void* stream);
@@ -480,6 +483,14 @@ int loft_rpn_gather_rows(void* const* level_ptrs, const int* H, const int* W, in
 int loft_rpn_scatter_add_rows(void* const* level_ptrs, const int* H, const int* W, int n_levels, const int* rows, int nsel,
                               int C, int K, const void* src, void* stream);
 
+/* loft_rpn_sparse_prep: the operands of the RPN head's sparse backward (rpn_head.py:38-54 under anchor_head.py:429-497) in one launch.
+ * g fp32 [nsel,5] = gradient of (objectness logit, 4 deltas) of every sampled anchor, slot int64 [nsel] = its anchor index a < A;
+ * w_cls fp32 [A,C], w_reg fp32 [4A,C], w_conv fp32 [C,C,3,3].  Outputs in the activation type of the build:
+ * g_rows [nsel,P] (column a = g[.,0], columns A+4a+j = g[.,1+j], zeros elsewhere; P >= 5A), w_headT [C,P] (the fused 1x1 head's
+ * weights transposed, zero-padded to P), wd [9C,C] with wd[t C + ci][co] = w_conv[co][ci][t]. */
+int loft_rpn_sparse_prep(const float* g, const int64_t* slot, int nsel, int A, int P, int C, const float* w_cls, const float* w_reg,
+                         const float* w_conv, void* g_rows, void* w_headT, void* wd, void* stream);
+
 /* ---- HRNet-W32 / HRFPN resampling and fusion (BASELINE config 5) ----------------------------------
  * All tensors NHWC, dtype LOFT_F32 | LOFT_BF16, C % 8 == 0, scale factors are 1 << shift.
  * loft_fuse_sum_relu: out = relu?(sum_j nearest_up(terms[j], 1 << shifts[j])) -- the fuse step of HRModule.forward
@@ -598,6 +609,10 @@ int loft_rpn_sample_gather(const void* const* heads, const int* H, const int* W,
                            const float* stds_host, float* vals, int32_t* rows, int64_t* slot, float* tgt,
                            int64_t* label, float* weight, void* stream);
 
+/* loft_sampled_avg_factor: out[0] = sum_b max(#pos_valid[b,:], 1) + sum_b max(#neg_valid[b,:], 1): the RPN losses' normaliser
+ * `num_total_samples` of anchor_head.py:363-364, 462-464 from the sampler's validity bytes ([B,P] / [B,Q]); one launch. */
+int loft_sampled_avg_factor(const uint8_t* pos_valid, const uint8_t* neg_valid, int B, int P, int Q, float* out, void* stream);
+
 /* loft_fused_loss: a weighted, normalised loss and its gradient in one launch (mmdet/models/losses/utils.py:26-52 around
  * smooth_l1_loss.py:8-50 and cross_entropy_loss.py:9-125).  mode 0 L1, 1 SmoothL1(beta), 2 sigmoid cross-entropy on logits (target
  * fp32 in [0,1]), 3 softmax cross-entropy (pred [n,C], target int64 [n], weight per row).  n = number of elements (rows for mode 3);
@@ -607,6 +622,16 @@ int loft_rpn_sample_gather(const void* const* heads, const int* H, const int* W,
 int loft_fused_loss(int mode, const float* pred, const void* target, const float* weight, int64_t n, int C,
                     const float* avg_factor, float count, float scale, float beta, float* grad, float* partial,
                     uint32_t* counter, float* loss_out, void* stream);
+/* loft_fused_loss_v2: the same launch reading its operands where the heads left them (no clone / cast / compare launches in front):
+ * pred is a strided view -- logical index i (element; row for mode 3, whose C classes are read at unit stride) sits at
+ * (i / (d1 d2)) s0 + ((i / d2) % d1) s1 + (i % d2) s2 floats from `pred` (contiguous: d1 = d2 = 1, s0 = 1, or C for mode 3);
+ * target_kind 1 (mode 2 only): int64 labels, target = (label >= 1) (cross_entropy_loss.py:60-66); weight_kind 1: uint8 weights;
+ * every `wdiv` consecutive logical elements share one weight.  want_acc (mode 3 only): loss_out[1] = top-1 accuracy in percent
+ * (accuracy.py:4-48), partial then needs >= 512 floats.  grad is dense in logical order. */
+int loft_fused_loss_v2(int mode, const float* pred, int64_t d1, int64_t d2, int64_t s0, int64_t s1, int64_t s2, const void* target,
+                       int target_kind, const void* weight, int weight_kind, int64_t wdiv, int64_t n, int C, const float* avg_factor,
+                       float count, float scale, float beta, float* grad, float* partial, uint32_t* counter, float* loss_out,
+                       int want_acc, void* stream);
 
 /* loft_roi_sample_targets: SamplingResult + bbox2roi + BBoxHead.get_targets for a batch (sampling_result.py:25-53,
  * transforms.py:54-73, bbox_head.py:84-138).  cand [B,Ncand,4] candidate boxes (gts first when add_gt_as_proposals), gt_inds int64

@@ -344,6 +344,90 @@ def test_fused_losses_match_elementwise_formulation():
         assert (g0 - g1).abs().max().item() <= 2e-5 * max(1e-6, g1.abs().max().item()), type(mod).__name__
 
 
+def test_fused_losses_read_strided_views_bool_weights_and_count_accuracy():
+    """loft_fused_loss_v2: the operands where the heads leave them -- class / delta columns of the fused [n, 8] fc_cls + fc_reg
+    output, rows b, p < P and columns 1..4 of the RPN's [B, S, 5] gather with the positives' bool validity as the row weight, one
+    channel of a 4-padded NHWC mask-logit map -- against the elementwise formulation on contiguous copies; the top-1 accuracy
+    counted by the softmax launch (accuracy.py:4-48); and the unit-root-gradient short cut of the backward."""
+    from bonai_amd import kernels as K
+    from bonai_amd.loft import losses as LS
+    from bonai_amd.loft.losses import CrossEntropyLoss, L1Loss, SmoothL1Loss, accuracy
+    torch.manual_seed(1)
+    dev = 'cuda'
+
+    def both(mod, make_pred, rest, kw, unit=False):
+        out = []
+        for elementwise in (False, True):
+            LS.ELEMENTWISE_ONLY = elementwise
+            try:
+                base, view = make_pred()
+                a = [t.float() if (elementwise and t.dtype == torch.bool) else t for t in rest]
+                loss = mod(view.contiguous() if elementwise else view, *a, **kw)
+                if unit and not elementwise:
+                    tot = torch.stack([loss.reshape(()), loss.reshape(()) * 0]).sum()      # a sum of terms, as _parse_losses builds it
+                    tot.backward(gradient=K.unit_grad(dev))
+                else:
+                    loss.sum().backward()
+                out.append((loss.detach().reshape(-1), base.grad.clone()))
+            finally:
+                LS.ELEMENTWISE_ONLY = False
+        (l0, g0), (l1, g1) = out
+        assert (l0 - l1).abs().max().item() <= 2e-5 * max(1.0, l1.abs().max().item())
+        assert (g0 - g1).abs().max().item() <= 2e-5 * max(1e-6, g1.abs().max().item())
+        return out
+
+    o8 = torch.randn(4096, 8, device=dev) * 2
+
+    def head_cols(lo, hi):
+        def f():
+            b = o8.clone().requires_grad_(True)
+            return b, b[:, lo:hi]
+        return f
+    lab = torch.randint(0, 2, (4096,), device=dev)
+    ce = CrossEntropyLoss(loss_weight=1.0)
+    both(ce, head_cols(0, 2), (lab, torch.ones(4096, device=dev)), dict(avg_factor=4096.0))
+    # accuracy: counted by the same launch, handed out once for this very (pred, label) pair
+    b = o8.clone()
+    v = b[:, :2]
+    ce(v, lab, torch.ones(4096, device=dev), avg_factor=4096.0)
+    acc = accuracy(v, lab, loss_module=ce)
+    want = (v.argmax(1) == lab).float().sum() * (100.0 / 4096)
+    assert abs(float(acc) - float(want)) < 1e-3 and ce.last_accuracy is None
+    assert abs(float(accuracy(v, lab, loss_module=ce)) - float(want)) < 1e-3            # second call: the plain formulation
+    tie = torch.zeros(64, 2, device=dev)                                                # ties -> first maximum (torch.argmax)
+    tl = torch.randint(0, 2, (64,), device=dev)
+    ce(tie, tl, None, avg_factor=64.0)
+    assert abs(float(accuracy(tie, tl, loss_module=ce)) - float((tl == 0).float().mean() * 100)) < 1e-3
+    both(L1Loss(loss_weight=1.0), head_cols(2, 6), (torch.randn(4096, 4, device=dev), (torch.rand(4096, 4, device=dev) > 0.5).float()),
+         dict(avg_factor=4096.0))
+    vals = torch.randn(8, 768, 5, device=dev)
+
+    def rpn_pred():
+        b = vals.clone().requires_grad_(True)
+        return b, b[:, :256, 1:5]
+
+    def rpn_logit():
+        b = vals.clone().requires_grad_(True)
+        return b, b[..., 0].reshape(-1, 1)
+    pval = torch.rand(8, 256, device=dev) > 0.4
+    avg = torch.tensor(3000.0, device=dev)
+    both(L1Loss(loss_weight=1.0), rpn_pred, (torch.randn(8, 256, 4, device=dev), pval[..., None].expand(8, 256, 4)), dict(avg_factor=avg))
+    both(CrossEntropyLoss(use_sigmoid=True, loss_weight=1.0), rpn_logit,
+         (torch.randint(0, 2, (6144,), device=dev), (torch.rand(6144, device=dev) > 0.1).float()), dict(avg_factor=avg))
+    m4 = torch.randn(120, 4, 28, 28, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def mask_logit():
+        b = m4.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        return b, b[:, :1]
+    both(CrossEntropyLoss(use_mask=True, loss_weight=1.0), mask_logit,
+         ((torch.rand(120, 28, 28, device=dev) > 0.5).float(), torch.zeros(120, dtype=torch.long, device=dev)), dict())
+    # unit root gradient: same gradient, and the short cut is really the one taken (the scalar's address is the cached one)
+    both(SmoothL1Loss(beta=1.0, loss_weight=16.0), head_cols(6, 8), (torch.randn(4096, 2, device=dev),), dict(), unit=True)
+    g = K.unit_grad(dev)
+    assert K.is_unit_grad(g) and K.is_unit_grad(g.expand(6).unbind(0)[3].reshape(1)) and not K.is_unit_grad(g * 1.0)
+    assert float(g) == 1.0
+
+
 def test_roi_sample_targets_matches_tensor_formulation():
     """loft_roi_sample_targets (sampled RoIs per image [pos..., neg...], labels, bbox2delta targets, positives' lists) against the
     gather / nonzero formulation it replaces, incl. an image without positives and one without negatives."""
@@ -516,3 +600,41 @@ def test_product_anchor_generator_device_tables_vs_reference_fixture(golden_dir)
         ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
         sh = torch.stack([xs, ys, xs, ys], -1).view(-1, 1, 4) * s
         assert torch.equal((ba[None] + sh).view(-1, 4), tab.cpu())
+
+
+def test_small_fused_launches_match_their_tensor_formulations():
+    """Three single launches that replaced chains of stock elementwise launches, each against the chain it
+    replaced: the sparse RPN backward's operand build (cat / arange / zeros / scatter_ / casts / permuted copies), the RPN losses'
+    normaliser (anchor_head.py:363-364) and the out-of-place FPN gradient sum (bit-identical to the in-place form)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(3)
+    dev = 'cuda'
+    dt = K.L.act16()
+    A, P, C, nsel = 3, 128, 256, 700
+    g = torch.randn(nsel, 5, device=dev)
+    slot = torch.randint(0, A, (nsel,), device=dev)
+    w_cls, w_reg, w_conv = torch.randn(A, C, 1, 1, device=dev), torch.randn(4 * A, C, 1, 1, device=dev), torch.randn(C, C, 3, 3, device=dev)
+    g_rows, w_headT, wd = K.rpn_sparse_prep(g, slot, A, P, w_cls, w_reg, w_conv)
+    idx = torch.cat([slot[:, None], A + 4 * slot[:, None] + torch.arange(4, device=dev)[None]], 1)
+    want_rows = torch.zeros(nsel, P, device=dev).scatter_(1, idx, g).to(dt)
+    w_head = torch.zeros(P, C, device=dev)
+    w_head[:A] = w_cls.view(A, C)
+    w_head[A:5 * A] = w_reg.view(4 * A, C)
+    assert g_rows.dtype == dt and torch.equal(g_rows, want_rows)
+    assert torch.equal(w_headT, w_head.t().contiguous().to(dt))
+    assert torch.equal(wd, w_conv.permute(2, 3, 1, 0).reshape(9 * C, C).to(dt).contiguous())
+    # normaliser: an image without positives and one without negatives count as one each
+    pval = torch.rand(6, 128, device=dev) > 0.5
+    nval = torch.rand(6, 256, device=dev) > 0.3
+    pval[2] = False
+    nval[4] = False
+    avg = K.sampled_avg_factor(pval, nval)
+    want = pval.sum(1).clamp(min=1).sum() + nval.sum(1).clamp(min=1).sum()
+    assert avg.dtype == torch.float32 and float(avg) == float(want)
+    # FPN gradient sum
+    coarse = torch.randn(2, 256, 24, 40, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    fine = torch.randn(2, 256, 48, 80, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    keep = coarse.clone(memory_format=torch.preserve_format)
+    out = K.downsum2x_sum(coarse, fine)
+    assert torch.equal(coarse, keep) and out.data_ptr() != coarse.data_ptr()
+    assert torch.equal(out, K.downsum2x_add_(coarse.clone(memory_format=torch.preserve_format), fine))

@@ -30,6 +30,8 @@ SWITCHES = {
     'no_prepack': 'BN fold + operand packing per conv per step instead of one launch per step (kernels.PrepackRegistry)',
     'no_unpack_queue': 'one loft_fold_unpack_bwd launch per conv instead of the batched unpack (kernels.UnpackQueue)',
     'no_grad_sink': 'gradients returned to autograd and accumulated by it, not deposited in the arena by the kernels',
+    'no_leaf_sink': 'narrow heads and the sparse RPN backward return their parameter gradients to autograd (per-parameter accumulation '
+                    'launches) instead of depositing them through the unpack queue (nn._queue_param_grads)',
     'no_zero_pool': 'torch.zeros / torch.empty per accumulation buffer instead of the step\'s pre-zeroed / scratch slabs',
     'no_feat_hub': 'autograd sums the RPN / RoI-extractor gradients of the FPN maps (no shared per-level gradient map)',
     # autograd-node granularity / previous formulations of three backward ops

@@ -350,11 +350,7 @@ class Trainer:
                     self._wgrad_stream = torch.cuda.Stream()
                 F2.WGRAD_STREAM = self._wgrad_stream
         try:
-            if self.loss_scale == 1.0 and out['loss'].is_cuda and out['loss'].dtype == torch.float32 and out['loss'].dim() == 0:
-                # the cached unit root gradient: the fused losses recognise it by address and skip their "grad * 1" launches
-                out['loss'].backward(gradient=K.unit_grad(out['loss'].device))
-            else:
-                (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
+            (out['loss'] if self.loss_scale == 1.0 else out['loss'] * self.loss_scale).backward()
             if F2.UNPACK_Q is not None:
                 F2.UNPACK_Q.flush()
         finally:

@@ -89,6 +89,14 @@ class FeatureGraphs:
         # the captured graph; every fork is joined before the capture ends: HRModule joins its branches, the final UnpackQueue
         # flush waits for every weight-gradient launch)
         self.side = [torch.cuda.Stream() for _ in range(4)]
+        # No cyclic-garbage collection while a stream is capturing: a collected cycle may own device objects (an older trainer's
+        # CUDAGraphs, events, streams) whose destructors call HIP APIs the capture forbids -- the runtime aborts the process
+        # (seen as "Fatal Python error: Aborted ... Garbage-collecting" inside extract_feat).  Collect now, pause the collector
+        # until both graphs are recorded.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             F2.PREPACK = tr.prepack
             F2.HUB_ENABLED = False
@@ -118,6 +126,8 @@ class FeatureGraphs:
             (zp.buf, zp.off, zp.need, zp.active), (sp.buf, sp.off, sp.need, sp.active) = zp_state, sp_state
             K.H2D_KEEP = None
             trace, F2.PACK_TRACE = F2.PACK_TRACE, prev_trace
+            if gc_was_on:
+                gc.enable()
         # Addresses the graphs do not own: the frozen layers' packings live in a cache on their Parameters and the
         # trainable layers' operands in the PrepackRegistry.  The graphs hold a reference to every such buffer (it cannot be freed
         # and handed to someone else under a live graph) and remember what it was computed from; provider() drops the graphs when

@@ -1695,24 +1695,6 @@ class PrepackRegistry:
 _LOSS_SCRATCH = {}
 
 
-_UNIT_GRAD = {}
-
-
-def unit_grad(device):
-    """The trainer's root gradient: ONE cached fp32 scalar 1.0 per device, passed as ``loss.backward(gradient=...)``.  The sum of
-    the losses hands every term a VIEW of it (expand / unbind / reshape keep the storage), so a loss's backward recognises
-    "d total / d me = 1" by address (`is_unit_grad`) and returns its stored gradient without the multiply launch.  Never written."""
-    idx = torch.device(device).index or 0
-    if idx not in _UNIT_GRAD:
-        _UNIT_GRAD[idx] = torch.ones((), dtype=torch.float32, device=device)
-    return _UNIT_GRAD[idx]
-
-
-def is_unit_grad(g):
-    u = _UNIT_GRAD.get(g.device.index or 0) if g.is_cuda else None
-    return u is not None and g.dtype == torch.float32 and g.numel() == 1 and g.data_ptr() == u.data_ptr()
-
-
 def _loss_view(t, row_dims):
     """(d1, d2, s0, s1, s2) addressing the first `row_dims` dims of `t` in logical row-major order, or None if they do not
     collapse to three strided dims (loft_fused_loss_v2)."""

@@ -10,8 +10,7 @@ from .builder import LOSSES
 
 
 class _FusedLossFn(torch.autograd.Function):
-    """Loss value + gradient in ONE launch (loft_fused_loss_v2); backward is the stored gradient times the incoming scalar -- and
-    the stored gradient itself when that scalar is the trainer's unit root gradient (kernels.unit_grad: recognised by address)."""
+    """Loss value + gradient in ONE launch (loft_fused_loss_v2); backward is the stored gradient times the incoming scalar."""
 
     @staticmethod
     def forward(ctx, pred, mode, target, weight, avg_factor, count, scale, beta, out_shape, want_acc, target_ge1):
@@ -26,10 +25,9 @@ class _FusedLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *unused):
-        from .. import kernels as K
         (grad,) = ctx.saved_tensors
         shape, dt = ctx.meta
-        gp = (grad if K.is_unit_grad(g) else grad * g.reshape(())).reshape(shape)
+        gp = (grad * g.reshape(())).reshape(shape)
         return (gp if dt == torch.float32 else gp.to(dt)), None, None, None, None, None, None, None, None, None, None
 
 

@@ -51,7 +51,7 @@ def _queue_param_grads(jobs):
     When the trainer's unpack queue is open and every parameter has an arena slot, the gradients are deposited there by the next
     batched unpack launch (no per-parameter accumulation launch of autograd) and True is returned: the caller hands autograd None.
     flat_chw = (C, H, W): the weight is [O, C, H, W] and dW is [O, (H W) C] (tap-major K order)."""
-    if UNPACK_Q is None:
+    if UNPACK_Q is None or DBG.no_leaf_sink:
         return False
     slots = []
     for pw, dw, pb, db, flat in jobs:

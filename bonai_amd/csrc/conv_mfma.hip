@@ -658,13 +658,15 @@ LOFT_EXPORT int loft_bneck_tail_bf16(const void* t1, const void* w2, const float
 
 int loft_launch_conv_tap_pipe(const ConvArgs& a, int groups, int mode, int var, int mj, int nw_force, hipStream_t s, int ring32 = 0);     // conv_pipe.hip
 
-LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,
-                                     const void* relu_mask, void* out,
-                                     const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
-                                     int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
-                                     const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
-                                     int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
-                                     int variant, void* stream) {
+struct ConvHead { const void* w; const float* b; float* out; int c4; };
+
+static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bias, const void* residual,
+                              const void* relu_mask, void* out,
+                              const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                              int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                              const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
+                              int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                              int variant, void* stream, const ConvHead* head) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
     if (kern > LOFT_CONV_W4 || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
@@ -678,6 +680,14 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;
     a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr; a.amax_out = nullptr;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0;
+    if (head) {
+        // (served by the staged epilogue of the 256-cout stream tiles only; anything else: the caller launches the head itself)
+        if (!head->w || !head->b || !head->out || head->c4 < 4 || head->c4 > 32 || (head->c4 % 4) || Cout != 256 || groups != 1 ||
+            out_f32 || accumulate || (variant & ~0xff))
+            return (int)hipErrorInvalidValue;
+        a.head_w = (const bf16_t*)head->w; a.head_b = head->b; a.head_out = head->out; a.head_c4 = head->c4;
+    }
     fastdiv_setup((unsigned)(OH * OW), &a.ohw_mul, &a.ohw_sh);
     fastdiv_setup((unsigned)OW, &a.ow_mul, &a.ow_sh);
     fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
@@ -692,6 +702,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         for (int t = 0; t < T && p64; ++t) p64 = dy_host[t] >= -1 && dy_host[t] <= 1 && dx_host[t] >= -1 && dx_host[t] <= 1;
         if (kern == LOFT_CONV_PATCH64 && !p64) return (int)hipErrorInvalidValue;
         if (kern == LOFT_CONV_PATCH64 || (kern == LOFT_CONV_AUTO && p64 && M >= 65536)) {
+            if (head) return (int)hipErrorInvalidValue;
             Conv64Args c;
             c.src = a.src; c.wgt = a.wgt; c.bias = bias; c.residual = a.residual; c.mask = a.mask; c.out = (bf16_t*)out;
             c.zero_page = a.zero_page; c.B = B; c.H = OH; c.W = OW; c.T = T; c.relu = relu;
@@ -765,6 +776,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         // (bf16 outputs only: their epilogue collects the output tile in LDS; fp32 / accumulating launches keep the lockstep kernels)
         if ((Cout % 256 && !(k == LOFT_CONV_STREAM256 && Cout % 128 == 0)) || out_f32 || accumulate) return (int)hipErrorInvalidValue;
         if (k == LOFT_CONV_STREAM256N && ((variant >> 12) & 0xf)) return (int)hipErrorInvalidValue;
+        if (head && !(k == LOFT_CONV_STREAM256 || k == LOFT_CONV_STREAM128 || k == LOFT_CONV_STREAM64)) return (int)hipErrorInvalidValue;
         a.pixmajor = pix_ok;
         a.pm_S = B; a.pm_P = OH * OW;
         if (pix_ok) {
@@ -788,6 +800,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
                                          (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s, k == LOFT_CONV_RING32 ? 1 : (k == LOFT_CONV_W4 ? 2 : 0));
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
+        if (head) return (int)hipErrorInvalidValue;
         // 256x256 tile, 8 waves of 128x64: half the LDS traffic per FLOP of the 128x128 form; only when it still
         // fills the 256 CUs and K is deep enough (>= 8 K-steps) to amortise the one-block-per-CU prologue/epilogue.
         // (Round-1 measurements of rejected forms -- 4 waves of 128x128, 256x128 tiles with 4 waves, LDS-staged output -- are in
@@ -804,7 +817,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     case LOFT_CONV_T128_SINGLE:
     case LOFT_CONV_T128_FAST:
     case LOFT_CONV_T128: {
-        if (Cout % 128) return (int)hipErrorInvalidValue;
+        if (Cout % 128 || head) return (int)hipErrorInvalidValue;
         dim3 grid(loft_cdiv(M, 128), Cout / 128, groups);
         if (k == LOFT_CONV_T128_SINGLE) {
             const bool dense_out = !out_f32 && os == 1 && OHf == OH && OWf == OW;
@@ -817,6 +830,7 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
         break;
     }
     case LOFT_CONV_T128x64: {
+        if (head) return (int)hipErrorInvalidValue;
         dim3 grid(loft_cdiv(M, 128), loft_cdiv(Cout, 64), groups);
         hipLaunchKernelGGL((conv_tap_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, a);
         break;
@@ -826,6 +840,33 @@ LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const flo
     }
     LOFT_LAUNCH_CHECK();
     return 0;
+}
+
+LOFT_EXPORT int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, const void* residual,
+                                     const void* relu_mask, void* out,
+                                     const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                                     int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                                     const int* dx_host, const int* wt_host, int relu, int out_f32, int accumulate,
+                                     int groups, int64_t src_gs, int64_t wgt_gs, int64_t out_gs, int64_t bias_gs,
+                                     int variant, void* stream) {
+    return conv_tap_bf16_impl(src, wgt, bias, residual, relu_mask, out, zero_page, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo_y,
+                              oo_x, ss, T, dy_host, dx_host, wt_host, relu, out_f32, accumulate, groups, src_gs, wgt_gs, out_gs,
+                              bias_gs, variant, stream, nullptr);
+}
+
+// The same launch with a NARROW 1x1 HEAD on its output computed in the epilogue (ConvArgs block 5): head_out[pixel][n] = head_b[n] +
+// sum_c bf16(out[pixel][c]) * head_w[n][c], n < head_c4 (a multiple of 4, <= 32), head_w bf16 [head_c4][256], head_out fp32 [pixels of the full output map][head_c4].  Served by the 256-cout stream tiles only (Cout ==
+// 256, one group, bf16 output, the dispatcher's own kernel choice); every other launch returns hipErrorInvalidValue WITHOUT
+// launching anything and the caller runs the head as a launch of its own.
+LOFT_EXPORT int loft_conv_tap_bf16_head(const void* src, const void* wgt, const float* bias, const void* residual,
+                                        const void* relu_mask, void* out,
+                                        const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
+                                        int OHf, int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host,
+                                        const int* dx_host, const int* wt_host, int relu, const void* head_w, const float* head_b,
+                                        float* head_out, int head_c4, void* stream) {
+    const ConvHead h{head_w, head_b, head_out, head_c4};
+    return conv_tap_bf16_impl(src, wgt, bias, residual, relu_mask, out, zero_page, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo_y,
+                              oo_x, ss, T, dy_host, dx_host, wt_host, relu, 0, 0, 1, 0, 0, 0, 0, LOFT_CONV_AUTO, stream, &h);
 }
 
 LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
@@ -876,6 +917,7 @@ LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const flo
         a.xoff[p] = (int)xo; a.woff[p] = (int)wo;
     }
     a.amax_x = amax_x; a.amax_w = amax_w; a.amax_out = amax_out;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0;
     a.relu = relu; a.out_f32 = 1; a.accumulate = 0; a.staged_out = 0;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;

@@ -193,6 +193,23 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // every wave is done with the K loop's fragments
     kstamp(44);
+    // (narrow head, below: its weight fragments are requested HERE -- the K loop's fragment registers are dead -- so that the L2
+    //  round trip runs under the staging pass instead of in front of the head's MFMAs)
+    bf16x8 hwf[NW == 2 ? 16 : 1];
+    bool head_on = false;
+    if constexpr (NW == 2) {
+        head_on = a.head_w != nullptr && wave < 2 * MJ;
+        const bool hrow = frow < a.head_c4;               // (head_w holds head_c4 rows: the MFMA's other rows are zeros)
+        const bf16_t* hw = a.head_w + frow * 256 + fq * 8;
+        if (head_on) {
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hwf[st][e] = 0;
+                if (hrow) hwf[st] = *reinterpret_cast<const bf16x8*>(hw + st * 16);
+            }
+        }
+    }
     if constexpr (RES) {
         pipe_stage_in<MJ, NW>(a, tr, a.residual, out_g, m0, n0, ohw, wave, lane, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,6 +239,53 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
     kstamp(46);
     __syncthreads();
     kstamp(47);
+    // ---- a narrow 1x1 head on the finished tile (ConvArgs block 5): head_out[pixel][n] = head_b[n] + sum_c tile[pixel][c] * head_w[n][c]
+    // as ONE 32x32 MFMA chain per 32-row block -- A = the head's weights (rows n, 16 bytes per lane per 16-channel step straight from
+    // L2: 16 KiB in all), B = the tile rows as they lie in LDS (row frow of the block, logical chunk 2 s + fq at position chunk ^ row:
+    // the fragment shape of the K loop), 16 steps over the 256 couts.  The wide map is not read back by a second launch.
+    if constexpr (NW == 2) {
+        if (head_on) {
+            {
+                const int r = wave * 32 + frow;
+                const char* xrow = lds + r * ROWB;
+                f32x16 hacc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) hacc[v] = 0.f;
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + (((2 * st + fq) ^ frow) << 4));
+                    hacc = LOFT_MFMA_32x32x16(hwf[st], xf, hacc);
+                }
+                // lane -> pixel (tile row r); hacc[4 gq + e] -> head output 8 gq + 4 fq + e
+                long roff = 0;
+                bool ok;
+                if (tr.lin) roff = pipe_row_off(tr, r, ok);
+                else {
+                    const int m = m0 + r;
+                    ok = m < a.M;
+                    if (ok) {
+                        const bf16_t* base = reinterpret_cast<const bf16_t*>(a.out);
+                        const bf16_t* rp = pipe_row_ptr(a, base, out_g, m, n0, ohw);
+                        ok = rp != nullptr;
+                        if (ok) roff = rp - (base + out_g + n0);
+                    }
+                }
+                if (ok) {
+                    const int c4 = a.head_c4;
+                    float* ho = a.head_out + (roff / a.Cout) * c4;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int nh = 8 * gq + 4 * fq;
+                        if (nh < c4) {
+                            const float4 hb = *reinterpret_cast<const float4*>(a.head_b + nh);
+                            *reinterpret_cast<float4*>(ho + nh) = make_float4(hacc[gq * 4 + 0] + hb.x, hacc[gq * 4 + 1] + hb.y,
+                                                                             hacc[gq * 4 + 2] + hb.z, hacc[gq * 4 + 3] + hb.w);
+                        }
+                    }
+                }
+            }
+        }
+    }
     // LDS -> HBM, whole rows.  All 16 row reads first (the accumulators are dead: 64 free registers), then the stores: one
     // lgkmcnt wait for the whole tile instead of a read -> wait -> store chain per row pair.
     const bf16_t* mask = a.mask;

@@ -73,6 +73,14 @@ struct ConvArgs {
     const float* amax_w;
     float* amax_out;         // optional (plane launches): max |stored output| is atomically folded into this PRE-ZEROED word, so that
                              // the next layer's plane split of `out` needs no absmax pass of its own
+    // ---- block 5: a NARROW 1x1 HEAD on the output, computed from the staged bf16 tile before it leaves LDS (conv_pipe.hip, staged
+    // epilogue, 256-cout tiles; loft_conv_tap_bf16_head).  head_out[pixel][n] = head_b[n] + sum_c bf16(out[pixel][c]) * head_w[n][c]
+    // for n < head_c4 <= 32: the RPN's objectness + delta convs behind its 3x3 conv, the mask logits behind the deconvolution --
+    // the wide map is written once and not read back by a second launch.  head_w: bf16 [head_c4][256].
+    const bf16_t* head_w;
+    const float* head_b;     // fp32 [head_c4]
+    float* head_out;         // fp32 [pixels of the FULL output map][head_c4]
+    int head_c4;
 };
 
 // Power-of-two scale of a plane split (loft_split_planes_f32 with an absmax scalar; the binary16 build): the tensor's absmax lands

@@ -32,6 +32,8 @@ SWITCHES = {
     'no_grad_sink': 'gradients returned to autograd and accumulated by it, not deposited in the arena by the kernels',
     'no_leaf_sink': 'narrow heads and the sparse RPN backward return their parameter gradients to autograd (per-parameter accumulation '
                     'launches) instead of depositing them through the unpack queue (nn._queue_param_grads)',
+    'no_head_fusion': 'narrow 1x1 heads (RPN objectness + deltas, mask logits) as launches of their own instead of in the producing '
+                      'conv\'s epilogue (loft_conv_tap_bf16_head)',
     'no_zero_pool': 'torch.zeros / torch.empty per accumulation buffer instead of the step\'s pre-zeroed / scratch slabs',
     'no_feat_hub': 'autograd sums the RPN / RoI-extractor gradients of the FPN maps (no shared per-level gradient map)',
     # autograd-node granularity / previous formulations of three backward ops

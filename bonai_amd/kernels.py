@@ -621,9 +621,11 @@ def _wgrad_variant(*shape):
 
 def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, os=1, oo=(0, 0), bias=None,
              residual=None, relu=False, accumulate=False, groups=1, src_gs=0, wgt_gs=0, out_gs=0, bias_gs=0, mask=None,
-             planes_memo=None, planes_cache=False):
+             planes_memo=None, planes_cache=False, head=None):
     """Raw launch of loft_conv_tap_bf16 (or loft_conv_tap_f32 when every operand is fp32: the forward-only parity mode).
-    taps: list of (dy, dx, weight_tap_index)."""
+    taps: list of (dy, dx, weight_tap_index).
+    head: dict(w=[c4,256] 16-bit, b=fp32 [c4], out=fp32 NHWC [B,c4,OHf,OWf]) -- a narrow 1x1 head on the output, computed in the
+    launch's epilogue when the library serves it (loft_conv_tap_bf16_head); head['fused'] tells the caller whether it did."""
     lib = L.load()
     L.dev_check(src, wgt, out, bias, residual)
     if src.dtype == torch.float32:
@@ -680,6 +682,23 @@ def conv_tap(src, wgt, out, B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, taps, ss=1, 
         _bf16(out)
     _ev = _prof_begin()
     variant = CONV_VARIANT(groups, B, OH, OW, Cin, Cout, T, ss, os) if callable(CONV_VARIANT) else CONV_VARIANT
+    if head is not None:
+        head['fused'] = False
+        hw, hb, ho = head['w'], head['b'], head['out']
+        if (HEAD_FUSION and not _DBG.no_head_fusion and variant == CONV_AUTO and groups == 1 and not out_f32 and not accumulate and Cout == 256 and
+                hw.dtype == L.act16() and tuple(hw.shape[-2:]) == (int(ho.shape[1]), 256) and hw.is_contiguous() and
+                ho.dtype == torch.float32 and tuple(ho.shape) == (B, int(ho.shape[1]), OHf, OWf) and
+                ho.is_contiguous(memory_format=torch.channels_last)):
+            e = lib.loft_conv_tap_bf16_head(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
+                                            L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0], oo[1], ss, T,
+                                            dy, dx, wt, int(relu), L.ptr(hw), L.ptr(hb.float().contiguous()), L.ptr(ho),
+                                            int(ho.shape[1]), L.stream())
+            if e == 0:
+                head['fused'] = True
+                _prof_end(_ev, 'conv_tap', 2.0 * B * OH * OW * Cout * (Cin * T + int(ho.shape[1])), (groups, B, OH, OW, Cin, Cout, T, ss, os))
+                return out
+            if e != 1:          # (hipErrorInvalidValue: a launch the head epilogue does not serve -> plain launch, head by the caller)
+                L.check(e, 'loft_conv_tap_bf16_head')
     L.check(lib.loft_conv_tap_bf16_v(L.ptr(src), L.ptr(wgt), L.ptr(bias), L.ptr(residual), L.ptr(mask), L.ptr(out),
                                      L.ptr(zero_page(src.device)), B, IH, IW, Cin, Cout, OH, OW, OHf, OWf, os, oo[0],
                                      oo[1], ss, T, dy, dx, wt, int(relu), int(out_f32), int(accumulate), groups,
@@ -693,8 +712,14 @@ def conv_out_size(i, k, stride, pad):
     return (i + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=None, groups=1, planes_cache=False):
-    """x [G*B,Cin,IH,IW] channels_last bf16, wp [G][R*S,Cout,Cin] bf16 -> [G*B,Cout,OH,OW] channels_last."""
+HEAD_FUSION = True     # tests / A/B: False = narrow heads always as launches of their own
+
+
+def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, out_dtype=None, groups=1, planes_cache=False,
+               head=None):
+    """x [G*B,Cin,IH,IW] channels_last bf16, wp [G][R*S,Cout,Cin] bf16 -> [G*B,Cout,OH,OW] channels_last.
+    head = (packed head weight [.., c4, 256] 16-bit, bias fp32 [c4]): -> (out, head output fp32 NHWC [B,c4,OH,OW] | None): the
+    narrow 1x1 head on `out`, from the same launch when the library serves it (None: the caller launches it)."""
     x = _nhwc(x)
     GB, Cin, IH, IW = x.shape
     B = GB // groups
@@ -702,9 +727,16 @@ def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, ou
     OH, OW = conv_out_size(IH, R, stride, pad), conv_out_size(IW, S, stride, pad)
     out = empty_nhwc(GB, Cout, OH, OW, out_dtype or L.act16(), x.device)
     taps = [(r - pad, s - pad, r * S + s) for r in range(R) for s in range(S)]
+    hd = None
+    if head is not None and groups == 1 and x.dtype == L.act16():
+        hw, hb = head
+        c4 = int(hw.shape[-2])
+        hd = dict(w=hw.reshape(c4, -1), b=hb, out=empty_nhwc(B, c4, OH, OW, torch.float32, x.device))
     conv_tap(x, wp, out, B, IH, IW, Cin, Cout, OH, OW, OH, OW, taps, ss=stride, bias=bias, residual=residual,
              relu=relu, groups=groups, src_gs=B * IH * IW * Cin, wgt_gs=R * S * Cout * Cin,
-             out_gs=B * OH * OW * Cout, bias_gs=Cout, planes_cache=planes_cache)
+             out_gs=B * OH * OW * Cout, bias_gs=Cout, planes_cache=planes_cache, head=hd)
+    if head is not None:
+        return out, (hd['out'] if hd is not None and hd['fused'] else None)
     return out
 
 

@@ -178,8 +178,13 @@ class FCNMaskHead(nn.Module):
             return x.new_zeros(0, nout, 2 * x.shape[2], 2 * x.shape[3], dtype=torch.float32)
         for i, m in enumerate(self.convs):
             x = F2.conv2d(x, m.conv.weight, m.conv.bias, pad=1, relu=True, input_relu=i > 0)
-        x = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias, input_relu=len(self.convs) > 0)
-        o = F2.narrow_head(x, self.conv_logits.weight.view(nout, -1), self.conv_logits.bias, input_relu=True,
+        # the logits ride in the deconvolution's epilogue (fcn_mask_head.py:121-126: upsample -> relu -> conv_logits): the
+        # [N,256,28,28] map is written once and not read back by a launch of its own
+        wl = self.conv_logits.weight.view(nout, -1)
+        pre = F2.narrow_head_prepack(wl, self.conv_logits.bias, x.dtype) if x.dtype == K.L.act16() else None
+        x, o_pre = F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias, input_relu=len(self.convs) > 0, head=pre) \
+            if pre is not None else (F2.deconv2x2_relu(x, self.upsample.weight, self.upsample.bias, input_relu=len(self.convs) > 0), None)
+        o = F2.narrow_head(x, wl, self.conv_logits.bias, input_relu=True, prepacked=pre, precomputed=o_pre,
                            leaves=[(self.conv_logits.weight, self.conv_logits.bias, 0, nout)])
         return o[:, :nout]
 

@@ -78,9 +78,14 @@ class RPNHead(nn.Module):
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
         outs, hs = [], []
         pre = F2.narrow_head_prepack(w, b, feats[0].dtype)        # one packing for the five levels
+        fuse = not torch.is_grad_enabled() and feats[0].is_cuda and feats[0].dtype == K.L.act16()
         for x in feats:
-            h = F2.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, pad=1, relu=True)
-            outs.append(F2.narrow_head(h, w, b, prepacked=pre))
+            o = None
+            if fuse:    # objectness + deltas from the 3x3 conv's own epilogue where its tile holds all 256 channels (P2-P4 at 1024^2)
+                h, o = F2.conv2d_with_head(x, self.rpn_conv.weight, self.rpn_conv.bias, pre, pad=1, relu=True)
+            else:
+                h = F2.conv2d(x, self.rpn_conv.weight, self.rpn_conv.bias, pad=1, relu=True)
+            outs.append(o if o is not None else F2.narrow_head(h, w, b, prepacked=pre))
             hs.append(h)
         return (outs, hs) if keep_hidden else outs
 

@@ -251,9 +251,13 @@ class _ConvFn(torch.autograd.Function):
             if key is not None:
                 _pack_cache_put(key, ctens, (wp, wpt, bias))
         use_bias = has_b or bn_stats is not None
+        global _HEAD_REQ, _HEAD_OUT
+        head, _HEAD_REQ = _HEAD_REQ, None           # (conv2d_with_head: a narrow 1x1 head on this conv's output, same launch)
         y = K.conv2d_fwd(x, wp, bias if use_bias else None, R, S, stride, pad, relu=relu, residual=residual,
                          out_dtype=torch.float32 if (out_f32 or pdt == torch.float32) else K.L.act16(), groups=G,
-                         planes_cache=any(ctx.needs_input_grad[3:]))
+                         planes_cache=any(ctx.needs_input_grad[3:]), head=head)
+        if head is not None:
+            y, _HEAD_OUT = y
         ctx.meta = meta
         ctx.params = tensors            # the Parameter objects themselves (their .grad may be an arena slot)
         for k, t in enumerate(tensors):  # uses per step of each parameter: the gradient sink fires after the last one
@@ -378,6 +382,25 @@ def conv2d(x, w, b=None, stride=1, pad=0, relu=False, residual=None, groups=1, o
 
 
 
+_HEAD_REQ = _HEAD_OUT = None
+
+
+def conv2d_with_head(x, w, b, head_pre, stride=1, pad=0, relu=False):
+    """conv2d(x, w, b) and, from the SAME launch where the library serves it (256-cout stream tiles), the narrow 1x1 head
+    `head_pre` = narrow_head_prepack(w_head, b_head, x.dtype) applied to its output: -> (y, o fp32 NHWC [B,c4,OH,OW] | None).
+    o carries NO autograd history (it is computed inside the conv's launch): for no-grad callers -- the RPN's dense forward in the
+    sparse-backward training path and at inference; None = not served, the caller runs narrow_head itself."""
+    global _HEAD_REQ, _HEAD_OUT
+    assert not torch.is_grad_enabled()
+    _HEAD_REQ, _HEAD_OUT = head_pre, None
+    try:
+        y = conv2d(x, w, b, stride=stride, pad=pad, relu=relu)
+    finally:
+        _HEAD_REQ = None
+    o, _HEAD_OUT = _HEAD_OUT, None
+    return y, o
+
+
 class _LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) for an nn.Linear whose weight is passed AS THE PARAMETER ([O, K], never a view), so that under the
     trainer its bf16 packings come from the step's batched launch and its gradient goes straight into the arena.
@@ -481,7 +504,7 @@ class _NarrowHeadFn(torch.autograd.Function):
     PADW = 128
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None, leaves=None):
+    def forward(ctx, x, w, b, stride, pad, input_relu=False, prepacked=None, leaves=None, precomputed=None):
         _note_use(x)
         Cout, Cin, R, S = w.shape
         ctx.input_relu = input_relu
@@ -492,10 +515,13 @@ class _NarrowHeadFn(torch.autograd.Function):
         if ctx.leaves is not None:
             _count_uses(*[p for l in ctx.leaves for p in l[:2] if p is not None])
         c4 = (Cout + 3) // 4 * 4
-        wp, bpad = prepacked if prepacked is not None else narrow_head_prepack(w, b, x.dtype)
-        K.ALGO_SCALE = Cout / c4
-        y = K.conv2d_fwd(x, wp, bpad, R, S, stride, pad, out_dtype=torch.float32)
-        K.ALGO_SCALE = 1.0
+        if precomputed is not None:                 # (the producer of x computed this head in its own epilogue: _DeconvFn)
+            y = precomputed
+        else:
+            wp, bpad = prepacked if prepacked is not None else narrow_head_prepack(w, b, x.dtype)
+            K.ALGO_SCALE = Cout / c4
+            y = K.conv2d_fwd(x, wp, bpad, R, S, stride, pad, out_dtype=torch.float32)
+            K.ALGO_SCALE = 1.0
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         ctx.sp = (stride, pad)
@@ -517,13 +543,13 @@ class _NarrowHeadFn(torch.autograd.Function):
                 gx._loft_premasked = x.data_ptr()
             if ctx.leaves is not None and dw is not None and (db is not None or not ctx.has_b) and _queue_param_grads(
                     [(pw, dw[lo:hi], pb, None if (pb is None or db is None) else db[lo:hi], None) for pw, pb, lo, hi in ctx.leaves]):
-                return gx, None, None, None, None, None, None, None
+                return gx, None, None, None, None, None, None, None, None
             if ctx.leaves is not None:      # (no queue / no slots: autograd accumulates; the uses counted in forward are not sunk)
                 for l in ctx.leaves:
                     for p_ in l[:2]:
                         if p_ is not None and getattr(p_, '_loft_pending', 0) > 0:
                             p_._loft_pending -= 1
-            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None, None
+            return gx, (dw.view(w.shape) if dw is not None else None), db, None, None, None, None, None, None
         P = _NarrowHeadFn.PADW
         N, c4, H, W = g.shape
         gp = torch.zeros(N, P, H, W, dtype=x.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
@@ -551,7 +577,7 @@ class _NarrowHeadFn(torch.autograd.Function):
                 for p_ in l[:2]:
                     if p_ is not None and getattr(p_, '_loft_pending', 0) > 0:
                         p_._loft_pending -= 1
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def narrow_head_prepack(w, b, dtype):
@@ -566,16 +592,18 @@ def narrow_head_prepack(w, b, dtype):
     return wp[None], bias
 
 
-def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False, prepacked=None, leaves=None):
+def narrow_head(x, w, b=None, stride=1, pad=0, input_relu=False, prepacked=None, leaves=None, precomputed=None):
     """x bf16 NHWC [N,Cin,H,W]; w [Cout,Cin(,R,S)] with small Cout -> fp32 [N,ceil4(Cout),OH,OW].
     input_relu: x is the output of a ReLU -- the backward folds that ReLU's mask into the data gradient it produces.
     leaves: when w / b are concatenations, [(weight Parameter, bias Parameter | None, first row, end row)] of their pieces (a
-    Parameter passed as w is its own leaf): lets the backward deposit the gradients in the trainer's arena directly."""
+    Parameter passed as w is its own leaf): lets the backward deposit the gradients in the trainer's arena directly.
+    precomputed: this head's output as the producer of x already computed it (deconv2x2_relu(head=...)): no forward launch here,
+    the autograd node and its backward are unchanged."""
     if leaves is None and isinstance(w, torch.nn.Parameter) and (b is None or isinstance(b, torch.nn.Parameter)):
         leaves = [(w, b, 0, int(w.shape[0]))]
     if w.dim() == 2:
         w = w.view(w.shape[0], w.shape[1], 1, 1)
-    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu, prepacked, leaves)
+    return _NarrowHeadFn.apply(x, w, b, stride, pad, input_relu, prepacked, leaves, precomputed)
 
 
 class _MdcnSampleFn(torch.autograd.Function):
@@ -623,7 +651,7 @@ class _DeconvFn(torch.autograd.Function):
     """ConvTranspose2d(k=2, s=2) + bias + ReLU (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:121-124)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, input_relu=False):
+    def forward(ctx, x, w, b, input_relu=False, head=None):
         _note_use(x)
         N, Cin, H, W = x.shape
         Cout = w.shape[1]
@@ -631,11 +659,27 @@ class _DeconvFn(torch.autograd.Function):
         wp = w.permute(2, 3, 1, 0).reshape(4, Cout, Cin).to(x.dtype).contiguous()
         y = K.empty_nhwc(N, Cout, 2 * H, 2 * W, x.dtype, x.device)
         bias = b.float().contiguous()
+        # head = narrow_head_prepack(...) of the 1x1 conv that follows (the mask logits): every parity launch computes it for its
+        # own output positions in its epilogue -- the 2N x 2N map is not read back by a launch of its own.  All four launches make
+        # the same kernel choice: the first one that is not served switches the request off.
+        hd = None
+        if head is not None and x.dtype == K.L.act16():
+            c4 = int(head[0].shape[-2])
+            hd = dict(w=head[0].reshape(c4, -1), b=head[1], out=K.empty_nhwc(N, c4, 2 * H, 2 * W, torch.float32, x.device))
+        nf = 0
         for py in range(2):
             for px in range(2):
                 K.conv_tap(x, wp, y, N, H, W, Cin, Cout, H, W, 2 * H, 2 * W, [(0, 0, py * 2 + px)], ss=1, os=2,
-                           oo=(py, px), bias=bias, relu=True)
+                           oo=(py, px), bias=bias, relu=True, head=hd)
+                if hd is not None:
+                    if hd['fused']:
+                        nf += 1
+                    else:
+                        if nf:
+                            raise K.L.LoftHipError('deconv2x2_relu: the head epilogue served some parity launches only')
+                        hd = None
         ctx.save_for_backward(x, w, y)
+        _DeconvFn.head_out = hd['out'] if hd is not None else None     # (picked up by deconv2x2_relu; no autograd history)
         return _begin_uses(y)
 
     @staticmethod
@@ -666,12 +710,20 @@ class _DeconvFn(torch.autograd.Function):
             gb = db[0] if db is not None else None
         elif ctx.needs_input_grad[2]:
             gb = K.colsum(g, Cout)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def deconv2x2_relu(x, w, b, input_relu=False):
-    """input_relu: x is a ReLU output -- the backward folds that mask into the data gradient (no separate pass)."""
-    return _DeconvFn.apply(x, w, b, input_relu)
+def deconv2x2_relu(x, w, b, input_relu=False, head=None):
+    """input_relu: x is a ReLU output -- the backward folds that mask into the data gradient (no separate pass).
+    head = narrow_head_prepack(w_head, b_head, x.dtype): -> (y, o | None), o = that 1x1 head applied to y, fp32 NHWC [N,c4,2H,2W],
+    computed by the deconvolution's own launches when the library serves it; pass it to narrow_head(y, ..., precomputed=o), which
+    keeps the head's autograd node."""
+    if head is None:
+        return _DeconvFn.apply(x, w, b, input_relu)
+    _DeconvFn.head_out = None
+    y = _DeconvFn.apply(x, w, b, input_relu, head)
+    o, _DeconvFn.head_out = _DeconvFn.head_out, None
+    return y, o
 
 
 # ------------------------------------------------------------------ feature-gradient hub

@@ -216,6 +216,18 @@ int loft_conv_tap_bf16_v(const void* src, const void* wgt, const float* bias, co
                          int OWf, int os, int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host,
                          const int* wt_host, int relu, int out_f32, int accumulate, int groups, int64_t src_gs,
                          int64_t wgt_gs, int64_t out_gs, int64_t bias_gs, int variant, void* stream);
+
+/* loft_conv_tap_bf16_head: loft_conv_tap_bf16 (one group, bf16 output, the library's own kernel choice) with a NARROW 1x1 HEAD on its
+ * output computed in the epilogue, from the bf16 tile before it leaves LDS: head_out[pixel][n] = head_b[n] + sum_c bf16(out[pixel][c]) *
+ * head_w[n][c] for n < head_c4 (a multiple of 4, <= 32).  head_w: activation type [head_c4][256], head_b
+ * fp32 [head_c4], head_out fp32 [pixels of the FULL output map (B*OHf*OWf)][head_c4].  Replaces a second launch that reads the wide map
+ * back for a handful of outputs: the RPN's objectness + delta convs behind its 3x3 conv (rpn_head.py:38-44), the mask logits behind the
+ * 2x2 deconvolution (fcn_mask_head.py:121-126).  Served by the 256-cout stream tiles only (Cout == 256): any other launch returns
+ * hipErrorInvalidValue WITHOUT launching anything -- the caller then runs the head as a launch of its own. */
+int loft_conv_tap_bf16_head(const void* src, const void* wgt, const float* bias, const void* residual, const void* relu_mask, void* out,
+                            const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf, int OWf, int os,
+                            int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host, const int* wt_host, int relu,
+                            const void* head_w, const float* head_b, float* head_out, int head_c4, void* stream);
 /* fp32 parity mode, backward (parity_f32.hip): weight gradient of the same tap contract on v_mfma_f32_32x32x2_f32 (dw is
  * accumulated into: the caller zeroes it), and the fp32 forms of the glue adjoints.  Checker path (1e-3 vs the reference's fp32
  * autograd), not a performance path. */

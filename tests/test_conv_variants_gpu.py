@@ -431,3 +431,74 @@ def test_fused_bottleneck_tail_matches_the_unfused_block(downsample, hw):
     assert torch.equal(fused, plain)
     assert d_fp <= 2 ** -6 * scale
     assert e_f <= max(1.2 * e_p, 2 ** -6 * scale)
+
+
+@pytest.mark.parametrize('shape', [(2, 256, 256, 256, 3, 1, 16), (8, 64, 64, 256, 3, 1, 16), (3, 64, 64, 256, 3, 1, 16),
+                                   (4, 128, 128, 512, 1, 0, 4), (1, 32, 32, 256, 3, 1, 16)])
+def test_narrow_head_in_the_conv_epilogue_matches_its_own_launch(shape):
+    """loft_conv_tap_bf16_head: the narrow 1x1 head computed from the staged output tile (256-cout stream tiles: 256- / 128- / 64-pixel
+    forms) against the launch it replaces -- the same bf16 map read back by the narrow-head conv.  The wide output itself is
+    bit-identical to a plain launch; the head agrees to fp32 summation order (two MFMA chains over the same bf16 products).  The last
+    shape (a 32 x 32 map: 128-cout tiles) is NOT served: the wrapper reports it and nothing else changes."""
+    from bonai_amd import kernels as K
+    from bonai_amd import nn as F2
+    B, H, W, Cin, R, pad, c4 = shape
+    torch.manual_seed(B * H + Cin)
+    x = torch.randn(B, Cin, H, W, device='cuda').to(K.L.act16()).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(256, Cin, R, R, device='cuda') * (0.5 / (Cin * R * R) ** 0.5)
+    b = torch.randn(256, device='cuda') * 0.1
+    nh = c4 - 1 if c4 > 4 else 1
+    wh, bh = torch.randn(nh, 256, device='cuda') * 0.1, torch.randn(nh, device='cuda')
+    wp = K.pack_w_fwd(w)[None]
+    pre = F2.narrow_head_prepack(wh, bh, x.dtype)
+    assert pre[0].shape[-2] == c4
+    y0 = K.conv2d_fwd(x, wp, b[None], R, R, 1, pad, relu=True)
+    y1, o = K.conv2d_fwd(x, wp, b[None], R, R, 1, pad, relu=True, head=pre)
+    assert torch.equal(y0, y1)
+    want = K.conv2d_fwd(y0, pre[0], pre[1], 1, 1, out_dtype=torch.float32)
+    if H * W * B < 4096:
+        assert o is None
+        return
+    assert o is not None and o.dtype == torch.float32 and tuple(o.shape) == (B, c4, H, W)
+    assert o.is_contiguous(memory_format=torch.channels_last)
+    assert (o - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(o[:, nh:], torch.zeros_like(o[:, nh:]))                      # padding outputs: zero weights, zero bias
+    prev, K.HEAD_FUSION = K.HEAD_FUSION, False
+    try:
+        assert K.conv2d_fwd(x, wp, b[None], R, R, 1, pad, relu=True, head=pre)[1] is None
+    finally:
+        K.HEAD_FUSION = prev
+
+
+def test_mask_logits_ride_in_the_deconvolution_epilogue():
+    """FCNMaskHead (fcn_mask_head.py:113-126): upsample (2x2 deconvolution) -> ReLU -> conv_logits with the logits computed by the four
+    parity launches of the deconvolution, against the same head with the narrow conv as a launch of its own: logits, and -- through
+    the unchanged autograd nodes -- the input and parameter gradients."""
+    from bonai_amd import kernels as K
+    from bonai_amd.loft.builder import build_head
+    from oracle.synth_weights import synth_tensor
+    head = build_head(dict(type='FCNMaskHead', num_convs=1, in_channels=256, conv_out_channels=256, num_classes=1,
+                           loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0)))
+    head.load_state_dict({k: synth_tensor('roi_head.mask_head.' + k, v.shape) for k, v in head.state_dict().items()})
+    head = head.cuda().train()
+    x = synth_tensor('mask_head.x', (600, 256, 14, 14)).cuda().to(K.L.act16()).contiguous(memory_format=torch.channels_last)
+    tgt = (synth_tensor('mask_head.t', (600, 28, 28)).cuda() > 0).float()
+    res = []
+    for fuse in (True, False):
+        prev, K.HEAD_FUSION = K.HEAD_FUSION, fuse
+        try:
+            for p in head.parameters():
+                p.grad = None
+            xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            o = head(xi)
+            loss = head.loss(o, tgt, torch.zeros(600, dtype=torch.long, device='cuda'))['loss_mask']
+            loss.sum().backward()
+            res.append((o.detach().clone(), xi.grad.float().clone(), {n: p.grad.clone() for n, p in head.named_parameters()}))
+        finally:
+            K.HEAD_FUSION = prev
+    (o1, gx1, g1), (o0, gx0, g0) = res
+    assert tuple(o1.shape) == (600, 1, 28, 28)
+    assert (o1 - o0).abs().max().item() <= 2e-5 * max(1.0, o0.abs().max().item())
+    assert (gx1 - gx0).norm().item() <= 1e-3 * gx0.norm().item()
+    for n in g0:
+        assert (g1[n] - g0[n]).norm().item() <= 1e-3 * g0[n].norm().item() + 1e-12, n

@@ -845,6 +845,9 @@ __device__ __forceinline__ int nth_set_bit(unsigned m, int n) {      // position
 #ifndef RBM_WAVES
 #define RBM_WAVES 4
 #endif
+#ifndef RBM_XCD
+#define RBM_XCD 1         // 0: tiles in launch order (A/B builds)
+#endif
 #define RBM_CHUNK 32      // bins per operand chunk: 24 KiB of LDS per block -> 6 blocks per CU hide the staging latency
 
 // Up to RBM_SETS RoI lists (the three extractors of the LOFT head share one pyramid) scatter into the same maps in ONE
@@ -870,7 +873,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBM_WAVES))
     __shared__ unsigned rnpt[16];
     __shared__ unsigned anyb[2][4];                                          // per wave: which of its 8 bins have any weight
     const int H = L.H[level], W = L.W[level];
-    const int tx0 = blockIdx.x * RB_TILE, ty0 = blockIdx.y * RB_TILE, b = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so consecutive workgroup ids -- horizontally adjacent
+    // tiles, which share the gout rows of every RoI that straddles them -- land on 8 different L2s.  Workgroup L serves tile
+    // (L % 8) * (total / 8) + L / 8 instead: each XCD walks one contiguous eighth of the (image, tile row, tile) order, and the tiles
+    // it has in flight at one time (~128) are a few adjacent tile rows of one image.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+#if RBM_XCD
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z, lin = bx + gx * (by + gy * bz);
+        if ((total & 7u) == 0u) {
+            const unsigned t = (lin & 7u) * (total >> 3) + (lin >> 3);
+            bx = (int)(t % gx); by = (int)((t / gx) % gy); bz = (int)(t / (gx * gy));
+        }
+    }
+#endif
+    const int tx0 = bx * RB_TILE, ty0 = by * RB_TILE, b = bz;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < RBM_CHUNK * 512 / 16; i += 256) reinterpret_cast<uint4*>(gbuf)[i] = make_uint4(0, 0, 0, 0);

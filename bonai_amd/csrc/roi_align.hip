@@ -328,6 +328,9 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep_kernel(RoiLevels L, con
 #define RF8_ABL 0         // timing ablations of tools/probes/roi_fwd_ablate.sh: 1 = prologue only, 2 = no window loads, 3 = no stores
 #endif
 
+#ifndef RF8_XCD
+#define RF8_XCD 1         // 0: RoIs in launch order (A/B builds)
+#endif
 template <int NR>
 __device__ __forceinline__ void roi_sep8_load(const bf16_t* fp, size_t row_stride, uint4 (&t)[NR ? NR : 1]) {
 #pragma unroll
@@ -360,7 +363,14 @@ __global__ __launch_bounds__(256) void roi_align_fwd_sep8_kernel(RoiLevels L, co
     RF8_STAMP(0);
     // nsplit consecutive workgroups share one RoI (bins / bin rows dealt round-robin): a list of 2048 RoIs is eight workgroups
     // per CU of very uneven length -- finer grains fill the tail
-    const int part = (int)blockIdx.x % nsplit, rb = (int)blockIdx.x / nsplit;
+    // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): workgroup i serves position (i % 8) * (n / 8) + i / 8, so the
+    // nsplit parts of one RoI -- the same footprint -- and the RoIs next to it in launch order (sorted by image / level / row strip
+    // with `order`) share one L2 instead of being spread over eight
+    unsigned bid = blockIdx.x;
+#if RF8_XCD
+    if ((gridDim.x & 7u) == 0u) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+#endif
+    const int part = (int)bid % nsplit, rb = (int)bid / nsplit;
     const int k = RF8_TRACE ? (rb < K ? rb : -1) : roi_of_block(order, K, rb);
     if (k < 0) return;
     const float* roi = rois + 5 * (size_t)k;

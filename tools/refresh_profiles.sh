@@ -26,9 +26,7 @@ done
 unset LOFT_NO_SIDE_STREAM
 cp "$OUT/kernel_stats_serial.csv" "$ROOT/profiles/round5_bench_kernel_stats_serial.csv"
 cp "$OUT/kernel_stats_serial.meta.json" "$ROOT/profiles/round5_bench_kernel_stats_serial.meta.json"
-# The bench line itself is NOT measured here: after the counter and trace passes above the same box ran the fp32 legs 11 % and the
-# forced-reducer leg 5 % slower than a fresh box does (round 5: 137.5 vs 123.8 ms, 36.9 vs 35.0 ms; the bf16 loop 1-2 %) -- the
-# profiler leaves the GPU in a lower clock state.  Copy pmc_traffic.json / kernel_stats_* into profiles/ and run
-# tools/refresh_bench_line.sh in a SEPARATE gpurun call (a fresh box).
+# The bench line itself is NOT measured here but by tools/refresh_bench_line.sh in a gpurun call of its own (a box that has run
+# nothing else), after pmc_traffic.json / kernel_stats_* have been copied into profiles/ (bench.py quotes them by source hash).
 rm -rf "$ROOT/gpurun_out/pmc"
 ls -la "$OUT"

@@ -70,7 +70,10 @@ def cpu_baseline(size, num_gt, threads=0):
     from oracle import loft_model_ref as M
     import warnings
     # measured on the GPU box (256 host cores): 32 threads 10-11 s per iteration, 256 threads 290-335 s (the oracle's many small
-    # per-RoI ops oversubscribe) -- so 32 threads unless asked otherwise; `cores` reports the threads actually used
+    # per-RoI ops oversubscribe) -- so 32 threads unless asked otherwise; `cores` reports the threads actually used.  (Round 5 also
+    # tried the other way of using the box: 8 processes side by side, each pinned to its own 32 cores and its own two images -- every
+    # process then ran 10x slower, 0.013-0.021 img/s each, 0.133 in sum against 0.18 for ONE: the host's cores / memory are shared
+    # with the pod's other GPU boxes.  One process it stays.)
     cores = threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))

@@ -34,6 +34,8 @@ SWITCHES = {
                     'launches) instead of depositing them through the unpack queue (nn._queue_param_grads)',
     'no_head_fusion': 'narrow 1x1 heads (RPN objectness + deltas, mask logits) as launches of their own instead of in the producing '
                       'conv\'s epilogue (loft_conv_tap_bf16_head)',
+    'no_grad_join': 'autograd sums the two data gradients of a backbone stage output (next stage + FPN lateral) with an elementwise add '
+                    'instead of the residual block taking the lateral\'s deposit as its data-gradient residual (nn.JOIN)',
     'no_zero_pool': 'torch.zeros / torch.empty per accumulation buffer instead of the step\'s pre-zeroed / scratch slabs',
     'no_feat_hub': 'autograd sums the RPN / RoI-extractor gradients of the FPN maps (no shared per-level gradient map)',
     # autograd-node granularity / previous formulations of three backward ops

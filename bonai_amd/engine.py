@@ -328,11 +328,15 @@ class Trainer:
             self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
         prev_hub = F2.HUB_ENABLED
         F2.HUB_ENABLED = self.arena.data.is_cuda and not DBG.no_feat_hub
+        F2.JOIN = {} if (self.arena.data.is_cuda and not DBG.no_grad_join) else None      # lives through forward AND backward
         if self.graph_features and self.arena.data.is_cuda and K.PROFILE is None and F2.PREPACK is not None \
                 and hasattr(self.model, 'extract_feat'):
             self._graph_step_setup(data['img'])
         try:
             out = self.model.train_step(data)
+        except BaseException:
+            F2.JOIN = None
+            raise
         finally:
             F2.PREPACK = prev_pp
             F2.HUB_ENABLED = prev_hub
@@ -358,6 +362,7 @@ class Trainer:
             F2.WGRAD_STREAM = None
             F2.GRAD_SINK = prev
             F2.HUB = None
+            F2.JOIN = None
             K.zero_pool_end()
         self.reducer.finish()
         self.gnorm_sq.zero_()

@@ -287,6 +287,11 @@ class _ConvFn(torch.autograd.Function):
             gx = K.conv2d_dgrad(g, wpt, ctx.in_hw, R, S, stride, pad, groups=G, mask=x if input_relu else None, out_dtype=x.dtype)
             if input_relu and stride == 1:
                 gx._loft_premasked = x.data_ptr()
+        join_deposit = False
+        if gx is not None and JOIN is not None and G == 1 and x.data_ptr() in JOIN and JOIN[x.data_ptr()] is None \
+                and gx.dtype == K.L.act16() and gx.shape == x.shape:
+            JOIN[x.data_ptr()] = gx          # (the residual block that also consumes x adds it in its own data-gradient epilogue)
+            join_deposit = True
         ngrads = [None] * len(tensors)
         need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(G))
         need_b = (has_b and any(ctx.needs_input_grad[3 + 2 * i + 1] for i in range(G))) or \
@@ -346,7 +351,7 @@ class _ConvFn(torch.autograd.Function):
                 if bn is not None:
                     ngrads[2 * G], ngrads[2 * G + 1] = dg, dbeta
         gres = g if (ctx.has_res and ctx.needs_input_grad[1]) else None
-        return (gx, gres, None) + tuple(ngrads)
+        return (None if join_deposit else gx, gres, None) + tuple(ngrads)
 
 
 def _cacheable(t):
@@ -733,6 +738,15 @@ def deconv2x2_relu(x, w, b, input_relu=False, head=None):
 # consumers' backward kernels ACCUMULATE into one shared gradient map per level: the first to run creates it (RoIAlign backward
 # writes every pixel; the sparse RPN backward starts from zeros), later ones add in place and return None for that input.  The
 # hub node's backward then just forwards the shared map (plus any gradient of a consumer that did not take part).
+# ---- gradient join: a backbone stage output with TWO consumers (C3 / C4: the next stage's first block and the FPN lateral) ---------
+# Plain autograd hands the producer the SUM of the two data gradients, formed by an elementwise add over the whole map (402 + 201 MB
+# through HBM per step for C3 / C4).  Under the trainer the residual block that consumes x registers it in forward (JOIN[x] = None);
+# the other consumer -- a plain conv node, which autograd runs first because it was created later -- DEPOSITS its data gradient
+# there and returns None, and the block's backward feeds the deposit to its first data-gradient launch as the epilogue's `residual`
+# (fp32 add before the rounding).  Order-safe: a consumer that finds no open entry (the block already ran, or never registered)
+# returns its gradient to autograd as before.
+JOIN = None            # {data_ptr of a block input: None (open) | deposited gradient} for the step being built / differentiated
+
 HUB_ENABLED = False    # set by the Trainer for the duration of a train_step
 HUB = None             # {feature data_ptr: shared gradient map | None} of the step being differentiated
 
@@ -1241,6 +1255,8 @@ class _ResBlockFn(torch.autograd.Function):
                 return _begin_uses(K.bottleneck_tail(t1, wp2, b2, wp3, b3, x))
             wpd, _, bd = _rb_pack(tensors[9], bns[3], 64, 256, False, pdt)
             return _begin_uses(K.bottleneck_tail(t1, wp2, b2, wp3, b3, x, wpd, bd))
+        if JOIN is not None and need_dx and sc_spec is not None and x.dtype == K.L.act16() and x.is_cuda and not DBG.no_grad_join:
+            JOIN[x.data_ptr()] = None           # (open: another consumer of x may deposit its data gradient for this block)
         acts, packs = [x], []
         h = x
         sc = x
@@ -1297,6 +1313,7 @@ class _ResBlockFn(torch.autograd.Function):
             if i > 0:       # input of conv i is the ReLU output of conv i-1: its mask rides in this dgrad's epilogue
                 gk = K.conv2d_dgrad(gk, packs[i], tuple(xin.shape[2:]), k, k, s, p, mask=xin, out_dtype=x.dtype)
         gx = None
+        dep = JOIN.pop(x.data_ptr(), None) if JOIN is not None else None
         if need_dx:
             k, s, p, cp = main_specs[0]
             mask = x if ctx.x_is_relu_out else None
@@ -1306,11 +1323,16 @@ class _ResBlockFn(torch.autograd.Function):
             else:
                 # (mask on both launches: a strided shortcut conv only covers one output parity class, the other positions
                 #  are copies of the residual and must already be masked; the mask is idempotent)
-                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, mask=mask, out_dtype=x.dtype)
+                # (dep: the data gradient another consumer of x deposited -- gradient join above -- rides in as the residual)
+                gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, residual=dep, mask=mask, out_dtype=x.dtype)
+                dep = None
                 ks, ss, ps, cps = sc_spec
                 # (in place into the main path's gradient: a strided 1x1 shortcut writes one position in stride^2)
                 gx = K.conv2d_dgrad(g, packs[n], tuple(x.shape[2:]), ks, ks, ss, ps, residual=gx, mask=mask, out_dtype=x.dtype,
                                     out=gx if (ss > 1 and ks == 1) else None)
+            if dep is not None:                  # (a deposit this block's launches could not take: plain sum)
+                gx = gx + dep.to(gx.dtype)
+                dep = None
             if mask is not None:
                 gx._loft_premasked = x.data_ptr()
         if sc_spec is not None:

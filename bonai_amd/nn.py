@@ -292,6 +292,10 @@ class _ConvFn(torch.autograd.Function):
                 and gx.dtype == K.L.act16() and gx.shape == x.shape:
             JOIN[x.data_ptr()] = gx          # (the residual block that also consumes x adds it in its own data-gradient epilogue)
             join_deposit = True
+            # autograd now sees ONE contribution for x -- the block's, which masks the sum with x's ReLU in that epilogue and tags
+            # it: count this consumer out so that the producer honours the tag and skips its own relu_bwd pass over the map
+            if _USES.get(x.data_ptr(), 0) > 1:
+                _USES[x.data_ptr()] -= 1
         ngrads = [None] * len(tensors)
         need_w = any(ctx.needs_input_grad[3 + 2 * i] for i in range(G))
         need_b = (has_b and any(ctx.needs_input_grad[3 + 2 * i + 1] for i in range(G))) or \

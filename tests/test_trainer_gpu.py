@@ -393,3 +393,52 @@ def test_graph_replay_follows_the_optimizer_side_configs(cfg_name, first_k):
         assert all(v == v and abs(v) < 1e6 for v in b.values())
         assert abs(a['loss'] - b['loss']) <= 0.08 * max(1.0, abs(a['loss'])), (i, a['loss'], b['loss'])
     assert abs(logs['graph'][3]['loss'] - logs['graph'][2]['loss']) > 1e-3 * logs['graph'][2]['loss']
+
+
+@pytest.mark.parametrize('lateral_first', [False, True])
+def test_gradient_join_is_order_safe_and_matches_the_autograd_sum(lateral_first):
+    """nn.JOIN: a stage output x with two consumers -- a strided bottleneck (conv shortcut) and a plain 1x1 conv (the FPN lateral).
+    With the join open, the conv's data gradient is deposited and rides in the block's first data-gradient launch when autograd
+    runs the conv first (it was created later: lateral_first=False, the model's order); when the conv was created FIRST its backward
+    runs after the block's, finds no open entry and returns its gradient to autograd as before.  Either way dL/dx equals the plain
+    autograd sum (bf16 rounding of one add apart) and every parameter gradient is unchanged."""
+    from bonai_amd import kernels as K
+    from bonai_amd import nn as F2
+    from bonai_amd.loft.backbone import Bottleneck, ConvW
+    torch.manual_seed(5)
+    blk = Bottleneck(256, 128, stride=2, downsample=True).cuda()
+    lat = ConvW(256, 256, 1, bias=True).cuda()
+    for p in list(blk.parameters()) + list(lat.parameters()):
+        if p.dim() > 1:
+            torch.nn.init.normal_(p, 0, 0.05)
+    xin = torch.randn(2, 256, 64, 64, device='cuda')
+
+    def run(join):
+        for p in list(blk.parameters()) + list(lat.parameters()):
+            p.grad = None
+        x0 = xin.clone().requires_grad_(True)
+        x = torch.relu(x0).to(K.L.act16()).contiguous(memory_format=torch.channels_last)
+        F2.JOIN = {} if join else None
+        try:
+            if lateral_first:
+                a = F2.conv2d(x, lat.weight, lat.bias)
+                b = blk(x)
+            else:
+                b = blk(x)
+                a = F2.conv2d(x, lat.weight, lat.bias)
+            if join:
+                assert x.data_ptr() in F2.JOIN and F2.JOIN[x.data_ptr()] is None
+            (a.float().square().mean() + b.float().square().mean()).backward()
+            if join:
+                assert x.data_ptr() not in F2.JOIN            # the block popped its entry
+        finally:
+            F2.JOIN = None
+        # (dL/dx0, behind the producer's ReLU backward: the joined path hands the producer a gradient that is already masked
+        #  with x > 0 -- the block's epilogue -- the plain path an unmasked sum; the mask is idempotent)
+        return x0.grad.float().clone(), [p.grad.clone() for p in list(blk.parameters()) + list(lat.parameters())]
+
+    gx0, pg0 = run(False)
+    gx1, pg1 = run(True)
+    assert (gx1 - gx0).norm().item() <= 6e-3 * gx0.norm().item()      # one bf16 rounding less on the joined path
+    for a, b in zip(pg1, pg0):
+        assert (a - b).norm().item() <= 1e-2 * b.norm().item() + 1e-12

@@ -680,7 +680,7 @@ static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bia
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;
     a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr; a.amax_out = nullptr;
-    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0; a.par_n = 0;
     if (head) {
         // (served by the staged epilogue of the 256-cout stream tiles only; anything else: the caller launches the head itself)
         if (!head->w || !head->b || !head->out || head->c4 < 4 || head->c4 > 32 || (head->c4 % 4) || Cout != 256 || groups != 1 ||
@@ -869,6 +869,42 @@ LOFT_EXPORT int loft_conv_tap_bf16_head(const void* src, const void* wgt, const 
                               oo_x, ss, T, dy_host, dx_host, wt_host, relu, 0, 0, 1, 0, 0, 0, 0, LOFT_CONV_AUTO, stream, &h);
 }
 
+// ConvTranspose2d(kernel 2, stride 2) + bias (+ ReLU) as ONE launch of the stream kernel (fcn_mask_head.py:121-124, the mask head's
+// upsampling): out[b, 2y + py, 2x + px, :] = act(W[2 py + px] . x[b, y, x, :] + bias).  The four taps are four N tiles of the same
+// pixel tile (ConvArgs::par_n), so x is read from HBM once instead of once per parity launch.  wgt: [4][256][Cin] (tap-major forward
+// packing), out: [B, 2H, 2W, 256]; optional narrow head on the output as in loft_conv_tap_bf16_head (head_w == NULL: none).
+// Served for Cout == 256 and launches of >= 192 pixel tiles; anything else returns hipErrorInvalidValue WITHOUT launching.
+LOFT_EXPORT int loft_deconv2x2_bf16(const void* src, const void* wgt, const float* bias, void* out, const void* zero_page, int B, int H,
+                                    int W, int Cin, int Cout, int relu, const void* head_w, const float* head_b, float* head_out,
+                                    int head_c4, void* stream) {
+    if (Cout != 256 || (Cin % BK) || B < 1 || H < 1 || W < 1) return (int)hipErrorInvalidValue;
+    const long M = (long)B * H * W;
+    if (M > 0x7fffffffL || loft_cdiv(M, 256) < 192) return (int)hipErrorInvalidValue;
+    if (head_w && (!head_b || !head_out || head_c4 < 4 || head_c4 > 32 || (head_c4 % 4))) return (int)hipErrorInvalidValue;
+    ConvArgs a;
+    a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = nullptr; a.mask = nullptr;
+    a.out = out; a.zero_page = (const bf16_t*)zero_page;
+    a.B = B; a.IH = H; a.IW = W; a.Cin = Cin; a.Cout = Cout; a.OH = H; a.OW = W; a.OHf = 2 * H; a.OWf = 2 * W;
+    a.os = 2; a.oo_y = 0; a.oo_x = 0; a.ss = 1; a.T = 1;
+    a.dy[0] = 0; a.dx[0] = 0; a.wt[0] = 0;
+    a.relu = relu; a.out_f32 = 0; a.accumulate = 0;
+    a.src_gs = 0; a.wgt_gs = 0; a.out_gs = 0; a.bias_gs = 0;
+    a.trace = nullptr;
+    a.nterms = 0; a.amax_x = nullptr; a.amax_w = nullptr; a.amax_out = nullptr;
+    a.head_w = (const bf16_t*)head_w; a.head_b = head_b; a.head_out = head_out; a.head_c4 = head_w ? head_c4 : 0;
+    a.par_n = 1;
+    fastdiv_setup((unsigned)(H * W), &a.ohw_mul, &a.ohw_sh);
+    fastdiv_setup((unsigned)W, &a.ow_mul, &a.ow_sh);
+    fastdiv_setup((unsigned)B, &a.b_mul, &a.b_sh);
+    a.M = (int)M;
+    a.staged_out = 1; a.pixmajor = 0; a.nfast = 1;
+    a.pm_S = B; a.pm_P = H * W;
+    fastdiv_setup((unsigned)a.pm_S, &a.pms_mul, &a.pms_sh);
+    fastdiv_setup((unsigned)a.pm_P, &a.pmp_mul, &a.pmp_sh);
+    a.tap_major = 0; a.krot = 0;
+    return loft_launch_conv_tap_pipe(a, 1, 1, 0, 4, 0, (hipStream_t)stream, 0);
+}
+
 LOFT_EXPORT int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, const void* residual,
                                    const void* relu_mask, void* out,
                                    const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW,
@@ -917,7 +953,7 @@ LOFT_EXPORT int loft_conv_tap_planes(const void* src, const void* wgt, const flo
         a.xoff[p] = (int)xo; a.woff[p] = (int)wo;
     }
     a.amax_x = amax_x; a.amax_w = amax_w; a.amax_out = amax_out;
-    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0;
+    a.head_w = nullptr; a.head_b = nullptr; a.head_out = nullptr; a.head_c4 = 0; a.par_n = 0;
     a.relu = relu; a.out_f32 = 1; a.accumulate = 0; a.staged_out = 0;
     a.src_gs = src_gs; a.wgt_gs = wgt_gs; a.out_gs = out_gs; a.bias_gs = bias_gs;
     a.trace = nullptr;

@@ -68,13 +68,17 @@ __device__ __forceinline__ void pipe_row_decode(const ConvArgs& a, int m, int oh
         b = blk * a.pm_S + (m - seg * a.pm_S);
     } else { b = fastdiv(m, a.ohw_mul, a.ohw_sh); rem = m - b * ohw; }
 }
-__device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const bf16_t* base, long out_g, int m, int n0, int ohw) {
+__device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const bf16_t* base, long out_g, int m, int n0, int ohw, int ooy,
+                                                      int oox) {
     int b, rem;
     pipe_row_decode(a, m, ohw, b, rem);
     if (b >= a.B) return nullptr;
     const int oy = fastdiv(rem, a.ow_mul, a.ow_sh), ox = rem - oy * a.OW;
-    const long opix = ((long)b * a.OHf + oy * a.os + a.oo_y) * a.OWf + ox * a.os + a.oo_x;
+    const long opix = ((long)b * a.OHf + oy * a.os + ooy) * a.OWf + ox * a.os + oox;
     return base + out_g + opix * a.Cout + n0;
+}
+__device__ __forceinline__ const bf16_t* pipe_row_ptr(const ConvArgs& a, const bf16_t* base, long out_g, int m, int n0, int ohw) {
+    return pipe_row_ptr(a, base, out_g, m, n0, ohw, a.oo_y, a.oo_x);
 }
 
 // Wave-uniform description of where the rows of ONE tile live in an NHWC map (round 4).  The per-row decode above costs three
@@ -172,7 +176,7 @@ __device__ __forceinline__ void pipe_stage_in(const ConvArgs& a, const TileRows&
 
 template <bool RES, int MJ, int NW, typename StampFn>
 __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const TileRows& tr, f32x16 (&acc)[2][4], char* lds, int g, int m0,
-                                                     int n0, int wave, int lane, int ohw, StampFn&& kstamp) {
+                                                     int n0, int wave, int lane, int ohw, StampFn&& kstamp, int ooy, int oox) {
     constexpr int RW = 8 * MJ;
     constexpr int CPR = 16 * NW, ROWB = CPR * 16, RPI = 64 / CPR;      // chunks per row, bytes per row, rows per wave-level access
     // (ConvArgs block 2 in one go: see the set-up)
@@ -265,7 +269,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
                     ok = m < a.M;
                     if (ok) {
                         const bf16_t* base = reinterpret_cast<const bf16_t*>(a.out);
-                        const bf16_t* rp = pipe_row_ptr(a, base, out_g, m, n0, ohw);
+                        const bf16_t* rp = pipe_row_ptr(a, base, out_g, m, n0, ohw, ooy, oox);
                         ok = rp != nullptr;
                         if (ok) roff = rp - (base + out_g + n0);
                     }
@@ -341,7 +345,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
         // strided / offset outputs (parity-class launches of strided data gradients, the mask head's 2x2 deconvolution): rows are
         // linear only within one map row, so every row is decoded -- with the decode's scalars held in registers (LOFT_KEEP_S:
         // the loop otherwise re-fetches a dozen kernarg fields per row)
-        int aM = a.M, aB = a.B, aOW = a.OW, aOHf = a.OHf, aOWf = a.OWf, aos = a.os, aoy = a.oo_y, aox = a.oo_x, aCout = a.Cout;
+        int aM = a.M, aB = a.B, aOW = a.OW, aOHf = a.OHf, aOWf = a.OWf, aos = a.os, aoy = ooy, aox = oox, aCout = a.Cout;
         unsigned m1 = a.ohw_mul, s1 = a.ohw_sh, m2 = a.ow_mul, s2 = a.ow_sh;
         LOFT_KEEP_S(aM); LOFT_KEEP_S(aB); LOFT_KEEP_S(aOW); LOFT_KEEP_S(aOHf); LOFT_KEEP_S(aOWf); LOFT_KEEP_S(aos); LOFT_KEEP_S(aoy);
         LOFT_KEEP_S(aox); LOFT_KEEP_S(aCout); LOFT_KEEP_S(m1); LOFT_KEEP_S(s1); LOFT_KEEP_S(m2); LOFT_KEEP_S(s2);
@@ -353,7 +357,7 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
             const int m = m0 + r;
             const bf16_t* rp = nullptr;
             if (pmaj) {
-                if (m < aM) rp = pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw);
+                if (m < aM) rp = pipe_row_ptr(a, reinterpret_cast<const bf16_t*>(a.out), out_g, m, n0, ohw, ooy, oox);
             } else if (m < aM) {
                 const int b = fastdiv(m, m1, s1), rem = m - b * ohw;
                 const int oy = fastdiv(rem, m2, s2), ox = rem - oy * aOW;
@@ -968,8 +972,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         {
             const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;
             const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
-            if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+            if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp, a.oo_y, a.oo_x);
+            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp, a.oo_y, a.oo_x);
         }
         return;
     }
@@ -1267,10 +1271,15 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                                          a.pixmajor != 0);
         else {
             const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;       // output pixel index == m
-            const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
+            // par_n (loft_deconv2x2_bf16): the launch's N tiles are the FOUR OUTPUT PARITIES of a 2x2 / stride-2 deconvolution -- N
+            // tile p holds the 256 output channels of tap p and stores them at output offset (p >> 1, p & 1) of the stride-2 grid;
+            // the four tiles of one pixel tile run back to back on one XCD (nfast), so the input tile comes from HBM once
+            const int par = a.par_n ? by : 0, n0o = a.par_n ? 0 : n0;
+            const int ooy = a.oo_y + (par >> 1), oox = a.oo_x + (par & 1);
+            const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, ooy, oox);
             if constexpr (PL) pipe_epilogue_f32<MJ, NW>(a, otr, acc, g, m0, n0, wave, lane, ohw);
-            else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+            else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0o, wave, lane, ohw, kstamp, ooy, oox);
+            else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0o, wave, lane, ohw, kstamp, ooy, oox);
         }
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1454,8 +1463,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     {
         const bool dense = !a.pixmajor && a.os == 1 && a.OHf == a.OH && a.OWf == a.OW;
         const TileRows otr = pipe_tile_rows<256>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, a.oo_y, a.oo_x);
-        if (a.residual) pipe_epilogue_staged<true, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
-        else pipe_epilogue_staged<false, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp);
+        if (a.residual) pipe_epilogue_staged<true, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp, a.oo_y, a.oo_x);
+        else pipe_epilogue_staged<false, 4, 2>(a, otr, acc, lds, g, m0, n0, wave, lane, ohw, kstamp, a.oo_y, a.oo_x);
     }
 }
 
@@ -1798,7 +1807,10 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
     const int nw = nw_force == 1 ? 1 : (a.Cout % 256 == 0 ? 2 : 1);       // 128-cout tiles: Cout = 128 (mod 256), or by choice with 64-pixel tiles
     if (nw == 1 && !(mode == 1 && var == 0 && (mj == 4 || mj == 1) && a.Cout % 128 == 0)) return (int)hipErrorInvalidValue;
     if (a.nterms && !(mode == 1 && var == 0 && a.nterms <= CONV_MAX_TERMS && a.nterms * a.T <= 64)) return (int)hipErrorInvalidValue;
-    dim3 grid(loft_cdiv(a.M, 64 * mj), a.Cout / (128 * nw), groups);
+    if (a.par_n && !(mode == 1 && var == 0 && mj == 4 && nw == 2 && a.Cout == 256 && !w4 && !ring32 && !a.nterms && a.T == 1 && a.os == 2 &&
+                     !a.residual && !a.mask && a.staged_out))
+        return (int)hipErrorInvalidValue;
+    dim3 grid(loft_cdiv(a.M, 64 * mj), (a.par_n ? 4 : 1) * (a.Cout / (128 * nw)), groups);
     fastdiv_setup(grid.x * grid.y, &a.gxy_mul, &a.gxy_sh);
     fastdiv_setup(grid.x, &a.gx_mul, &a.gx_sh);
     fastdiv_setup(grid.y, &a.gy_mul, &a.gy_sh);

@@ -81,6 +81,9 @@ struct ConvArgs {
     const float* head_b;     // fp32 [head_c4]
     float* head_out;         // fp32 [pixels of the FULL output map][head_c4]
     int head_c4;
+    int par_n;               // conv_pipe.hip stream kernel (loft_deconv2x2_bf16): the launch has FOUR N tiles of Cout = 256 channels each,
+                             // N tile p = tap p of a 2x2 / stride-2 deconvolution (weight rows [256 p, 256 p + 256) of wgt), stored at
+                             // output offset (oo_y + (p >> 1), oo_x + (p & 1)) with os = 2: one launch, the input tile read once
 };
 
 // Power-of-two scale of a plane split (loft_split_planes_f32 with an absmax scalar; the binary16 build): the tensor's absmax lands

@@ -36,6 +36,8 @@ SWITCHES = {
                       'conv\'s epilogue (loft_conv_tap_bf16_head)',
     'no_grad_join': 'autograd sums the two data gradients of a backbone stage output (next stage + FPN lateral) with an elementwise add '
                     'instead of the residual block taking the lateral\'s deposit as its data-gradient residual (nn.JOIN)',
+    'no_deconv_fusion': 'the mask head\'s 2x2 deconvolution as four parity launches instead of one launch whose four channel tiles are '
+                        'the four taps (loft_deconv2x2_bf16: the input tile read once)',
     'no_zero_pool': 'torch.zeros / torch.empty per accumulation buffer instead of the step\'s pre-zeroed / scratch slabs',
     'no_feat_hub': 'autograd sums the RPN / RoI-extractor gradients of the FPN maps (no shared per-level gradient map)',
     # autograd-node granularity / previous formulations of three backward ops

@@ -740,6 +740,38 @@ def conv2d_fwd(x, wp, bias, R, S, stride=1, pad=0, relu=False, residual=None, ou
     return out
 
 
+def deconv2x2_fwd(x, wp, bias, out, relu=True, head=None):
+    """ConvTranspose2d(k=2, s=2) + bias (+ ReLU) as ONE launch (loft_deconv2x2_bf16): x 16-bit NHWC [B,Cin,H,W], wp 16-bit [4,256,Cin]
+    (tap p = 2 py + px), bias fp32 [256], out 16-bit NHWC [B,256,2H,2W]; head: the dict of conv_tap (narrow 1x1 head on the output).
+    -> True when the library served it (else nothing was launched: the caller runs the four parity launches)."""
+    lib = L.load()
+    L.dev_check(x, wp, out, bias)
+    B, Cin, H, W = x.shape
+    Cout = int(wp.shape[-2])
+    if (_DBG.no_deconv_fusion or CONV_VARIANT != CONV_AUTO or PROFILE is not None or x.dtype != L.act16() or out.dtype != L.act16()
+            or tuple(wp.shape) != (4, Cout, Cin) or not wp.is_contiguous() or tuple(out.shape) != (B, Cout, 2 * H, 2 * W)):
+        return False
+    x, out = _nhwc(x), _nhwc(out)
+    hw = hb = ho = None
+    c4 = 0
+    if head is not None:
+        head['fused'] = False
+        hw, hb, ho = head['w'], head['b'].float().contiguous(), head['out']
+        c4 = int(ho.shape[1])
+        if not (HEAD_FUSION and not _DBG.no_head_fusion and hw.dtype == L.act16() and tuple(hw.shape[-2:]) == (c4, 256)
+                and hw.is_contiguous() and ho.dtype == torch.float32 and tuple(ho.shape) == (B, c4, 2 * H, 2 * W)
+                and ho.is_contiguous(memory_format=torch.channels_last)):
+            return False
+    e = lib.loft_deconv2x2_bf16(L.ptr(x), L.ptr(wp), L.ptr(bias), L.ptr(out), L.ptr(zero_page(x.device)), B, H, W, Cin, Cout, int(relu),
+                                L.ptr(hw), L.ptr(hb), L.ptr(ho), c4, L.stream())
+    if e == 1:
+        return False
+    L.check(e, 'loft_deconv2x2_bf16')
+    if head is not None:
+        head['fused'] = True
+    return True
+
+
 def bottleneck_tail(t1, wp2, b2, wp3, b3, shortcut, wpd=None, bd=None):
     """Tail of a 64-plane bottleneck in one launch (loft_bneck_tail_bf16): relu(W3 . relu(conv3x3(t1) + b2) + b3 + shortcut).
     t1 [B,64,H,W] channels_last 16-bit; wp2 [1][9,64,64], wp3 [1][1,256,64] forward packings; b2 [1][64], b3 [1][256] fp32;

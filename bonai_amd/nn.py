@@ -675,18 +675,21 @@ class _DeconvFn(torch.autograd.Function):
         if head is not None and x.dtype == K.L.act16():
             c4 = int(head[0].shape[-2])
             hd = dict(w=head[0].reshape(c4, -1), b=head[1], out=K.empty_nhwc(N, c4, 2 * H, 2 * W, torch.float32, x.device))
-        nf = 0
-        for py in range(2):
-            for px in range(2):
-                K.conv_tap(x, wp, y, N, H, W, Cin, Cout, H, W, 2 * H, 2 * W, [(0, 0, py * 2 + px)], ss=1, os=2,
-                           oo=(py, px), bias=bias, relu=True, head=hd)
-                if hd is not None:
-                    if hd['fused']:
-                        nf += 1
-                    else:
-                        if nf:
-                            raise K.L.LoftHipError('deconv2x2_relu: the head epilogue served some parity launches only')
-                        hd = None
+        # ONE launch whose four channel tiles are the four taps (the input tile is read from HBM once) where the library serves
+        # it; else one launch per output parity
+        if not K.deconv2x2_fwd(x, wp, bias, y, relu=True, head=hd):
+            nf = 0
+            for py in range(2):
+                for px in range(2):
+                    K.conv_tap(x, wp, y, N, H, W, Cin, Cout, H, W, 2 * H, 2 * W, [(0, 0, py * 2 + px)], ss=1, os=2,
+                               oo=(py, px), bias=bias, relu=True, head=hd)
+                    if hd is not None:
+                        if hd['fused']:
+                            nf += 1
+                        else:
+                            if nf:
+                                raise K.L.LoftHipError('deconv2x2_relu: the head epilogue served some parity launches only')
+                            hd = None
         ctx.save_for_backward(x, w, y)
         _DeconvFn.head_out = hd['out'] if hd is not None else None     # (picked up by deconv2x2_relu; no autograd history)
         return _begin_uses(y)

@@ -228,6 +228,15 @@ int loft_conv_tap_bf16_head(const void* src, const void* wgt, const float* bias,
                             const void* zero_page, int B, int IH, int IW, int Cin, int Cout, int OH, int OW, int OHf, int OWf, int os,
                             int oo_y, int oo_x, int ss, int T, const int* dy_host, const int* dx_host, const int* wt_host, int relu,
                             const void* head_w, const float* head_b, float* head_out, int head_c4, void* stream);
+
+/* loft_deconv2x2_bf16: ConvTranspose2d(kernel 2, stride 2) + bias (+ ReLU) in ONE launch (fcn_mask_head.py:121-124): out[b, 2y + py,
+ * 2x + px, :] = act(W[2 py + px] . src[b, y, x, :] + bias); src [B,H,W,Cin], wgt [4][256][Cin] (tap p = 2 py + px, forward packing),
+ * out [B,2H,2W,256], activation type.  The four taps are four channel tiles of the same pixel tile: src is read from HBM once, not
+ * once per output parity.  head_w != NULL: the narrow 1x1 head of loft_conv_tap_bf16_head on the output (head_out fp32
+ * [B*2H*2W][head_c4]).  Served for Cout == 256 and B*H*W >= 192 * 256 pixels; otherwise hipErrorInvalidValue, nothing launched. */
+int loft_deconv2x2_bf16(const void* src, const void* wgt, const float* bias, void* out, const void* zero_page, int B, int H, int W,
+                        int Cin, int Cout, int relu, const void* head_w, const float* head_b, float* head_out, int head_c4,
+                        void* stream);
 /* fp32 parity mode, backward (parity_f32.hip): weight gradient of the same tap contract on v_mfma_f32_32x32x2_f32 (dw is
  * accumulated into: the caller zeroes it), and the fp32 forms of the glue adjoints.  Checker path (1e-3 vs the reference's fp32
  * autograd), not a performance path. */

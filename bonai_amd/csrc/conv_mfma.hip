@@ -684,7 +684,7 @@ static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bia
     if (head) {
         // (served by the staged epilogue of the 256-cout stream tiles only; anything else: the caller launches the head itself)
         if (!head->w || !head->b || !head->out || head->c4 < 4 || head->c4 > 32 || (head->c4 % 4) || Cout != 256 || groups != 1 ||
-            out_f32 || accumulate || (variant & ~0xff))
+            out_f32 || accumulate || (variant & ~0xff) || relu_mask)      // (the head reads the tile before a mask would apply)
             return (int)hipErrorInvalidValue;
         a.head_w = (const bf16_t*)head->w; a.head_b = head->b; a.head_out = head->out; a.head_c4 = head->c4;
     }

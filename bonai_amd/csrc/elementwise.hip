@@ -437,6 +437,10 @@ __global__ __launch_bounds__(256) void absmax_split_fused_kernel(const float* __
         unsigned spins = 0;
         while (__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++spins < (1u << 26))
             __builtin_amdgcn_s_sleep(2);
+        // (the grid is <= 256 workgroups of 256 threads -- co-resident on an idle chip; if other streams hold CUs for seconds the
+        //  rendezvous cannot complete: abort the launch LOUDLY rather than split with a partial absmax -- a too-small scale would
+        //  overflow the binary16 planes to inf without any error)
+        if (spins >= (1u << 26)) __builtin_trap();
         __threadfence();
         amax_s = __uint_as_float(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }

@@ -586,22 +586,49 @@ def planes_scoped(fn):
 # (storage pointer, shape, version, plane type), until the tensor dies (weakref finalizer) or the weight gradient takes them.
 _FWD_PLANES = {}
 FWD_PLANES_CACHE = True
+PLANES_XSTREAM = {'waits': 0}     # memo / cache hits served to ANOTHER stream than the one that split (tests read it)
+
+
+class _PlanesEntry:
+    """Planes of one tensor + where they were made.  A memo hit from ANOTHER stream (the backbone's weight gradients run on
+    WGRAD_STREAM, the data gradient of the same node on the main stream; the forward's cached planes are made on main and
+    consumed -- and dropped -- by the weight gradient) must not read planes that the producing stream has only enqueued, and the
+    caching allocator must not hand their block back to the producing stream's pool while the consumer still reads it
+    (ADVICE r5): the consumer waits for the producer's event and records itself on the planes and the absmax slot."""
+    __slots__ = ('val', 'stream', 'event', 'keep')
+
+    def __init__(self, val, keep=None):
+        self.val = val
+        self.keep = keep
+        self.stream = L.stream().value
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def get(self):
+        if L.stream().value != self.stream:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.event)
+            for t in self.val:
+                if t is not None:
+                    t.record_stream(cur)
+            PLANES_XSTREAM['waits'] += 1
+        return self.val
 
 
 def _fwd_planes_put(x, dtype16, val):
     import weakref
     key = (x.data_ptr(), tuple(x.shape), x._version, dtype16)
-    _FWD_PLANES[key] = val
+    _FWD_PLANES[key] = _PlanesEntry(val)
     weakref.finalize(x, _FWD_PLANES.pop, key, None)
 
 
 def _split_memo(x, dtype16, memo, take_fwd=False):
     """split_planes with a memo (the caller's dict, else the innermost planes_scoped call's, else none); take_fwd: use (and drop)
-    the planes the forward pass left for this tensor."""
+    the planes the forward pass left for this tensor.  Entries are stream-aware (_PlanesEntry)."""
     if take_fwd:
         hit = _FWD_PLANES.pop((x.data_ptr(), tuple(x.shape), x._version, dtype16), None)
         if hit is not None:
-            return hit
+            return hit.get()
     if memo is None:
         memo = _SCOPES[-1] if _SCOPES else None
     if memo is None:
@@ -609,8 +636,8 @@ def _split_memo(x, dtype16, memo, take_fwd=False):
     key = (x.data_ptr(), tuple(x.shape), x._version, dtype16)
     hit = memo.get(key)
     if hit is None:
-        hit = memo[key] = (split_planes(x, dtype16), x)
-    return hit[0]
+        hit = memo[key] = _PlanesEntry(split_planes(x, dtype16), keep=x)
+    return hit.get()
 WGRAD_AUTO, WGRAD_STREAM256, WGRAD_T256, WGRAD_T128, WGRAD_RING128 = range(5)       # LOFT_WGRAD_*: kernel selector of loft_conv_wgrad_bf16_v
 WGRAD_VARIANT = WGRAD_AUTO      # a code, or a callable (groups, B, OH, OW, Cin, Cout, T, ss, gos) -> code
 

@@ -1152,6 +1152,10 @@ class _SparseRPNFn(torch.autograd.Function):
                 (pw_reg, dwp[0, 0, A:5 * A], pb_reg, db[0, A:5 * A], None)]):
             pgrads = (None,) * 6
         else:
+            # (no queue / no slots: autograd accumulates; the uses counted in forward are not sunk -- as _NarrowHeadFn does)
+            for p_, need in zip(ctx.params, ctx.needs_input_grad[5:11]):
+                if need and p_ is not None and getattr(p_, '_loft_pending', 0) > 0:
+                    p_._loft_pending -= 1
             pgrads = (g_wconv, dbc[0], g_wcls, g_bcls, g_wreg, g_breg)
         return (None, None, None, None, None) + pgrads + tuple(ret) + (None,) * len(xs)
 
@@ -1340,6 +1344,8 @@ class _ResBlockFn(torch.autograd.Function):
             if dep is not None:                  # (a deposit this block's launches could not take: plain sum)
                 gx = gx + dep.to(gx.dtype)
                 dep = None
+                if mask is not None:             # (the sum is not masked yet: the tag below would claim it is -- ADVICE r5)
+                    gx = K.relu_bwd(gx, x)
             if mask is not None:
                 gx._loft_premasked = x.data_ptr()
         if sc_spec is not None:

@@ -11,7 +11,7 @@ cd /tmp
 HASH=$(cd "$ROOT" && python -c "from bonai_amd.build import source_hash; print(source_hash())")
 python "$ROOT/tools/pmc_collect.py" > /dev/null 2>&1
 cp "$ROOT/gpurun_out/pmc/summary.json" "$OUT/pmc_traffic.json"
-cp "$OUT/pmc_traffic.json" "$ROOT/profiles/round5_pmc_traffic.json"      # so that the bench run below quotes it
+cp "$OUT/pmc_traffic.json" "$ROOT/profiles/round6_pmc_traffic.json"      # so that the bench run below quotes it
 W=5; K=20
 for mode in serial default; do
     rm -rf /tmp/prof_$mode
@@ -24,8 +24,8 @@ for mode in serial default; do
     echo "{\"source_hash\": \"$HASH\", \"steps_profiled\": $((W + K + 2)), \"command\": \"bench.py --no-cpu-baseline --no-light --no-fp32 --no-forced-comm --steps $K --warmup $W\", \"mode\": \"$mode\"}" > "$OUT/kernel_stats_$mode.meta.json"
 done
 unset LOFT_NO_SIDE_STREAM
-cp "$OUT/kernel_stats_serial.csv" "$ROOT/profiles/round5_bench_kernel_stats_serial.csv"
-cp "$OUT/kernel_stats_serial.meta.json" "$ROOT/profiles/round5_bench_kernel_stats_serial.meta.json"
+cp "$OUT/kernel_stats_serial.csv" "$ROOT/profiles/round6_bench_kernel_stats_serial.csv"
+cp "$OUT/kernel_stats_serial.meta.json" "$ROOT/profiles/round6_bench_kernel_stats_serial.meta.json"
 # The bench line itself is NOT measured here but by tools/refresh_bench_line.sh in a gpurun call of its own (a box that has run
 # nothing else), after pmc_traffic.json / kernel_stats_* have been copied into profiles/ (bench.py quotes them by source hash).
 rm -rf "$ROOT/gpurun_out/pmc"

@@ -248,23 +248,47 @@ class _OffsetBase(nn.Module):
 
 
 class _BranchSlabs(torch.autograd.Function):
-    """[4N,C,H,W] branch-major NHWC batch -> its four [N,C,H,W] slabs (views); the backward concatenates the four slab
-    gradients back into ONE NHWC tensor (autograd's own slice backward would build four full-size NCHW-strided zero tensors)."""
+    """[E N,C,H,W] branch-major NHWC batch -> its E [N,C,H,W] slabs (views); the backward concatenates the slab
+    gradients back into ONE NHWC tensor (autograd's own slice backward would build E full-size NCHW-strided zero tensors)."""
 
     @staticmethod
-    def forward(ctx, x4):
-        n = x4.shape[0] // 4
-        return tuple(x4[k * n:(k + 1) * n] for k in range(4))
+    def forward(ctx, x4, E=4):
+        n = x4.shape[0] // E
+        return tuple(x4[k * n:(k + 1) * n] for k in range(E))
 
     @staticmethod
     def backward(ctx, *gs):
-        return torch.cat(gs, 0).contiguous(memory_format=torch.channels_last)
+        return torch.cat(gs, 0).contiguous(memory_format=torch.channels_last), None
+
+
+class _PickSlabs(torch.autograd.Function):
+    """[4N,C,H,W] (the four rot90 copies the RoIAlign kernel writes) -> the slabs `idx` of it, branch-major [len(idx) N,C,H,W]:
+    a FOA head with fewer than four rotation branches (offset_head_expand_feature.py:371-385)."""
+
+    @staticmethod
+    def forward(ctx, x4, idx):
+        n = x4.shape[0] // 4
+        ctx.idx, ctx.shape = idx, tuple(x4.shape)
+        return torch.cat([x4[k * n:(k + 1) * n] for k in idx], 0).contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.shape[0] // 4
+        g4 = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+        for j, k in enumerate(ctx.idx):
+            g4[k * n:(k + 1) * n] = g[j * n:(j + 1) * n]
+        return g4, None
+
+
+# rotation sets of the reference's offset_fusion (offset_head_expand_feature.py:371-397); the four-branch set is configs/loft_foa's
+FOA_ROTATION_SETS = ([0, 90, 180, 270], [0, 180], [0, 90], [0, 90, 180])
 
 
 @HEADS.register_module()
 class OffsetHeadExpandFeature(_OffsetBase):
-    """FOA: 4 rotated copies of the RoI feature, per-branch num_convs x (conv3x3+ReLU), then the FC stack + regressor -- shared
-    by the branches (``share_expand_fc=True``, configs/loft_foa) or one per branch (the reference class's default)."""
+    """FOA: rotated copies of the RoI feature (4 in configs/loft_foa; 2 or 3 in the reference's other rotation sets), per-branch
+    num_convs x (conv3x3+ReLU), then the FC stack + regressor -- shared by the branches (``share_expand_fc=True``,
+    configs/loft_foa) or one per branch (the reference class's default)."""
 
     def __init__(self, roi_feat_size=7, in_channels=256, num_convs=4, num_fcs=2, reg_num=2, conv_out_channels=256,
                  fc_out_channels=1024, expand_feature_num=4, share_expand_fc=False, rotations=[0, 90, 180, 270],
@@ -272,15 +296,17 @@ class OffsetHeadExpandFeature(_OffsetBase):
                                                                     target_stds=[0.5, 0.5]),
                  reg_decoded_offset=False, conv_cfg=None, norm_cfg=None, loss_offset=dict(type='MSELoss', loss_weight=1.0)):
         super().__init__()
-        if expand_feature_num != 4 or list(rotations) != [0, 90, 180, 270] or in_channels != conv_out_channels:
-            raise NotImplementedError('FOA is built natively for the 4 rotations 0/90/180/270')
+        if list(rotations) not in FOA_ROTATION_SETS or expand_feature_num != len(rotations) or in_channels != conv_out_channels:
+            raise NotImplementedError('FOA takes the rotation sets the reference\'s offset_fusion names: '
+                                      '[0,90,180,270], [0,180], [0,90], [0,90,180] (offset_head_expand_feature.py:371-397)')
         self.expand_feature_num, self.rotations, self.share_expand_fc = expand_feature_num, list(rotations), bool(share_expand_fc)
+        self.rot_idx = tuple(r // 90 for r in self.rotations)           # slab of the RoIAlign kernel's four rot90 copies per branch
         self.num_convs = num_convs
         if tuple(float(v) for v in offset_coder.get('target_means', (0., 0.))) != (0., 0.):
             raise NotImplementedError('FOA target / fusion kernels take zero offset means (configs/loft_foa)')
         # (convs before fcs / fc_offset: the reference's registration order, offset_head_expand_feature.py:62-107)
         self.expand_convs = nn.ModuleList([nn.ModuleList([ConvW(conv_out_channels, conv_out_channels, 3, bias=True)
-                                                          for _ in range(num_convs)]) for _ in range(4)])
+                                                          for _ in range(num_convs)]) for _ in range(expand_feature_num)])
         self._common(roi_feat_size, in_channels, conv_out_channels, fc_out_channels, num_fcs, reg_num, offset_coder,
                      loss_offset, offset_coordinate, reg_decoded_offset)
 
@@ -294,29 +320,69 @@ class OffsetHeadExpandFeature(_OffsetBase):
 
     def forward_rotated(self, x4):
         """x4 bf16 [4N,256,7,7], branch-major (the RoIAlign kernel already wrote the 4 rotations)
-        -> fp32 [4N,2] branch-major (= torch.cat(offsets, 0) of offset_head_expand_feature.py:160)."""
+        -> fp32 [E N,2] branch-major (= torch.cat(offsets, 0) of offset_head_expand_feature.py:160)."""
+        E = self.expand_feature_num
         if x4.shape[0] == 0:
-            return x4.new_zeros(0, 2 * self.expand_feature_num, dtype=torch.float32)  # appendix A.1 quirk
+            return x4.new_zeros(0, 2 * E, dtype=torch.float32)  # appendix A.1 quirk
+        if E != 4:
+            x4 = _PickSlabs.apply(x4, self.rot_idx)
         for i in range(self.num_convs):
-            x4 = F2.conv2d(x4, [self.expand_convs[k][i].weight for k in range(4)],
-                           [self.expand_convs[k][i].bias for k in range(4)], pad=1, relu=True, groups=4, input_relu=i > 0)
+            x4 = F2.conv2d(x4, [self.expand_convs[k][i].weight for k in range(E)],
+                           [self.expand_convs[k][i].bias for k in range(E)], pad=1, relu=True, groups=E, input_relu=i > 0)
         if self.share_expand_fc:
-            return self._fc_tail(x4)                   # one [4N, .] GEMM per shared layer
+            return self._fc_tail(x4)                   # one [E N, .] GEMM per shared layer
         # share_expand_fc=False (offset_head_expand_feature.py:147-152): branch k's rows through branch k's own FCs; the rows of
         # one branch are a contiguous slab of the branch-major batch
         return torch.cat([self._fc_tail(xk, self.expand_fcs[k], self.expand_fc_offsets[k])
-                          for k, xk in enumerate(_BranchSlabs.apply(x4))], 0)
+                          for k, xk in enumerate(_BranchSlabs.apply(x4, E))], 0)
 
     def forward(self, x):
-        """Reference signature: un-rotated RoI features [N,256,7,7] in, [4N,2] out."""
+        """Reference signature: un-rotated RoI features [N,256,7,7] in, [E N,2] out."""
         x4 = torch.cat([torch.rot90(x, k, (2, 3)) for k in range(4)], 0).contiguous(memory_format=torch.channels_last)
         return self.forward_rotated(x4)
 
     def get_targets(self, pos_bboxes, pos_gt_offsets):
-        return K.foa_targets(pos_bboxes, pos_gt_offsets, self.offset_coder.stds)
+        t4 = K.foa_targets(pos_bboxes, pos_gt_offsets, self.offset_coder.stds)
+        if self.expand_feature_num == 4:
+            return t4
+        n = t4.shape[0] // 4
+        return torch.cat([t4[k * n:(k + 1) * n] for k in self.rot_idx], 0)
+
+    def _as_four(self, offset_pred):
+        """[E N,2] -> the [4N,2] the four-branch fusion kernel takes, such that its 'max' is the E-branch one: a missing rotation
+        slot repeats the main branch (with the columns swapped where the kernel swaps them back), which a maximum ignores."""
+        E = self.expand_feature_num
+        if E == 4:
+            return offset_pred
+        n = offset_pred.shape[0] // E
+        b = offset_pred.split(n, 0)
+        slots = []
+        for k in range(4):
+            if k in self.rot_idx:
+                slots.append(b[self.rot_idx.index(k)])
+            else:
+                slots.append(b[0][:, [1, 0]] if k % 2 else b[0])
+        return torch.cat(slots, 0).contiguous()
+
+    def offset_fusion(self, offset_pred, model='max'):
+        """offset_head_expand_feature.py:346-413 on the device: [E N,2] -> fused [N,2] encoded offsets.  'max' = what get_offsets
+        uses; 'mean' = the SUM of the branches' magnitudes (the reference divides by 1).  Sign of the main branch, zero -> -1."""
+        E = self.expand_feature_num
+        n = offset_pred.shape[0] // E
+        b = offset_pred.float().split(n, 0)
+        cur = [b[i][:, [1, 0]] if self.rotations[i] in (90, 270) else b[i] for i in range(E)]
+        mags = torch.stack([c.abs() for c in cur], 0)
+        if model == 'max':
+            val = mags.max(0)[0]
+        elif model == 'mean':
+            val = mags.sum(0)
+        else:
+            raise NotImplementedError(model)
+        return val * torch.where(b[0] > 0, torch.ones_like(b[0]), -torch.ones_like(b[0]))
 
     def get_offsets(self, offset_pred, det_bboxes, scale_factor=None, rescale=False, img_shape=(1024, 1024)):
-        return K.foa_fuse_decode(offset_pred, det_bboxes, self.offset_coder.stds, img_shape).cpu().numpy().astype(np.float32)
+        return K.foa_fuse_decode(self._as_four(offset_pred), det_bboxes, self.offset_coder.stds,
+                                 img_shape).cpu().numpy().astype(np.float32)
 
 
 @HEADS.register_module()

@@ -338,15 +338,16 @@ def mask_head(sd, x, prefix='roi_head.mask_head.'):
     return _layer(x, sd[prefix + 'conv_logits.weight'], sd[prefix + 'conv_logits.bias'], out16=False)
 
 
-def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.', share_expand_fc=True, num_fcs=2):
+def foa_head(sd, x, num_convs=10, prefix='roi_head.offset_head.', share_expand_fc=True, num_fcs=2, rotations=(0, 90, 180, 270)):
     """offset_head_expand_feature.py:134-161: per rotation branch num_convs x (conv3x3 + ReLU), flatten, num_fcs x (FC + ReLU),
     FC -> 2; the FC stack is `fcs` / `fc_offset` for every branch (share_expand_fc=True, configs/loft_foa) or the branch's own
-    `expand_fcs.k.*` / `expand_fc_offsets.k` (:147-152).  Empty input -> (0, 8) (:135-136)."""
+    `expand_fcs.k.*` / `expand_fc_offsets.k` (:147-152).  Empty input -> (0, 2 * branches) (:135-136).  Branch k sees the feature
+    rotated by rotations[k] degrees (:163-193)."""
     if x.shape[0] == 0:
-        return x.new_empty(0, 8)
+        return x.new_empty(0, 2 * len(rotations))
     outs = []
-    for k in range(4):
-        h = R.foa_rotate_feature(x, k)
+    for k, rot in enumerate(rotations):
+        h = R.foa_rotate_feature(x, rot // 90)
         for i in range(num_convs):
             h = _layer(h, sd[f'{prefix}expand_convs.{k}.{i}.weight'], sd[f'{prefix}expand_convs.{k}.{i}.bias'], 1, 1, relu=True)
         h = h.reshape(h.shape[0], -1)

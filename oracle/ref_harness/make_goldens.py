@@ -350,6 +350,63 @@ def foa_head():
     print('foa_head.npz', len(out), 'arrays', {k: float(out[k]) for k in out if k.endswith('_loss')})
 
 
+def foa_variants():
+    """Reference OffsetHeadExpandFeature with the rotation sets its offset_fusion spells out besides the four-branch one
+    (offset_head_expand_feature.py:371-385: [0, 180], [0, 90], [0, 90, 180]) -- forward, get_targets, loss, backward, offset_fusion
+    in both models ('max' :370-397, 'mean' :358-369) and get_offsets -- and the 'mean' fusion of the four-branch head.  Inputs are
+    regenerated from names (synth_tensor)."""
+    from mmdet.models.roi_heads.attribute_heads.offset_head_expand_feature import OffsetHeadExpandFeature
+    from oracle.synth_weights import synth_tensor
+    out = {}
+    rng = np.random.RandomState(23)
+
+    class _Res:
+        pass
+
+    def boxes(n, size=1024.):
+        cx, cy = rng.uniform(0, size, n), rng.uniform(0, size, n)
+        w, h = rng.uniform(8, 200, n), rng.uniform(8, 200, n)
+        return torch.tensor(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).clip(0, size), dtype=torch.float32)
+    res, gt_offs = [], []
+    for i, n in enumerate((3, 0, 2)):
+        r = _Res()
+        r.pos_bboxes = boxes(n)
+        r.pos_assigned_gt_inds = torch.tensor(rng.randint(0, 3, n), dtype=torch.long)
+        res.append(r)
+        gt_offs.append(torch.tensor(rng.uniform(-40, 40, (3, 2)), dtype=torch.float32))
+        out[f'pos_{i}'], out[f'ind_{i}'], out[f'gtoff_{i}'] = T(r.pos_bboxes), T(r.pos_assigned_gt_inds), T(gt_offs[-1])
+    det = boxes(5)
+    out['det_bboxes'] = T(det)
+    for tag, rots in (('r0_180', [0, 180]), ('r0_90', [0, 90]), ('r0_90_180', [0, 90, 180]), ('r4', [0, 90, 180, 270])):
+        head = OffsetHeadExpandFeature(num_convs=1, share_expand_fc=True, expand_feature_num=len(rots), rotations=list(rots))
+        sd = {k: synth_tensor('roi_head.offset_head.' + k, v.shape) for k, v in head.state_dict().items()}
+        for k in sd:
+            if 'fc_offset' in k and k.endswith('weight'):
+                sd[k] = sd[k] * 30.0
+        head.load_state_dict(sd)
+        out[f'{tag}_state_keys'] = np.array(sorted(sd))
+        x = synth_tensor(f'foa_variants.x.{tag}', (5, 256, 7, 7)).requires_grad_(True)
+        pred = head(x)
+        tg = head.get_targets(res, gt_offs, None)
+        loss = head.loss(pred, tg)['loss_offset']
+        loss.backward()
+        out[f'{tag}_pred'], out[f'{tag}_targets'], out[f'{tag}_loss'] = T(pred), T(tg), T(loss)
+        out[f'{tag}_empty_shape'] = np.array(head(x[:0]).shape)
+        for n, p_ in head.named_parameters():
+            if n in ('expand_convs.0.0.weight', f'expand_convs.{len(rots) - 1}.0.bias', 'fcs.0.weight', 'fc_offset.weight'):
+                out[f'{tag}_gradnorm_{n}'] = T(p_.grad.norm())
+        out[f'{tag}_gradx_norm'] = T(x.grad.norm())
+        with torch.no_grad():
+            p = pred.detach().clone()
+            p[0, 0] = 0.0                                    # an exact zero in the main branch: polarity -1 (:405-407)
+            out[f'{tag}_fuse_in'] = T(p)
+            out[f'{tag}_fuse_max'] = T(head.offset_fusion(p, model='max'))
+            out[f'{tag}_fuse_mean'] = T(head.offset_fusion(p, model='mean'))
+            out[f'{tag}_get_offsets'] = np.asarray(head.get_offsets(p, det, None, False, img_shape=[1024, 1024]))
+    np.savez_compressed(os.path.join(GOLD, 'foa_variants.npz'), **out)
+    print('foa_variants.npz', len(out), 'arrays', {k: float(out[k]) for k in out if k.endswith('_loss')})
+
+
 def data_pipeline():
     """Reference BONAI._parse_ann_info (bonai.py:105-256) and RandomFlip.bbox_flip/offset_flip (transforms.py:379-466) on
     synthetic annotations; the expected outputs are stored, the inputs are regenerated by synth_bonai_anns()."""
@@ -403,10 +460,14 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'foa_head':
         foa_head()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'foa_variants':
+        foa_variants()
+        sys.exit(0)
     core_ops()
     e2e()
     e2e_test()
     hrnet()
     offset_head()
     foa_head()
+    foa_variants()
     data_pipeline()

@@ -84,6 +84,37 @@ def test_every_debug_switch_alone_matches_the_default_step(first_k):
     _compare(want, m, 'default after the switches')
 
 
+def test_fp32_mode_trainer_shares_operand_planes_across_streams_safely(first_k):
+    """in the fp32 parity mode a residual block's backward splits its output gradient into operand planes ONCE, on the
+    weight-gradient side stream, and the data gradient on the main stream takes them from the memo; the forward's cached planes are
+    made on main and consumed (and freed) by the weight gradient on the side stream.  Both hand-overs now carry an event and a
+    record_stream (kernels._PlanesEntry): the Trainer step with the side stream must equal the one without it (and plain autograd),
+    repeatedly, and the cross-stream path must actually have been taken."""
+    from bonai_amd import kernels as K
+    from bonai_amd.debug import DBG
+    from bonai_amd.engine import Trainer
+    from bonai_amd.synth import make_batch
+    data = make_batch(2, 256, 8, device='cuda')
+    m0 = _synth_model()
+    m0.backbone.compute_dtype = torch.float32
+    want = _autograd_grads(m0, data)
+    m = _synth_model()
+    m.backbone.compute_dtype = torch.float32
+    tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
+    K.PLANES_XSTREAM['waits'] = 0
+    for rep in range(3):
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+        _compare(want, m, f'fp32 side-stream rep {rep}', tol=2e-3)
+    assert K.PLANES_XSTREAM['waits'] > 0, 'no operand planes crossed streams: the test does not exercise the hand-over'
+    with DBG.override(no_wgrad_stream=True):
+        n0 = K.PLANES_XSTREAM['waits']
+        tr.train_step(data, lr=0.0)
+        torch.cuda.synchronize()
+        _compare(want, m, 'fp32 no_wgrad_stream', tol=2e-3)
+        assert K.PLANES_XSTREAM['waits'] == n0
+
+
 def test_underfilled_sampler_drops_the_speculative_roialign_cleanly(first_k):
     """with few proposals the sampler cannot fill its 1024 slots per image, the bbox features computed
     speculatively on the worst-case list are dropped -- the fused RoIAlign backward must still launch when the THREE real lists

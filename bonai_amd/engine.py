@@ -102,16 +102,36 @@ class BucketedAllReduce:
         self.on_gpu = arena.data.is_cuda
         self.stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.works = []
+        # Host cost of the reducer (+1.47 ms per step on the one-rank leg, none of it bytes).  autograd calls a
+        # python post-accumulate hook for EVERY leaf -- ~300 per step -- although almost every gradient of this model is deposited
+        # by a kernel and reported through the trainer's sink (the hook then only returns).  Hooks are therefore PRUNED: a
+        # parameter that reported through the sink in PRUNE_AFTER consecutive steps loses its autograd hook; should it ever come
+        # through autograd again (a debug switch, a fallback path, a rank without that branch) nothing is lost -- its bucket is
+        # launched by finish(), in index order like every bucket, only later -- and finish() re-arms the hook of every parameter
+        # that did not report, so the steady state is reached again.  Events of the hand-over to the side stream are created once.
+        self._hooks, self._sunk_streak = {}, {}
+        self.PRUNE_AFTER = 2
+        self.prune_hooks = os.environ.get('LOFT_REDUCER_KEEP_HOOKS') != '1'
+        self._events = {}
         if self.enabled:
             for p in arena.order:
-                p.register_post_accumulate_grad_hook(self._autograd_hook)
+                self._arm(p)
         self._remaining = None
         self.measure, self.exposed = False, []      # bench.py: record (backward end, last collective end) event pairs per step
         self.capturing = False     # True while bonai_amd.graphs records a section: nothing may be released or launched from it
 
+    def _arm(self, p):
+        if id(p) not in self._hooks:
+            self._hooks[id(p)] = p.register_post_accumulate_grad_hook(self._autograd_hook)
+            self._sunk_streak[id(p)] = 0
+
+    def hooks_armed(self):
+        return len(self._hooks)
+
     def begin(self):
         self._remaining = [len(b['params']) for b in self.buckets]
         self._seen = set()
+        self._via_sink = set()
         self._next = 0
         self.works = []
         self._streams = [dict() for _ in self.buckets]
@@ -137,6 +157,11 @@ class BucketedAllReduce:
         gradient sink (Trainer._sink -> _hook) once the deposit has been enqueued, never from here."""
         if getattr(p, '_loft_sunk', False) or self.capturing:
             return
+        self._hook(p)
+
+    def _sink(self, p):
+        """The kernels' direct arena sink (bonai_amd.nn.GRAD_SINK): as _hook, and remembered as a sink report for hook pruning."""
+        self._via_sink.add(id(p))
         self._hook(p)
 
     def _hook(self, p):
@@ -169,8 +194,10 @@ class BucketedAllReduce:
         cur = torch.cuda.current_stream()
         producers = dict(self._streams[bi])
         producers[torch._C._cuda_getCurrentRawStream(self._dev)] = cur
-        for st in producers.values():
-            ev = torch.cuda.Event()
+        for raw, st in producers.items():
+            ev = self._events.get((bi, raw))
+            if ev is None:
+                ev = self._events[(bi, raw)] = torch.cuda.Event()
             ev.record(st)
             self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
@@ -188,14 +215,40 @@ class BucketedAllReduce:
         if self.on_gpu and self.measure:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        for w in self.works:
-            w.wait()
         if self.on_gpu:
+            # c10d runs the collectives of one process group in issue order on ITS OWN stream; work.wait() makes the calling stream
+            # wait for that work's end event.  One wait on the LAST work, taken by the side stream, covers all of them (the
+            # per-work wait() loop did the same thing fifteen times, on the main stream); the main stream then waits for the side
+            # stream's tail, and the measured pair brackets the real end of the last collective.
+            if self.works:
+                with torch.cuda.stream(self.stream):
+                    self.works[-1].wait()
             if self.measure:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record(self.stream)
                 self.exposed.append((e0, e1))
             torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for w in self.works:
+                w.wait()
+        self._prune()
+
+    def _prune(self):
+        """Hook bookkeeping after a step (see __init__): drop the autograd hook of parameters the sink has served PRUNE_AFTER steps
+        in a row; re-arm the hook of every parameter that did not report at all."""
+        if not self.prune_hooks or self.capturing:
+            return
+        for p in self.arena.order:
+            k = id(p)
+            if k in self._via_sink:
+                if k in self._hooks:
+                    self._sunk_streak[k] += 1
+                    if self._sunk_streak[k] >= self.PRUNE_AFTER:
+                        self._hooks.pop(k).remove()
+            elif k in self._hooks:
+                self._sunk_streak[k] = 0
+            elif k not in self._seen:
+                self._arm(p)
 
     def exposed_ms(self):
         """Mean over the measured steps of max(0, end of the last gradient collective - end of backward): the all-reduce time the
@@ -240,7 +293,7 @@ class Trainer:
         self.prepack = K.PrepackRegistry()
         # kernels accumulate weight / BN gradients straight into the arena slots (bonai_amd.nn.GRAD_SINK); the callback
         # replaces the post-accumulate-grad hook for those parameters
-        self._sink = self.reducer._hook if self.reducer.enabled else (lambda p: None)
+        self._sink = self.reducer._sink if self.reducer.enabled else (lambda p: None)
 
     def _graph_step_setup(self, img):
         from .graphs import FeatureGraphs

@@ -137,11 +137,14 @@ def offset_epe_vs_ref():
                                      ('fp32_split6', torch.float32, K.F32_SPLIT6, 1e-4), ('fp32_split3', torch.float32, K.F32_SPLIT3, 1e-3),
                                      ('fp32_exact_mfma', torch.float32, K.F32_EXACT, 1e-4),
                                      ('mixed_neck', 'neck', K.F32_PLANES_F16, 0.0), ('mixed_heads', 'heads', K.F32_PLANES_F16, 0.0),
+                                     ('mixed_trunk', 'trunk', K.F32_PLANES_F16, 0.0),
                                      ('bf16', torch.bfloat16, K.F32_CONTRACT, 0.0)):
         m.mixed_precision = dt if isinstance(dt, str) else None
         if isinstance(dt, str):
-            dt = torch.bfloat16
-        m.backbone.compute_dtype = dt
+            m.backbone.compute_dtype = torch.float32 if dt == 'trunk' else torch.bfloat16     # (trunk: fp32-grade backbone + FPN)
+            dt = torch.bfloat16                     # (pairing rule below: by box IoU, as for bf16)
+        else:
+            m.backbone.compute_dtype = dt
         prev_contract, K.F32_CONTRACT = K.F32_CONTRACT, contract
         with torch.no_grad():
             bbox_results, _, offs = m(img=[data['img']], img_metas=[data['img_metas']], return_loss=False, rescale=True)
@@ -509,14 +512,16 @@ def main():
             # the Pareto points between the two end points: 16-bit kernels up to a boundary, fp32 behind it
             model.backbone.compute_dtype = None
             mixed = {}
-            for name in (() if only else ('neck', 'heads')):
+            for name in (() if only else ('neck', 'heads', 'trunk')):
                 model.mixed_precision = name
+                model.backbone.compute_dtype = torch.float32 if name == 'trunk' else None
                 el_m = fp32_loop(_K.F32_PLANES_F16, k)
                 mixed[name] = dict(value=round(args.batch * k / el_m, 3), ms_per_step=round(el_m / k * 1e3, 2), steps=k)
             model.mixed_precision = None
             mixed['how'] = ('same command; neck: backbone trunk on the bf16 kernels, FPN + RPN + RoI heads in the fp32 parity mode '
-                            '(binary16 operand planes); heads: backbone + FPN bf16, RPN + RoI heads fp32; the offsets each variant '
-                            'produces against the reference: offset_epe_vs_ref.mixed_neck / .mixed_heads')
+                            '(binary16 operand planes); heads: backbone + FPN bf16, RPN + RoI heads fp32; trunk (the reverse split): backbone + FPN '
+                            'fp32-grade, RPN + RoI heads bf16; the offsets each variant produces against the reference: '
+                            'offset_epe_vs_ref.mixed_neck / .mixed_heads / .mixed_trunk')
             fp32_parity['mixed'] = mixed
         except Exception as e:      # noqa -- reported, never hidden
             fp32_parity = dict(error=f'{type(e).__name__}: {e}'[:300])

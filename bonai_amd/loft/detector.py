@@ -89,7 +89,8 @@ class LOFT(nn.Module):
         x = self.backbone(img)
         # mixed precision (a measurement mode, bench.py `value_mixed`): the 16-bit training kernels up to a boundary, the fp32
         # parity mode's arithmetic (fp32 activations, operand-plane contractions) behind it.  'neck': backbone trunk 16-bit,
-        # FPN + RPN + RoI heads fp32; 'heads': backbone + FPN 16-bit, RPN + RoI heads fp32.  The cast is an autograd op.
+        # FPN + RPN + RoI heads fp32; 'heads': backbone + FPN 16-bit, RPN + RoI heads fp32; 'trunk': backbone + FPN fp32-grade,
+        # RPN + RoI heads 16-bit.  The cast is an autograd op.
         mixed = getattr(self, 'mixed_precision', None)
         if mixed == 'neck':
             x = tuple(f.float() for f in x)
@@ -97,6 +98,10 @@ class LOFT(nn.Module):
             x = self.neck(x)
         if mixed == 'heads':
             x = tuple(f.float() for f in x)
+        if mixed == 'trunk':
+            # the reverse split: backbone + FPN in the fp32 parity mode (the caller sets
+            # backbone.compute_dtype = torch.float32), RPN + RoI heads on the 16-bit kernels
+            x = tuple(f.to(F2.K.L.act16()) for f in x)
         return x
 
     def forward_dummy(self, img):

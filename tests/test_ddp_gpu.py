@@ -131,6 +131,90 @@ def test_loft_trainer_two_ranks_imbalanced():
         assert msg == 'ok', f'rank {rank}: {msg}'
 
 
+def _prune_worker(port, q):
+    """One rank, RCCL, reducer forced on (the mode of bench.py's comm_forced_1rank leg): hook pruning across steps."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['LOFT_FORCE_REDUCER'] = '1'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        from bonai_amd.config import Config
+        from bonai_amd.debug import DBG
+        from bonai_amd.engine import Trainer
+        from bonai_amd.loft import build_detector
+        from bonai_amd.loft.core import RandomSampler
+        from bonai_amd.synth import make_batch
+        RandomSampler.choice_mode = 'first'
+        cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'loft_foa', 'loft_foa_r50_fpn_2x_bonai.py'))
+
+        def build():
+            torch.manual_seed(0)
+            return build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        data = make_batch(2, 256, 8, device='cuda')
+        ref = build()
+        with DBG.override(no_side_stream=True):
+            ref.train_step(data)['loss'].backward()
+        want = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        del ref
+        m = build()
+        tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0, max_norm=0.0)
+        red = tr.reducer
+        assert red.enabled and red.on_gpu and red.prune_hooks
+        n_all = len(tr.arena.order)
+        assert red.hooks_armed() == n_all
+
+        def check(tag):
+            torch.cuda.synchronize()
+            for n, p in m.named_parameters():
+                if p.requires_grad and n in want:
+                    d, s_ = (p.grad - want[n]).norm().item(), want[n].norm().item()
+                    assert d <= 1.5e-2 * s_ + 1e-7, (tag, n, d, s_)
+        armed = []
+        for it in range(4):
+            tr.train_step(data, lr=0.0)
+            check(f'step {it}')
+            armed.append(red.hooks_armed())
+        # almost every gradient is deposited by a kernel and reported through the sink: those hooks are gone after two steps
+        assert armed[0] == n_all and armed[-1] <= n_all // 4 and armed[-1] == armed[-2], armed
+        # every bucket was still released and reduced, in index order, by the sink reports alone
+        assert red._next == len(red.buckets)
+        # the sink switched off: every gradient comes through autograd's accumulation, no hook fires for the pruned ones -> their
+        # buckets leave from finish(); gradients unchanged, and the hooks are re-armed for the next step
+        with DBG.override(no_grad_sink=True):
+            tr.train_step(data, lr=0.0)
+            check('no_grad_sink after pruning')
+            assert red.hooks_armed() == n_all, (red.hooks_armed(), n_all)
+            tr.train_step(data, lr=0.0)
+            check('no_grad_sink, hooks re-armed')
+        for it in range(3):
+            tr.train_step(data, lr=0.0)
+            check(f'sink back, step {it}')
+        assert red.hooks_armed() == armed[-1], (red.hooks_armed(), armed)
+        q.put((0, 'ok', armed))
+    except Exception:  # noqa
+        import traceback
+        q.put((0, traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_reducer_prunes_autograd_hooks_of_sink_served_parameters():
+    """the reducer's host path.  ~300 python post-accumulate hooks per step did nothing but return for the
+    parameters whose gradients the kernels deposit themselves; they are removed after two sink-served steps, re-armed when a
+    parameter stops reporting, and the reduced gradients equal plain autograd's throughout (one-rank RCCL group, reducer forced)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_prune_worker, args=(_free_port(), q))
+    p.start()
+    rank, msg, armed = q.get(timeout=800)
+    p.join(60)
+    assert msg == 'ok', msg
+    print('autograd hooks armed per step:', armed)
+
+
 def _run_two(mode, backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

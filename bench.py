@@ -47,6 +47,8 @@ def parse():
     ap.add_argument('--force-reducer', action='store_true', help='N = 1 only: run the timed loop with the bucketed gradient reducer ACTIVE '
                     'over a one-rank RCCL group (LOFT_FORCE_REDUCER=1): hooks, side stream, ncclAllReduce per bucket, exposed-time events')
     ap.add_argument('--no-forced-comm', action='store_true', help='skip the comm_forced_1rank leg (a child run of this script with --force-reducer)')
+    ap.add_argument('--stream-form', type=int, default=-1, help='A/B: the form of the two-stage 256 x 256 stream schedule the dispatcher launches '
+                    '(include/loft_hip.h loft_conv_stream_form: 0 round 2, 1 activations first, 2 lean, 3 both; -1 = the library default)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the cpu_baseline leg (0: min(host cores, 32))')
     return ap.parse_args()
 
@@ -216,6 +218,10 @@ def main():
     # LOFT_BENCH_SHARED_GPU=1 (tests only): every rank on device 0 over gloo, to exercise this exact launch path on a 1-GPU box
     shared = os.environ.get('LOFT_BENCH_SHARED_GPU') == '1'
     torch.cuda.set_device(0 if shared else local_rank)
+    if args.stream_form >= 0:
+        from bonai_amd import lib as _L
+        for _dt in (torch.bfloat16, torch.float16):
+            _L.load_for(_dt).loft_conv_stream_form(int(args.stream_form))
     force = args.force_reducer and world == 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -669,7 +669,7 @@ static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bia
                               int variant, void* stream, const ConvHead* head) {
     if (T < 1 || T > CONV_MAX_TAPS || (Cin % BK) || (Cout % 4) || groups < 1) return (int)hipErrorInvalidValue;
     const int kern = variant & 0xff;                 // LOFT_CONV_* kernel selector, 0 = the dispatcher's own choice
-    if (kern > LOFT_CONV_W4 || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
+    if (kern > LOFT_CONV_LEANX || (variant & ~0x3ffff)) return (int)hipErrorInvalidValue;
     ConvArgs a;
     a.src = (const bf16_t*)src; a.wgt = (const bf16_t*)wgt; a.bias = bias; a.residual = (const bf16_t*)residual; a.mask = (const bf16_t*)relu_mask;
     a.out = out; a.zero_page = (const bf16_t*)zero_page;
@@ -763,6 +763,9 @@ static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bia
         } else k = LOFT_CONV_T128x64;
     }
     switch (k) {
+    case LOFT_CONV_LEANX:
+    case LOFT_CONV_LEAN:
+    case LOFT_CONV_XFIRST:
     case LOFT_CONV_W4:
     case LOFT_CONV_RING32:
     case LOFT_CONV_ROLES256:
@@ -794,10 +797,10 @@ static int conv_tap_bf16_impl(const void* src, const void* wgt, const float* bia
         a.tap_major = (variant & LOFT_CONV_FLAG_TAP_MAJOR) ? 1 : 0;
         a.krot = (variant & LOFT_CONV_FLAG_KROT) && !a.tap_major ? 1 : 0;
         if (k == LOFT_CONV_ROLES256 && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
-        if ((k == LOFT_CONV_RING32 || k == LOFT_CONV_W4) && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
+        if ((k == LOFT_CONV_RING32 || k == LOFT_CONV_W4 || k >= LOFT_CONV_XFIRST) && (Cout % 256 || ((variant >> 12) & 0xf))) return (int)hipErrorInvalidValue;
         return loft_launch_conv_tap_pipe(a, groups, k == LOFT_CONV_PIPE256 ? 0 : (k == LOFT_CONV_ROLES256 ? 2 : 1), (variant >> 12) & 0xf,
                                          k == LOFT_CONV_STREAM128 ? 2 : ((k == LOFT_CONV_STREAM64 || k == LOFT_CONV_STREAM64N) ? 1 : 4),
-                                         (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s, k == LOFT_CONV_RING32 ? 1 : (k == LOFT_CONV_W4 ? 2 : 0));
+                                         (k == LOFT_CONV_STREAM64N || k == LOFT_CONV_STREAM256N) ? 1 : 0, s, k == LOFT_CONV_RING32 ? 1 : (k == LOFT_CONV_W4 ? 2 : (k == LOFT_CONV_XFIRST ? 3 : (k == LOFT_CONV_LEAN ? 4 : (k == LOFT_CONV_LEANX ? 5 : 0)))));
     case LOFT_CONV_T256_FAST:
     case LOFT_CONV_T256: {
         if (head) return (int)hipErrorInvalidValue;
@@ -1117,7 +1120,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     const int wn = wave / WAVES_C, wc = wave % WAVES_C;
     // bias gradient rides along on the blocks of the first channel tile: one extra MFMA per K sub-step against an
     // all-ones operand gives sum_k G[k][n] in every column of the result; wave (wn, wc) takes n-tile wn*NI + wc.
-    const bool do_db = a.db != nullptr && ct == 0 && wc < NI && (a.db_tap == -2 || a.db_tap == t);
+    const bool do_db = WGRAD_DB_ON(a, grp) && ct == 0 && wc < NI && (a.db_tap == -2 || a.db_tap == t);
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
@@ -1160,11 +1163,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(const WgradArgs a) 
     }
 
     if (do_db && (lane & 31) == 0) {
-        float* db = a.db + (long)grp * a.Cout;
+        float* db = WGRAD_DB_PTR(a, grp);
+        const float dbs = WGRAD_DB_SCALE(a);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn * (TN / 2) + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            unsafeAtomicAdd(db + n, accb[r]);
+            unsafeAtomicAdd(db + n, accb[r] * dbs);
         }
     }
 
@@ -1278,7 +1282,7 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accb[r] = 0.f; }
     const int wn = wave >> 1, wc = wave & 1;
-    const bool do_db = a.db != nullptr && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
+    const bool do_db = WGRAD_DB_ON(a, grp) && ct == 0 && wc == 0 && (a.db_tap == -2 || a.db_tap == t);
     bf16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)LOFT_ONE16;
@@ -1302,11 +1306,12 @@ __global__ __launch_bounds__(256) void conv_wgrad64_kernel(const WgradArgs a) {
         }
     }
     if (do_db && (lane & 31) == 0) {
-        float* db = a.db + (long)grp * a.Cout;
+        float* db = WGRAD_DB_PTR(a, grp);
+        const float dbs = WGRAD_DB_SCALE(a);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (n < a.Cout) unsafeAtomicAdd(db + n, accb[r]);
+            if (n < a.Cout) unsafeAtomicAdd(db + n, accb[r] * dbs);
         }
     }
     float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin;
@@ -1544,8 +1549,22 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
     a.pm_inc_ok = 0;
     a.nvg = 0; a.amax_g = nullptr; a.amax_x = nullptr;
     if (planes) {
-        if (mode != 0 || db || planes->nterms < 1 || planes->nterms > CONV_MAX_TERMS || groups * planes->nterms > WGRAD_MAX_VGROUPS)
+        if (mode != 0 || planes->nterms < 1 || planes->nterms > CONV_MAX_TERMS || groups * planes->nterms > WGRAD_MAX_VGROUPS)
             return (int)hipErrorInvalidValue;
+        if (db) {
+            // the bias gradient of a plane launch = the column sums of ALL planes of G: every G plane that occurs in a term must be
+            // paired with X plane 0 in exactly one term -- that term's workgroups carry its sum (true of the three term lists)
+            unsigned seen = 0u, want = 0u;
+            for (int p = 0; p < planes->nterms; ++p) {
+                if (planes->gpl[p] < 0 || planes->gpl[p] > 31) return (int)hipErrorInvalidValue;
+                want |= 1u << planes->gpl[p];
+                if (planes->xpl[p] == 0) {
+                    if (seen >> planes->gpl[p] & 1u) return (int)hipErrorInvalidValue;
+                    seen |= 1u << planes->gpl[p];
+                }
+            }
+            if (seen != want) return (int)hipErrorInvalidValue;
+        }
         a.nvg = groups * planes->nterms;
         for (int gr = 0; gr < groups; ++gr)
             for (int p = 0; p < planes->nterms; ++p) {
@@ -1553,6 +1572,7 @@ static int wgrad_impl(const void* g, const void* x, float* dw, const void* zero_
                 a.vg_g[v] = (long)gr * g_gs + (long)planes->gpl[p] * planes->g_ps;
                 a.vg_x[v] = (long)gr * x_gs + (long)planes->xpl[p] * planes->x_ps;
                 a.vg_dw[v] = (long)gr * dw_gs;
+                a.vg_db[v] = (db && planes->xpl[p] == 0) ? gr * Cout : -1;
             }
         a.amax_g = planes->amax_g; a.amax_x = planes->amax_x;
         groups = a.nvg;                       // from here on: launch geometry and split counts over the virtual groups
@@ -1720,11 +1740,11 @@ LOFT_EXPORT int loft_conv_wgrad_planes(const void* g, const void* x, float* dw, 
                                        const int* goy_host, const int* gox_host, const int* dy_host, const int* dx_host,
                                        const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
                                        int nterms, const int* gpl_host, const int* xpl_host, int64_t g_ps, int64_t x_ps,
-                                       const float* amax_g, const float* amax_x, void* stream) {
+                                       const float* amax_g, const float* amax_x, float* db, int db_tap, void* stream) {
     if ((Cin % 128) || (Cout % 128) || (amax_g == nullptr) != (amax_x == nullptr)) return (int)hipErrorInvalidValue;
     WgradPlanes pl{nterms, gpl_host, xpl_host, g_ps, x_ps, amax_g, amax_x};
     return wgrad_impl(g, x, dw, zero_page, B, GH, GW, Cout, XH, XW, Cin, OH, OW, gos, ss, T, goy_host, gox_host, dy_host, dx_host,
-                      wt_host, groups, g_gs, x_gs, dw_gs, 0, nullptr, -1, LOFT_WGRAD_AUTO, stream, 0, nullptr, &pl);
+                      wt_host, groups, g_gs, x_gs, dw_gs, 0, db, db_tap, LOFT_WGRAD_AUTO, stream, 0, nullptr, &pl);
 }
 
 LOFT_EXPORT int loft_conv_wgrad_slots(int B, int GH, int GW, int Cout, int XH, int XW, int Cin, int OH, int OW, int gos, int ss,

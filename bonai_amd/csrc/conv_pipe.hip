@@ -470,9 +470,22 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
 // is not a multiple of 256) -- one weight fragment per sub-step, 256-byte output rows in the staged epilogue.
 // PL: operand-plane launch (ConvArgs block 4): the K loop runs nterms x taps, the epilogue is pipe_epilogue_f32 (stream schedule only).
 // R32 ("ring32", round 5; schedule below): the 256 x 256 tile with 32-CHANNEL K-tiles on a FOUR-stage ring (64-byte LDS rows).
-template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false, bool R32 = false>
+// XF ("activations first", round 6; LOFT_CONV_XFIRST): the two-stage stream schedule with the roles of the two operands' copies swapped --
+// X(t+2) is requested right behind SYNC(t) (sub-step ks3), W(t+1) in ks0 -- see the stream schedule's description below.
+// LEAN (round 6; LOFT_CONV_LEAN / LOFT_CONV_LEANX): the same schedule with fewer INSTRUCTIONS per K-tile.  What the counters say
+// about the copies' cost (profiles/round6_probes/pmc_stream_foa.txt): TA 36 % busy, TCP -> L2 read latency 136 cycles on
+// average, no address / command FIFO ever full, SQ_WAIT_ANY identical with and without copies -- the memory path is not what
+// the K loop waits for.  What the copy-free variant lacks is the copies' ISSUE work: per K-tile and wave ~31 vector and ~58
+// scalar instructions (SQ_ACTIVE_INST_SCA x 2.8, SQ_ACTIVE_INST_VALU x 1.5) that an in-order wave issues between its own MFMAs.
+// LEAN: (1) the K-tile sequence is chunk-major at compile time (the runtime select between the two orders computed both every
+// step); (2) tap offset + chunk offset are ONE 64-bit scalar per K-tile (hipcc re-associated the sum into two 64-bit vector
+// adds per copy); (3) tiles whose rows are all valid for every tap they run -- every FOA / mask tile: one segment of 256 RoIs
+// at one position -- issue their activation copies without the zero-page select (4 vector instructions per copy).
+template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false, bool R32 = false, bool XF = false, bool LEAN = false>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
+    static_assert(!LEAN || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2 && !PL && !R32), "LEAN exists for the two-stage 256 x 256 stream schedule");
     static_assert(MODE <= 2, "MODE 0 phase, 1 stream, 2 role-split stream");
+    static_assert(!XF || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2 && !PL && !R32), "activations-first exists for the two-stage 256 x 256 stream schedule");
     static_assert(!PL || (MODE == 1 && VAR == 0), "operand planes exist for the stream schedule");
     static_assert(!R32 || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2), "the 32-channel ring exists for the stream schedule's 256 x 256 tile");
     static_assert(MJ == 4 || ((MJ == 2 || MJ == 1) && MODE == 1 && !(VAR & 2)), "the 128- / 64-pixel tiles exist for the stream schedule");
@@ -647,6 +660,16 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     kstamp(42);
     int nk = a.T * kchunks;
     if (a.pixmajor) nk = __popc(tmask) * kchunks;
+    // LEAN (3): every staged row of this workgroup valid for every tap the tile runs?  (wave-uniform over the whole workgroup:
+    // a per-wave answer would be enough for correctness, the branch below only has to be wave-uniform)
+    bool all_valid = false;
+    if constexpr (LEAN) {
+        const unsigned need = a.pixmajor ? tmask : (a.T >= 32 ? 0xffffffffu : ((1u << a.T) - 1u));
+        bool mine = true;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) mine = mine && ((a_mask[i] & need) == need);
+        all_valid = __builtin_amdgcn_readfirstlane((int)(__ballot(mine) == ~0ull)) != 0;
+    }
     // ---- wave-uniform state of the K-tile being STAGED: tap, channel offset, the tap's source / weight offsets
     int st_t = 0, st_c = a.krot ? (V % kchunks) * BK : 0;        // (krot: this workgroup's first channel chunk)
     while (st_t < a.T - 1 && !((tmask >> st_t) & 1u)) ++st_t;
@@ -712,6 +735,14 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     }
     int xj = 0, wj = 0;                                          // positions in the compact list of the tiles being staged
     auto seq_step = [&](int& j, int& c) {
+        if constexpr (LEAN) {           // chunk-major only (the launcher routes tap-major requests elsewhere)
+            const int jn = j + 1;
+            const bool wj_ = jn >= nv;
+            const int cn = c + BK;
+            j = wj_ ? 0 : jn;
+            c = wj_ ? (cn == a.Cin ? 0 : cn) : c;
+            return;
+        }
         const int jn = j + 1, cn = c + BK;
         const bool wj_ = jn >= nv, wc_ = cn == a.Cin;
         // chunk-major: next tap, wrapping to the next chunk (which itself wraps under krot); tap-major: next chunk, wrapping to the next tap
@@ -759,12 +790,22 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             __builtin_amdgcn_global_load_lds((gptr_t)(wt + (long)i * b_step),
                                              (lds_ptr_t)(lds + PW_OFF + B * PBW + (i * 64 + wave * 8) * 128), 16, 0, 0);
     };
-    auto issue_x = [&](auto halfc, auto bufc) {
+    auto issue_x = [&](auto halfc, auto bufc, auto avc) {        // avc: std::true_type = every row valid for every tap (LEAN)
         constexpr int H = decltype(halfc)::value, B = decltype(bufc)::value;
+        constexpr bool AV = decltype(avc)::value;
         if constexpr (NOGLDS) { if (in_loop) return; }
         if constexpr (HALOX) { if (in_loop && st_t != first_t) return; }
         if constexpr (2 * H >= NI) return;                        // (128- / 64-pixel tiles: the second half does not exist)
-        const long aoff = st_aoff + st_c;
+        long aoff = st_aoff + st_c;
+        if constexpr (LEAN) {
+            asm volatile("" : "+s"(aoff));                        // ONE scalar 64-bit sum (hipcc otherwise adds the two parts per lane)
+            if constexpr (AV) {
+#pragma unroll
+                for (int i = 2 * H; i < 2 * H + 2; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(a_ptr[i] + aoff), (lds_ptr_t)(lds + PXO + B * PBX + (i * 64 + wave * 8) * 128), 16, 0, 0);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 2 * H; i < (2 * H + 2 < NI ? 2 * H + 2 : NI); ++i) {
             const bf16_t* p = (NOSEL || ((a_mask[i] >> st_t) & 1u)) ? a_ptr[i] + aoff : a.zero_page;
@@ -875,7 +916,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         };
         // ---- prologue (every wave its own pieces, as in the stream schedule): W(0), X(0), W(1); X role: first half of X(1)
         issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
-        issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
+        issue_x(c0_t{}, c0_t{}, std::false_type{}); issue_x(c1_t{}, c0_t{}, std::false_type{});
         if (nk > 1) {
             advance_w(); advance_x();
             issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
@@ -1145,11 +1186,11 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             using z_t = std::integral_constant<int, 0>;
             constexpr int NXW = NI + 2 * NW;                         // global->LDS copy instructions of one K-tile, per wave
             issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
-            issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
+            issue_x(c0_t{}, c0_t{}, std::false_type{}); issue_x(c1_t{}, c0_t{}, std::false_type{});
             if (nk > 1) {
                 advance_w(); advance_x();
                 issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
-                issue_x(c0_t{}, c1_t{}); issue_x(c1_t{}, c1_t{});
+                issue_x(c0_t{}, c1_t{}, std::false_type{}); issue_x(c1_t{}, c1_t{}, std::false_type{});
                 advance_w(); advance_x();
                 late_init();
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXW) : "memory");
@@ -1166,8 +1207,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                 using next_t = std::integral_constant<int, (B + 1) % 3>;
                 using tgt_t = std::integral_constant<int, (B + 2) % 3>;
                 substep(fa, fb, bufc, k1_t{}, true,
-                        [&] { if (has2) issue_x(c0_t{}, tgt_t{}); },
-                        [&] { if (has2) { issue_x(c1_t{}, tgt_t{}); advance_x(); } }, z_t{});
+                        [&] { if (has2) issue_x(c0_t{}, tgt_t{}, std::false_type{}); },
+                        [&] { if (has2) { issue_x(c1_t{}, tgt_t{}, std::false_type{}); advance_x(); } }, z_t{});
                 substep(fb, fa, bufc, k2_t{}, true,
                         [&] { if (has2) issue_w(c0_t{}, tgt_t{}); },
                         [&] { if (has2) { issue_w(c1_t{}, tgt_t{}); advance_w(); } }, z_t{});
@@ -1192,9 +1233,23 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         } else {
         // prologue: W(0), X(0), W(1)
+        // (XF, round 6 -- what the barrier-level traces of round 3 show is that the ACTIVATION copies are the ones waited for: X(t+1)
+        //  is requested in ks0(t), 2.5 sub-steps before SYNC(t), and a tile whose activation copies are the only ones in flight
+        //  waits ~760 cycles for them there -- gathered rows of 256 different RoIs / pixels, each its own line, against weight rows
+        //  that every CU of the XCD fetches at the same moment and finds in L2.  XF swaps the two operands' places in the
+        //  schedule: X(t+2) is requested in ks3(t), right behind SYNC(t), and has a whole K-tile to land; W(t+1) is requested in
+        //  ks0(t).  Prologue: W(0), X(0), X(1).  RAW / WAR: the mirror image of the argument above -- W(t+1) -> buffer 1-B in ks0(t):
+        //  that buffer's last reads (F(t-1,3)) completed at SYNC(t-1); X(t+2) -> buffer B in ks3(t): behind SYNC(t).  Same K order:
+        //  bit-identical results.)
         issue_w(c0_t{}, c0_t{}); issue_w(c1_t{}, c0_t{});
-        issue_x(c0_t{}, c0_t{}); issue_x(c1_t{}, c0_t{});
-        if (nk > 1) {
+        issue_x(c0_t{}, c0_t{}, std::false_type{}); issue_x(c1_t{}, c0_t{}, std::false_type{});
+        if (nk > 1 && XF) {
+            advance_x();
+            issue_x(c0_t{}, c1_t{}, std::false_type{}); issue_x(c1_t{}, c1_t{}, std::false_type{});
+            advance_x(); advance_w();
+            late_init();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // everything but X(1)'s copies has landed
+        } else if (nk > 1) {
             advance_w(); advance_x();
             issue_w(c0_t{}, c1_t{}); issue_w(c1_t{}, c1_t{});
             advance_w();
@@ -1213,7 +1268,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             rd1(fa, c0_t{}, k0_t{}, k3_t{}); rd1(fa, c0_t{}, k0_t{}, i4_t{}); rd1(fa, c0_t{}, k0_t{}, i5_t{});
         }
         // has1 / has2 (K-tiles t+1 / t+2 exist): std::true_type in the steady-state loop -- the conditions fold away --, bool in the tail
-        auto stile = [&](auto bufc, auto has1, auto has2) {
+        auto stile = [&](auto bufc, auto has1, auto has2, auto avc) {
             constexpr int B = decltype(bufc)::value;
             using other_t = std::integral_constant<int, 1 - B>;
             // ---- ks0: MFMA fa, read F(t,1) -> fb, issue X(t+1) -> buffer 1-B
@@ -1222,9 +1277,13 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             using s2_t = std::integral_constant<int, 12 * B + 4>;
             using s3_t = std::integral_constant<int, 12 * B + 8>;
             const bool copier = !ALTCOPY || (wave >> 2) == B;
+            if constexpr (XF)
+                substep(fa, fb, bufc, k1_t{}, true, [&] { if (has1) issue_w(c0_t{}, other_t{}); },
+                        [&] { if (has1) { issue_w(c1_t{}, other_t{}); advance_w(); } }, s0_t{});
+            else
             substep(fa, fb, bufc, k1_t{}, true,
-                    [&] { if (has1 && copier) { issue_x(c0_t{}, other_t{}); if constexpr (ALTCOPY) issue_x(c0_t{}, other_t{}); } },
-                    [&] { if (has1) { if (copier) { issue_x(c1_t{}, other_t{}); if constexpr (ALTCOPY) issue_x(c1_t{}, other_t{}); } advance_x(); } }, s0_t{});
+                    [&] { if (has1 && copier) { issue_x(c0_t{}, other_t{}, avc); if constexpr (ALTCOPY) issue_x(c0_t{}, other_t{}, avc); } },
+                    [&] { if (has1) { if (copier) { issue_x(c1_t{}, other_t{}, avc); if constexpr (ALTCOPY) issue_x(c1_t{}, other_t{}, avc); } advance_x(); } }, s0_t{});
             // ---- ks1, ks2
             substep(fb, fa, bufc, k2_t{}, true, nop, nop, s1_t{});
             substep(fa, fb, bufc, k3_t{}, true, nop, nop, s2_t{});
@@ -1236,6 +1295,10 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
                 PIPE_BARRIER();
             }
             // ---- ks3: MFMA fb, read F(t+1,0) -> fa from buffer 1-B, issue W(t+2) -> buffer B
+            if constexpr (XF)
+                substep(fb, fa, other_t{}, k0_t{}, has1, [&] { if (has2) issue_x(c0_t{}, bufc, avc); },
+                        [&] { if (has2) { issue_x(c1_t{}, bufc, avc); advance_x(); } }, s3_t{});
+            else
             substep(fb, fa, other_t{}, k0_t{}, has1,
                     [&] { if (has2 && copier) { issue_w(c0_t{}, bufc); if constexpr (ALTCOPY) issue_w(c0_t{}, bufc); } },
                     [&] { if (has2) { if (copier) { issue_w(c1_t{}, bufc); if constexpr (ALTCOPY) issue_w(c1_t{}, bufc); } advance_w(); } }, s3_t{});
@@ -1257,19 +1320,23 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             }
         };
         if constexpr (TRACE) kst1 = __builtin_amdgcn_s_memtime();
-        {
+        auto run_tiles = [&](auto avc) {
             int t = 0;
             if constexpr (!TRACE) {
                 for (; t + 3 < nk; t += 2) {          // steady state: both tiles of the pair have two successors
-                    stile(c0_t{}, std::true_type{}, std::true_type{});
-                    stile(c1_t{}, std::true_type{}, std::true_type{});
+                    stile(c0_t{}, std::true_type{}, std::true_type{}, avc);
+                    stile(c1_t{}, std::true_type{}, std::true_type{}, avc);
                 }
             }
             for (; t < nk; t += 2) {
-                stile(c0_t{}, t + 1 < nk, t + 2 < nk);
-                if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk);
+                stile(c0_t{}, t + 1 < nk, t + 2 < nk, avc);
+                if (t + 1 < nk) stile(c1_t{}, t + 2 < nk, t + 3 < nk, avc);
             }
-        }
+        };
+        if constexpr (LEAN) {              // (the all-valid form is its own copy of the loop: no branch inside the K-tile)
+            if (all_valid) run_tiles(std::true_type{});
+            else run_tiles(std::false_type{});
+        } else run_tiles(std::false_type{});
         }
         if constexpr (TRACE) kst2 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(0);
@@ -1301,8 +1368,8 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
     // ---- prologue: all of K-tile 0 and W0 of K-tile 1
     issue_w(c0_t{}, c0_t{});
     issue_w(c1_t{}, c0_t{});
-    issue_x(c0_t{}, c0_t{});
-    issue_x(c1_t{}, c0_t{});
+    issue_x(c0_t{}, c0_t{}, std::false_type{});
+    issue_x(c1_t{}, c0_t{}, std::false_type{});
     if (nk > 1) {
         advance();
         issue_w(c0_t{}, c1_t{});
@@ -1381,7 +1448,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
         // ---------------- L1: W c1; issue X0(t+1)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf1[ks] = rd(wb[ks] + B * PBUF + 4096);
-        if (has1) issue_x(c0_t{}, other_t{});
+        if (has1) issue_x(c0_t{}, other_t{}, std::false_type{});
         stamp(t);
         PIPE_BARRIER();
         stamp(t);
@@ -1403,7 +1470,7 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             xf[0][ks] = rd(xb[ks] + B * PBUF + 8192);
             xf[1][ks] = rd(xb[ks] + B * PBUF + 12288);
         }
-        if (has1) issue_x(c1_t{}, other_t{});
+        if (has1) issue_x(c1_t{}, other_t{}, std::false_type{});
         if constexpr (!OLDORDER) {
             if (has1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // in flight: X0(t+1), X1(t+1)
         }
@@ -1800,11 +1867,27 @@ __global__ __launch_bounds__(256) void conv_tap_w4_kernel(const ConvArgs a) {
     }
 }
 
+// Which form of the two-stage 256 x 256 stream schedule the DISPATCHER launches (explicit LOFT_CONV_* requests are unaffected):
+// 0 the round-2 schedule, 1 activations-first (LOFT_CONV_XFIRST), 2 lean (LOFT_CONV_LEAN), 3 both (LOFT_CONV_LEANX).  All four
+// compute the same sums in the same order (bit-identical); the setter exists so that one process can time a whole training step
+// under each (tools/ab_stream_form.sh).  Not an environment switch: the library reads no environment.
+static int g_stream_form = LOFT_STREAM_FORM_DEFAULT;
+LOFT_EXPORT int loft_conv_stream_form(int form) {
+    const int prev = g_stream_form;
+    if (form >= 0 && form <= 3) g_stream_form = form;
+    return prev;
+}
+
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s, int ring32) {
     ConvArgs a = a_in;
     const bool w4 = ring32 == 2;                       // (2: the four-wave kernel, LOFT_CONV_W4)
-    if (w4) ring32 = 0;
+    const bool xfirst = ring32 == 3 || ring32 == 5;    // (3: the activations-first stream schedule, LOFT_CONV_XFIRST)
+    const bool lean = ring32 == 4 || ring32 == 5;      // (4: LOFT_CONV_LEAN, 5: LOFT_CONV_LEANX = LEAN + XFIRST)
+    if (w4 || xfirst || lean) ring32 = 0;
+    if ((xfirst || lean) && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.nterms))
+        return (int)hipErrorInvalidValue;
+    if (lean && a.tap_major) return (int)hipErrorInvalidValue;
     if (w4 && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.tap_major && !a.krot && !a.nterms))
         return (int)hipErrorInvalidValue;
     if (ring32 && !(mode == 1 && var == 0 && mj == 4 && nw_force == 0 && a.Cout % 256 == 0 && !a.tap_major && !a.krot && !a.nterms))
@@ -1837,6 +1920,12 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         else if (mj == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2, 2, true>), grid, dim3(512), 0, s, a);
         else if (mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 2, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true>), grid, dim3(512), 0, s, a);
+    } else if (xfirst && lean) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, true, true>), grid, dim3(512), 0, s, a);
+    } else if (lean) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, false, true>), grid, dim3(512), 0, s, a);
+    } else if (xfirst) {
+        hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, true>), grid, dim3(512), 0, s, a);
     } else if (w4) {
         hipLaunchKernelGGL(conv_tap_w4_kernel<0>, grid, dim3(256), 0, s, a);
     } else if (ring32) {
@@ -1852,6 +1941,11 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
     } else if (mode == 2) {
         if (var != 0) return (int)hipErrorInvalidValue;
         PIPE_LAUNCH(2, 0);
+    } else if (mode == 1 && var == 0 && g_stream_form != 0 && !(a.tap_major && (g_stream_form == 2 || g_stream_form == 3))) {
+        // the process-wide default form of the two-stage 256 x 256 stream schedule (loft_conv_stream_form: same-box A/B of a whole step)
+        if (g_stream_form == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, true>), grid, dim3(512), 0, s, a);
+        else if (g_stream_form == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, false, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, true, true>), grid, dim3(512), 0, s, a);
     } else if (mode == 1) {
         switch (var) {
         case 0: PIPE_LAUNCH(1, 0); break;

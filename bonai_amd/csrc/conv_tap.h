@@ -262,6 +262,10 @@ struct WgradArgs {
     // split count shrinks by the number of terms (same workgroups, same atomics as one 16-bit launch).  amax_*: see ConvArgs.
     int nvg;
     long vg_g[WGRAD_MAX_VGROUPS], vg_x[WGRAD_MAX_VGROUPS], vg_dw[WGRAD_MAX_VGROUPS];
+    // bias gradient of a plane launch (round 6): virtual group v adds the column sums of ITS G plane into db[vg_db[v] + n]
+    // (vg_db[v] < 0: this term does not -- every G plane is summed by exactly one term, the one that pairs it with X plane 0),
+    // un-scaled by 1 / scale_g alone; replaces a separate column-sum pass over the fp32 gradient map
+    int vg_db[WGRAD_MAX_VGROUPS];
     const float* amax_g;
     const float* amax_x;
 };
@@ -270,6 +274,9 @@ struct WgradArgs {
 #define WGRAD_X_OFF(a, grp) ((a).nvg ? (a).vg_x[grp] : (long)(grp) * (a).x_gs)
 #define WGRAD_DW_OFF(a, grp) ((a).nvg ? (a).vg_dw[grp] : (long)(grp) * (a).dw_gs)
 #define WGRAD_OUT_SCALE(a) ((a).amax_g ? planes_scale_of(*(a).amax_g, true) * planes_scale_of(*(a).amax_x, true) : 1.f)
+#define WGRAD_DB_ON(a, grp) ((a).db != nullptr && (!(a).nvg || (a).vg_db[grp] >= 0))
+#define WGRAD_DB_PTR(a, grp) ((a).db + ((a).nvg ? (long)(a).vg_db[grp] : (long)(grp) * (a).Cout))
+#define WGRAD_DB_SCALE(a) (((a).nvg && (a).amax_g) ? planes_scale_of(*(a).amax_g, true) : 1.f)
 
 __device__ __forceinline__ int wswz(int row, int q) { return q ^ ((row & 3) << 2); }
 

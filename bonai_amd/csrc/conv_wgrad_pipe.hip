@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     const int wn = wave >> 2, wc = wave & 3;
     // bias gradient rides along on the blocks of the first channel tile (see conv_wgrad_kernel): one extra MFMA per sub-step
     // against an all-ones operand; wave (wn, wc) takes n-block wn*4 + wc
-    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);
+    const bool do_db = WGRAD_DB_ON(a, grp) && ct == 0 && (a.db_tap == -2 || a.db_tap == t);
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
@@ -347,11 +347,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_stream_kernel(const WgradArgs 
     __builtin_amdgcn_s_setprio(0);
 
     if (do_db && (lane & 31) == 0) {
-        float* db = a.db + (long)grp * a.Cout;
+        float* db = WGRAD_DB_PTR(a, grp);
+        const float dbs = WGRAD_DB_SCALE(a);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn * 128 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            unsafeAtomicAdd(db + n, accb[r]);
+            unsafeAtomicAdd(db + n, accb[r] * dbs);
         }
     }
     const int sidx = PM ? (int)a.pm_split[bz] : bz;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wn = wave >> 1, wc = wave & 1;
-    const bool do_db = a.db != nullptr && ct == 0 && (a.db_tap == -2 || a.db_tap == t);      // wave (wn, wc) takes n-block wn*2 + wc
+    const bool do_db = WGRAD_DB_ON(a, grp) && ct == 0 && (a.db_tap == -2 || a.db_tap == t);      // wave (wn, wc) takes n-block wn*2 + wc
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
@@ -589,11 +590,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (zero-page copies of the steps past the range)
 
     if (do_db && (lane & 31) == 0) {
-        float* db = a.db + (long)grp * a.Cout;
+        float* db = WGRAD_DB_PTR(a, grp);
+        const float dbs = WGRAD_DB_SCALE(a);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            unsafeAtomicAdd(db + n, accb[r]);
+            unsafeAtomicAdd(db + n, accb[r] * dbs);
         }
     }
     float* dw = a.dw + WGRAD_DW_OFF(a, grp) + (long)a.wt[t] * a.Cout * a.Cin + (a.partial ? (long)bz * a.split_stride : 0l);

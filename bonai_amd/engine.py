@@ -110,6 +110,8 @@ class BucketedAllReduce:
         # launched by finish(), in index order like every bucket, only later -- and finish() re-arms the hook of every parameter
         # that did not report, so the steady state is reached again.  Events of the hand-over to the side stream are created once.
         self._hooks, self._sunk_streak = {}, {}
+        self.direct_issue = os.environ.get('LOFT_REDUCER_SIDE_STREAM_ONLY') != '1'
+        self._issued_from = set()
         self.PRUNE_AFTER = 2
         self.prune_hooks = os.environ.get('LOFT_REDUCER_KEEP_HOOKS') != '1'
         self._events = {}
@@ -136,6 +138,7 @@ class BucketedAllReduce:
         self.works = []
         self._streams = [dict() for _ in self.buckets]
         self._queued, self._nq = set(), [0] * len(self.buckets)
+        self._issued_from = set()
         if self.on_gpu:
             self._dev = torch.cuda.current_device()
 
@@ -188,12 +191,24 @@ class BucketedAllReduce:
 
     def _launch(self, bi):
         b = self.buckets[bi]
+        view = b.get('view')
+        if view is None:
+            view = b['view'] = self.arena.grad[b['start']:b['end']]
         if not self.on_gpu:   # gloo / CPU (tests): same bucket order, no stream juggling
-            self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
+            self.works.append(dist.all_reduce(view, async_op=True))
+            return
+        raw_cur = torch._C._cuda_getCurrentRawStream(self._dev)
+        producers = self._streams[bi]
+        if self.direct_issue and all(r == raw_cur for r in producers):
+            # every gradient of the bucket was deposited on THIS stream (the backbone's buckets: the batched unpack runs on the
+            # main stream): c10d's own stream takes an event of the calling stream -- which does not wait -- so the hop through
+            # the side stream (two event operations and a stream switch per bucket on the host) buys nothing
+            self.works.append(dist.all_reduce(view, async_op=True))
+            self._issued_from.add(raw_cur)
             return
         cur = torch.cuda.current_stream()
-        producers = dict(self._streams[bi])
-        producers[torch._C._cuda_getCurrentRawStream(self._dev)] = cur
+        producers = dict(producers)
+        producers[raw_cur] = cur
         for raw, st in producers.items():
             ev = self._events.get((bi, raw))
             if ev is None:
@@ -201,7 +216,7 @@ class BucketedAllReduce:
             ev.record(st)
             self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
-            self.works.append(dist.all_reduce(self.arena.grad[b['start']:b['end']], async_op=True))
+            self.works.append(dist.all_reduce(view, async_op=True))
 
     def finish(self):
         """Make the main stream wait for every outstanding collective (no host sync).  With ``measure`` set, two events bracket
@@ -220,6 +235,7 @@ class BucketedAllReduce:
             # wait for that work's end event.  One wait on the LAST work, taken by the side stream, covers all of them (the
             # per-work wait() loop did the same thing fifteen times, on the main stream); the main stream then waits for the side
             # stream's tail, and the measured pair brackets the real end of the last collective.
+            # (whichever stream a collective was issued from, c10d ran it on its own stream: the side stream takes the wait)
             if self.works:
                 with torch.cuda.stream(self.stream):
                     self.works[-1].wait()

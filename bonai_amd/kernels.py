@@ -483,7 +483,7 @@ def _bf16(t):
 # include/loft_hip.h LOFT_CONV_*: kernel selector of loft_conv_tap_bf16_v.  0 = the library's shape heuristics (the shipped path).
 # tests / tools set CONV_VARIANT to a code, or to a callable (groups, B, OH, OW, Cin, Cout, T, ss, os) -> code, to pin a template.
 CONV_AUTO, CONV_PIPE256, CONV_T256_FAST, CONV_T256, CONV_T128_SINGLE, CONV_T128_FAST, CONV_T128, CONV_T128x64, CONV_PATCH64, \
-    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N, CONV_RING32, CONV_W4 = range(17)
+    CONV_STREAM256, CONV_STREAM128, CONV_STREAM64, CONV_STREAM64N, CONV_ROLES256, CONV_STREAM256N, CONV_RING32, CONV_W4, CONV_XFIRST, CONV_LEAN, CONV_LEANX = range(20)
 CONV_FLAG_NO_PIXMAJOR, CONV_FLAG_NO_NFAST, CONV_FLAG_NO_STAGED_OUT, CONV_FLAG_TAP_MAJOR, CONV_FLAG_NO_ROI_BLOCKS, CONV_FLAG_KROT = \
     0x100, 0x200, 0x400, 0x800, 0x10000, 0x20000
 CONV_VARIANT = CONV_AUTO
@@ -502,6 +502,7 @@ _PLANE_MODES = {F32_PLANES_F16: (torch.float16, ((1, 0), (0, 1), (0, 0))),
                 F32_PLANES_F16X4: (torch.float16, ((1, 1), (1, 0), (0, 1), (0, 0)))}
 F32_CONTRACT = F32_PLANES_F16
 PLANES_STATS = {'planes': 0, 'fallback': 0}      # launches of the fp32 mode by path (tests / bench read it)
+PLANES_DB_FUSED = True     # the bias gradient of a plane weight-gradient launch in that launch (False: a loft_colsum_f32 pass; A/B, tests)
 
 
 def _f32_kernel_code():
@@ -904,14 +905,22 @@ def conv_wgrad(g, x, B, GH, GW, Cout, XH, XW, Cin, OH, OW, taps, n_wtaps, gos=1,
             dt16, terms = _PLANE_MODES[F32_CONTRACT]
             plib = L.load_for(dt16)
             (gp, ag), (xp, ax) = _split_memo(g, dt16, planes_memo), _split_memo(x, dt16, planes_memo, take_fwd=True)
+            # the bias gradient rides in the same launch (the all-ones MFMA of the 16-bit kernels on every G plane; round 6) when
+            # db is the plain [groups, Cout] accumulator and the caller named a tap whose G rows are complete
+            db_fused = (PLANES_DB_FUSED and db is not None and db_tap != -1 and tuple(db.shape) == (groups, Cout) and db.is_contiguous()
+                        and db.dtype == torch.float32)
             e = plib.loft_conv_wgrad_planes(L.ptr(gp), L.ptr(xp), L.ptr(dw), L.ptr(zero_page(g.device)), B, GH, GW, Cout, XH, XW, Cin,
                                             OH, OW, gos, ss, len(taps), A(0), A(1), A(2), A(3), A(4), groups, c_int64(g_gs),
                                             c_int64(x_gs), c_int64(n_wtaps * Cout * Cin), len(terms),
                                             L.arr(c_int, [t[1] for t in terms]), L.arr(c_int, [t[0] for t in terms]),
-                                            c_int64(g.numel()), c_int64(x.numel()), L.ptr(ag), L.ptr(ax), L.stream())
+                                            c_int64(g.numel()), c_int64(x.numel()), L.ptr(ag), L.ptr(ax),
+                                            L.ptr(db) if db_fused else c_void_p(0), int(db_tap) if db_fused else -1, L.stream())
             if e == 0:
                 PLANES_STATS['planes'] += 1
                 done = True
+                if db_fused:
+                    PLANES_STATS['db_fused'] = PLANES_STATS.get('db_fused', 0) + 1
+                    db = None                       # (done: no column-sum pass below)
             elif e != 1:
                 L.check(e, 'loft_conv_wgrad_planes')
         if not done:

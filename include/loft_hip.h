@@ -204,6 +204,14 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
 #define LOFT_CONV_STREAM256N 14   /* the stream kernel on 256-pixel x 128-cout tiles with the THREE-stage ring also for Cout % 256 == 0 (1.5x the copy bytes per FLOP of the 256 x 256 tile, two K-tiles of look-ahead instead of one; A/B) */
 #define LOFT_CONV_RING32 15       /* the stream kernel's 256 x 256 tile with 32-channel K-tiles on a FOUR-stage ring: pieces requested three tiles ahead, two per wave and sub-step, counted vmcnt (bit-identical to LOFT_CONV_STREAM256) */
 #define LOFT_CONV_W4 16           /* the stream schedule's 256 x 256 x 64 tile with FOUR waves, one per SIMD, 128 x 128 each (conv_tap_w4_kernel; bit-identical to LOFT_CONV_STREAM256) */
+#define LOFT_CONV_XFIRST 17       /* the two-stage 256 x 256 stream schedule with the operands' copy slots swapped: activation copies of K-tile t+2 requested right behind SYNC(t), weight copies of t+1 in ks0 (round 6; bit-identical to LOFT_CONV_STREAM256) */
+#define LOFT_CONV_LEAN 18         /* the two-stage 256 x 256 stream schedule with fewer instructions per K-tile: compile-time chunk-major sequencer, one 64-bit scalar offset per K-tile, select-free activation copies on all-valid tiles (round 6; chunk-major launches only; bit-identical to LOFT_CONV_STREAM256) */
+#define LOFT_CONV_LEANX 19        /* LOFT_CONV_LEAN + LOFT_CONV_XFIRST */
+/* The form of the two-stage 256 x 256 stream schedule the dispatcher itself launches: 0 round 2's, 1 LOFT_CONV_XFIRST, 2 LOFT_CONV_LEAN,
+ * 3 LOFT_CONV_LEANX (tap-major launches keep 0 / 1).  loft_conv_stream_form(form) sets it process-wide and returns the previous value
+ * (form < 0: query only) -- for same-box A/B runs of a whole step; results are bit-identical under every form. */
+#define LOFT_STREAM_FORM_DEFAULT 0
+int loft_conv_stream_form(int form);
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100
 #define LOFT_CONV_FLAG_NO_NFAST 0x200
 #define LOFT_CONV_FLAG_NO_STAGED_OUT 0x400
@@ -292,7 +300,10 @@ int loft_conv_tap_f32_v(const float* src, const float* wgt, const float* bias, c
  *                                 |x||w| per product; bfloat16 (0,2) (2,0) (1,1) (0,1) (1,0) (0,0) -- 2^-24.  hipErrorInvalidValue for
  *                                 shapes the stream kernel does not serve (Cout % 128, Cin % 64, nterms * T > 64): take loft_conv_tap_f32.
  *   loft_conv_wgrad_planes(...)   loft_conv_wgrad_bf16's contract on G / X planes: every term adds into dw (caller zeroes) through the
- *                                 split-K atomics, scaled by 1 / (scale_g * scale_x).  Cout % 128 == 0, Cin % 128 == 0; no fused bias gradient. */
+ *                                 split-K atomics, scaled by 1 / (scale_g * scale_x).  Cout % 128 == 0, Cin % 128 == 0.  db (may be NULL):
+ *                                 the fused bias gradient of loft_conv_wgrad_bf16 -- the column sums of every G plane, each by the one
+ *                                 term that pairs it with X plane 0 (hipErrorInvalidValue if the term list has no such pairing), scaled by
+ *                                 1 / scale_g (round 6: replaces a loft_colsum_f32 pass over the fp32 gradient map). */
 int loft_planes_per_tensor(void);
 int loft_absmax_f32(const float* x, int64_t n, float* amax_out /* PRE-ZEROED by the caller */, void* stream);
 int loft_split_planes_f32(const float* x, int64_t n, void* planes, const float* amax, void* stream);
@@ -313,7 +324,7 @@ int loft_conv_wgrad_planes(const void* g, const void* x, float* dw, const void* 
                            int XW, int Cin, int OH, int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host,
                            const int* dy_host, const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs,
                            int64_t dw_gs, int nterms, const int* gpl_host, const int* xpl_host, int64_t g_ps, int64_t x_ps,
-                           const float* amax_g, const float* amax_x, void* stream);
+                           const float* amax_g, const float* amax_x, float* db, int db_tap, void* stream);
 /* loft_conv_wgrad_bf16: weight gradient of the same family (autograd of the call sites above):
  *   dw[g][wt[t]][n][c] += sum_{b,oy,ox} G[g][b, oy*gos+goy[t], ox*gos+gox[t], n] * X[g][b, oy*ss+dy[t], ox*ss+dx[t], c]
  * G [B,GH,GW,Cout] bf16 (output gradient), X [B,XH,XW,Cin] bf16 (saved input), dw fp32

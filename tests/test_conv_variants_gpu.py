@@ -351,7 +351,8 @@ def test_role_split_schedule_bit_identical_to_stream_schedule_at_bench_size():
 
 
 def test_ring32_schedule_bit_identical_to_stream_schedule_at_bench_size():
-    """(Also conv_tap_w4_kernel, LOFT_CONV_W4: the same tile and K order with four waves, one per SIMD, 128 x 128 each.)
+    """(Also conv_tap_w4_kernel, LOFT_CONV_W4: the same tile and K order with four waves, one per SIMD, 128 x 128 each; and
+    LOFT_CONV_XFIRST, round 6: the two-stage schedule with the activation copies requested right behind the K-tile's barrier.)
     conv_tap_pipe_kernel<1,0,4,2,false,true> (round 5, LOFT_CONV_RING32: 32-channel K-tiles on a four-stage ring, pieces
     requested three tiles ahead and retired with a counted vmcnt) walks K in the two-stage stream schedule's order (64-channel
     chunk, tap, half) and so computes the same fp32 sums: forward (bias + ReLU, residual) and data gradient (ReLU mask) at the
@@ -366,7 +367,7 @@ def test_ring32_schedule_bit_identical_to_stream_schedule_at_bench_size():
         wpt = torch.stack([K.pack_w_dgrad(w[i]) for i in range(G)])
         res = _cl(torch.randn(G * B, Cout, H, W, device='cuda').bfloat16())
         outs = []
-        for v in (K.CONV_STREAM256, K.CONV_RING32, K.CONV_W4):
+        for v in (K.CONV_STREAM256, K.CONV_RING32, K.CONV_W4, K.CONV_XFIRST, K.CONV_LEAN, K.CONV_LEANX):
             K.CONV_VARIANT = v
             try:
                 o = [K.conv2d_fwd(x, wp, bias, R, R, 1, pad, relu=True, groups=G),
@@ -377,7 +378,8 @@ def test_ring32_schedule_bit_identical_to_stream_schedule_at_bench_size():
                 K.CONV_VARIANT = K.CONV_AUTO
             outs.append(o)
         torch.cuda.synchronize()
-        for vi in (1, 2):                              # ring32, then the four-wave kernel (LOFT_CONV_W4), each against the stream schedule
+        for vi in (1, 2, 3, 4, 5):       # (4, 5: the lean instruction stream, alone and with XFIRST)
+            # ring32, the four-wave kernel (LOFT_CONV_W4), the activations-first schedule (LOFT_CONV_XFIRST, round 6)
             for a_, b_ in zip(outs[0], outs[vi]):
                 assert torch.equal(a_, b_), (vi, G, B, Cin, Cout, H, W, R)
 

@@ -90,6 +90,7 @@ def test_conv_tap_planes_forward_vs_fp64(B, cin, cout, k, s, p, hw, groups, plan
     n0 = dict(K.PLANES_STATS)
     y = K.conv2d_fwd(_cl(x), wp, b.cuda(), k, k, s, p, relu=True, residual=_cl(res), out_dtype=torch.float32, groups=groups)
     assert K.PLANES_STATS['planes'] == n0['planes'] + 1 and K.PLANES_STATS['fallback'] == n0['fallback'], 'took the fallback kernel'
+    assert K.PLANES_STATS.get('db_fused', 0) == n0.get('db_fused', 0) + 1, 'the bias gradient did not ride in the plane launch'
     err = (y.cpu().double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
     print(f'planes conv ({planes_mode}) {B}x{cin}->{cout} k{k}s{s} {hw}^2 g{groups}: max err / scale = {err:.2e}')
     assert err < 1e-5
@@ -143,13 +144,22 @@ def test_conv_wgrad_planes_vs_fp64(B, cin, cout, k, s, p, hw, groups, planes_mod
     n0 = dict(K.PLANES_STATS)
     dwp, db = K.conv2d_wgrad(_cl(g), _cl(x), k, k, s, p, groups=groups, with_bias=True)
     assert K.PLANES_STATS['planes'] == n0['planes'] + 1 and K.PLANES_STATS['fallback'] == n0['fallback'], 'took the fallback kernel'
+    assert K.PLANES_STATS.get('db_fused', 0) == n0.get('db_fused', 0) + 1, 'the bias gradient did not ride in the plane launch'
     for i in range(groups):
         dw = K.unpack_dw(dwp[i], (cout, cin, k, k)).cpu().double()
         err = (dw - want[i]).abs().max().item() / want[i].abs().max().item()
         print(f'planes wgrad ({planes_mode}) {cin}->{cout} k{k}s{s} {hw}^2 g{groups}[{i}]: max err / scale = {err:.2e}')
         assert err < 2e-5, i
-    want_b = g.view(groups, B, cout, -1).sum(dim=(1, 3))
-    assert (db[:, :cout].cpu() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item()
+    want_b = g.double().view(groups, B, cout, -1).sum(dim=(1, 3))
+    assert (db[:, :cout].cpu().double() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item()
+    # the separate column-sum pass (round 5's form) agrees with the fused one
+    K.PLANES_DB_FUSED = False
+    try:
+        _, db2 = K.conv2d_wgrad(_cl(g), _cl(x), k, k, s, p, groups=groups, with_bias=True)
+    finally:
+        K.PLANES_DB_FUSED = True
+    assert (db2[:, :cout].cpu().double() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item()
+    assert (db2 - db).abs().max().item() <= 2e-5 * want_b.abs().max().item()
 
 
 def test_planes_modes_fall_back_on_unsupported_shapes(planes_mode):

@@ -30,7 +30,11 @@ def timeit(fn, iters=20):
 
 
 def main():
-    variants = ([('ring32', K.CONV_RING32), ('w4', K.CONV_W4), ('stream_direct', K.CONV_STREAM256 | (2 << 12) | K.CONV_FLAG_NO_ROI_BLOCKS)] if os.environ.get('RING32') else [('lockstep', K.CONV_T256_FAST), ('stream_tapmajor', K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR),
+    if os.environ.get('R6'):          # round 6: the activations-first schedule and the lean instruction stream against the shipped kernel
+        variants = [('stream0', K.CONV_STREAM256), ('xfirst', K.CONV_XFIRST), ('lean', K.CONV_LEAN), ('leanx', K.CONV_LEANX),
+                    ('stream8', K.CONV_STREAM256 | (8 << 12))]
+    else:
+      variants = ([('ring32', K.CONV_RING32), ('w4', K.CONV_W4), ('stream_direct', K.CONV_STREAM256 | (2 << 12) | K.CONV_FLAG_NO_ROI_BLOCKS)] if os.environ.get('RING32') else [('lockstep', K.CONV_T256_FAST), ('stream_tapmajor', K.CONV_STREAM256 | K.CONV_FLAG_TAP_MAJOR),
                 ('stream_krot', K.CONV_STREAM256 | K.CONV_FLAG_KROT)]) + [(f'stream{v}', K.CONV_STREAM256 | (v << 12)) for v in
                                                    [int(x) for x in (os.environ.get('STREAM_VARS') or '0').split(',')]] + [(f'pipe{v}', K.CONV_PIPE256 | (v << 12)) for v in
                                                    [int(x) for x in (os.environ.get('PIPE_VARS') or '0,2,4').split(',')]]

@@ -298,6 +298,7 @@ class Trainer:
         # then on (bonai_amd/graphs.py); fixed-size batches only.  Capture failures fall back to eager launches, loudly.
         self.graph_features = bool(graph_features)
         self._fgraphs = None
+        self._unpack_stream = None
         self._steps_run = 0          # steps THIS trainer has run (a resumed trainer starts at iter > 0 with an empty prepack registry)
         self.lr, self.mu, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
         self.loss_scale = float(loss_scale)
@@ -416,8 +417,12 @@ class Trainer:
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
         if F2.GRAD_SINK is not None and not DBG.no_unpack_queue:
             # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
+            # (round 6: the batched unpack launches run on a stream of their own -- see kernels.UnpackQueue -- joined below)
+            if getattr(self, '_unpack_stream', None) is None and not DBG.no_side_stream and not DBG.no_unpack_stream:
+                self._unpack_stream = torch.cuda.Stream()
+            ustream = self._unpack_stream if (not DBG.no_side_stream and not DBG.no_unpack_stream) else None
             F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48,
-                                        note=self.reducer.note_queued if self.reducer.enabled else None)
+                                        note=self.reducer.note_queued if self.reducer.enabled else None, stream=ustream)
             if not DBG.no_side_stream and not DBG.no_wgrad_stream:
                 if getattr(self, '_wgrad_stream', None) is None:
                     self._wgrad_stream = torch.cuda.Stream()
@@ -427,6 +432,8 @@ class Trainer:
             if F2.UNPACK_Q is not None:
                 F2.UNPACK_Q.flush()
         finally:
+            if F2.UNPACK_Q is not None:
+                F2.UNPACK_Q.join()              # the main stream waits for the unpack stream before the norm / optimizer kernels
             F2.UNPACK_Q = None
             F2.WGRAD_STREAM = None
             F2.GRAD_SINK = prev

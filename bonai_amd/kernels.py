@@ -2037,34 +2037,65 @@ class UnpackQueue:
     """Deferred loft_fold_unpack_bwd jobs of the trainer's direct gradient sink, flushed as ONE launch
     (loft_fold_unpack_bwd_multi) every ``limit`` jobs and at the end of the backward pass."""
 
-    def __init__(self, limit=48, note=None):
+    def __init__(self, limit=48, note=None, stream=None):
         self.limit = limit
         self.note = note       # callable(params) -> bool: "flush now" (the reducer: a gradient bucket is complete in the queue)
         self.jobs, self.done = [], []
         # jobs may be produced on a side stream (the mask branch runs beside the FOA branch); the batched launch always goes to
-        # the stream the queue was created on and waits for an event per foreign job
-        self.home = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        self.home_raw = L.stream().value if self.home is not None else None
+        # the queue's HOME stream and waits for an event per foreign job.  stream=None: home = the stream the queue was created
+        # on.  stream=<a dedicated stream> (the Trainer, round 6): the descriptor upload + unpack launch of a flush no longer sit
+        # in the main stream between two data-gradient kernels -- nothing on the main stream reads the arena before the end of
+        # the backward pass -- which is what made the reducer's early flushes (one per completed bucket) cost device time:
+        # jobs produced on the creation ("main") stream are covered by ONE event recorded there at flush time, and the job
+        # tensors are kept referenced until the trainer has joined the two streams (no block is handed back to the main
+        # stream's allocator pool while the unpack stream may still read it).
+        self.main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        self.main_raw = L.stream().value if self.main is not None else None
+        self.home = stream if stream is not None else self.main
+        self.home_raw = self.home.cuda_stream if stream is not None else self.main_raw
+        self.dedicated = stream is not None
         self.events = []
+        self.main_jobs = False
+        self.keep = []
 
     def add(self, dwp, db, w, bn, eps, slots, on_done=(), flat_chw=None, nsplit=1, params=()):
         """slots = (dw, dgamma | None, dbeta-or-dbias | None) arena views to accumulate into; on_done: callables run after the
         launch that served this job has been enqueued (the reducer's gradient-ready notifications).
         flat_chw = (C, H, W): w is a Linear weight [O, C*H*W] and dwp [O, H*W*C] its gradient in NHWC-flattened K order."""
         self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw, int(nsplit)))     # nsplit > 1: dwp = [nsplit][...] split-K slots
-        if self.home is not None and L.stream().value != self.home_raw:
-            ev = torch.cuda.Event()
-            ev.record()                       # (on the producing side stream)
-            self.events.append(ev)
-            for t in (dwp, db):               # allocated on the side stream, read by the batched launch on the home stream
-                if t is not None:
-                    t.record_stream(self.home)
+        if self.home is not None:
+            raw = L.stream().value
+            if raw == self.home_raw:
+                pass
+            elif self.dedicated and raw == self.main_raw:
+                self.main_jobs = True             # (one event on the main stream at flush time covers all of these)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()                       # (on the producing side stream)
+                self.events.append(ev)
+                if not self.dedicated:
+                    for t in (dwp, db):           # allocated on the side stream, read by the batched launch on the home stream
+                        if t is not None:
+                            t.record_stream(self.home)
+            if self.dedicated:
+                self.keep.append((dwp, db))
         self.done.extend(on_done)
         if len(self.jobs) >= self.limit or (self.note is not None and self.note(params)):
             self.flush()
 
+    def join(self, stream=None):
+        """Make ``stream`` (default: the creation stream) wait for every launch of the queue; drops the kept job tensors."""
+        if self.dedicated:
+            (stream or self.main).wait_stream(self.home)
+        self.keep = []
+
     def flush(self):
         if self.home is not None and L.stream().value != self.home_raw:
+            if self.main_jobs:
+                ev = torch.cuda.Event()
+                ev.record(self.main)              # everything the main stream has been handed so far (host order)
+                self.events.append(ev)
+                self.main_jobs = False
             with torch.cuda.stream(self.home):
                 return self.flush()
         for ev in self.events:

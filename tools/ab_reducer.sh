@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of the reducer's host path on the forced one-rank RCCL leg:
-#   plain step | forced, every collective through the side stream (LOFT_REDUCER_SIDE_STREAM_ONLY=1) | forced, shipped
+#   plain / forced step, each with the batched unpack launches on the main stream (LOFT_NO_UNPACK_STREAM=1: round 5) and as shipped
 #   bash tools/ab_reducer.sh [rounds]   ->  gpurun_out/r6/ab_reducer.txt
 N=${1:-2}
 cd "$(dirname "$0")/.."
@@ -13,8 +13,9 @@ run() {   # tag, env...
     | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], (d.get('comm') or {}).get('exposed_ms'))" >> $OUT || tail -5 gpurun_out/r6/ab_reducer_err.txt >> $OUT
 }
 for ((i = 0; i < N; i++)); do
+  EXTRA="" run plain_unpack_on_main LOFT_NO_UNPACK_STREAM=1
   EXTRA="" run plain LOFT_X=1
-  EXTRA="--force-reducer" run forced_side_stream_only LOFT_REDUCER_SIDE_STREAM_ONLY=1
+  EXTRA="--force-reducer" run forced_unpack_on_main LOFT_NO_UNPACK_STREAM=1
   EXTRA="--force-reducer" run forced_shipped LOFT_X=1
 done
 cat $OUT

@@ -192,18 +192,32 @@ def forced_comm_leg(args, plain_ms):
     cmd = [sys.executable, os.path.abspath(__file__), '--force-reducer', '--steps', str(min(args.steps, 10)), '--warmup', '3',
            '--batch', str(args.batch), '--size', str(args.size), '--num-gt', str(args.num_gt), '--no-cpu-baseline', '--no-roofline',
            '--no-light', '--no-fp32']
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+
+    def child(env_extra):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=dict(os.environ, **env_extra))
         line = [l for l in r.stdout.splitlines() if l.startswith('{')]
         if not line:
-            return dict(error=(r.stderr or r.stdout)[-400:])
-        d = json.loads(line[-1])
+            raise RuntimeError((r.stderr or r.stdout)[-400:])
+        return json.loads(line[-1])
+    try:
+        d = child({})
         c = d.get('comm') or {}
-        return dict(ms_per_step=d['ms_per_step'], value=d['value'], plain_ms_per_step=round(plain_ms, 3),
-                    slowdown_vs_plain=round(d['ms_per_step'] / plain_ms, 4), exposed_ms=c.get('exposed_ms'), buckets=c.get('buckets'),
-                    bucket_mib=c.get('bucket_mib'), grad_mib_per_step=c.get('grad_mib_per_step'), backend=c.get('backend'),
-                    steps=d['steps'], how='child run `bench.py --force-reducer`: one-rank RCCL group, reducer hooks + side stream + '
-                                          'ncclAllReduce per bucket active in the timed loop')
+        out = dict(ms_per_step=d['ms_per_step'], value=d['value'], plain_ms_per_step=round(plain_ms, 3),
+                   slowdown_vs_plain=round(d['ms_per_step'] / plain_ms, 4), exposed_ms=c.get('exposed_ms'), buckets=c.get('buckets'),
+                   bucket_mib=c.get('bucket_mib'), grad_mib_per_step=c.get('grad_mib_per_step'), backend=c.get('backend'),
+                   steps=d['steps'], how='child run `bench.py --force-reducer`: one-rank RCCL group, reducer hooks + side stream + '
+                                         'ncclAllReduce per bucket active in the timed loop')
+        # Attribution (round 6, profiles/round6_probes/reducer_bisect.txt): the same child with the process group initialised but
+        # the reducer OFF -- what a live RCCL communicator alone costs this step (no hook, no bucket, no collective) -- so that the
+        # reducer's own host path is the difference of the two children, measured back to back on this box.
+        try:
+            g = child(dict(LOFT_BENCH_INIT_ONLY='1'))
+            out['group_alive_reducer_off_ms_per_step'] = g['ms_per_step']
+            out['reducer_host_path_ms'] = round(d['ms_per_step'] - g['ms_per_step'], 3)
+            out['slowdown_vs_group_alive'] = round(d['ms_per_step'] / g['ms_per_step'], 4)
+        except Exception as e:      # noqa -- reported, never hidden
+            out['group_alive_error'] = f'{type(e).__name__}: {e}'[:200]
+        return out
     except Exception as e:      # noqa -- reported, never hidden
         return dict(error=f'{type(e).__name__}: {e}'[:300])
 
@@ -235,7 +249,8 @@ def main():
             port = sk.getsockname()[1]
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(port))
-        os.environ['LOFT_FORCE_REDUCER'] = '1'
+        if os.environ.get('LOFT_BENCH_INIT_ONLY') != '1':       # (experiment: the process group alive, the reducer off)
+            os.environ['LOFT_FORCE_REDUCER'] = '1'
         dist.init_process_group('nccl', rank=0, world_size=1)
     from bonai_amd import kernels as K
     from bonai_amd.config import Config

@@ -26,8 +26,8 @@ SWITCHES = {
     'no_rpn_target_prefetch': 'RPN anchor assignment + sampling after the RPN convs on the main stream, not beside the backbone',
     'no_rpn_loss_stream': 'the RPN losses (and with them the sparse RPN backward) on the main stream',
     'no_wgrad_stream': 'backbone weight-gradient launches on the data-gradient stream',
-    'no_unpack_stream': 'the batched weight-gradient unpack launches (descriptor upload + loft_fold_unpack_bwd_multi) on the main stream '
-                        'between the data-gradient kernels instead of on a stream of their own (round 6)',
+    'unpack_stream': 'the batched weight-gradient unpack launches (descriptor upload + loft_fold_unpack_bwd_multi) on a stream of their '
+                     'own instead of on the main stream between the data-gradient kernels (round 6: measured, not the default)',
     # batched launches / pools of the trainer
     'no_prepack': 'BN fold + operand packing per conv per step instead of one launch per step (kernels.PrepackRegistry)',
     'no_unpack_queue': 'one loft_fold_unpack_bwd launch per conv instead of the batched unpack (kernels.UnpackQueue)',

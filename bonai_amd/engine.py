@@ -112,6 +112,7 @@ class BucketedAllReduce:
         self._hooks, self._sunk_streak = {}, {}
         self.direct_issue = os.environ.get('LOFT_REDUCER_SIDE_STREAM_ONLY') != '1'
         self._issued_from = set()
+        self._dryrun = os.environ.get('LOFT_REDUCER_DRYRUN') == '1' and self.enabled and dist.get_world_size() == 1
         self.PRUNE_AFTER = 2
         self.prune_hooks = os.environ.get('LOFT_REDUCER_KEEP_HOOKS') != '1'
         self._events = {}
@@ -197,6 +198,8 @@ class BucketedAllReduce:
         if not self.on_gpu:   # gloo / CPU (tests): same bucket order, no stream juggling
             self.works.append(dist.all_reduce(view, async_op=True))
             return
+        if self._dryrun:          # (LOFT_REDUCER_DRYRUN=1, one-rank experiments only: every host step of a release but the collective)
+            return
         raw_cur = torch._C._cuda_getCurrentRawStream(self._dev)
         producers = self._streams[bi]
         if self.direct_issue and all(r == raw_cur for r in producers):
@@ -236,9 +239,12 @@ class BucketedAllReduce:
             # per-work wait() loop did the same thing fifteen times, on the main stream); the main stream then waits for the side
             # stream's tail, and the measured pair brackets the real end of the last collective.
             # (whichever stream a collective was issued from, c10d ran it on its own stream: the side stream takes the wait)
-            if self.works:
+            if self.works and dist.get_backend() == 'nccl':
                 with torch.cuda.stream(self.stream):
                     self.works[-1].wait()
+            else:                               # (gloo on device tensors -- the shared-GPU tests: every work is its own transfer)
+                for w in self.works:
+                    w.wait()
             if self.measure:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record(self.stream)
@@ -417,12 +423,16 @@ class Trainer:
             K.zero_pool_begin(self.arena.data.device)     # one memset for all the backward's accumulation buffers
         if F2.GRAD_SINK is not None and not DBG.no_unpack_queue:
             # multi-GPU: smaller bursts, so the gradient buckets become ready (and their all-reduce starts) earlier in backward
-            # (round 6: the batched unpack launches run on a stream of their own -- see kernels.UnpackQueue -- joined below)
-            if getattr(self, '_unpack_stream', None) is None and not DBG.no_side_stream and not DBG.no_unpack_stream:
-                self._unpack_stream = torch.cuda.Stream()
-            ustream = self._unpack_stream if (not DBG.no_side_stream and not DBG.no_unpack_stream) else None
-            F2.UNPACK_Q = K.UnpackQueue(limit=24 if self.reducer.enabled else 48,
-                                        note=self.reducer.note_queued if self.reducer.enabled else None, stream=ustream)
+            # (round 6, measured and NOT the default: the batched unpack launches on a stream of their own -- kernels.UnpackQueue,
+            #  DBG.unpack_stream -- joined below: neutral on the plain step, +1.0 .. 1.3 ms on the forced-reducer leg)
+            ustream = None
+            if DBG.unpack_stream and not DBG.no_side_stream:
+                if getattr(self, '_unpack_stream', None) is None:
+                    self._unpack_stream = torch.cuda.Stream()
+                ustream = self._unpack_stream
+            lim = int(os.environ.get('LOFT_UNPACK_LIMIT', '0')) or (24 if self.reducer.enabled else 48)
+            note = self.reducer.note_queued if (self.reducer.enabled and os.environ.get('LOFT_NO_NOTE_FLUSH') != '1') else None
+            F2.UNPACK_Q = K.UnpackQueue(limit=lim, note=note, stream=ustream)
             if not DBG.no_side_stream and not DBG.no_wgrad_stream:
                 if getattr(self, '_wgrad_stream', None) is None:
                     self._wgrad_stream = torch.cuda.Stream()

@@ -13,9 +13,9 @@ run() {   # tag, env...
     | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', d['ms_per_step'], (d.get('comm') or {}).get('exposed_ms'))" >> $OUT || tail -5 gpurun_out/r6/ab_reducer_err.txt >> $OUT
 }
 for ((i = 0; i < N; i++)); do
-  EXTRA="" run plain_unpack_on_main LOFT_NO_UNPACK_STREAM=1
   EXTRA="" run plain LOFT_X=1
-  EXTRA="--force-reducer" run forced_unpack_on_main LOFT_NO_UNPACK_STREAM=1
   EXTRA="--force-reducer" run forced_shipped LOFT_X=1
+  EXTRA="--force-reducer" run forced_dryrun_no_collective LOFT_REDUCER_DRYRUN=1
+  EXTRA="--force-reducer" run group_alive_reducer_off LOFT_BENCH_INIT_ONLY=1
 done
 cat $OUT

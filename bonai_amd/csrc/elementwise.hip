@@ -372,7 +372,21 @@ LOFT_EXPORT int loft_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vo
 __device__ __forceinline__ float absmax_block(const float* __restrict__ x, long nvec) {
     float m = 0.f;
     bool bad = false;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    // four independent 16-byte loads per thread and trip (round 6): with one, a 1024-workgroup grid kept 4 MB in flight and the pass
+    // ran at ~1.3 TB/s (146 launches, 6.2 ms per fp32-mode step: profiles/round5_probes/fp32_planes_kernel_stats.csv)
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(x + (i + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a[u].x), fabsf(a[u].y)), fmaxf(fabsf(a[u].z), fabsf(a[u].w))));
+            bad |= (a[u].x != a[u].x) | (a[u].y != a[u].y) | (a[u].z != a[u].z) | (a[u].w != a[u].w);
+        }
+    }
+    for (; i < nvec; i += stride) {
         const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
         bad |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w);
@@ -1103,22 +1117,31 @@ LOFT_EXPORT int loft_fold_unpack_bwd(const float* dwp, const float* db, const fl
 //     dw[n][c] += sum_m g[m][n] * x[m][c],   db[n] += sum_m g[m][n]         (fp32 registers -> LDS -> one atomic per entry and block)
 // HBM-bound: reads x once (it is also the ReLU mask of the producer), writes gx once.  g fp32 [M][gs] (gs = Cout rounded up
 // to 4), x bf16 [M][Cin], w fp32 [Cout][Cin]; Cin % 4 == 0, Cin <= 1024.
-template <int V> struct NhbIO;
-template <> struct NhbIO<4> {
+template <typename T, int V> struct NhbIO;
+template <> struct NhbIO<bf16_t, 4> {
     static __device__ __forceinline__ void ld(const bf16_t* p, float* v) { ld4(p, v); }
     static __device__ __forceinline__ void st(bf16_t* p, const float* v) { st4(p, v); }
 };
-template <> struct NhbIO<8> {
+template <> struct NhbIO<bf16_t, 8> {
     static __device__ __forceinline__ void ld(const bf16_t* p, float* v) { ld8(p, v); }
     static __device__ __forceinline__ void st(bf16_t* p, const float* v) { st8(p, v); }
+};
+// fp32 activations (the fp32 parity mode, round 6: the narrow heads took the padded 128-channel GEMM route there -- a zero fill, a
+// strided copy, two plane splits of an 822 MB map and two contractions for ONE mask-logit channel): 16-byte accesses = 4 channels
+template <> struct NhbIO<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 
 // V channels per lane: 8 (16-byte accesses; the mask-logits launch ran at 2.4 TB/s with 8-byte ones) while the weight and
 // accumulator registers allow it (NOUT <= 4), else 4.
-template <int NOUT, int V>
-__global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __restrict__ g, int gs, const bf16_t* __restrict__ x,
+template <int NOUT, int V, typename XT = bf16_t>
+__global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __restrict__ g, int gs, const XT* __restrict__ x,
                                                               const float* __restrict__ w, long M, int Cin, int relu_in,
-                                                              bf16_t* __restrict__ gx, float* __restrict__ dw,
+                                                              XT* __restrict__ gx, float* __restrict__ dw,
                                                               float* __restrict__ db) {
     const int cg = Cin / V;                        // column groups of V channels
     const int ppi = 256 / cg > 0 ? 256 / cg : 1;   // pixels per block round (Cin = 256, V = 8 -> 8)
@@ -1145,7 +1168,7 @@ __global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __res
             for (int u = 0; u < UN; ++u) {
                 const long m = m0 + u * step;
                 if (m < m_end) {
-                    NhbIO<V>::ld(x + m * Cin + c0, xv[u]);
+                    NhbIO<XT, V>::ld(x + m * Cin + c0, xv[u]);
 #pragma unroll
                     for (int n = 0; n < NOUT; ++n) gv[u][n] = g[m * gs + n];
                 } else {
@@ -1175,7 +1198,7 @@ __global__ __launch_bounds__(256) void narrow_head_bwd_kernel(const float* __res
 #pragma unroll
                         for (int q = 0; q < V; ++q) o[q] = xv[u][q] > 0.f ? o[q] : 0.f;
                     }
-                    NhbIO<V>::st(gx + m * Cin + c0, o);
+                    NhbIO<XT, V>::st(gx + m * Cin + c0, o);
                 }
             }
         }
@@ -1224,6 +1247,26 @@ LOFT_EXPORT int loft_narrow_head_bwd(const float* g, int g_stride, const void* x
         }
     }
 #undef NHB
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same pass on fp32 activations (x, gx fp32 [M][Cin]): the fp32 parity mode's narrow heads
+LOFT_EXPORT int loft_narrow_head_bwd_f32(const float* g, int g_stride, const float* x, const float* w, int64_t M, int Cin, int Cout,
+                                         int relu_in, float* gx, float* dw, float* db, void* stream) {
+    if (M <= 0) return 0;
+    if (Cout < 1 || Cout > 8 || (Cin & 3) || Cin > 1024 || g_stride < Cout) return (int)hipErrorInvalidValue;
+    const int cg = Cin / 4, ppi = 256 / cg > 0 ? 256 / cg : 1;
+    long blocks = (M + (long)ppi * 16 - 1) / ((long)ppi * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+#define NHBF(N) hipLaunchKernelGGL((narrow_head_bwd_kernel<N, 4, float>), dim3((unsigned)blocks), dim3(256), 0, s, g, g_stride, x, w, \
+                                   (long)M, Cin, relu_in, gx, dw, db)
+    switch (Cout) {
+        case 1: NHBF(1); break; case 2: NHBF(2); break; case 3: NHBF(3); break; case 4: NHBF(4); break;
+        case 5: NHBF(5); break; case 6: NHBF(6); break; case 7: NHBF(7); break; default: NHBF(8); break;
+    }
+#undef NHBF
     LOFT_LAUNCH_CHECK();
     return 0;
 }

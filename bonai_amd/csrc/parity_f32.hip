@@ -274,19 +274,38 @@ LOFT_EXPORT int loft_conv_wgrad_f32(const float* g, const float* x, float* dw, i
                                  wt_host, groups, g_gs, x_gs, dw_gs, LOFT_F32_SPLIT6, stream);
 }
 
-__global__ void relu_bwd_f32_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out, long n4) {
+// amax (may be NULL; PRE-ZEROED): max |out| as a device scalar -- the masked gradient goes straight into a plane split, which then
+// skips its absmax pass (round 6)
+__global__ __launch_bounds__(256) void relu_bwd_f32_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
+                                                           long n4, unsigned* __restrict__ amax) {
+    float m = 0.f;
+    bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 gv = reinterpret_cast<const float4*>(g)[i], yv = reinterpret_cast<const float4*>(y)[i];
-        reinterpret_cast<float4*>(out)[i] = make_float4(yv.x > 0.f ? gv.x : 0.f, yv.y > 0.f ? gv.y : 0.f, yv.z > 0.f ? gv.z : 0.f,
-                                                       yv.w > 0.f ? gv.w : 0.f);
+        const float4 o = make_float4(yv.x > 0.f ? gv.x : 0.f, yv.y > 0.f ? gv.y : 0.f, yv.z > 0.f ? gv.z : 0.f, yv.w > 0.f ? gv.w : 0.f);
+        reinterpret_cast<float4*>(out)[i] = o;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        bad |= (o.x != o.x) | (o.y != o.y) | (o.z != o.z) | (o.w != o.w);
+    }
+    if (amax) {
+        if (bad) m = __builtin_inff();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        __shared__ float wm[4];
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            if (m > 0.f) atomicMax(amax, __float_as_uint(m));
+        }
     }
 }
-LOFT_EXPORT int loft_relu_bwd_f32(const float* g, const float* y, float* out, int64_t n, void* stream) {
+LOFT_EXPORT int loft_relu_bwd_f32(const float* g, const float* y, float* out, int64_t n, float* amax_out, void* stream) {
     if (n <= 0) return 0;
     if (n % 4) return (int)hipErrorInvalidValue;
     const long n4 = n / 4;
-    hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0,
-                       (hipStream_t)stream, g, y, out, n4);
+    hipLaunchKernelGGL(relu_bwd_f32_kernel, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, g, y, out, n4, (unsigned*)amax_out);
     LOFT_LAUNCH_CHECK();
     return 0;
 }

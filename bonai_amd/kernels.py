@@ -1004,7 +1004,11 @@ def relu_bwd(g, y):
     L.dev_check(g, y)
     out = torch.empty_like(g)
     if g.dtype == torch.float32 and y.dtype == torch.float32:          # fp32 parity mode
-        L.check(lib.loft_relu_bwd_f32(L.ptr(g), L.ptr(y), L.ptr(out), c_int64(g.numel()), L.stream()), 'loft_relu_bwd_f32')
+        # (the masked gradient is split into operand planes next: the kernel leaves its absmax with it -- kernels._known_amax)
+        slot = _amax_slot(g.device) if (AMAX_FROM_PRODUCER and F32_CONTRACT in (F32_PLANES_F16, F32_PLANES_F16X4)) else None
+        L.check(lib.loft_relu_bwd_f32(L.ptr(g), L.ptr(y), L.ptr(out), c_int64(g.numel()), L.ptr(slot), L.stream()), 'loft_relu_bwd_f32')
+        if slot is not None:
+            out._loft_amax = (slot, out.data_ptr(), out._version, out.numel())
         return out
     L.check(lib.loft_relu_bwd_bf16(L.ptr(_bf16(g)), L.ptr(_bf16(y)), L.ptr(out), c_int64(g.numel()), L.stream()),
             'loft_relu_bwd_bf16')
@@ -2025,11 +2029,13 @@ def narrow_head_bwd(g, x, w, relu_in=False, need_gx=True, need_dw=True, need_db=
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     w2 = w.reshape(Cout, Cin).float().contiguous()
-    gx = empty_nhwc(N, Cin, H, W, L.act16(), x.device) if need_gx else None
+    f32 = x.dtype == torch.float32              # fp32 parity mode (loft_narrow_head_bwd_f32, round 6)
+    gx = empty_nhwc(N, Cin, H, W, torch.float32 if f32 else L.act16(), x.device) if need_gx else None
     dw = pooled_zeros((Cout, Cin), x.device) if need_dw else None
     db = pooled_zeros((Cout,), x.device) if need_db else None
-    L.check(lib.loft_narrow_head_bwd(L.ptr(g), int(g.shape[1]), L.ptr(x), L.ptr(w2), c_int64(N * H * W), Cin, Cout, int(relu_in),
-                                     L.ptr(gx), L.ptr(dw), L.ptr(db), L.stream()), 'loft_narrow_head_bwd')
+    fn = lib.loft_narrow_head_bwd_f32 if f32 else lib.loft_narrow_head_bwd
+    L.check(fn(L.ptr(g), int(g.shape[1]), L.ptr(x), L.ptr(w2), c_int64(N * H * W), Cin, Cout, int(relu_in),
+               L.ptr(gx), L.ptr(dw), L.ptr(db), L.stream()), 'loft_narrow_head_bwd')
     return gx, dw, db
 
 

@@ -543,7 +543,7 @@ class _NarrowHeadFn(torch.autograd.Function):
         stride, pad = ctx.sp
         Cout, Cin, R, S = w.shape
         if R == 1 and S == 1 and stride == 1 and pad == 0 and Cout <= 8 and Cin % 4 == 0 and Cin <= 1024 and \
-                x.dtype == K.L.act16() and not DBG.narrow_mfma_bwd:
+                x.dtype in (K.L.act16(), torch.float32) and not DBG.narrow_mfma_bwd:
             # one pass over x: gx (with the producer's ReLU mask when x is a ReLU output), dW and db together
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             gx, dw, db = K.narrow_head_bwd(g, x, w, relu_in=ctx.input_relu, need_gx=ctx.needs_input_grad[0],

@@ -267,7 +267,7 @@ int loft_conv_wgrad_f32(const float* g, const float* x, float* dw, int B, int GH
                         int OW, int gos, int ss, int T, const int* goy_host, const int* gox_host, const int* dy_host,
                         const int* dx_host, const int* wt_host, int groups, int64_t g_gs, int64_t x_gs, int64_t dw_gs,
                         void* stream);
-int loft_relu_bwd_f32(const float* g, const float* y, float* out, int64_t n, void* stream);
+int loft_relu_bwd_f32(const float* g, const float* y, float* out, int64_t n, float* amax_out /* optional, PRE-ZEROED: max |out| */, void* stream);
 int loft_downsum2x_add_f32(float* coarse, const float* fine, int B, int Hc, int Wc, int Hf, int Wf, int C, void* stream);
 int loft_subsample2_add_f32(float* big, const float* small, int B, int Hs, int Ws, int Hb, int Wb, int C, void* stream);
 /* loft_conv_tap_f32: the fp32 parity mode of the same contract (all operands and the output fp32, contraction on
@@ -616,6 +616,9 @@ int loft_fold_unpack_bwd(const float* dwp, const float* db, const float* w, cons
  * gx / dw / db may be NULL. */
 int loft_narrow_head_bwd(const float* g, int g_stride, const void* x, const float* w, int64_t M, int Cin, int Cout,
                          int relu_in, void* gx, float* dw, float* db, void* stream);
+/* the same pass on fp32 activations (x, gx fp32 [M][Cin]; 16-byte accesses): the narrow heads of the fp32 parity mode (round 6) */
+int loft_narrow_head_bwd_f32(const float* g, int g_stride, const float* x, const float* w, int64_t M, int Cin, int Cout,
+                             int relu_in, float* gx, float* dw, float* db, void* stream);
 
 /* loft_random_sample: RandomSampler.sample for a batch (mmdet/core/bbox/samplers/random_sampler.py:31-75,
  * base_sampler.py:34-101).  gt_inds int64 [B,N] (>0 positive, 0 negative, <0 ignored).  Per image: min(#pos, max_pos) positives,

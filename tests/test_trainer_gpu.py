@@ -105,13 +105,13 @@ def test_fp32_mode_trainer_shares_operand_planes_across_streams_safely(first_k):
     for rep in range(3):
         tr.train_step(data, lr=0.0)
         torch.cuda.synchronize()
-        _compare(want, m, f'fp32 side-stream rep {rep}', tol=2e-3)
+        _compare(want, m, f'fp32 side-stream rep {rep}', tol=1e-4)      # (measured 1.3e-6; the same-slot race of round 6 was 8-30 %)
     assert K.PLANES_XSTREAM['waits'] > 0, 'no operand planes crossed streams: the test does not exercise the hand-over'
     with DBG.override(no_wgrad_stream=True):
         n0 = K.PLANES_XSTREAM['waits']
         tr.train_step(data, lr=0.0)
         torch.cuda.synchronize()
-        _compare(want, m, 'fp32 no_wgrad_stream', tol=2e-3)
+        _compare(want, m, 'fp32 no_wgrad_stream', tol=1e-4)
         assert K.PLANES_XSTREAM['waits'] == n0
 
 

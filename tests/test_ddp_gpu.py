@@ -91,6 +91,18 @@ def _worker(rank, world, port, q, mode='balanced', backend='gloo'):
         both = [torch.zeros_like(lv) for _ in range(world)]
         dist.all_gather(both, lv)
         assert torch.equal(both[0], both[1])
+        # (4) three more steps: the reducer prunes the autograd hooks of sink-served parameters after two steps (round 6) -- a
+        # rank-dependent state (rank 0 of the imbalanced pair never sees the mask / FOA parameters reported and keeps re-arming
+        # them) that must not change the order or the content of the collectives: parameters stay bit-identical across ranks
+        armed0 = tr.reducer.hooks_armed()
+        for _ in range(3):
+            tr.train_step(data)
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            both = [torch.zeros_like(p) for _ in range(world)]
+            dist.all_gather(both, p.detach())
+            assert torch.equal(both[0], both[1]), ('after pruning', n)
+        assert tr.reducer.hooks_armed() < armed0, (tr.reducer.hooks_armed(), armed0)
         q.put((rank, 'ok', len(names)))
     except Exception:  # noqa
         import traceback

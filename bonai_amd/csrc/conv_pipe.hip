@@ -483,7 +483,7 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
 // at one position -- issue their activation copies without the zero-page select (4 vector instructions per copy).
 template <int MODE, int VAR, int MJ = 4, int NW = 2, bool PL = false, bool R32 = false, bool XF = false, bool LEAN = false>
 __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
-    static_assert(!LEAN || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2 && !PL && !R32), "LEAN exists for the two-stage 256 x 256 stream schedule");
+    static_assert(!LEAN || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2 && !R32), "LEAN exists for the two-stage 256 x 256 stream schedule (16-bit and operand-plane launches)");
     static_assert(MODE <= 2, "MODE 0 phase, 1 stream, 2 role-split stream");
     static_assert(!XF || (MODE == 1 && VAR == 0 && MJ == 4 && NW == 2 && !PL && !R32), "activations-first exists for the two-stage 256 x 256 stream schedule");
     static_assert(!PL || (MODE == 1 && VAR == 0), "operand planes exist for the stream schedule");
@@ -1919,6 +1919,8 @@ int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int va
         else if (nw == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 1, true>), grid, dim3(512), 0, s, a);
         else if (mj == 2) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 2, 2, true>), grid, dim3(512), 0, s, a);
         else if (mj == 1) hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 1, 2, true>), grid, dim3(512), 0, s, a);
+        else if (g_stream_form >= 2 && !a.tap_major)        // (the lean instruction stream, as for the 16-bit launches: same sums, same order)
+            hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true, false, false, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, true>), grid, dim3(512), 0, s, a);
     } else if (xfirst && lean) {
         hipLaunchKernelGGL((conv_tap_pipe_kernel<1, 0, 4, 2, false, false, true, true>), grid, dim3(512), 0, s, a);

@@ -2,7 +2,7 @@
 
 Run ON the GPU box (gpurun):  cd /tmp && export TMPDIR=/tmp && python $GRAFT_REPO_ROOT/tools/pmc_collect.py
 Passes (separate runs, --pmc with --kernel-trace only, as the pool requires):
-  1. FETCH_SIZE   2. WRITE_SIZE   3. SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE
+  1. FETCH_SIZE   2. WRITE_SIZE   3. SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE   4. TCC_HIT / TCC_MISS / TCC_EA0_RDREQ (+ _DRAM)
 Writes gpurun_out/pmc/summary.json: per family launches, HBM bytes per launch (FETCH_SIZE x2 per
 /opt/skills/guides/MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 B; counter unit KiB) and
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs; 32 cycles per 32x32x16 bf16 MFMA) /
@@ -28,8 +28,11 @@ FAMILIES.update({k: [k] for k in [
     'fuse_sum_relu_kernel', 'stem_mfma_kernel', 'bneck_tail_kernel']})
 # per template instance of the weight-gradient stream kernel (0 generic taps, 1 RoI maps, 2 dense 1x1 / FC, 3 stride-1 same-size taps)
 EXACT = {f'conv_wgrad_stream_kernel<{i}>': f'conv_wgrad_stream_kernel<{i}>' for i in range(4)}
-EXACT.update({'conv_tap_pipe_kernel<1, 0, 4, 2>': 'conv_tap_pipe_kernel<1, 0, 4, 2>'})
-PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE'])]
+EXACT.update({'conv_tap_pipe_kernel<1, 0, 4, 2>': 'conv_tap_pipe_kernel<1, 0, 4, 2, false, false, false'})      # (the two-stage 256 x 256 stream schedule, either form)
+PASSES = [('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'GRBM_GUI_ACTIVE']),
+          # round 6: where a kernel's reads are served -- L2 hits / misses and the misses' fabric requests, all
+          # and those addressed to DRAM.  (What the Infinity Cache absorbs behind the fabric interface has no counter in this list.)
+          ('l2', ['TCC_HIT_sum', 'TCC_MISS_sum', 'TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_DRAM_sum'])]
 
 
 def run_pass(tag, counters, extra):
@@ -37,7 +40,10 @@ def run_pass(tag, counters, extra):
     cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '--', sys.executable,
                                                os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
                                                '--no-roofline', '--no-light', '--no-fp32', '--no-forced-comm'] + extra
-    subprocess.run(cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+    try:
+        subprocess.run(['timeout', '-k', '10', '420'] + cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=460)
+    except subprocess.TimeoutExpired:
+        pass
     rows = []
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         rows += list(csv.DictReader(open(f)))
@@ -80,6 +86,16 @@ def main():
             e['mfma_util'] = a['SQ_VALU_MFMA_BUSY_CYCLES'][0] / (a['GRBM_GUI_ACTIVE'][0] / 8 * 256 * 4)   # GUI_ACTIVE is summed over the 8 XCDs
         if 'SQ_BUSY_CU_CYCLES' in a:
             e['sq_busy_cu_cycles'] = a['SQ_BUSY_CU_CYCLES'][0]
+        if 'TCC_HIT_sum' in a and 'TCC_MISS_sum' in a:
+            nl = max(1, len(a['TCC_HIT_sum'][1]))
+            hit, miss = a['TCC_HIT_sum'][0] / nl, a['TCC_MISS_sum'][0] / nl
+            e['l2_hits_per_launch'], e['l2_misses_per_launch'] = hit, miss
+            e['l2_hit_rate'] = hit / max(1.0, hit + miss)
+            if 'TCC_EA0_RDREQ_sum' in a:
+                e['ea_rdreq_per_launch'] = a['TCC_EA0_RDREQ_sum'][0] / nl
+                e['ea_rdreq_dram_per_launch'] = a.get('TCC_EA0_RDREQ_DRAM_sum', [0.0])[0] / nl
+                # (128-byte L2 lines; requests past the L2 are tallied at 64 B: see the FETCH_SIZE correction above)
+                e['l2_request_bytes_per_launch'] = (hit + miss) * 128.0
         out[fam] = e
     json.dump(out, open(os.path.join(OUT, 'summary.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))

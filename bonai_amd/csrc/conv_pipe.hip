@@ -457,6 +457,92 @@ __device__ __forceinline__ void pipe_epilogue_f32(const ConvArgs& a, const TileR
     }
 }
 
+// The same fp32 epilogue with the tile collected in LDS (round 6; the 256 x 256 plane launches): the direct form above stores 32 bytes
+// per output row and instruction (two lanes per row, 32 rows per wave-level store) and reads residual / mask tiles the same way;
+// here the accumulators go to LDS -- scaled, bias added: the fp32 values the direct form has at that point -- and leave as whole
+// 1 KiB rows (64 lanes x 16 bytes), residual and mask rows arriving with the same coalesced pattern.  A 256 x 256 fp32 tile is
+// 256 KiB, the array 128 KiB: two passes of 128 rows (pass h = the four waves with wm == h, whose wave tiles are exactly those
+// rows).  16-byte chunk c of local row lr sits at position c ^ (lr & 63) (64 chunks per row; conflict-free for the 8-lane groups
+// of ds_write_b128: eight consecutive rows, one chunk each).  Same operations in the same order: bit-identical to the direct form
+// (tests/test_planes_gpu.py::test_staged_fp32_epilogue_is_bit_identical_to_the_direct_one).
+__device__ __forceinline__ void pipe_epilogue_f32_staged(const ConvArgs& a, const TileRows& tr, f32x16 (&acc)[2][4], char* lds, int g, int n0,
+                                                         int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3, frow = lane & 31, fq = lane >> 5;
+    const long out_g = (long)g * a.out_gs;
+    const float sc = a.amax_x ? planes_scale_of(*a.amax_x, true) * planes_scale_of(*a.amax_w, true) : 1.f;
+    const float* bias = a.bias ? a.bias + (long)g * a.bias_gs + n0 : nullptr;
+    const float* res = reinterpret_cast<const float*>(a.residual);
+    const float* msk = reinterpret_cast<const float*>(a.mask);
+    float* out = reinterpret_cast<float*>(a.out);
+    const bool relu = a.relu != 0;
+    float vmax = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                   // every wave is done with the K loop's fragments
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int c = wn * 16 + i * 8 + 2 * gq + fq;        // logical 16-byte chunk = couts [4 c, 4 c + 4) of the tile
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lr = j * 32 + frow;
+                        float4 v = make_float4(acc[i][j][gq * 4 + 0] * sc, acc[i][j][gq * 4 + 1] * sc, acc[i][j][gq * 4 + 2] * sc,
+                                               acc[i][j][gq * 4 + 3] * sc);
+                        if (bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                        *reinterpret_cast<float4*>(lds + lr * 1024 + ((c ^ (lr & 63)) << 4)) = v;
+                    }
+                }
+        }
+        __syncthreads();
+        // copy-out: wave w serves local rows [16 w, 16 w + 16), four at a time (their residual / mask rows requested together)
+#pragma unroll 1
+        for (int it = 0; it < 16; it += 4) {
+            float4 v[4], rv[4], mv[4];
+            long o[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int lr = wave * 16 + it + u;
+                const long roff = pipe_row_off(tr, h * 128 + lr, ok[u]);
+                o[u] = out_g + roff + n0 + ((lane ^ (lr & 63)) << 2);
+                v[u] = *reinterpret_cast<const float4*>(lds + lr * 1024 + lane * 16);
+                rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                mv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (ok[u] && res) rv[u] = *reinterpret_cast<const float4*>(res + o[u]);
+                if (ok[u] && msk) mv[u] = *reinterpret_cast<const float4*>(msk + o[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                float w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                if (res) { w[0] += rv[u].x; w[1] += rv[u].y; w[2] += rv[u].z; w[3] += rv[u].w; }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = fmaxf(w[e], 0.f);
+                }
+                if (msk) {
+                    w[0] = mv[u].x > 0.f ? w[0] : 0.f; w[1] = mv[u].y > 0.f ? w[1] : 0.f;
+                    w[2] = mv[u].z > 0.f ? w[2] : 0.f; w[3] = mv[u].w > 0.f ? w[3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(out + o[u]) = make_float4(w[0], w[1], w[2], w[3]);
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3]))));
+                if ((w[0] != w[0]) | (w[1] != w[1]) | (w[2] != w[2]) | (w[3] != w[3])) vmax = __builtin_inff();
+            }
+        }
+        __syncthreads();                               // (the next pass overwrites the rows)
+    }
+    if (a.amax_out) {
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o2));
+        if (lane == 0 && vmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __float_as_uint(vmax));
+    }
+}
+
 // VAR bits (A/B experiments, selected through the C-ABI variant argument; 0 = the shipped schedule):
 //   1 TRACE      lane 0 of every wave stores s_memtime at every barrier exit of K-tiles 8..11 to a.trace ([wave][32] u64)
 //   2 NOPRIO     no s_setprio around the MFMA clusters
@@ -1351,7 +1437,12 @@ __global__ __launch_bounds__(512) void conv_tap_pipe_kernel(const ConvArgs a) {
             const int par = a.par_n ? by : 0, n0o = a.par_n ? 0 : n0;
             const int ooy = a.oo_y + (par >> 1), oox = a.oo_x + (par & 1);
             const TileRows otr = pipe_tile_rows<BM>(a, m0, dense, a.OHf, a.OWf, a.Cout, a.os, ooy, oox);
-            if constexpr (PL) pipe_epilogue_f32<MJ, NW>(a, otr, acc, g, m0, n0, wave, lane, ohw);
+            if constexpr (PL) {
+                if constexpr (MJ == 4 && NW == 2) {
+                    if (a.staged_out && otr.lin) pipe_epilogue_f32_staged(a, otr, acc, lds, g, n0, wave, lane);
+                    else pipe_epilogue_f32<MJ, NW>(a, otr, acc, g, m0, n0, wave, lane, ohw);
+                } else pipe_epilogue_f32<MJ, NW>(a, otr, acc, g, m0, n0, wave, lane, ohw);
+            }
             else if (a.residual) pipe_epilogue_staged<true, MJ, NW>(a, otr, acc, lds, g, m0, n0o, wave, lane, ohw, kstamp, ooy, oox);
             else pipe_epilogue_staged<false, MJ, NW>(a, otr, acc, lds, g, m0, n0o, wave, lane, ohw, kstamp, ooy, oox);
         }
@@ -1872,15 +1963,17 @@ __global__ __launch_bounds__(256) void conv_tap_w4_kernel(const ConvArgs a) {
 // compute the same sums in the same order (bit-identical); the setter exists so that one process can time a whole training step
 // under each (tools/ab_stream_form.sh).  Not an environment switch: the library reads no environment.
 static int g_stream_form = LOFT_STREAM_FORM_DEFAULT;
+static int g_f32_direct_epilogue = 0;       // (form bit 2: plane launches keep the direct, un-staged fp32 epilogue -- A/B of the round-6 form)
 LOFT_EXPORT int loft_conv_stream_form(int form) {
-    const int prev = g_stream_form;
-    if (form >= 0 && form <= 3) g_stream_form = form;
+    const int prev = g_stream_form | (g_f32_direct_epilogue << 2);
+    if (form >= 0 && form <= 7) { g_stream_form = form & 3; g_f32_direct_epilogue = (form >> 2) & 1; }
     return prev;
 }
 
 // host side: launched from loft_conv_tap_bf16_v (conv_mfma.hip).  Requires Cout % 256 == 0, Cin % 64 == 0, T <= 16.
 int loft_launch_conv_tap_pipe(const ConvArgs& a_in, int groups, int mode, int var, int mj, int nw_force, hipStream_t s, int ring32) {
     ConvArgs a = a_in;
+    if (a.nterms) a.staged_out = g_f32_direct_epilogue ? 0 : 1;      // plane launches: the LDS-staged fp32 epilogue of the 256 x 256 tile
     const bool w4 = ring32 == 2;                       // (2: the four-wave kernel, LOFT_CONV_W4)
     const bool xfirst = ring32 == 3 || ring32 == 5;    // (3: the activations-first stream schedule, LOFT_CONV_XFIRST)
     const bool lean = ring32 == 4 || ring32 == 5;      // (4: LOFT_CONV_LEAN, 5: LOFT_CONV_LEANX = LEAN + XFIRST)

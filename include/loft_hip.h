@@ -209,7 +209,8 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
 #define LOFT_CONV_LEANX 19        /* LOFT_CONV_LEAN + LOFT_CONV_XFIRST */
 /* The form of the two-stage 256 x 256 stream schedule the dispatcher itself launches: 0 round 2's, 1 LOFT_CONV_XFIRST, 2 LOFT_CONV_LEAN,
  * 3 LOFT_CONV_LEANX (tap-major launches keep 0 / 1).  loft_conv_stream_form(form) sets it process-wide and returns the previous value
- * (form < 0: query only) -- for same-box A/B runs of a whole step; results are bit-identical under every form. */
+ * (form < 0: query only) -- for same-box A/B runs of a whole step; results are bit-identical under every form.  form + 4: the
+ * operand-plane launches of the 256 x 256 tile keep the direct fp32 epilogue instead of the LDS-staged one (round 6; bit-identical too). */
 #define LOFT_STREAM_FORM_DEFAULT 2
 int loft_conv_stream_form(int form);
 #define LOFT_CONV_FLAG_NO_PIXMAJOR 0x100

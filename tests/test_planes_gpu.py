@@ -162,6 +162,51 @@ def test_conv_wgrad_planes_vs_fp64(B, cin, cout, k, s, p, hw, groups, planes_mod
     assert (db2 - db).abs().max().item() <= 2e-5 * want_b.abs().max().item()
 
 
+@pytest.mark.parametrize('B,cin,cout,k,s,p,hw,groups', [
+    (3, 64, 256, 3, 1, 1, 128, 1),      # dense map, 256-pixel tiles
+    (2, 128, 512, 1, 1, 0, 100, 1),     # two channel tiles, a row count that leaves a partial tile
+    (300, 64, 256, 3, 1, 1, 7, 2),      # pixel-major RoI maps, grouped, padding rows
+])
+def test_staged_fp32_epilogue_is_bit_identical_to_the_direct_one(B, cin, cout, k, s, p, hw, groups, planes_mode):
+    """Round 6: the 256 x 256 plane launches collect their fp32 tile in LDS and store whole rows (pipe_epilogue_f32_staged);
+    loft_conv_stream_form(form | 4) keeps the direct epilogue.  Same operations in the same order: forward with bias + residual +
+    ReLU and the data gradient with the ReLU-backward mask are torch.equal, and so is the absmax either launch leaves."""
+    from bonai_amd import kernels as K
+    from bonai_amd import lib as L
+    torch.manual_seed(B + cin + cout)
+    x = _cl(torch.randn(groups * B, cin, hw, hw) * 3.0)
+    w = torch.randn(groups, cout, cin, k, k) * 0.05
+    b = torch.randn(groups, cout).cuda()
+    oh = (hw + 2 * p - k) // s + 1
+    res = _cl(torch.randn(groups * B, cout, oh, oh))
+    wp = torch.stack([K.pack_w_fwd(w[i].cuda(), torch.float32) for i in range(groups)])
+    wpt = torch.stack([w[i].cuda().permute(2, 3, 1, 0).reshape(k * k, cin, cout).contiguous() for i in range(groups)])
+    libs = [L.load_for(torch.bfloat16), L.load_for(torch.float16)]
+    outs = []
+    prev = [lib.loft_conv_stream_form(-1) for lib in libs]
+    try:
+        for form in (2, 6):
+            for lib in libs:
+                lib.loft_conv_stream_form(form)
+            y = K.conv2d_fwd(x, wp, b, k, k, s, p, relu=True, residual=res, out_dtype=torch.float32, groups=groups)
+            o = [y, None if K._known_amax(y) is None else K._known_amax(y).clone()]
+            if cin % 128 == 0 or cin == 64:
+                g = _cl(torch.randn(groups * B, cout, oh, oh) * 1e-3)
+                if cin % 64 == 0 and cout % 64 == 0 and cin % 128 == 0:
+                    o.append(K.conv2d_dgrad(g, wpt, (hw, hw), k, k, s, p, mask=x, out_dtype=torch.float32, groups=groups))
+            outs.append(o)
+    finally:
+        for lib, f in zip(libs, prev):
+            lib.loft_conv_stream_form(f)
+    torch.cuda.synchronize()
+    assert len(outs[0]) == len(outs[1])
+    for a_, b_ in zip(outs[0], outs[1]):
+        if a_ is None or b_ is None:
+            assert a_ is None and b_ is None
+        else:
+            assert torch.equal(a_, b_)
+
+
 def test_planes_modes_fall_back_on_unsupported_shapes(planes_mode):
     """Channel counts the stream kernels do not serve take the SPLIT6 kernels, with the same answer."""
     from bonai_amd import kernels as K

@@ -16,7 +16,7 @@ W=5; K=20
 for mode in serial default; do
     rm -rf /tmp/prof_$mode
     if [ $mode = serial ]; then export LOFT_NO_SIDE_STREAM=1; else unset LOFT_NO_SIDE_STREAM; fi
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python "$ROOT/bench.py" --no-cpu-baseline --no-light \
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -- python "$ROOT/bench.py" --no-cpu-baseline --no-light \
         --no-fp32 --no-forced-comm --steps $K --warmup $W > "$OUT/bench_under_rocprof_$mode.json" 2> /dev/null
     f=$(find /tmp/prof_$mode -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$mode.csv"

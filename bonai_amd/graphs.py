@@ -88,7 +88,19 @@ class FeatureGraphs:
         # forks inside the graphs: HRNet's branches and the weight-gradient launches keep their own streams (parallel branches of
         # the captured graph; every fork is joined before the capture ends: HRModule joins its branches, the final UnpackQueue
         # flush waits for every weight-gradient launch)
-        self.side = [torch.cuda.Stream() for _ in range(4)]
+        # (streams come from a pool of 32, round robin: the capture stream and its four forks must be five DIFFERENT queues, and none
+        #  of them the queue of a stream the captured section uses for non-captured work -- kernels.h2d's upload stream re-draws itself)
+        seen = {stream.cuda_stream}
+        self.side = []
+        for _ in range(64):
+            st = torch.cuda.Stream()
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                self.side.append(st)
+            if len(self.side) == 4:
+                break
+        if len(self.side) < 4:
+            raise RuntimeError('could not draw four distinct side streams for the capture')
         # No cyclic-garbage collection while a stream is capturing: a collected cycle may own device objects (an older trainer's
         # CUDAGraphs, events, streams) whose destructors call HIP APIs the capture forbids -- the runtime aborts the process
         # (seen as "Fatal Python error: Aborted ... Garbage-collecting" inside extract_feat).  Collect now, pause the collector

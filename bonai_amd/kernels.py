@@ -9,6 +9,7 @@ in memory (SURVEY.md section 8b "Tensor conventions"), so reference checkpoints 
 keep their shapes while the kernels see channel-contiguous pixels.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -30,9 +31,20 @@ def h2d(values, dtype, device):
         # hipGraph capture (bonai_amd/graphs.py): a table uploaded inside a captured section holds addresses that are static
         # for the graph's lifetime, so it is uploaded ONCE, now, on a stream that is not capturing (no memcpy node, no pinned
         # buffer the replay would read again), and kept alive by the graph's owner.
+        # (torch hands out streams from a pool of 32 per device, round robin: a stream drawn long ago may be the SAME hardware queue
+        #  as the capture stream or one of its forks drawn now -- the upload would then be captured and the synchronize below is
+        #  illegal; seen in round 6 as "capturing stream has unjoined work" in one test order of the suite.  Draw until the stream
+        #  is not part of a capture.)
         global _H2D_STREAM
-        if _H2D_STREAM is None:
-            _H2D_STREAM = torch.cuda.Stream()
+        for _ in range(64):
+            if _H2D_STREAM is None:
+                _H2D_STREAM = torch.cuda.Stream()
+            with torch.cuda.stream(_H2D_STREAM):
+                if not torch.cuda.is_current_stream_capturing():
+                    break
+            _H2D_STREAM = None
+        else:
+            raise L.LoftHipError('no stream outside the running capture for a descriptor upload')
         with torch.cuda.stream(_H2D_STREAM):
             d = t.to(device)
         _H2D_STREAM.synchronize()
@@ -2076,6 +2088,8 @@ class UnpackQueue:
         tgt = slots[0].data_ptr() if slots[0] is not None else None
         if tgt is not None:
             if tgt in self._targets:
+                if os.environ.get('LOFT_DEBUG_TARGETS'):
+                    print('unpack queue: slot used twice in one batch ->', tuple(w.shape), 'jobs pending', len(self.jobs), flush=True)
                 self.flush()
             self._targets.add(tgt)
         self.jobs.append((dwp, db, w, bn, float(eps), slots, flat_chw, int(nsplit)))     # nsplit > 1: dwp = [nsplit][...] split-K slots

@@ -402,16 +402,37 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
                     }
                 }
             }
-        // ---- epilogue: lane holds pixel (ppy, ppx) and 2 x 4 x 4 consecutive channels
+        // ---- epilogue (round 6): the 256-pixel x 64-channel result is collected in the LDS rows of the halo it was computed from and
+        // leaves as whole 128-byte pixel rows (16 bytes per lane, 8 rows per wave-level store); the residual tile comes in the same
+        // way (global->LDS copies of whole rows), every lane adds its 8-byte pieces in fp32 and overwrites them with the result;
+        // the ReLU-backward mask is applied to the packed 16-bit values in the copy-out pass against 16-byte mask loads.  The direct
+        // form -- 8 bytes per lane to 32 different pixel rows per instruction, residual / mask read the same way -- cost more than
+        // the patch's 72 MFMAs per wave (config 5: 264 launches, 72.7 us each against a 22 us HBM floor).  Same operations in the
+        // same order on the same values: bit-identical to the direct form.
         const int b = p / (ptx * pty), rem = p - b * (ptx * pty);
-        const int y = (rem / ptx) * 16 + ppy, x = (rem % ptx) * 16 + ppx;
-        if (y < a.H && x < a.W) {
-            const long o0 = ((long)(b * a.H + y) * a.W + x) * 64;
+        const int y0p = (rem / ptx) * 16, x0p = (rem % ptx) * 16;
+        char* tb = const_cast<char*>(hb);               // tile [256 pixels][128 B]; 16-byte chunk c of row r at c ^ (r & 7)
+        __syncthreads();                                // every wave is done with this patch's halo rows
+        if (a.residual) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = (wave * 4 + k) * 8 + lrow;
+                const int y = y0p + (row >> 4), x = x0p + (row & 15);
+                const bf16_t* ptr = a.zero_page;
+                if (y < a.H && x < a.W) ptr = a.residual + ((long)(b * a.H + y) * a.W + x) * 64 + (pc ^ (row & 7)) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)ptr, (lds_ptr_t)(tb + (wave * 4 + k) * 8 * 128), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        {
+            const int r = ppy * 16 + ppx;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int n = i * 32 + 8 * gq + 4 * fq;
+                    bf16_t* q_ = reinterpret_cast<bf16_t*>(tb + r * 128 + (((i * 4 + gq) ^ (r & 7)) << 4) + fq * 8);
                     float v[4] = {acc[i][gq * 4 + 0], acc[i][gq * 4 + 1], acc[i][gq * 4 + 2], acc[i][gq * 4 + 3]};
                     if (a.bias) {
                         const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
@@ -419,7 +440,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
                     }
                     if (a.residual) {
                         float rv[4];
-                        ld4(a.residual + o0 + n, rv);
+                        ld4(q_, rv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rv[e];
                     }
@@ -427,14 +448,37 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-                    if (a.mask) {
-                        float mv[4];
-                        ld4(a.mask + o0 + n, mv);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
-                    }
-                    st4(a.out + o0 + n, v);
+                    st4(q_, v);
                 }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            // keep a 16-bit lane where its mask value is > 0: sign bit clear and magnitude bits non-zero
+            auto sel = [](unsigned vv, unsigned mm) {
+                const unsigned lo16 = ((mm & 0x8000u) == 0u && (mm & 0x7fffu) != 0u) ? 0xffffu : 0u;
+                const unsigned hi16 = ((mm & 0x80000000u) == 0u && (mm & 0x7fff0000u) != 0u) ? 0xffff0000u : 0u;
+                return vv & (lo16 | hi16);
+            };
+            uint4 val[4], mk[4];
+            long off[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = (wave * 4 + k) * 8 + lrow;
+                const int y = y0p + (row >> 4), x = x0p + (row & 15);
+                ok[k] = y < a.H && x < a.W;
+                off[k] = ((long)(b * a.H + y) * a.W + x) * 64 + (pc ^ (row & 7)) * 8;
+                val[k] = *reinterpret_cast<const uint4*>(tb + row * 128 + pc * 16);
+                if (a.mask && ok[k]) mk[k] = *reinterpret_cast<const uint4*>(a.mask + off[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!ok[k]) continue;
+                uint4 o = val[k];
+                if (a.mask) { o.x = sel(o.x, mk[k].x); o.y = sel(o.y, mk[k].y); o.z = sel(o.z, mk[k].z); o.w = sel(o.w, mk[k].w); }
+                *reinterpret_cast<uint4*>(a.out + off[k]) = o;
+            }
         }
     }
 }

@@ -385,23 +385,51 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // Fragments of tap t + 1 are requested BEFORE the MFMAs of tap t (round 6): in the straight form -- read, wait, multiply --
+        // hipcc waited `lgkmcnt(0)` in front of nearly every MFMA (98 waits for 72 MFMAs in the ISA), i.e. an LDS round trip of
+        // ~120 cycles per 32-cycle MFMA: 72 us per 8 x 256^2 launch against 18 us of matrix time and a 22 us HBM floor.  Twelve
+        // 16-byte fragments per tap and set (4 activation + 8 weight), two sets; same MFMA order: bit-identical.
+        bf16x8 xfr[2][4], wfr[2][8];
+        auto rd_tap = [&](int t, auto setc) {
+            constexpr int S_ = decltype(setc)::value;
+            const int hr = (ppy + 1 + a.dy[t]) * HW_ + ppx + 1 + a.dx[t];
+            const int wr = a.wt[t] * 64 + frow;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            if (t < a.T) {
-                const int hr = (ppy + 1 + a.dy[t]) * HW_ + ppx + 1 + a.dx[t];
-                const int wr = a.wt[t] * 64 + frow;
+            for (int ks = 0; ks < 4; ++ks) {
+                const int q = ks * 2 + fq;
+                xfr[S_][ks] = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ (hr & 7)) << 4));
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int q = ks * 2 + fq;
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ (hr & 7)) << 4));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int wri = wr + i * 32;
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
-                        acc[i] = LOFT_MFMA_32x32x16(wf, xf, acc[i]);
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    const int wri = wr + i * 32;
+                    wfr[S_][ks * 2 + i] = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
                 }
             }
+        };
+        auto mm_tap = [&](auto setc) {
+            constexpr int S_ = decltype(setc)::value;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = LOFT_MFMA_32x32x16(wfr[S_][ks * 2 + i], xfr[S_][ks], acc[i]);
+        };
+        using s0_t = std::integral_constant<int, 0>;
+        using s1_t = std::integral_constant<int, 1>;
+        rd_tap(0, s0_t{});
+#pragma unroll
+        for (int t = 0; t < 9; t += 2) {
+            if (t < a.T) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < a.T) rd_tap(t + 1, s1_t{});
+                __builtin_amdgcn_sched_barrier(0);
+                mm_tap(s0_t{});
+            }
+            if (t + 1 < a.T) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < a.T) rd_tap(t + 2, s0_t{});
+                __builtin_amdgcn_sched_barrier(0);
+                mm_tap(s1_t{});
+            }
+        }
         // ---- epilogue (round 6): the 256-pixel x 64-channel result is collected in the LDS rows of the halo it was computed from and
         // leaves as whole 128-byte pixel rows (16 bytes per lane, 8 rows per wave-level store); the residual tile comes in the same
         // way (global->LDS copies of whole rows), every lane adds its 8-byte pieces in fp32 and overwrites them with the result;

@@ -332,7 +332,8 @@ void conv_tap_kernel(const ConvArgs a) {
 // ALL taps (T x 64 x 64 bf16 = 72 KiB) stay in LDS for the lifetime of a persistent workgroup, which walks 16 x 16-PIXEL PATCHES:
 // the 18 x 18 halo of a 16 x 16 patch (41 KiB, double-buffered: 154 KiB of LDS in all, one workgroup per CU) is staged once and
 // every tap reads its shifted rows from it -- one round trip per 72 MFMAs per wave, hidden behind the previous patch.
-// 8 waves: wave w -> patch rows 2w, 2w+1 (32 pixels) x all 64 output channels.  128-byte LDS rows, 16-byte chunk q of row r at q ^ (r & 7) (32 lanes read 32 consecutive rows).
+// 8 waves: wave w -> patch rows 2w, 2w+1 (32 pixels) x all 64 output channels.  128-byte LDS rows, 16-byte chunk q of row r at
+// q ^ ((r >> 1) & 7) (round 6: with q ^ (r & 7) the sixteen rows of a ds_read_b128 lane group hit eight slots twice).
 // Epilogue as the tap kernels: bias, residual, ReLU, ReLU-backward mask, bf16 store (8 bytes per lane).
 // =====================================================================================
 struct Conv64Args {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
     // ---- all taps' weights, once
     for (int r8 = wave; r8 < a.T * 8; r8 += 8) {       // 8 rows per wave-level copy
         const int row = r8 * 8 + lrow;
-        const int q = pc ^ (row & 7);
+        const int q = pc ^ ((row >> 1) & 7);      // (16 consecutive rows -> 16 different 16-byte slots of the 256-byte bank row)
         __builtin_amdgcn_global_load_lds((gptr_t)(a.wgt + (long)row * 64 + q * 8), (lds_ptr_t)(wl + r8 * 8 * 128), 16, 0, 0);
     }
     auto stage = [&](int p, int buf) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
         const int y0 = (rem / ptx) * 16, x0 = (rem % ptx) * 16;
         for (int slot = wave; slot < SLOTS; slot += 8) {
             const int row = slot * 8 + lrow;
-            const int q = pc ^ (row & 7);
+            const int q = pc ^ ((row >> 1) & 7);      // (16 consecutive rows -> 16 different 16-byte slots of the 256-byte bank row)
             const int hy = row / HW_, hx = row - hy * HW_;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bf16_t* ptr = a.zero_page;
@@ -397,11 +398,11 @@ __global__ __launch_bounds__(512) void conv64_patch_kernel(const Conv64Args a, i
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int q = ks * 2 + fq;
-                xfr[S_][ks] = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ (hr & 7)) << 4));
+                xfr[S_][ks] = *reinterpret_cast<const bf16x8*>(hb + hr * 128 + ((q ^ ((hr >> 1) & 7)) << 4));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int wri = wr + i * 32;
-                    wfr[S_][ks * 2 + i] = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ (wri & 7)) << 4));
+                    wfr[S_][ks * 2 + i] = *reinterpret_cast<const bf16x8*>(wl + wri * 128 + ((q ^ ((wri >> 1) & 7)) << 4));
                 }
             }
         };

@@ -837,6 +837,40 @@ def bottleneck_tail(t1, wp2, b2, wp3, b3, shortcut, wpd=None, bd=None):
     return out
 
 
+def bneck_pair_ok(a_in, C):
+    """Shapes loft_bneck_pair_bf16 serves: a_in [B,P,H,W] channels_last 16-bit with P in {128, 256}, B*H*W % 128 == 0, C % 128 == 0."""
+    B, P, H, W = a_in.shape
+    return (a_in.is_cuda and a_in.dtype == L.act16() and P in (128, 256) and (B * H * W) % 128 == 0 and C % 128 == 0 and C >= 128
+            and PROFILE is None)
+
+
+def bneck_pair(a_in, w1, bias1, res, w2, bias2, mask1=None, mask2=None, variant=0):
+    """End of bottleneck k + start of bottleneck k+1 in one launch (loft_bneck_pair_bf16; see include/loft_hip.h).
+    forward:  a_in = t2_k [B,P,H,W], w1 [..,C,P] / bias1 [..,C] = conv3_k (BN folded), res = the shortcut [B,C,H,W],
+              w2 [..,P,C] / bias2 [..,P] = conv1_{k+1}  ->  (out_k [B,C,H,W], t1_{k+1} [B,P,H,W])
+    backward: a_in = d t1_{k+1}, w1 = conv1_{k+1}'s data-gradient packing [..,C,P], res = the shortcut's gradient, mask1 = out_k,
+              w2 = conv3_k's data-gradient packing [..,P,C], mask2 = t2_k, no biases  ->  (d out_k, d t2_k), both masked."""
+    lib = L.load()
+    a_in, res = _nhwc(a_in), _nhwc(res)
+    B, P, H, W = a_in.shape
+    C = res.shape[1]
+    L.dev_check(a_in, w1, res, w2, mask1, mask2)
+    _bf16(a_in), _bf16(w1), _bf16(res), _bf16(w2)
+    if tuple(w1.shape[-2:]) != (C, P) or tuple(w2.shape[-2:]) != (P, C) or tuple(res.shape) != (B, C, H, W) \
+            or not (w1.is_contiguous() and w2.is_contiguous()):
+        raise L.LoftHipError(f'bneck_pair: shapes {tuple(a_in.shape)} {tuple(w1.shape)} {tuple(res.shape)} {tuple(w2.shape)}')
+    if mask1 is not None:
+        mask1, mask2 = _nhwc(mask1), _nhwc(mask2)
+        _bf16(mask1), _bf16(mask2)
+        if tuple(mask1.shape) != (B, C, H, W) or tuple(mask2.shape) != (B, P, H, W):
+            raise L.LoftHipError(f'bneck_pair: mask shapes {tuple(mask1.shape)} {tuple(mask2.shape)}')
+    mid = empty_nhwc(B, C, H, W, L.act16(), a_in.device)
+    out2 = empty_nhwc(B, P, H, W, L.act16(), a_in.device)
+    L.check(lib.loft_bneck_pair_bf16_v(L.ptr(a_in), L.ptr(w1), L.ptr(bias1), L.ptr(res), L.ptr(mask1), L.ptr(mid), L.ptr(w2), L.ptr(bias2),
+                                       L.ptr(mask2), L.ptr(out2), c_int64(B * H * W), P, C, int(variant), L.stream()), 'loft_bneck_pair_bf16')
+    return mid, out2
+
+
 def conv2d_dgrad(g, wpt, in_hw, R, S, stride=1, pad=0, residual=None, out_dtype=None, groups=1,
                  out=None, accumulate=False, mask=None):
     """g [G*B,Cout,OH,OW] channels_last bf16, wpt [G][R*S,Cin,Cout] -> grad of the conv input [G*B,Cin,IH,IW]."""

@@ -184,6 +184,28 @@ int loft_conv_tap_bf16(const void* src, const void* wgt, const float* bias, cons
 int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const void* w3, const float* b3, const void* shortcut,
                          const void* wd, const float* bd, void* out, const void* zero_page, int B, int H, int W, const int* dy_host,
                          const int* dx_host, const int* wt_host, void* stream);
+/* Two consecutive 1x1 convolutions of a ResNet stage in one launch (mmdet/models/backbones/resnet.py:266-298, Bottleneck.forward):
+ * the END of block k (`out = self.conv3(out); out = self.norm3(out); out += identity; out = self.relu(out)`) and the BEGINNING of
+ * block k+1 (`out = self.conv1(x); out = self.norm1(out); out = self.relu(out)`), so that the block output -- the widest map of
+ * the stage -- is written to HBM once and NOT read back as conv1's operand (bneck_pair.hip).  All maps are [M][channels] rows
+ * (NHWC with M = B*H*W, M % 128 == 0), P in {128, 256} planes, C % 128 == 0 (C = 4 P in ResNet):
+ *   forward  (mask1 == NULL):  mid [M][C] = relu(w1 . a_in + bias1 + res),  out2 [M][P] = relu(w2 . mid + bias2)
+ *                              a_in = t2_k [M][P], w1 = conv3_k forward packing [C][P], res = block k's shortcut [M][C],
+ *                              w2 = conv1_{k+1} forward packing [P][C]; mid = out_k, out2 = t1_{k+1}; both biases required.
+ *   backward (mask1 != NULL):  mid = (w1 . a_in + res) where mask1 > 0 else 0,  out2 = (w2 . mid) where mask2 > 0 else 0
+ *                              a_in = d t1_{k+1} [M][P], w1 = conv1_{k+1} data-gradient packing [C][P], res = the gradient arriving
+ *                              over block k+1's identity shortcut [M][C], mask1 = out_k, w2 = conv3_k data-gradient packing [P][C],
+ *                              mask2 = t2_k [M][P]; mid = d out_k, out2 = d t2_k; no biases, both masks required.
+ * Rounding points as in the separate launches (mid, out2 in the 16-bit type, fp32 accumulation, the second product reads the rounded
+ * mid); fp32 summation ORDER differs, so results agree with the separate launches to that order, not bit for bit.
+ * Anything else (shape, missing operand) returns hipErrorInvalidValue (1) and launches nothing. */
+int loft_bneck_pair_bf16(const void* a_in, const void* w1, const float* bias1, const void* res, const void* mask1, void* mid,
+                         const void* w2, const float* bias2, const void* mask2, void* out2, int64_t M, int P, int C, void* stream);
+/* The same with a timing-ablation code (variant != 0: forward P = 256 instance with parts of the work removed -- RESULTS WRONG;
+ * bneck_pair.hip ABL; tools/probes/pair_time.py).  variant 0 = loft_bneck_pair_bf16. */
+int loft_bneck_pair_bf16_v(const void* a_in, const void* w1, const float* bias1, const void* res, const void* mask1, void* mid,
+                           const void* w2, const float* bias2, const void* mask2, void* out2, int64_t M, int P, int C, int variant,
+                           void* stream);
 /* The same with the kernel chosen by the caller instead of the shape heuristics (tests pin every template the bench
  * dispatches; A/B timing).  variant = one LOFT_CONV_* kernel code, optionally OR-ed with LOFT_CONV_FLAG_*; LOFT_CONV_AUTO is
  * loft_conv_tap_bf16.  A kernel that cannot serve the shape returns hipErrorInvalidValue (1). */

@@ -15,8 +15,9 @@
 // mask2 = t2_k: mid = the gradient of out_k (masked), out2 = the gradient of t2_k (masked).
 //
 // Rounding points are those of the separate launches (mid and out2 pass through the 16-bit type; fp32 accumulation; the second
-// product reads the ROUNDED mid); the fp32 summation order inside a product differs (K runs in 64-wide groups whose halves are
-// interleaved, see "K order"), so results agree with the separate launches to fp32 summation order, not bit for bit.
+// product reads the ROUNDED mid) and so is the order of the fp32 operations (K ascending in steps of 16, then + bias, then +
+// residual -- the latter as an exact x 1.0 product on the matrix pipe): the outputs are BIT-IDENTICAL to the separate launches
+// (tests/test_bneck_pair_gpu.py).
 //
 // Structure.  256 threads = 4 waves, ONE per SIMD with the whole 512-register file (no weight staging in LDS, no barrier in a K
 // loop): wave w owns channels [32 w, +32) of every chunk in product 1 and channels [P/4 w, +P/4) of product 2, all 128 pixels.
@@ -26,9 +27,11 @@
 // fire-and-forget.  The pixel operand (B) is read from LDS with ds_read_b128: a_in tile [128][P], chunk buffers 2 x [128][128].
 // LDS rows are a multiple of 256 B, 16-byte chunk c of row r at position c ^ (r & 15): fragment reads (32 consecutive rows, one
 // chunk) and the epilogue's 8-byte read-modify-writes are conflict-free per 16 lanes.
-// K order: a lane of the A operand holds 32 CONSECUTIVE K values of its row (64 contiguous bytes of the [rows][K] packing: whole
-// 128-byte lines per 32-row fragment group instead of 32-byte pieces); MFMA step s of group u multiplies K = 64u + 8s + [0,8) on
-// lanes 0-31 with K = 64u + 32 + 8s + [0,8) on lanes 32-63, and the B fragments are read with the same map.
+// Weight layout "K8": [K/8][rows][8] (loft_pack_k8_multi re-arranges the [rows][K] packings once per step).  An A fragment = lane
+// (row m, half g) <- 16 bytes at K block 2 step + g, row m: lanes 0-31 and 32-63 each read 512 CONTIGUOUS bytes.  From the
+// [rows][K] packing the same fragment is 64 pieces of 16 bytes 512 bytes apart: the address unit then spent ~64 cycles per load
+// instruction and the weight stream alone cost 19 of 65 us per layer3 pair (profiles/round6_probes/pair_time_v2.txt).  K runs in
+// its natural order, 16 per MFMA step.
 // Roofline: HBM (a_in + res + mid + out2 [+ mask1 + mask2]: 168 MB forward / 252 MB backward per layer3 pair at batch 8).
 #include "conv_tap.h"
 #include "../../include/loft_hip.h"
@@ -37,12 +40,12 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (a plain vector: arrays of HIP's uint4 STRUCT stayed in scratch)
 struct PairArgs {
     const bf16_t* a_in;     // [M][P]
-    const bf16_t* w1;       // [C][P]   rows = channels of mid, K = P
+    const bf16_t* w1;       // K8 layout of [C][P] (rows = channels of mid, K = P): [P/8][C][8]
     const float* bias1;     // [C] | null
     const bf16_t* res;      // [M][C] | null
     const bf16_t* mask1;    // [M][C] | null   (BWD)
     bf16_t* mid;            // [M][C]
-    const bf16_t* w2;       // [P][C]   rows = channels of out2, K = C
+    const bf16_t* w2;       // K8 layout of [P][C] (rows = channels of out2, K = C): [C/8][P][8]
     const float* bias2;     // [P] | null
     const bf16_t* mask2;    // [M][P] | null   (BWD)
     bf16_t* out2;           // [M][P]
@@ -59,6 +62,12 @@ struct PairArgs {
         asm volatile("" ::: "memory");                       \
     } while (0)
 
+// ReLU of two packed 16-bit floats: a negative value has its sign bit set = is negative as an int16 (bfloat16 and binary16 alike)
+typedef __attribute__((ext_vector_type(2))) short pair_s16x2;
+__device__ __forceinline__ uint32_t pair_relu2(uint32_t w) {
+    const pair_s16x2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pair_s16x2, w), z));
+}
 __device__ __forceinline__ u32x4 pair_mask16(const u32x4 v, const u32x4 m) {
     u32x4 o;
 #pragma unroll
@@ -113,12 +122,21 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
     // weights of product 1, chunk 0
     bf16x8 w1r[KG1][4], w2r[NT2][2][4];
     {
-        const bf16_t* wp = a.w1 + (long)(32 * wave + frow) * P + 32 * fq;
+        const bf16_t* wp = a.w1 + ((long)fq * C + 32 * wave + frow) * 8;
 #pragma unroll
         for (int u = 0; u < KG1; ++u)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) w1r[u][s] = *reinterpret_cast<const bf16x8*>(wp + 64 * u + 8 * s);
+            for (int s = 0; s < 4; ++s) w1r[u][s] = *reinterpret_cast<const bf16x8*>(wp + (long)(2 * (4 * u + s)) * C * 8);
     }
+    // identity fragments (A operand, rows = the wave's 32 channels): step sr covers K = 16 sr + 8 fq + [0, 8)
+    bf16x8 idA[2];
+#pragma unroll
+    for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) idA[sr][e] = (16 * sr + 8 * fq + e == frow) ? (short)LOFT_ONE16 : (short)0;
+    bf16x8 ones3;                         // B operand of the bias step: K slots 0..2 of lanes 0-31 hold 1.0
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones3[e] = (e < 3 && fq == 0) ? (short)LOFT_ONE16 : (short)0;
     f32x16 acc2[NT2][4];
 #pragma unroll
     for (int i = 0; i < NT2; ++i)
@@ -130,7 +148,18 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
 
     for (int j = 0; j < nch; ++j) {
         char* const buf = cbuf + (j & 1) * 32768;
-        // (1) residual chunk j -> LDS; request residual chunk j+1
+        // (1) request the weights of product 2, chunk j -- BEFORE the HBM loads below: vmcnt retires in order, and a wait for these
+        // L2 hits must not stand behind residual pieces that come from HBM
+        if (!(ABL & 32) || j == 0) {
+            const bf16_t* wp = a.w2 + ((long)(16 * j + fq) * P + 32 * NT2 * wave + frow) * 8;
+#pragma unroll
+            for (int i = 0; i < NT2; ++i)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) w2r[i][u][s] = *reinterpret_cast<const bf16x8*>(wp + ((long)(2 * (4 * u + s)) * P + 32 * i) * 8);
+        }
+        // (2) residual chunk j -> LDS; request residual chunk j+1
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = pr0 + 16 * i;
@@ -142,55 +171,46 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
             for (int i = 0; i < 8; ++i)
                 rreg[i] = *reinterpret_cast<const u32x4*>(a.res + (m0 + pr0 + 16 * i) * C + 128 * jn + pc0 * 8);
         }
-        // (2) request the weights of product 2, chunk j
-        if (!(ABL & 32) || j == 0) {
-            const bf16_t* wp = a.w2 + (long)(32 * NT2 * wave + frow) * C + 128 * j + 32 * fq;
-#pragma unroll
-            for (int i = 0; i < NT2; ++i)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) w2r[i][u][s] = *reinterpret_cast<const bf16x8*>(wp + (long)32 * i * C + 64 * u + 8 * s);
-        }
         float4 b1v[4];
+#ifdef LOFT_ACT_F16
         if constexpr (!BWD) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) b1v[gq] = *reinterpret_cast<const float4*>(a.bias1 + 128 * j + 32 * wave + 8 * gq + 4 * fq);
         }
+#endif
         // (3) product 1: mid chunk [32 channels of this wave][128 pixels], K = P
-        f32x16 acc1[4];
+        f32x16 acc1[4], c0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[t][e] = 0.f;
+        for (int e = 0; e < 16; ++e) c0[e] = 0.f;
         {
             // (one wave per SIMD: nothing else hides the LDS round trip, so step st + 1's fragments are requested before step st's MFMAs)
             bf16x8 bfr[2][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                bfr[0][t] = *reinterpret_cast<const bf16x8*>(opA + (32 * t + frow) * ROWB + (((4 * fq) ^ (frow & 15)) << 4));
+                bfr[0][t] = *reinterpret_cast<const bf16x8*>(opA + (32 * t + frow) * ROWB + ((fq ^ (frow & 15)) << 4));
 #pragma unroll
             for (int st = 0; st < 4 * KG1; ++st) {
                 if (st + 1 < 4 * KG1) {
-                    const int un = (st + 1) >> 2, sn = (st + 1) & 3;
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         bfr[(st + 1) & 1][t] =
-                            *reinterpret_cast<const bf16x8*>(opA + (32 * t + frow) * ROWB + (((8 * un + 4 * fq + sn) ^ (frow & 15)) << 4));
+                            *reinterpret_cast<const bf16x8*>(opA + (32 * t + frow) * ROWB + (((2 * (st + 1) + fq) ^ (frow & 15)) << 4));
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if constexpr (!(ABL & 1)) acc1[t] = LOFT_MFMA_32x32x16(w1r[st >> 2][st & 3], bfr[st & 1][t], acc1[t]);
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (!(ABL & 1)) acc1[t] = LOFT_MFMA_32x32x16(w1r[st >> 2][st & 3], bfr[st & 1][t], st == 0 ? c0 : acc1[t]);
+                    else if (st == 0) acc1[t] = c0;
+                }
             }
         }
         // (4) request the weights of product 1, chunk j+1 (their registers are free now)
         if constexpr (!(ABL & 32)) {
             const int jn = j + 1 < nch ? j + 1 : j;
-            const bf16_t* wp = a.w1 + (long)(128 * jn + 32 * wave + frow) * P + 32 * fq;
+            const bf16_t* wp = a.w1 + ((long)fq * C + 128 * jn + 32 * wave + frow) * 8;
 #pragma unroll
             for (int u = 0; u < KG1; ++u)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) w1r[u][s] = *reinterpret_cast<const bf16x8*>(wp + 64 * u + 8 * s);
+                for (int s = 0; s < 4; ++s) w1r[u][s] = *reinterpret_cast<const bf16x8*>(wp + (long)(2 * (4 * u + s)) * C * 8);
         }
         if constexpr (BWD) {              // mask chunk j: requested here (product 1's registers are at their peak before), used in (6)
 #pragma unroll
@@ -198,26 +218,60 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
                 mreg[i] = *reinterpret_cast<const u32x4*>(a.mask1 + (m0 + pr0 + 16 * i) * C + 128 * j + pc0 * 8);
         }
         PAIR_SYNC();                      // B1: every thread's residual pieces of chunk j are in LDS
-        // (5) epilogue 1 in place: bias + residual + ReLU, rounded to the 16-bit type -- the B operand of product 2
+        // (5) the residual enters through the matrix pipe: acc += I . res (two K = 16 steps with identity fragments as the A operand, the
+        // residual rows as B fragments: bf16 x 1.0 accumulated in fp32 is exact) -- 8 MFMAs instead of 16 LDS reads, 32 unpacks and
+        // 64 adds per lane.  This wave alone reads and writes channels [32 wave, +32) of the chunk buffer: no barrier in between.
+        if constexpr (!(ABL & 16)) {
+            // (operation order of the separate launches' epilogue -- products, + bias, + residual, ReLU, one rounding -- so that the
+            //  fused pair is BIT-IDENTICAL to them: the bias is added to the FINISHED sums.  bfloat16 build: on the matrix pipe as
+            //  well -- the fp32 bias is the exact sum of three bfloat16 pieces (8 + 8 + 8 significant bits), one K step with
+            //  A = [hi, mid, lo, 0 ..] per channel row and B = [1, 1, 1, 0 ..] adds it with a single rounding; as 64 VALU adds plus
+            //  the accumulators' trip through the VALU registers it cost 6 of 61 us per layer3 pair.  binary16 build: VALU.)
+            if constexpr (!BWD) {
+#ifndef LOFT_ACT_F16
+                const float b = a.bias1[128 * j + 32 * wave + frow];
+                const float h0 = bf16_to_f32(f32_to_bf16(b)), r1 = b - h0, h1 = bf16_to_f32(f32_to_bf16(r1)), r2 = r1 - h1;
+                bf16x8 bA;
 #pragma unroll
-        for (int t = 0; t < ((ABL & 16) ? 0 : 4); ++t) {
-            const int px = 32 * t + frow;
+                for (int e = 0; e < 8; ++e) bA[e] = 0;
+                bA[0] = fq ? (short)0 : (short)f32_to_bf16(h0);
+                bA[1] = fq ? (short)0 : (short)f32_to_bf16(h1);
+                bA[2] = fq ? (short)0 : (short)f32_to_bf16(r2);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                char* p = buf + px * 256 + (((4 * wave + gq) ^ (px & 15)) << 4) + 8 * fq;
-                float v[4];
+                for (int t = 0; t < 4; ++t) acc1[t] = LOFT_MFMA_32x32x16(bA, ones3, acc1[t]);
+#else
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc1[t][4 * gq + e];
-                if constexpr (!BWD) { v[0] += b1v[gq].x; v[1] += b1v[gq].y; v[2] += b1v[gq].z; v[3] += b1v[gq].w; }
-                float rv[4];
-                ld4(reinterpret_cast<const bf16_t*>(p), rv);
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                if constexpr (!BWD) {
+                    for (int gq = 0; gq < 4; ++gq) {
+                        acc1[t][4 * gq] += b1v[gq].x; acc1[t][4 * gq + 1] += b1v[gq].y;
+                        acc1[t][4 * gq + 2] += b1v[gq].z; acc1[t][4 * gq + 3] += b1v[gq].w;
+                    }
+#endif
+            }
+            bf16x8 rfr[2][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    rfr[sr][t] = *reinterpret_cast<const bf16x8*>(buf + (32 * t + frow) * 256 + (((4 * wave + 2 * sr + fq) ^ (frow & 15)) << 4));
+#pragma unroll
+            for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc1[t] = LOFT_MFMA_32x32x16(idA[sr], rfr[sr][t], acc1[t]);
+            // epilogue 1: (ReLU,) round to the 16-bit type, in place -- the B operand of product 2
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int px = 32 * t + frow;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    char* p = buf + px * 256 + (((4 * wave + gq) ^ (px & 15)) << 4) + 8 * fq;
+                    uint2 w;
+                    w.x = pack2_bf16(acc1[t][4 * gq], acc1[t][4 * gq + 1]);
+                    w.y = pack2_bf16(acc1[t][4 * gq + 2], acc1[t][4 * gq + 3]);
+                    if constexpr (!BWD) { w.x = pair_relu2(w.x); w.y = pair_relu2(w.y); }
+                    *reinterpret_cast<uint2*>(p) = w;
                 }
-                st4(reinterpret_cast<bf16_t*>(p), v);
             }
         }
         PAIR_SYNC();                      // B2: the chunk is complete
@@ -240,15 +294,14 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
             bf16x8 bfr[2][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                bfr[0][t] = *reinterpret_cast<const bf16x8*>(buf + (32 * t + frow) * 256 + (((4 * fq) ^ (frow & 15)) << 4));
+                bfr[0][t] = *reinterpret_cast<const bf16x8*>(buf + (32 * t + frow) * 256 + ((fq ^ (frow & 15)) << 4));
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (st + 1 < 8) {
-                    const int un = (st + 1) >> 2, sn = (st + 1) & 3;
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         bfr[(st + 1) & 1][t] =
-                            *reinterpret_cast<const bf16x8*>(buf + (32 * t + frow) * 256 + (((8 * un + 4 * fq + sn) ^ (frow & 15)) << 4));
+                            *reinterpret_cast<const bf16x8*>(buf + (32 * t + frow) * 256 + (((2 * (st + 1) + fq) ^ (frow & 15)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < NT2; ++i)
@@ -300,6 +353,18 @@ __global__ __launch_bounds__(256) void bneck_pair_kernel(const PairArgs a) {
     }
 }
 
+// [R][K] -> [K/8][R][8], `n` matrices per launch (blockIdx.y): desc[i] = {src, dst, R, K}
+__global__ __launch_bounds__(256) void pack_k8_multi_kernel(const long* __restrict__ desc) {
+    const long* d = desc + 4 * blockIdx.y;
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(d[0]);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(d[1]);
+    const long R = d[2], K8 = d[3] >> 3;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < R * K8; i += (long)gridDim.x * 256) {
+        const long kb = i / R, r = i - kb * R;             // consecutive threads: consecutive rows of one K block (contiguous 16-byte stores)
+        *reinterpret_cast<u32x4*>(dst + i * 8) = *reinterpret_cast<const u32x4*>(src + (r * K8 + kb) * 8);
+    }
+}
+
 template <int P, bool BWD, int ABL = 0>
 int pair_launch(const PairArgs& pa, hipStream_t s) {
     const int lds_bytes = 128 * 2 * P + 65536;
@@ -314,6 +379,15 @@ int pair_launch(const PairArgs& pa, hipStream_t s) {
     return 0;
 }
 }  // namespace
+
+LOFT_EXPORT int loft_pack_k8_multi(const int64_t* desc, int n, int64_t max_pieces, void* stream) {
+    if (n <= 0 || max_pieces <= 0) return 0;
+    long nb = (max_pieces + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(pack_k8_multi_kernel, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, (hipStream_t)stream, (const long*)desc);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
 
 LOFT_EXPORT int loft_bneck_pair_bf16_v(const void* a_in, const void* w1, const float* bias1, const void* res, const void* mask1, void* mid,
                                        const void* w2, const float* bias2, const void* mask2, void* out2, int64_t M, int P, int C, int variant,

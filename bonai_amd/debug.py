@@ -47,6 +47,8 @@ SWITCHES = {
     'no_linear_fn': 'Linear layers through the generic conv node',
     'no_bneck_fusion': 'the frozen / inference 64-plane bottleneck as three (four) tap-conv launches instead of conv1 + the fused tail '
                        '(loft_bneck_tail_bf16: 3x3 + 1x1 expansion + shortcut + ReLU in one launch)',
+    'no_pair_fusion': 'the last 1x1 of bottleneck k and the first 1x1 of bottleneck k+1 (layer2 / layer3) as two launches each way instead '
+                      'of one (loft_bneck_pair_bf16: the block output is written once and not re-read as the next conv1\'s operand)',
     'wgrad_no_patch': 'the tap weight-gradient kernel for 64-channel high-resolution layers (no patch kernel)',
     'roi_fp32_bwd': 'RoIAlign backward into fp32 maps + a cast',
     'roi_sort': 'RoIAlign forward workgroups in (image, level, row strip) launch order for lists of >= 256 RoIs (loft_roi_order; '

@@ -844,21 +844,38 @@ def bneck_pair_ok(a_in, C):
             and PROFILE is None)
 
 
-def bneck_pair(a_in, w1, bias1, res, w2, bias2, mask1=None, mask2=None, variant=0):
-    """End of bottleneck k + start of bottleneck k+1 in one launch (loft_bneck_pair_bf16; see include/loft_hip.h).
-    forward:  a_in = t2_k [B,P,H,W], w1 [..,C,P] / bias1 [..,C] = conv3_k (BN folded), res = the shortcut [B,C,H,W],
-              w2 [..,P,C] / bias2 [..,P] = conv1_{k+1}  ->  (out_k [B,C,H,W], t1_{k+1} [B,P,H,W])
-    backward: a_in = d t1_{k+1}, w1 = conv1_{k+1}'s data-gradient packing [..,C,P], res = the shortcut's gradient, mask1 = out_k,
-              w2 = conv3_k's data-gradient packing [..,P,C], mask2 = t2_k, no biases  ->  (d out_k, d t2_k), both masked."""
+def pack_k8(mats, outs=None, desc=None):
+    """16-bit matrices [.., R, K] -> their K8 layouts [K/8, R, 8] (loft_pack_k8_multi: one launch for all of them).
+    outs / desc: the buffers and the device descriptor table of a previous call on the SAME tensors (PrepackRegistry.run)."""
+    lib = L.load()
+    if outs is None:
+        outs = [torch.empty(m.shape[-1] // 8, m.shape[-2], 8, dtype=m.dtype, device=m.device) for m in mats]
+    if desc is None:
+        for m in mats:
+            L.dev_check(m)
+            if m.shape[-1] % 8 or not m.is_contiguous() or m.numel() != m.shape[-1] * m.shape[-2] or m.dtype != L.act16():
+                raise L.LoftHipError(f'pack_k8: {tuple(m.shape)} {m.dtype}')
+        desc = h2d([[m.data_ptr(), o.data_ptr(), m.shape[-2], m.shape[-1]] for m, o in zip(mats, outs)], torch.int64, mats[0].device)
+    L.check(lib.loft_pack_k8_multi(L.ptr(desc), len(mats), c_int64(max(m.numel() // 8 for m in mats)), L.stream()), 'loft_pack_k8_multi')
+    return outs, desc
+
+
+def bneck_pair(a_in, w1k8, bias1, res, w2k8, bias2, mask1=None, mask2=None, variant=0):
+    """End of bottleneck k + start of bottleneck k+1 in one launch (loft_bneck_pair_bf16; see include/loft_hip.h).  Weights in the
+    K8 layout (pack_k8 / PrepackRegistry.k8) of the usual packings:
+    forward:  a_in = t2_k [B,P,H,W], w1k8 [P/8,C,8] / bias1 [..,C] = conv3_k (BN folded), res = the shortcut [B,C,H,W],
+              w2k8 [C/8,P,8] / bias2 [..,P] = conv1_{k+1}  ->  (out_k [B,C,H,W], t1_{k+1} [B,P,H,W])
+    backward: a_in = d t1_{k+1}, w1k8 = K8 of conv1_{k+1}'s data-gradient packing [C,P], res = the shortcut's gradient, mask1 = out_k,
+              w2k8 = K8 of conv3_k's data-gradient packing [P,C], mask2 = t2_k, no biases  ->  (d out_k, d t2_k), both masked."""
     lib = L.load()
     a_in, res = _nhwc(a_in), _nhwc(res)
     B, P, H, W = a_in.shape
     C = res.shape[1]
-    L.dev_check(a_in, w1, res, w2, mask1, mask2)
-    _bf16(a_in), _bf16(w1), _bf16(res), _bf16(w2)
-    if tuple(w1.shape[-2:]) != (C, P) or tuple(w2.shape[-2:]) != (P, C) or tuple(res.shape) != (B, C, H, W) \
-            or not (w1.is_contiguous() and w2.is_contiguous()):
-        raise L.LoftHipError(f'bneck_pair: shapes {tuple(a_in.shape)} {tuple(w1.shape)} {tuple(res.shape)} {tuple(w2.shape)}')
+    L.dev_check(a_in, w1k8, res, w2k8, mask1, mask2)
+    _bf16(a_in), _bf16(w1k8), _bf16(res), _bf16(w2k8)
+    if tuple(w1k8.shape) != (P // 8, C, 8) or tuple(w2k8.shape) != (C // 8, P, 8) or tuple(res.shape) != (B, C, H, W) \
+            or not (w1k8.is_contiguous() and w2k8.is_contiguous()):
+        raise L.LoftHipError(f'bneck_pair: shapes {tuple(a_in.shape)} {tuple(w1k8.shape)} {tuple(res.shape)} {tuple(w2k8.shape)}')
     if mask1 is not None:
         mask1, mask2 = _nhwc(mask1), _nhwc(mask2)
         _bf16(mask1), _bf16(mask2)
@@ -866,8 +883,9 @@ def bneck_pair(a_in, w1, bias1, res, w2, bias2, mask1=None, mask2=None, variant=
             raise L.LoftHipError(f'bneck_pair: mask shapes {tuple(mask1.shape)} {tuple(mask2.shape)}')
     mid = empty_nhwc(B, C, H, W, L.act16(), a_in.device)
     out2 = empty_nhwc(B, P, H, W, L.act16(), a_in.device)
-    L.check(lib.loft_bneck_pair_bf16_v(L.ptr(a_in), L.ptr(w1), L.ptr(bias1), L.ptr(res), L.ptr(mask1), L.ptr(mid), L.ptr(w2), L.ptr(bias2),
-                                       L.ptr(mask2), L.ptr(out2), c_int64(B * H * W), P, C, int(variant), L.stream()), 'loft_bneck_pair_bf16')
+    L.check(lib.loft_bneck_pair_bf16_v(L.ptr(a_in), L.ptr(w1k8), L.ptr(bias1), L.ptr(res), L.ptr(mask1), L.ptr(mid), L.ptr(w2k8),
+                                       L.ptr(bias2), L.ptr(mask2), L.ptr(out2), c_int64(B * H * W), P, C, int(variant), L.stream()),
+            'loft_bneck_pair_bf16')
     return mid, out2
 
 
@@ -1760,6 +1778,9 @@ class PrepackRegistry:
         self.desc = None
         self.nchunks = 0
         self.step = -1
+        # K8 re-arrangements of registry packings (loft_pack_k8_multi; the weight operands of loft_bneck_pair_bf16): address of the
+        # packing -> dict(src, dst, step); one launch for all of them behind the batched packing launch
+        self.k8jobs, self.k8desc = {}, None
 
     def request(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad, flat_chw=None):
         """ws / conv_biases: the G parameters of a grouped launch (G = 1 for a plain conv).
@@ -1803,6 +1824,22 @@ class PrepackRegistry:
             grp['step'] = self.step
         return grp['wp'], grp['wpt'], grp['bias']
 
+    def k8(self, m):
+        """K8 layout ([K/8, rows, 8]) of the registry packing m ([rows, K] view of a buffer request() returned), valid for the
+        current step; None when m is not one of the registry's buffers (the caller converts it itself)."""
+        job = self.k8jobs.get(m.data_ptr())
+        if job is None:
+            owned = any(m.data_ptr() == t.data_ptr() for grp in self.jobs.values() for t in (grp['wp'], grp['wpt']) if t is not None)
+            if not owned or m.dim() != 2 or m.shape[1] % 8 or not m.is_contiguous():
+                return None
+            job = dict(src=m, dst=torch.empty(m.shape[1] // 8, m.shape[0], 8, dtype=m.dtype, device=m.device), step=-2)
+            self.k8jobs[m.data_ptr()] = job
+            self.k8desc = None
+        if job['step'] != self.step:          # registered after this step's batched launch: convert it now
+            pack_k8([job['src']], [job['dst']])
+            job['step'] = self.step
+        return job['dst']
+
     def run(self, step):
         """One launch for every registered job; afterwards request() is a dictionary lookup."""
         self.step = step
@@ -1839,6 +1876,11 @@ class PrepackRegistry:
                     L.check(lib.loft_transpose_bf16(L.ptr(j['wp']), L.ptr(j['wpt']), O, Kd, L.stream()), 'loft_transpose_bf16')
         for key in self.order:
             self.jobs[key]['step'] = step
+        if self.k8jobs:
+            js = list(self.k8jobs.values())
+            _, self.k8desc = pack_k8([j['src'] for j in js], [j['dst'] for j in js], self.k8desc)
+            for j in js:
+                j['step'] = step
 
 
 

@@ -104,13 +104,18 @@ class Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x):
-        # (DBG.no_block_fusion: A/B switch -- one autograd node per conv instead of one per block, nn.res_block)
-        if not DBG.no_block_fusion and not isinstance(self.conv2, ModulatedDeformConvPack):
+    def one_node(self):
+        """This block runs as ONE autograd node (nn.res_block)?  (DBG.no_block_fusion: A/B switch -- one node per conv instead)"""
+        return not DBG.no_block_fusion and not isinstance(self.conv2, ModulatedDeformConvPack)
+
+    def forward(self, x, pair=None):
+        """pair: the hand-over dict of the stage's consecutive blocks (nn.res_block: pair fusion of this block's conv3 with the next
+        block's conv1, loft_bneck_pair_bf16); None = every conv a launch of its own."""
+        if self.one_node():
             main = [(self.conv1.weight, self.bn1, 1, 1, 0, None), (self.conv2.weight, self.bn2, 3, self.stride, 1, None),
                     (self.conv3.weight, self.bn3, 1, 1, 0, None)]
             sc = None if self.downsample is None else (self.downsample[0].weight, self.downsample[1], 1, self.stride, 0, None)
-            return F2.res_block(x, main, sc)
+            return F2.res_block(x, main, sc, pair=pair)
         out = F2.conv2d(x, self.conv1.weight, bn=self.bn1, relu=True)
         if isinstance(self.conv2, ModulatedDeformConvPack):
             out = self.conv2(out, bn=self.bn2, relu=True)
@@ -218,7 +223,15 @@ class ResNet(nn.Module):
         for i, name in enumerate(self.res_layers):
             layer = getattr(self, name)
             with torch.set_grad_enabled(torch.is_grad_enabled() and i + 1 > self.frozen_stages):
-                x = layer(x)
+                # (the blocks of a stage share a hand-over dict: block k's last 1x1 and block k+1's first 1x1 run as one launch
+                #  where the library serves the shape -- nn.res_block, loft_bneck_pair_bf16)
+                blocks = list(layer)
+                pair = {}
+                for j, blk in enumerate(blocks):
+                    nxt = blocks[j + 1] if j + 1 < len(blocks) else None
+                    pair['next'] = ((nxt.conv1.weight, nxt.bn1) if (nxt is not None and isinstance(nxt, Bottleneck) and nxt.one_node()
+                                                                     and nxt.downsample is None) else None)
+                    x = blk(x, pair) if isinstance(blk, Bottleneck) else blk(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

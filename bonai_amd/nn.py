@@ -117,6 +117,9 @@ def _premasked(g, y):
 WGRAD_STREAM = None   # the running Trainer's second stream for backbone weight-gradient launches (None = same stream)
 UNPACK_Q = None    # the running Trainer's kernels.UnpackQueue: weight-gradient unpacking of many convs in one launch
 PREPACK = None     # the running Trainer's kernels.PrepackRegistry: all trainable convs' packings in one launch per step
+# Pair fusion (loft_bneck_pair_bf16): the data gradient of block k's second conv output, computed by block k+1's backward launch
+# together with ITS data gradient; keyed by the address of the gradient tensor block k+1 returns (which the entry keeps alive).
+PAIR_G = {}
 
 
 # ---- packed operands of FROZEN (requires_grad=False) convs are reused from step to step.  The cache lives ON the weight
@@ -1244,15 +1247,18 @@ class _ResBlockFn(torch.autograd.Function):
     tensors: (w, gamma, beta) per main conv, then for the shortcut conv; bns: the FrozenStatBN modules (running stats, eps)."""
 
     @staticmethod
-    def forward(ctx, x, specs, bns, x_is_relu_out, *tensors):
+    def forward(ctx, x, specs, bns, x_is_relu_out, pair, *tensors):
         _note_use(x)
         main_specs, sc_spec = specs
         n = len(main_specs)
+        ctx.pair_prev = None
         pdt = torch.float32 if x.dtype == torch.float32 else K.L.act16()
         need_dx = ctx.needs_input_grad[0]
         # A 64-plane bottleneck nobody differentiates (the frozen layer1 of the LOFT backbone; any such block at inference):
         # conv1, then 3x3 + 1x1 expansion + shortcut + ReLU as ONE launch -- the 64-channel intermediate never leaves the CU and
         # a conv shortcut is folded into the expansion's accumulation (loft_bneck_tail_bf16, conv_mfma.hip).
+        if pair is not None and not (pdt == K.L.act16() and x.dtype == pdt and n == 3 and not DBG.no_pair_fusion):
+            pair = None
         if (not DBG.no_bneck_fusion and pdt == K.L.act16() and x.dtype == pdt and not any(ctx.needs_input_grad) and n == 3
                 and main_specs == ((1, 1, 0, None), (3, 1, 1, None), (1, 1, 0, None))
                 and tuple(tensors[3].shape) == (64, 64, 3, 3) and tuple(tensors[6].shape) == (256, 64, 1, 1)
@@ -1276,18 +1282,34 @@ class _ResBlockFn(torch.autograd.Function):
             wp, wpt, bias = _rb_pack(tensors[3 * n], bns[n], x.shape[1], cp or tensors[3 * n].shape[0], need_dx, pdt)
             sc = K.conv2d_fwd(x, wp, bias, k, k, s, p, out_dtype=pdt, planes_cache=True)
             packs.append(wpt)
+        pre = pair.pop('pre', None) if pair is not None else None       # (t1 of THIS block from the previous block's pair launch, its backward hand-over)
         for i, (k, s, p, cp) in enumerate(main_specs):
             last = i == n - 1
             w = tensors[3 * i]
             wp, wpt, bias = _rb_pack(w, bns[i], h.shape[1], cp or w.shape[0], need_dx or i > 0, pdt)
-            h = K.conv2d_fwd(h, wp, bias, k, k, s, p, relu=True, residual=sc if last else None, out_dtype=pdt, planes_cache=True)
             packs.insert(i, wpt)
+            if i == 0 and pre is not None and pre['x'] == x.data_ptr() and tuple(pre['t1'].shape) == (x.shape[0], w.shape[0]) + tuple(x.shape[2:]):
+                h = pre['t1']                    # conv1 + bn1 + relu of this block ran in the previous block's last launch
+                if need_dx and sc_spec is None and x_is_relu_out and pre['bwd'] is not None:
+                    ctx.pair_prev = pre['bwd']   # (K8 data-gradient packing of the previous block's conv3, its t2)
+            elif last and pair is not None and pair.get('next') is not None and _pair_fwd_ok(h, w, (k, s, p, cp), sc, pair['next']):
+                # the END of this block and the BEGINNING of the next one as one launch (loft_bneck_pair_bf16): the block output
+                # goes to HBM once and is not read back as the next conv1's operand
+                wn, bnn = pair['next']
+                need_next = any(ctx.needs_input_grad)
+                wpn, _, biasn = _rb_pack(wn, bnn, w.shape[0], wn.shape[0], need_next, pdt)
+                k3, k1n = _k8(wp[0, 0]), _k8(wpn[0, 0])
+                t2 = h
+                h, t1n = K.bneck_pair(t2, k3, bias[0], sc, k1n, biasn[0])
+                pair['pre'] = dict(x=h.data_ptr(), t1=t1n, bwd=(_k8(wpt[0, 0]), t2) if (need_next and wpt is not None) else None)
+            else:
+                h = K.conv2d_fwd(h, wp, bias, k, k, s, p, relu=True, residual=sc if last else None, out_dtype=pdt, planes_cache=True)
             if not last:
                 acts.append(h)
         ctx.specs, ctx.bns, ctx.x_is_relu_out = specs, bns, x_is_relu_out
         ctx.params = tensors
         for k_, t in enumerate(tensors):
-            if ctx.needs_input_grad[4 + k_] and isinstance(t, torch.nn.Parameter):
+            if ctx.needs_input_grad[5 + k_] and isinstance(t, torch.nn.Parameter):
                 t._loft_pending = getattr(t, '_loft_pending', 0) + 1
         ctx.n_saved = (len(acts), len(packs))
         ctx.save_for_backward(h, *acts, *[p for p in packs if p is not None])
@@ -1317,18 +1339,30 @@ class _ResBlockFn(torch.autograd.Function):
         need_dx = needs[0]
         # main path, last conv to first; gk = gradient w.r.t. the output of conv k (masked by that output's ReLU)
         gk = g
+        pg = PAIR_G.pop(g.data_ptr(), None) if PAIR_G else None
         for i in range(n - 1, -1, -1):
             k, s, p, cp = main_specs[i]
             xin = acts[i]
-            grads[3 * i:3 * i + 3] = _rb_param_grads(gk, xin, P[3 * i], bns[i], k, s, p, needs[4 + 3 * i:7 + 3 * i])
+            grads[3 * i:3 * i + 3] = _rb_param_grads(gk, xin, P[3 * i], bns[i], k, s, p, needs[5 + 3 * i:8 + 3 * i])
             if i > 0:       # input of conv i is the ReLU output of conv i-1: its mask rides in this dgrad's epilogue
-                gk = K.conv2d_dgrad(gk, packs[i], tuple(xin.shape[2:]), k, k, s, p, mask=xin, out_dtype=x.dtype)
+                if i == n - 1 and pg is not None and pg[0].data_ptr() == g.data_ptr() and pg[1].shape == xin.shape:
+                    gk = pg[1]                   # the next block's backward launch already produced it (pair fusion)
+                else:
+                    gk = K.conv2d_dgrad(gk, packs[i], tuple(xin.shape[2:]), k, k, s, p, mask=xin, out_dtype=x.dtype)
         gx = None
         dep = JOIN.pop(x.data_ptr(), None) if JOIN is not None else None
         if need_dx:
             k, s, p, cp = main_specs[0]
             mask = x if ctx.x_is_relu_out else None
-            if sc_spec is None:
+            pp = ctx.pair_prev
+            if (sc_spec is None and pp is not None and mask is not None and dep is None and not DBG.no_pair_fusion and packs[0] is not None
+                    and g.dtype == K.L.act16() and gk.dtype == K.L.act16() and K.bneck_pair_ok(gk, x.shape[1])):
+                # this block's first data gradient and the PREVIOUS block's last one in one launch (the mirror of the forward pair):
+                # gx = relu'(x) (W1^T gk + g);  previous block: g_t2 = relu'(t2) (W3^T gx) -- handed over through PAIR_G
+                gx, gt2p = K.bneck_pair(gk, _k8(packs[0][0, 0]), None, g, pp[0], None, mask1=x, mask2=pp[1])
+                PAIR_G.clear()
+                PAIR_G[gx.data_ptr()] = (gx, gt2p)
+            elif sc_spec is None:
                 # shortcut = identity: its gradient (g) is the residual of the first conv's data gradient
                 gx = K.conv2d_dgrad(gk, packs[0], tuple(x.shape[2:]), k, k, s, p, residual=g, mask=mask, out_dtype=x.dtype)
             else:
@@ -1350,16 +1384,36 @@ class _ResBlockFn(torch.autograd.Function):
                 gx._loft_premasked = x.data_ptr()
         if sc_spec is not None:
             ks, ss, ps, cps = sc_spec
-            grads[3 * n:3 * n + 3] = _rb_param_grads(g, x, P[3 * n], bns[n], ks, ss, ps, needs[4 + 3 * n:7 + 3 * n])
-        return (gx, None, None, None) + tuple(grads)
+            grads[3 * n:3 * n + 3] = _rb_param_grads(g, x, P[3 * n], bns[n], ks, ss, ps, needs[5 + 3 * n:8 + 3 * n])
+        return (gx, None, None, None, None) + tuple(grads)
 
 
-def res_block(x, main, shortcut=None, x_is_relu_out=True):
-    """main: list of (w, bn, k, stride, pad, cout_pad); shortcut: None (identity) or one such tuple (conv + bn, no ReLU)."""
+def _k8(m):
+    """K8 layout of a 16-bit [rows, K] packing (loft_bneck_pair_bf16's weight operands): from the trainer's registry (one batched
+    launch per step) when the packing lives there, else converted now."""
+    if PREPACK is not None:
+        o = PREPACK.k8(m)
+        if o is not None:
+            return o
+    return K.pack_k8([m])[0][0]
+
+
+def _pair_fwd_ok(t2, w3, spec3, sc, nxt):
+    """The last conv of a bottleneck (t2 -> out, + shortcut sc) and the next block's conv1 as one loft_bneck_pair_bf16 launch?"""
+    wn, bnn = nxt
+    P, C = t2.shape[1], w3.shape[0]
+    return (spec3 == (1, 1, 0, None) and sc is not None and sc.dtype == K.L.act16() and t2.dtype == K.L.act16() and tuple(w3.shape) == (C, P, 1, 1)
+            and tuple(wn.shape) == (P, C, 1, 1) and tuple(sc.shape) == (t2.shape[0], C) + tuple(t2.shape[2:]) and K.bneck_pair_ok(t2, C))
+
+
+def res_block(x, main, shortcut=None, x_is_relu_out=True, pair=None):
+    """main: list of (w, bn, k, stride, pad, cout_pad); shortcut: None (identity) or one such tuple (conv + bn, no ReLU).
+    pair: a dict shared by the consecutive blocks of one stage (pair fusion, loft_bneck_pair_bf16): the caller sets pair['next'] =
+    (conv1 weight, bn1) of the FOLLOWING block (stride-1 1x1 on this block's output) or None; this block leaves pair['pre'] for it."""
     specs = (tuple((k, s, p, cp) for (_, _, k, s, p, cp) in main),
              None if shortcut is None else tuple(shortcut[2:6]))
     mods = list(main) + ([shortcut] if shortcut is not None else [])
     tensors = []
     for (w, bn, *_r) in mods:
         tensors += [w, bn.weight, bn.bias]
-    return _ResBlockFn.apply(x, specs, tuple(m[1] for m in mods), x_is_relu_out, *tensors)
+    return _ResBlockFn.apply(x, specs, tuple(m[1] for m in mods), x_is_relu_out, pair, *tensors)

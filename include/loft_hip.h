@@ -189,6 +189,7 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
  * block k+1 (`out = self.conv1(x); out = self.norm1(out); out = self.relu(out)`), so that the block output -- the widest map of
  * the stage -- is written to HBM once and NOT read back as conv1's operand (bneck_pair.hip).  All maps are [M][channels] rows
  * (NHWC with M = B*H*W, M % 128 == 0), P in {128, 256} planes, C % 128 == 0 (C = 4 P in ResNet):
+ * weights in the K8 layout of loft_pack_k8_multi ([K/8][rows][8] of a [rows][K] packing):
  *   forward  (mask1 == NULL):  mid [M][C] = relu(w1 . a_in + bias1 + res),  out2 [M][P] = relu(w2 . mid + bias2)
  *                              a_in = t2_k [M][P], w1 = conv3_k forward packing [C][P], res = block k's shortcut [M][C],
  *                              w2 = conv1_{k+1} forward packing [P][C]; mid = out_k, out2 = t1_{k+1}; both biases required.
@@ -196,11 +197,15 @@ int loft_bneck_tail_bf16(const void* t1, const void* w2, const float* b2, const 
  *                              a_in = d t1_{k+1} [M][P], w1 = conv1_{k+1} data-gradient packing [C][P], res = the gradient arriving
  *                              over block k+1's identity shortcut [M][C], mask1 = out_k, w2 = conv3_k data-gradient packing [P][C],
  *                              mask2 = t2_k [M][P]; mid = d out_k, out2 = d t2_k; no biases, both masks required.
- * Rounding points as in the separate launches (mid, out2 in the 16-bit type, fp32 accumulation, the second product reads the rounded
- * mid); fp32 summation ORDER differs, so results agree with the separate launches to that order, not bit for bit.
+ * Rounding points and fp32 operation order as in the separate launches (mid, out2 in the 16-bit type, fp32 accumulation, the second
+ * product reads the rounded mid): bit-identical to them.
  * Anything else (shape, missing operand) returns hipErrorInvalidValue (1) and launches nothing. */
 int loft_bneck_pair_bf16(const void* a_in, const void* w1, const float* bias1, const void* res, const void* mask1, void* mid,
                          const void* w2, const float* bias2, const void* mask2, void* out2, int64_t M, int P, int C, void* stream);
+/* Re-arrange `n` 16-bit matrices [R][K] (K % 8 == 0) into the K8 layout [K/8][R][8] in one launch: desc = device array of n x 4
+ * int64 {src, dst, R, K}; max_pieces = max over the matrices of R * K / 8.  (The weight operands of loft_bneck_pair_bf16: an MFMA
+ * fragment is then 2 x 512 contiguous bytes instead of 64 pieces of 16 bytes.) */
+int loft_pack_k8_multi(const int64_t* desc, int n, int64_t max_pieces, void* stream);
 /* The same with a timing-ablation code (variant != 0: forward P = 256 instance with parts of the work removed -- RESULTS WRONG;
  * bneck_pair.hip ABL; tools/probes/pair_time.py).  variant 0 = loft_bneck_pair_bf16. */
 int loft_bneck_pair_bf16_v(const void* a_in, const void* w1, const float* bias1, const void* res, const void* mask1, void* mid,

@@ -1,7 +1,8 @@
 """GPU parity of loft_bneck_pair_bf16 (bneck_pair.hip): the end of bottleneck k + the start of bottleneck k+1 in one launch, forward and
 backward, against (a) the separate launches of the library and (b) torch fp32 on the same 16-bit-rounded operands
-(mmdet/models/backbones/resnet.py:266-298).  The fused launch keeps the separate launches' rounding points; its fp32 summation
-order differs, so (a) is compared at one unit of the 16-bit type on a vanishing fraction of the elements, not bit for bit."""
+(mmdet/models/backbones/resnet.py:266-298).  The fused launch keeps the separate launches' rounding points and fp32 operation order; the
+residual (and the bias) are added on the matrix pipe as exact x 1.0 products, whose final rounding differs from the VALU add once in
+~5e5 elements (measured: 0 of 655 360 at 256 planes, 1 of 524 288 at 128): (a) is "the same bits but for a handful of elements"."""
 import pytest
 import torch
 
@@ -17,10 +18,12 @@ def _rows(t):
     return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).float()
 
 
-def _close_to_ulp(got, want, frac_ok=2e-3):
+def _close_to_ulp(got, want, frac_ok=1e-4, exact=False):
     """got / want: bf16 tensors that went through the same rounding points; equal up to fp32 summation order = identical on nearly
-    every element, one bf16 unit apart on a few (a sum that lands next to a rounding boundary)."""
+    every element, one bf16 unit apart on a few (a sum that lands next to a rounding boundary).  exact: bit for bit."""
     g, w = got.float(), want.float()
+    if exact:
+        frac_ok = max(2.0 / g.numel(), 4e-6)
     diff = (g - w).abs()
     # (+ an absolute floor: an output that is the difference of O(1) partial sums carries their fp32 rounding, ~1e-6, whatever its size)
     ulp = torch.maximum(g.abs(), w.abs()) * 2.0 ** -7 + 1e-5 * float(w.abs().max())
@@ -45,13 +48,15 @@ def test_pair_forward_matches_separate_launches_and_fp32(B, P, H, W):
     out_s = K.conv2d_fwd(t2, wp3[None], b3[None], 1, 1, 1, 0, relu=True, residual=x)
     t1_s = K.conv2d_fwd(out_s, wp1n[None], b1n[None], 1, 1, 1, 0, relu=True)
     assert K.bneck_pair_ok(t2, C)
-    out_f, t1_f = K.bneck_pair(t2, wp3, b3, x, wp1n, b1n)
+    (k3, k1), _ = K.pack_k8([wp3, wp1n])
+    out_f, t1_f = K.bneck_pair(t2, k3, b3, x, k1, b1n)
     torch.cuda.synchronize()
     assert out_f.shape == out_s.shape and t1_f.shape == t1_s.shape
     assert out_f.is_contiguous(memory_format=torch.channels_last) and t1_f.is_contiguous(memory_format=torch.channels_last)
-    _close_to_ulp(out_f, out_s)
+    _close_to_ulp(out_f, out_s, exact=P == 256)
+    _close_to_ulp(t1_f, t1_s, exact=P == 256)
     # the second product reads the fused launch's own (rounded) mid: compare it with a separate launch on THAT tensor
-    _close_to_ulp(t1_f, K.conv2d_fwd(out_f, wp1n[None], b1n[None], 1, 1, 1, 0, relu=True))
+    _close_to_ulp(t1_f, K.conv2d_fwd(out_f, wp1n[None], b1n[None], 1, 1, 1, 0, relu=True), exact=True)
     # fp32 reference on the same rounded operands
     ref_out = (_rows(t2) @ wp3[0].float().t() + b3 + _rows(x)).relu()
     assert (_rows(out_f) - ref_out).abs().max().item() < 1e-2 * max(1.0, ref_out.abs().max().item())
@@ -73,10 +78,12 @@ def test_pair_backward_matches_separate_launches_and_fp32(B, P, H, W):
     wpt1n, wpt3 = K.pack_w_dgrad(w1n), K.pack_w_dgrad(w3)       # [1, C, P], [1, P, C]
     gx_s = K.conv2d_dgrad(g_t1, wpt1n[None], (H, W), 1, 1, 1, 0, residual=g_sc, mask=out_k)
     gt2_s = K.conv2d_dgrad(gx_s, wpt3[None], (H, W), 1, 1, 1, 0, mask=t2)
-    gx_f, gt2_f = K.bneck_pair(g_t1, wpt1n, None, g_sc, wpt3, None, mask1=out_k, mask2=t2)
+    (k1, k3), _ = K.pack_k8([wpt1n, wpt3])
+    gx_f, gt2_f = K.bneck_pair(g_t1, k1, None, g_sc, k3, None, mask1=out_k, mask2=t2)
     torch.cuda.synchronize()
-    _close_to_ulp(gx_f, gx_s)
-    _close_to_ulp(gt2_f, K.conv2d_dgrad(gx_f, wpt3[None], (H, W), 1, 1, 1, 0, mask=t2))
+    _close_to_ulp(gx_f, gx_s, exact=P == 256)
+    _close_to_ulp(gt2_f, gt2_s, exact=P == 256)
+    _close_to_ulp(gt2_f, K.conv2d_dgrad(gx_f, wpt3[None], (H, W), 1, 1, 1, 0, mask=t2), exact=True)
     ref_gx = (_rows(g_t1) @ wpt1n[0].float().t() + _rows(g_sc)) * (_rows(out_k) > 0)
     assert (_rows(gx_f) - ref_gx).abs().max().item() < 1e-2 * max(1.0, ref_gx.abs().max().item())
     ref_gt2 = (_rows(gx_f) @ wpt3[0].float().t()) * (_rows(t2) > 0)
@@ -92,6 +99,6 @@ def test_pair_rejects_what_it_does_not_serve():
     assert not K.bneck_pair_ok(_cl(torch.randn(1, 128, 9, 9)), 512)        # 81 rows
     x = _cl(torch.randn(1, 512, 16, 8))
     a = _cl(torch.randn(1, 128, 16, 8))
-    w1, w2 = torch.zeros(1, 512, 128, device='cuda', dtype=torch.bfloat16), torch.zeros(1, 128, 512, device='cuda', dtype=torch.bfloat16)
+    w1, w2 = torch.zeros(16, 512, 8, device='cuda', dtype=torch.bfloat16), torch.zeros(64, 128, 8, device='cuda', dtype=torch.bfloat16)
     with pytest.raises(L.LoftHipError):                                    # forward form without its biases
         K.bneck_pair(a, w1, None, x, w2, None)

@@ -40,7 +40,24 @@ def _build(sample_first=True):
     return m.cuda().train()
 
 
-def test_e2e_losses_features_grads_vs_reference_fixture():
+# Round 6: the default path runs the last 1x1 of bottleneck k and the first 1x1 of bottleneck k+1 as one launch (loft_bneck_pair_bf16).
+# At kernel level it equals the separate launches except for ~1 element in 5e5 by one bf16 unit (the residual is added on the matrix
+# pipe; tests/test_bneck_pair_gpu.py) -- but this random-weight detector selects proposals by score order and IoU thresholds, and ONE
+# flipped selection moves the losses by 1e-3 and single gradient norms by percents: with the fusion the distances to the reference
+# are features 0.0467, losses <= 5.7e-3 (inside the bounds above), gradient norms 2.13e-2 (0.55e-2 without;
+# tools/probes/e2e_measured.py, identical run to run).  The test therefore runs BOTH ways: the separate launches at the bounds above
+# (a regression of any kernel they share cannot hide), the fused default at 1.5 x ITS measured gradient-norm distance.
+GRADNORM_PAIR = 3.2e-2
+
+
+@pytest.mark.parametrize('pair_fusion', [False, True])
+def test_e2e_losses_features_grads_vs_reference_fixture(pair_fusion):
+    from bonai_amd.debug import DBG
+    with DBG.override(no_pair_fusion=not pair_fusion):
+        _e2e_vs_fixture(dict(TOL_BF16, gradnorm=GRADNORM_PAIR) if pair_fusion else TOL_BF16)
+
+
+def _e2e_vs_fixture(TOL_BF16):
     from bonai_amd.synth import make_batch
     gd = np.load(os.path.join(GOLD, 'e2e_256.npz'))
     size, batch, num_gt = [int(v) for v in gd['meta']]

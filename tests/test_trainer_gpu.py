@@ -25,9 +25,9 @@ def _synth_model(cfg=None):
     return m.cuda().train()
 
 
-def _autograd_grads(m, data):
+def _autograd_grads(m, data, **switches):
     from bonai_amd.debug import DBG
-    with DBG.override(**dict({k: False for k in DBG.active()}, no_side_stream=True)):
+    with DBG.override(**dict({k: False for k in DBG.active()}, no_side_stream=True, **switches)):
         m.train_step(data)['loss'].backward()
     return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
 
@@ -65,6 +65,10 @@ def test_every_debug_switch_alone_matches_the_default_step(first_k):
     from bonai_amd.synth import make_batch
     data = make_batch(2, 256, 8, device='cuda')
     want = _autograd_grads(_synth_model(), data)
+    # (no_pair_fusion, and no_block_fusion which implies it: the separate launches differ from the fused pair in ~1 element of 5e5 by
+    #  one bf16 unit, enough to flip one proposal selection of this random-weight detector and move single gradients by percents --
+    #  those two switches are compared with plain autograd on THEIR arithmetic)
+    want_sep = _autograd_grads(_synth_model(), data, no_pair_fusion=True)
     m = _synth_model()
     tr = Trainer(m, lr=0.0, momentum=0.0, weight_decay=0.0)
     for rep in range(2):
@@ -77,7 +81,7 @@ def test_every_debug_switch_alone_matches_the_default_step(first_k):
             assert DBG.active() == [sw]
             tr.train_step(data, lr=0.0)
             torch.cuda.synchronize()
-            _compare(want, m, sw)
+            _compare(want_sep if sw in ('no_pair_fusion', 'no_block_fusion') else want, m, sw)
     assert DBG.active() == []
     tr.train_step(data, lr=0.0)                       # and back: the default path is intact after every detour
     torch.cuda.synchronize()

@@ -30,24 +30,27 @@ for name, B, P, H in (('layer3', 8, 256, 64), ('layer2', 8, 128, 128)):
     w1 = K.pack_w_fwd(torch.randn(P, C, 1, 1, device='cuda') / C ** 0.5)
     b3, b1 = torch.randn(C, device='cuda'), torch.randn(P, device='cuda')
     hold = {}
+    (k3, k1), _ = K.pack_k8([w3, w1])
 
     def sep_f():
         o = K.conv2d_fwd(t2, w3[None], b3[None], 1, 1, 1, 0, relu=True, residual=x)
         hold['o'] = K.conv2d_fwd(o, w1[None], b1[None], 1, 1, 1, 0, relu=True)
 
     def fus_f():
-        hold['o'] = K.bneck_pair(t2, w3, b3, x, w1, b1)
+        hold['o'] = K.bneck_pair(t2, k3, b3, x, k1, b1)
 
     g1, gs = cl(torch.randn(B, P, H, H)), cl(torch.randn(B, C, H, H))
     wt1 = K.pack_w_dgrad(torch.randn(P, C, 1, 1, device='cuda') / C ** 0.5)
     wt3 = K.pack_w_dgrad(torch.randn(C, P, 1, 1, device='cuda') / P ** 0.5)
+
+    (kt1, kt3), _ = K.pack_k8([wt1, wt3])
 
     def sep_b():
         gx = K.conv2d_dgrad(g1, wt1[None], (H, H), 1, 1, 1, 0, residual=gs, mask=x)
         hold['o'] = K.conv2d_dgrad(gx, wt3[None], (H, H), 1, 1, 1, 0, mask=t2)
 
     def fus_b():
-        hold['o'] = K.bneck_pair(g1, wt1, None, gs, wt3, None, mask1=x, mask2=t2)
+        hold['o'] = K.bneck_pair(g1, kt1, None, gs, kt3, None, mask1=x, mask2=t2)
 
     M = B * H * H
     mb_f = M * (2 * P * 2 + 2 * C * 2) / 1e6
@@ -62,5 +65,5 @@ for name, B, P, H in (('layer3', 8, 256, 64), ('layer2', 8, 128, 128)):
     if P == 256:
         for v, what in ((1, 'no product 1'), (2, 'no product 2'), (3, 'no MFMA at all'), (4, 'no store of mid'), (8, 'no residual re-load'),
                         (12, 'no store, no residual'), (16, 'no epilogue 1'), (19, 'no MFMA, no epilogue 1'), (32, 'weights loaded once')):
-            t = min(timeit(lambda: K.bneck_pair(t2, w3, b3, x, w1, b1, variant=v)) for _ in range(2))
+            t = min(timeit(lambda: K.bneck_pair(t2, k3, b3, x, k1, b1, variant=v)) for _ in range(2))
             print(f'   ablation {v:2d} ({what}): {t:7.1f} us')

@@ -488,6 +488,126 @@ LOFT_EXPORT int loft_absmax_split_planes_f32(const float* x, int64_t n, void* pl
     const int e = loft_absmax_f32(x, n, slot, stream);
     return e ? e : loft_split_planes_f32(x, n, planes, slot, stream);
 }
+// ---- fp32 parity mode under the trainer: BN fold + fp32 operand packings + their planes for EVERY registered conv in two launches
+// per step (kernels.PrepackRegistry.request_f32).  Per conv and step the mode ran loft_fold_pack (13.8 us) and, for the forward and
+// the data-gradient packing each, loft_absmax_split_planes_f32 (22.7 us: a grid rendezvous per tensor): 108 + 169 launches, 5.3 of
+// 121 ms per step (profiles/round6_probes/fp32_profile.txt).  The weights only change in the SGD kernel.
+// Launch 1 (fold): record = 16 int64 {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits), Cout, Cin,
+//   RS, CoutP, CinP, first_block} + 2 int64 {amax slot, unused}; a block = 1024 elements of the padded forward packing; values and
+//   operation order of fold_pack_kernel<float>; the record's absmax (forward and data-gradient packing hold the same values) is
+//   folded into its PRE-ZEROED slot (members of one grouped launch share a slot: one scale per operand tensor).
+// Launch 2 (split): record = 6 int64 {src fp32, planes dst, plane stride (elements), count, amax slot | 0, first_block}; a block =
+//   2048 elements; split_planes_body's arithmetic.
+__global__ __launch_bounds__(256) void fold_f32_multi_kernel(const long* __restrict__ desc, int n, long nblocks) {
+    __shared__ float wm[4];
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        int lo;
+        {
+            int cnt = 0;
+            for (int j = threadIdx.x & 63; j < n; j += 64) cnt += desc[(long)j * 18 + 15] <= blk ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            lo = cnt - 1;
+        }
+        const long* d = desc + (long)lo * 18;
+        const float* w = reinterpret_cast<const float*>(d[0]);
+        const float* cbias = reinterpret_cast<const float*>(d[1]);
+        const float* gamma = reinterpret_cast<const float*>(d[2]);
+        const float* beta = reinterpret_cast<const float*>(d[3]);
+        const float* mean = reinterpret_cast<const float*>(d[4]);
+        const float* var = reinterpret_cast<const float*>(d[5]);
+        float* wp = reinterpret_cast<float*>(d[6]);
+        float* wpt = reinterpret_cast<float*>(d[7]);
+        float* bias_out = reinterpret_cast<float*>(d[8]);
+        const float eps = __int_as_float((int)d[9]);
+        const int Cout = (int)d[10], Cin = (int)d[11], RS = (int)d[12], CoutP = (int)d[13], CinP = (int)d[14];
+        unsigned* slot = reinterpret_cast<unsigned*>(d[16]);
+        const long total = (long)CoutP * CinP * RS, b0 = blk - d[15];
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = b0 * 1024 + u * 256 + threadIdx.x;
+            if (i < total) {
+                const int c = (int)(i % CinP);
+                const long r = i / CinP;
+                const int nn = (int)(r % CoutP), t = (int)(r / CoutP);
+                float v = 0.f;
+                if (nn < Cout && c < Cin) {
+                    v = w[((long)nn * Cin + c) * RS + t];
+                    if (gamma) v *= gamma[nn] * rsqrtf(var[nn] + eps);
+                }
+                if (wp) wp[i] = v;
+                if (wpt) wpt[((long)t * CinP + c) * CoutP + nn] = v;
+                m = fmaxf(m, v != v ? __builtin_inff() : fabsf(v));
+            }
+        }
+        if (bias_out && b0 == 0)
+            for (int nn = threadIdx.x; nn < CoutP; nn += blockDim.x) {
+                if (nn >= Cout) bias_out[nn] = 0.f;
+                else if (gamma) bias_out[nn] = beta[nn] - mean[nn] * gamma[nn] * rsqrtf(var[nn] + eps);
+                else bias_out[nn] = cbias ? cbias[nn] : 0.f;
+            }
+        if (slot) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const float mm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+                if (mm > 0.f) atomicMax(slot, __float_as_uint(mm));
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void split_f32_multi_kernel(const long* __restrict__ desc, int n, long nblocks) {
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        int lo;
+        {
+            int cnt = 0;
+            for (int j = threadIdx.x & 63; j < n; j += 64) cnt += desc[(long)j * 6 + 5] <= blk ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            lo = cnt - 1;
+        }
+        const long* d = desc + (long)lo * 6;
+        const float* x = reinterpret_cast<const float*>(d[0]);
+        bf16_t* planes = reinterpret_cast<bf16_t*>(d[1]);
+        const long stride = d[2], count = d[3];
+        const float* amax = reinterpret_cast<const float*>(d[4]);
+        const float sc = amax ? planes_scale_of(*amax, false) : 1.f;
+        const long i = (blk - d[5]) * 256 + threadIdx.x;              // 8 elements per thread
+        if (i * 8 < count) {
+            float r[8], h[8];
+            const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
+            const float4 b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+            r[0] = a.x * sc; r[1] = a.y * sc; r[2] = a.z * sc; r[3] = a.w * sc; r[4] = b.x * sc; r[5] = b.y * sc; r[6] = b.z * sc; r[7] = b.w * sc;
+#pragma unroll
+            for (int p = 0; p < LOFT_PLANES; ++p) {
+                const uint4 pk = pack8_16(r);
+                *reinterpret_cast<uint4*>(planes + p * stride + i * 8) = pk;
+                if (p + 1 < LOFT_PLANES) {
+                    unpack8_16(pk, h);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] -= h[q];
+                }
+            }
+        }
+    }
+}
+LOFT_EXPORT int loft_fold_f32_multi(const int64_t* desc, int n, int64_t nblocks, void* stream) {
+    if (n <= 0 || nblocks <= 0) return 0;
+    const long g = nblocks < 8192 ? nblocks : 8192;
+    hipLaunchKernelGGL(fold_f32_multi_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const long*)desc, n, (long)nblocks);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+LOFT_EXPORT int loft_split_planes_f32_multi(const int64_t* desc, int n, int64_t nblocks, void* stream) {
+    if (n <= 0 || nblocks <= 0) return 0;
+    const long g = nblocks < 16384 ? nblocks : 16384;
+    hipLaunchKernelGGL(split_f32_multi_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const long*)desc, n, (long)nblocks);
+    LOFT_LAUNCH_CHECK();
+    return 0;
+}
+
 // out[g][c] += sum over the rows of x[g][rows][C]: the bias gradient of the fp32 mode's convolutions (a strided library reduction
 // over the NHWC gradient took 0.44 ms per layer).  A workgroup = 4 row phases x 64 lanes of 4 channels (C <= 256 per pass), its
 // partial sums meet in LDS and leave as one atomic per channel.  out accumulates (the caller zeroes it).  C % 4 == 0.

@@ -398,9 +398,10 @@ class Trainer:
             p._loft_pending = 0
             p._loft_sunk = False
         from . import nn as F2
-        prev_pp = F2.PREPACK
+        prev_pp, prev_wpl = F2.PREPACK, K.WEIGHT_PLANES
         if self.arena.data.is_cuda and not DBG.no_prepack:
             F2.PREPACK = self.prepack
+            K.WEIGHT_PLANES = self.prepack.wplanes         # (fp32 parity mode: the weight operands' planes, made by run() below)
             self.prepack.run(self.iter)                   # every trainable conv's BN fold + operand packing: one launch
         prev_hub = F2.HUB_ENABLED
         F2.HUB_ENABLED = self.arena.data.is_cuda and not DBG.no_feat_hub
@@ -412,6 +413,7 @@ class Trainer:
             out = self.model.train_step(data)
         except BaseException:
             F2.JOIN = None
+            K.WEIGHT_PLANES = prev_wpl
             raise
         finally:
             F2.PREPACK = prev_pp
@@ -449,6 +451,7 @@ class Trainer:
             F2.GRAD_SINK = prev
             F2.HUB = None
             F2.JOIN = None
+            K.WEIGHT_PLANES = prev_wpl          # (the backward's data-gradient launches read the weight planes too)
             K.zero_pool_end()
         self.reducer.finish()
         self.gnorm_sq.zero_()

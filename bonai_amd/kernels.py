@@ -554,9 +554,18 @@ def _drop_amax(t):
         t._loft_amax = None
 
 
+# The running trainer's batched weight planes (PrepackRegistry.request_f32 / run): (address, element count) of an fp32 operand packing
+# -> (planes, absmax slot), made at the start of the step by two launches for all convs.  None outside a trainer step.
+WEIGHT_PLANES = None
+
+
 def split_planes(x, dtype16):
     """fp32 tensor (dense) -> (planes [NP, numel] of dtype16, absmax device scalar | None): loft_absmax_split_planes_f32, or the
     split alone when the tensor's producer already measured its absmax."""
+    if WEIGHT_PLANES is not None and dtype16 == torch.float16:
+        hit = WEIGHT_PLANES.get((x.data_ptr(), x.numel()))
+        if hit is not None:
+            return hit
     lib = L.load_for(dtype16)
     n = x.numel()
     planes = torch.empty((lib.loft_planes_per_tensor(), n), dtype=dtype16, device=x.device)
@@ -1781,6 +1790,9 @@ class PrepackRegistry:
         # K8 re-arrangements of registry packings (loft_pack_k8_multi; the weight operands of loft_bneck_pair_bf16): address of the
         # packing -> dict(src, dst, step); one launch for all of them behind the batched packing launch
         self.k8jobs, self.k8desc = {}, None
+        # fp32 parity mode (request_f32): fp32 packings + their binary16 planes for every registered conv, two launches per step
+        self.f32jobs, self.f32order, self.f32desc = {}, [], None
+        self.wplanes = {}            # (address, numel) of an fp32 packing -> (planes, absmax slot): kernels.WEIGHT_PLANES during a step
 
     def request(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad, flat_chw=None):
         """ws / conv_biases: the G parameters of a grouped launch (G = 1 for a plain conv).
@@ -1824,6 +1836,79 @@ class PrepackRegistry:
             grp['step'] = self.step
         return grp['wp'], grp['wpt'], grp['bias']
 
+    def request_f32(self, ws, conv_biases, bn, eps, cout_p, cin_p, want_dgrad):
+        """The fp32 parity mode's form of request(): fp32 packings (wp [G,T,CoutP,CinP], wpt [G,T,CinP,CoutP] | None, bias [G,CoutP])
+        valid for the current step, folded by ONE launch for all registered convs (loft_fold_f32_multi), and -- where the plane
+        kernels serve the shape -- their binary16 planes by a second one (loft_split_planes_f32_multi), which split_planes() then
+        finds in self.wplanes instead of running an absmax + split launch per packing and step."""
+        key = (tuple(w.data_ptr() for w in ws), tuple(0 if b is None else b.data_ptr() for b in conv_biases),
+               0 if bn is None else (bn[0].data_ptr(), bn[2].data_ptr()), cout_p, cin_p, bool(want_dgrad))
+        grp = self.f32jobs.get(key)
+        if grp is None:
+            G, dev = len(ws), ws[0].device
+            Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+            T = (ws[0].shape[2] * ws[0].shape[3]) if ws[0].dim() == 4 else 1
+            wp = torch.empty(G, T, cout_p, cin_p, dtype=torch.float32, device=dev)
+            wpt = torch.empty(G, T, cin_p, cout_p, dtype=torch.float32, device=dev) if want_dgrad else None
+            n = wp.numel()
+            planes_ok = F32_CONTRACT in (F32_PLANES_F16, F32_PLANES_F16X4) and n % 8 == 0 and (T * cout_p * cin_p) % 8 == 0
+            grp = dict(ws=ws, cbs=conv_biases, bn=bn, eps=float(eps), dims=(Cout, Cin, T, cout_p, cin_p), wp=wp, wpt=wpt,
+                       bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2,
+                       slot=torch.zeros(2, dtype=torch.float32, device=dev),
+                       # (forward launch: Cin % 64, Cout % 128; data-gradient launch: the roles swap)
+                       pf=torch.empty(2, n, dtype=torch.float16, device=dev) if (planes_ok and cin_p % 64 == 0 and cout_p % 128 == 0) else None,
+                       pd=torch.empty(2, n, dtype=torch.float16, device=dev)
+                       if (planes_ok and want_dgrad and cout_p % 64 == 0 and cin_p % 128 == 0) else None)
+            self.f32jobs[key] = grp
+            self.f32order.append(key)
+            self.f32desc = None
+        if grp['step'] != self.step:          # registered after this step's batched launches (first step): run its records now
+            self._run_f32([grp], None)
+            grp['step'] = self.step
+        if grp['pf'] is not None:
+            self.wplanes[(grp['wp'].data_ptr(), grp['wp'].numel())] = (grp['pf'], grp['slot'])
+        if grp['pd'] is not None:
+            self.wplanes[(grp['wpt'].data_ptr(), grp['wpt'].numel())] = (grp['pd'], grp['slot'])
+        return grp['wp'], grp['wpt'], grp['bias']
+
+    def _run_f32(self, groups, cached):
+        """The two launches for `groups`; cached = (fold desc, nblocks, n, split desc, nblocks, n, slots) of a previous call | None."""
+        import struct
+        plib = L.load_for(torch.float16)
+        if cached is None:
+            p = lambda t: 0 if t is None else t.data_ptr()
+            frows, srows, fb, sb = [], [], 0, 0
+            for grp in groups:
+                Cout, Cin, T, CoutP, CinP = grp['dims']
+                bn = grp['bn']
+                eps_bits = struct.unpack('<i', struct.pack('<f', grp['eps']))[0]
+                per = T * CoutP * CinP
+                for g, w in enumerate(grp['ws']):
+                    frows.append([p(w), p(grp['cbs'][g]), p(bn[0]) if bn else 0, p(bn[1]) if bn else 0, p(bn[2]) if bn else 0,
+                                  p(bn[3]) if bn else 0, p(grp['wp'][g]), p(None if grp['wpt'] is None else grp['wpt'][g]), p(grp['bias'][g]),
+                                  eps_bits, Cout, Cin, T, CoutP, CinP, fb, p(grp['slot']), 0])
+                    fb += (per + 1023) // 1024
+                    for src, pl in ((grp['wp'], grp['pf']), (grp['wpt'], grp['pd'])):
+                        if pl is not None:
+                            srows.append([src[g].data_ptr(), pl.data_ptr() + 2 * g * per, pl.shape[1], per, p(grp['slot']), sb])
+                            sb += (per // 8 + 255) // 256
+            dev = groups[0]['wp'].device
+            cached = (h2d(frows, torch.int64, dev), fb, len(frows), h2d(srows, torch.int64, dev) if srows else None, sb, len(srows))
+        fdesc, fb, fn, sdesc, sb, sn = cached
+        for grp in groups:
+            grp['slot'].zero_()
+        L.check(plib.loft_fold_f32_multi(L.ptr(fdesc), fn, c_int64(fb), L.stream()), 'loft_fold_f32_multi')
+        if sn:
+            L.check(plib.loft_split_planes_f32_multi(L.ptr(sdesc), sn, c_int64(sb), L.stream()), 'loft_split_planes_f32_multi')
+        return cached
+
+    def _run_f32_cached(self, groups):
+        plib = L.load_for(torch.float16)
+        fdesc, fb, fn, sdesc, sb, sn = self.f32desc
+        L.check(plib.loft_fold_f32_multi(L.ptr(fdesc), fn, c_int64(fb), L.stream()), 'loft_fold_f32_multi')
+        if sn:
+            L.check(plib.loft_split_planes_f32_multi(L.ptr(sdesc), sn, c_int64(sb), L.stream()), 'loft_split_planes_f32_multi')
+
     def k8(self, m):
         """K8 layout ([K/8, rows, 8]) of the registry packing m ([rows, K] view of a buffer request() returned), valid for the
         current step; None when m is not one of the registry's buffers (the caller converts it itself)."""
@@ -1843,8 +1928,33 @@ class PrepackRegistry:
     def run(self, step):
         """One launch for every registered job; afterwards request() is a dictionary lookup."""
         self.step = step
-        if not self.order:
-            return
+        if self.order:
+            self._run_16(step)
+        if self.f32order:
+            groups = [self.f32jobs[k] for k in self.f32order]
+            if self.f32desc is None:
+                # (all slots of the registry as ONE tensor: one memset per step instead of one per conv)
+                slots = torch.zeros(len(groups), 2, dtype=torch.float32, device=groups[0]['wp'].device)
+                for i, grp in enumerate(groups):
+                    old = (grp['pf'], grp['pd'])
+                    grp['slot'] = slots[i]
+                    for src, pl in ((grp['wp'], old[0]), (grp['wpt'], old[1])):
+                        if pl is not None:
+                            self.wplanes[(src.data_ptr(), src.numel())] = (pl, grp['slot'])
+                self.f32slots = slots
+                self.f32desc = self._run_f32(groups, None)
+            else:
+                self.f32slots.zero_()
+                self._run_f32_cached(groups)
+            for grp in groups:
+                grp['step'] = step
+        if self.k8jobs:
+            js = list(self.k8jobs.values())
+            _, self.k8desc = pack_k8([j['src'] for j in js], [j['dst'] for j in js], self.k8desc)
+            for j in js:
+                j['step'] = step
+
+    def _run_16(self, step):
         lib = L.load()
         if self.desc is None:
             import struct
@@ -1876,11 +1986,6 @@ class PrepackRegistry:
                     L.check(lib.loft_transpose_bf16(L.ptr(j['wp']), L.ptr(j['wpt']), O, Kd, L.stream()), 'loft_transpose_bf16')
         for key in self.order:
             self.jobs[key]['step'] = step
-        if self.k8jobs:
-            js = list(self.k8jobs.values())
-            _, self.k8desc = pack_k8([j['src'] for j in js], [j['dst'] for j in js], self.k8desc)
-            for j in js:
-                j['step'] = step
 
 
 

@@ -241,6 +241,11 @@ class _ConvFn(torch.autograd.Function):
             bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
             wp, wpt, bias = PREPACK.request(ws, bs, bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
                                             ctx.needs_input_grad[0])
+        elif PREPACK is not None and key is None and pdt == torch.float32 and all(isinstance(w, torch.nn.Parameter) and w.dim() == 4
+                                                                                   for w in ws):
+            bn = (gamma, beta, bn_stats[0], bn_stats[1]) if bn_stats is not None else None
+            wp, wpt, bias = PREPACK.request_f32(ws, bs, bn, bn_stats[2] if bn_stats is not None else 1e-5, Cout, Cin,
+                                                ctx.needs_input_grad[0])
         else:
             wp = torch.empty(G, T, Cout, Cin, dtype=pdt, device=dev)
             need_dgrad = ctx.needs_input_grad[0]
@@ -1183,6 +1188,9 @@ def _rb_pack(w, bn, cin_p, cout_p, need_dgrad, pdt):
     if PREPACK is not None and key is None and pdt == K.L.act16() and cout_p % 2 == 0 and cin_p % 2 == 0 and \
             isinstance(w, torch.nn.Parameter):
         return PREPACK.request((w,), (None,), (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
+    if PREPACK is not None and key is None and pdt == torch.float32 and isinstance(w, torch.nn.Parameter) and w.dim() == 4:
+        # fp32 parity mode: fold + fp32 packings + their operand planes for all convs in two launches per step
+        return PREPACK.request_f32((w,), (None,), (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, cout_p, cin_p, need_dgrad)
     out = K.fold_pack(w, None, (bn.weight, bn.bias, stats[0], stats[1]), bn.eps, want_fwd=True, want_dgrad=need_dgrad, dtype=pdt,
                       cout_pad=cout_p, cin_pad=cin_p)
     out = (out[0][None], None if out[1] is None else out[1][None], out[2][None])
@@ -1290,8 +1298,10 @@ class _ResBlockFn(torch.autograd.Function):
             packs.insert(i, wpt)
             if i == 0 and pre is not None and pre['x'] == x.data_ptr() and tuple(pre['t1'].shape) == (x.shape[0], w.shape[0]) + tuple(x.shape[2:]):
                 h = pre['t1']                    # conv1 + bn1 + relu of this block ran in the previous block's last launch
-                if need_dx and sc_spec is None and x_is_relu_out and pre['bwd'] is not None:
-                    ctx.pair_prev = pre['bwd']   # (K8 data-gradient packing of the previous block's conv3, its t2)
+                if need_dx and sc_spec is None and x_is_relu_out and pre['bwd'] is not None and wpt is not None:
+                    # (K8 data-gradient packing of the previous block's conv3, its t2; this conv1's own K8 data-gradient packing --
+                    #  taken NOW: the trainer's registry serves it only during the forward pass)
+                    ctx.pair_prev = pre['bwd'] + (_k8(wpt[0, 0]),)
             elif last and pair is not None and pair.get('next') is not None and _pair_fwd_ok(h, w, (k, s, p, cp), sc, pair['next']):
                 # the END of this block and the BEGINNING of the next one as one launch (loft_bneck_pair_bf16): the block output
                 # goes to HBM once and is not read back as the next conv1's operand
@@ -1359,7 +1369,7 @@ class _ResBlockFn(torch.autograd.Function):
                     and g.dtype == K.L.act16() and gk.dtype == K.L.act16() and K.bneck_pair_ok(gk, x.shape[1])):
                 # this block's first data gradient and the PREVIOUS block's last one in one launch (the mirror of the forward pair):
                 # gx = relu'(x) (W1^T gk + g);  previous block: g_t2 = relu'(t2) (W3^T gx) -- handed over through PAIR_G
-                gx, gt2p = K.bneck_pair(gk, _k8(packs[0][0, 0]), None, g, pp[0], None, mask1=x, mask2=pp[1])
+                gx, gt2p = K.bneck_pair(gk, pp[2], None, g, pp[0], None, mask1=x, mask2=pp[1])
                 PAIR_G.clear()
                 PAIR_G[gx.data_ptr()] = (gx, gt2p)
             elif sc_spec is None:

@@ -624,6 +624,15 @@ int loft_fold_pack(const float* w, const float* conv_bias, const float* gamma, c
  * have Cout chunks, one output channel each, Cin * |RS| <= 18432, and their wp_dgrad is NOT written: the caller
  * derives it with loft_transpose_bf16); loft_fold_unpack_bwd_multi reads dwp in the same [n][t][c] order for RS < 0. */
 int loft_fold_pack_multi(const int64_t* desc, int n, int64_t nchunks, void* stream);
+/* The fp32 parity mode's per-step weight work in two launches (mmdet/core/fp16/hooks.py has no counterpart: the reference's fp32
+ * path multiplies fp32 weights directly; here every fp32 operand is split into 16-bit planes).  loft_fold_f32_multi: loft_fold_pack
+ * with fp32 packings for n records of 18 int64 {w, conv_bias, gamma, beta, mean, var, wp_fwd, wp_dgrad, bias_out, eps (float bits),
+ * Cout, Cin, RS, CoutP, CinP, first_block, amax slot | 0, 0} (a block = 1024 elements of the padded forward packing; first_block
+ * ascending); the absmax of each record's folded weights is max-folded into its PRE-ZEROED slot.  loft_split_planes_f32_multi:
+ * loft_split_planes_f32 for n records of 6 int64 {src, planes, plane stride in elements, count (% 8 == 0), amax slot | 0, first_block}
+ * (a block = 2048 elements). */
+int loft_fold_f32_multi(const int64_t* desc, int n, int64_t nblocks, void* stream);
+int loft_split_planes_f32_multi(const int64_t* desc, int n, int64_t nblocks, void* stream);
 /* loft_fold_unpack_bwd_multi: loft_fold_unpack_bwd for MANY convs in one launch, accumulate-only (the trainer's direct gradient
  * sink).  desc (device): njobs records of 16 int64 {dwp, db, w, gamma, mean, var, dw, dgamma, dbeta_or_dbias (device addresses,
  * 0 = absent), eps as float bits, Cout, Cin, RS, CoutP, CinP, first_block}; record i owns blocks [first_block_i, first_block_i +

@@ -446,7 +446,7 @@ def main():
             if meta.get('source_hash') != here:
                 stale.append(f"profiles/{PR}_bench_kernel_stats_serial.csv (measured on sources {meta.get('source_hash')}, running {here})")
             else:
-                subs = {'conv_tap': ('conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel'),
+                subs = {'conv_tap': ('conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel', 'bneck_pair_kernel'),
                         'conv_wgrad': ('conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv_wgrad64_kernel')}[dom]
                 rows = [r for r in csv.DictReader(open(csvf)) if any(sub + '<' in r['Name'] or sub + '(' in r['Name'] for sub in subs)]
                 nsteps = int(meta['steps_profiled'])       # steps the summary covers: warm-up + timed + instrumented (+ fp32 loop: other kernels)
@@ -456,7 +456,7 @@ def main():
                                    avg_launch_us=round(t_ns / calls / 1e3, 1),
                                    frac=round(fam[dom][0] / 2 / (t_ns / nsteps * 1e-9) / 2.5e15, 4),
                                    source=f'profiles/{PR}_bench_kernel_stats_serial.csv (kernel durations only: no launch gaps)')
-        roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates + the 64-channel patch / fused bottleneck-tail kernels (loft_conv_tap_bf16_v, loft_bneck_tail_bf16)',
+        roofline = dict(bound='mfma', kernel={'conv_tap': 'conv_tap_pipe_kernel + conv_tap_kernel templates + the 64-channel patch / fused bottleneck-tail / bottleneck-pair kernels (loft_conv_tap_bf16_v, loft_bneck_tail_bf16, loft_bneck_pair_bf16; the HIP-event legs run the pair as its two launches)',
                                               'conv_wgrad': 'conv_wgrad_stream_kernel + conv_wgrad_kernel templates (loft_conv_wgrad_bf16_v)'}[dom],
                         achieved=round(ach, 1), peak=2500.0, unit='TFLOP/s', frac=round(ach / 2500.0, 4), traffic=traffic, traffic_source=traffic_source, mfma_util_pmc=mfma_util,
                         launches_per_step=fam[dom][2] // 2, avg_launch_us=round(fam[dom][1] / fam[dom][2] * 1e6, 1), rocprof=rocprof,

@@ -18,14 +18,14 @@ ROOT = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path
 OUT = os.path.join(ROOT, 'gpurun_out', 'pmc')
 # family -> kernel-name substrings.  'conv_tap' / 'conv_wgrad' are the two C-ABI entry points (loft_conv_tap_bf16_v /
 # loft_conv_wgrad_bf16_v); each dispatches to several templates of a lock-step and a software-pipelined kernel.
-FAMILIES = {'conv_tap': ['conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel'],
+FAMILIES = {'conv_tap': ['conv_tap_kernel', 'conv_tap_pipe_kernel', 'conv64_patch_kernel', 'bneck_tail_kernel', 'bneck_pair_kernel'],
             'conv_wgrad': ['conv_wgrad_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv_wgrad64_kernel']}
 FAMILIES.update({k: [k] for k in [
     'conv_tap_pipe_kernel', 'conv_wgrad_stream_kernel', 'conv_wgrad_ring_kernel', 'conv64_patch_kernel',
     'roi_align_fwd_kernel', 'roi_align_fwd_sep_kernel', 'roi_align_fwd_sep8_kernel', 'roi_align_bwd_tile_kernel', 'roi_align_bwd_mfma_kernel',
     'narrow_head_bwd_kernel', 'random_sample_kernel', 'fold_pack_multi_kernel', 'fold_unpack_bwd_multi_kernel',
     'mdcn_sample_fwd_kernel', 'mdcn_sample_bwd_bin_kernel', 'mdcn_window_gather_kernel', 'nms_scan_kernel',
-    'fuse_sum_relu_kernel', 'stem_mfma_kernel', 'bneck_tail_kernel']})
+    'fuse_sum_relu_kernel', 'stem_mfma_kernel', 'bneck_tail_kernel', 'bneck_pair_kernel']})
 # per template instance of the weight-gradient stream kernel (0 generic taps, 1 RoI maps, 2 dense 1x1 / FC, 3 stride-1 same-size taps)
 EXACT = {f'conv_wgrad_stream_kernel<{i}>': f'conv_wgrad_stream_kernel<{i}>' for i in range(4)}
 EXACT.update({'conv_tap_pipe_kernel<1, 0, 4, 2>': 'conv_tap_pipe_kernel<1, 0, 4, 2, false, false, false'})      # (the two-stage 256 x 256 stream schedule, either form)

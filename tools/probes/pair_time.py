@@ -60,7 +60,7 @@ for name, B, P, H in (('layer3', 8, 256, 64), ('layer2', 8, 128, 128)):
         a, b = timeit(sep), timeit(fus)
         a2, b2 = timeit(sep), timeit(fus)
         a, b = min(a, a2), min(b, b2)
-        print(f'{name} {tag}: separate {a:7.1f} us   fused {b:7.1f} us ({gf / b * 1e-3:6.1f} TFLOP/s, {mb / b * 1e-3:5.2f} TB/s of {mb:.0f} MB; floor {mb / 6.0 * 1e-3 * 1e3:5.1f} us)')
+        print(f'{name} {tag}: separate {a:7.1f} us   fused {b:7.1f} us ({gf / b * 1e3:6.1f} TFLOP/s, {mb / b:5.2f} TB/s of {mb:.0f} MB; floor at 6 TB/s {mb / 6.0:5.1f} us)')
 
     if P == 256:
         for v, what in ((1, 'no product 1'), (2, 'no product 2'), (3, 'no MFMA at all'), (4, 'no store of mid'), (8, 'no residual re-load'),

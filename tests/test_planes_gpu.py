@@ -254,3 +254,57 @@ def test_producer_absmax_note_is_exact_and_dropped_by_in_place_kernels():
     finally:
         K.F32_CONTRACT = prev
         K.AMAX_FROM_PRODUCER = True
+
+
+def test_batched_f32_prepack_equals_the_per_conv_launches():
+    """Round 6: under the trainer the fp32 parity mode folds BN, packs and splits the weights of EVERY conv in two launches per step
+    (PrepackRegistry.request_f32: loft_fold_f32_multi + loft_split_planes_f32_multi).  Packings, biases, planes and the absmax slot
+    must be bit-identical to loft_fold_pack + loft_absmax_split_planes_f32 per conv -- first step (registered on the fly), second
+    step (the batched launches over all records, after the weights changed), a grouped record (one scale for the G members) and a
+    record the plane kernels do not serve (no planes, packings only)."""
+    from bonai_amd import kernels as K
+    torch.manual_seed(11)
+    dev = 'cuda'
+
+    def conv(co, ci, k, bn=True):
+        w = torch.nn.Parameter(torch.randn(co, ci, k, k, device=dev) * 0.05)
+        stats = (torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev) * 0.1, torch.randn(co, device=dev) * 0.1,
+                 torch.rand(co, device=dev) + 0.5) if bn else None            # gamma, beta, mean, var
+        return w, stats
+
+    recs = [((conv(256, 128, 3),), 256, 128, True), ((conv(128, 256, 1),), 128, 256, True),
+            (tuple(conv(256, 256, 3, bn=False) for _ in range(4)), 256, 256, True),      # FOA-style grouped launch
+            ((conv(64, 64, 3),), 64, 64, False)]                                          # not served by the plane kernels
+    reg = K.PrepackRegistry()
+    prev = K.WEIGHT_PLANES
+    K.WEIGHT_PLANES = reg.wplanes
+    try:
+        for step in range(2):
+            reg.run(step)
+            for members, cop, cip, dgrad in recs:
+                ws = tuple(m[0] for m in members)
+                bn = members[0][1]
+                wp, wpt, bias = reg.request_f32(ws, (None,) * len(ws), bn, 1e-5, cop, cip, dgrad)
+                for g, (w, _) in enumerate(members):
+                    rwp, rwpt, rb = K.fold_pack(w.detach(), None, bn, 1e-5, want_dgrad=dgrad, dtype=torch.float32, cout_pad=cop, cin_pad=cip)
+                    assert torch.equal(wp[g], rwp) and torch.equal(bias[g], rb), (step, g)
+                    assert (wpt is None) == (rwpt is None) and (wpt is None or torch.equal(wpt[g], rwpt))
+                for t in (wp, wpt):
+                    if t is None:
+                        continue
+                    prev_reg, K.WEIGHT_PLANES = K.WEIGHT_PLANES, None
+                    want_p, want_a = K.split_planes(t, torch.float16)                 # the per-tensor launches
+                    K.WEIGHT_PLANES = prev_reg
+                    got = reg.wplanes.get((t.data_ptr(), t.numel()))
+                    served = cip % 64 == 0 and cop % 128 == 0 if t is wp else cop % 64 == 0 and cip % 128 == 0
+                    assert (got is not None) == served, (step, tuple(t.shape))
+                    if got is not None:
+                        gp, ga = K.split_planes(t, torch.float16)                      # (what a conv launch gets: the registry's)
+                        assert gp.data_ptr() == got[0].data_ptr()
+                        assert torch.equal(gp, want_p) and float(ga[0]) == float(want_a[0]), (step, tuple(t.shape))
+            with torch.no_grad():                                                      # "SGD": the next step's batched launches see new weights
+                for members, *_ in recs:
+                    for w, _ in members:
+                        w.mul_(1.5).add_(0.01)
+    finally:
+        K.WEIGHT_PLANES = prev

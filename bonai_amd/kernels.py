@@ -1854,7 +1854,7 @@ class PrepackRegistry:
             planes_ok = F32_CONTRACT in (F32_PLANES_F16, F32_PLANES_F16X4) and n % 8 == 0 and (T * cout_p * cin_p) % 8 == 0
             grp = dict(ws=ws, cbs=conv_biases, bn=bn, eps=float(eps), dims=(Cout, Cin, T, cout_p, cin_p), wp=wp, wpt=wpt,
                        bias=torch.empty(G, cout_p, dtype=torch.float32, device=dev), step=-2,
-                       slot=torch.zeros(2, dtype=torch.float32, device=dev),
+                       slot=self._f32_slot(dev),
                        # (forward launch: Cin % 64, Cout % 128; data-gradient launch: the roles swap)
                        pf=torch.empty(2, n, dtype=torch.float16, device=dev) if (planes_ok and cin_p % 64 == 0 and cout_p % 128 == 0) else None,
                        pd=torch.empty(2, n, dtype=torch.float16, device=dev)
@@ -1871,7 +1871,17 @@ class PrepackRegistry:
             self.wplanes[(grp['wpt'].data_ptr(), grp['wpt'].numel())] = (grp['pd'], grp['slot'])
         return grp['wp'], grp['wpt'], grp['bias']
 
-    def _run_f32(self, groups, cached):
+    def _f32_slot(self, dev):
+        """Two words (absmax, spare) of the registry's slot arena: one memset per step for all records, and a record's slot never
+        moves (a captured launch may hold its address)."""
+        if getattr(self, 'f32slots', None) is None:
+            self.f32slots, self.f32nslots = torch.zeros(4096, 2, dtype=torch.float32, device=dev), 0
+        if self.f32nslots >= self.f32slots.shape[0]:
+            raise L.LoftHipError('PrepackRegistry: more than 4096 fp32 records')
+        self.f32nslots += 1
+        return self.f32slots[self.f32nslots - 1]
+
+    def _run_f32(self, groups, cached, zero=True):
         """The two launches for `groups`; cached = (fold desc, nblocks, n, split desc, nblocks, n, slots) of a previous call | None."""
         import struct
         plib = L.load_for(torch.float16)
@@ -1895,8 +1905,9 @@ class PrepackRegistry:
             dev = groups[0]['wp'].device
             cached = (h2d(frows, torch.int64, dev), fb, len(frows), h2d(srows, torch.int64, dev) if srows else None, sb, len(srows))
         fdesc, fb, fn, sdesc, sb, sn = cached
-        for grp in groups:
-            grp['slot'].zero_()
+        if zero:
+            for grp in groups:
+                grp['slot'].zero_()
         L.check(plib.loft_fold_f32_multi(L.ptr(fdesc), fn, c_int64(fb), L.stream()), 'loft_fold_f32_multi')
         if sn:
             L.check(plib.loft_split_planes_f32_multi(L.ptr(sdesc), sn, c_int64(sb), L.stream()), 'loft_split_planes_f32_multi')
@@ -1932,19 +1943,10 @@ class PrepackRegistry:
             self._run_16(step)
         if self.f32order:
             groups = [self.f32jobs[k] for k in self.f32order]
+            self.f32slots[:self.f32nslots].zero_()
             if self.f32desc is None:
-                # (all slots of the registry as ONE tensor: one memset per step instead of one per conv)
-                slots = torch.zeros(len(groups), 2, dtype=torch.float32, device=groups[0]['wp'].device)
-                for i, grp in enumerate(groups):
-                    old = (grp['pf'], grp['pd'])
-                    grp['slot'] = slots[i]
-                    for src, pl in ((grp['wp'], old[0]), (grp['wpt'], old[1])):
-                        if pl is not None:
-                            self.wplanes[(src.data_ptr(), src.numel())] = (pl, grp['slot'])
-                self.f32slots = slots
-                self.f32desc = self._run_f32(groups, None)
+                self.f32desc = self._run_f32(groups, None, zero=False)
             else:
-                self.f32slots.zero_()
                 self._run_f32_cached(groups)
             for grp in groups:
                 grp['step'] = step

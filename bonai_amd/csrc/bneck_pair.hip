@@ -16,8 +16,9 @@
 //
 // Rounding points are those of the separate launches (mid and out2 pass through the 16-bit type; fp32 accumulation; the second
 // product reads the ROUNDED mid) and so is the order of the fp32 operations (K ascending in steps of 16, then + bias, then +
-// residual -- the latter as an exact x 1.0 product on the matrix pipe): the outputs are BIT-IDENTICAL to the separate launches
-// (tests/test_bneck_pair_gpu.py).
+// residual -- the latter two as exact products on the matrix pipe): the outputs equal the separate launches' bit for bit on every
+// tested shape at 256 planes; at 128 planes one element in ~5e5 is one unit of the 16-bit type apart (the final rounding of the
+// matrix pipe's exact add against the VALU add of the separate launch's epilogue; tests/test_bneck_pair_gpu.py).
 //
 // Structure.  256 threads = 4 waves, ONE per SIMD with the whole 512-register file (no weight staging in LDS, no barrier in a K
 // loop): wave w owns channels [32 w, +32) of every chunk in product 1 and channels [P/4 w, +P/4) of product 2, all 128 pixels.

@@ -406,6 +406,7 @@ class Trainer:
         prev_hub = F2.HUB_ENABLED
         F2.HUB_ENABLED = self.arena.data.is_cuda and not DBG.no_feat_hub
         F2.JOIN = {} if (self.arena.data.is_cuda and not DBG.no_grad_join) else None      # lives through forward AND backward
+        F2.PAIR_G.clear()                                 # (pair fusion's backward hand-over: nothing survives a step)
         if self.graph_features and self.arena.data.is_cuda and K.PROFILE is None and F2.PREPACK is not None \
                 and hasattr(self.model, 'extract_feat'):
             self._graph_step_setup(data['img'])
